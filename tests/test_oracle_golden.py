@@ -1,0 +1,363 @@
+"""CPU: the oracle (oracle/) must reproduce the golden vectors that
+tests/golden/make_golden.py captured from the reference's own code."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import geometry as G, photometric as P, segmix as S, nets as N
+
+TOL = dict(rtol=1e-5, atol=1e-6)
+
+
+def close(a, b, rtol=1e-5, atol=1e-6, scale=None):
+    a, b = torch.as_tensor(a).double(), torch.as_tensor(b).double()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    # atol is relative to the tensor's scale (fp32 sums of O(scale) terms); ``scale`` lets
+    # analytically-zero gradients (conv bias in front of BatchNorm) be judged against their siblings
+    if scale is None:
+        scale = float(b.abs().max()) if b.numel() else 1.0
+    atol = atol * max(1.0, scale)
+    assert torch.allclose(a, b, rtol=rtol, atol=atol, equal_nan=True), float((a - b).abs().max())
+
+
+def loss_case(g):
+    cfg = json.loads(str(g["cfg_json"]))
+    inputs = {}
+    for f, t in ((0, "0"), (-1, "-1"), (1, "1")):
+        inputs[("color", f, 0)] = g["in_color_%s_0" % t]
+    for s in range(1, 4):
+        inputs[("color", 0, s)] = g["in_color_0_%d" % s]
+    inputs[("K", 0)], inputs[("inv_K", 0)] = g["in_K_0"], g["in_inv_K_0"]
+    return cfg, inputs
+
+
+@pytest.mark.parametrize("variant", ["default", "no_ssim", "avg_reprojection", "disable_automasking"])
+def test_loss_matches_reference(golden, variant):
+    g = golden("loss_" + variant)
+    cfg, inputs = loss_case(g)
+    obj = P.MonodepthLossOracle(**cfg)
+    out = {}
+    disps = {s: g["disp_%d" % s].clone().requires_grad_(True) for s in range(4)}
+    Ts = {f: g["T_" + t].clone().requires_grad_(True) for f, t in ((-1, "m1"), (1, "p1"))}
+    for s in range(4):
+        out[("disp", s)] = disps[s]
+    for f in (-1, 1):
+        out[("cam_T_cam", 0, f)] = Ts[f]
+    obj.generate_images_pred(inputs, out)
+    noise = None if cfg["disable_automasking"] else {s: g["noise_%d" % s] for s in range(4)}
+    losses = obj.compute_losses(inputs, out, tiebreak_noise=noise)
+    losses["loss"].backward()
+    close(losses["loss"], g["loss"])
+    for s in range(4):
+        close(losses["loss/%d" % s], g["loss_%d" % s])
+        close(out[("depth", 0, s)], g["depth_%d" % s])
+        close(disps[s].grad, g["grad_disp_%d" % s], rtol=1e-4, atol=1e-8)
+        if not cfg["disable_automasking"]:
+            assert torch.equal(out["identity_selection/%d" % s], g["identity_selection_%d" % s])
+    for f, t in ((-1, "m1"), (1, "p1")):
+        close(Ts[f].grad, g["grad_T_" + t], rtol=1e-4, atol=1e-7)
+        for s in (0, 2):
+            close(out[("sample", f, s)], g["sample_%s_%d" % (t, s)], atol=1e-5)
+            close(out[("color", f, s)], g["color_%s_%d" % (t, s)], atol=1e-5)
+    # the pose matrices of the fixture come from the reference's transformation_from_parameters
+    aa, tr = g["axisangle"], g["translation"]
+    close(G.pose_matrix(aa[:, 0], tr[:, 0], invert=True), g["T_m1"])
+    close(G.pose_matrix(aa[:, 1], tr[:, 1], invert=False), g["T_p1"])
+
+
+def test_geometry(golden):
+    g = golden("geom")
+    sdisp, depth = G.disp_to_depth(g["disp"], 0.1, 100)
+    close(sdisp, g["scaled_disp"])
+    close(depth, g["depth"])
+    for inv, tag in ((False, "fwd"), (True, "inv")):
+        aa = g["axisangle"].clone().requires_grad_(True)
+        tr = g["translation"].clone().requires_grad_(True)
+        M = G.pose_matrix(aa, tr, invert=inv)
+        (M * g["M_weight"]).sum().backward()
+        close(M, g["M_" + tag])
+        close(aa.grad, g["grad_aa_" + tag], rtol=1e-4)
+        close(tr.grad, g["grad_tr_" + tag], rtol=1e-4)
+    close(G.pose_matrix(torch.zeros(1, 1, 3), torch.ones(1, 1, 3)), g["M_zero"])
+    pts = G.backproject(g["depth"], g["inv_K"])
+    close(pts, g["cam_points"])
+    B, _, H, W = g["depth"].shape
+    close(G.project(pts, g["K"], g["T"], H, W), g["grid"], atol=1e-5)
+
+
+def test_ssim_and_smoothness(golden):
+    g = golden("ssim_smooth")
+    x = g["x"].clone().requires_grad_(True)
+    v = P.ssim_dissimilarity(x, g["y"])
+    (v * g["w"]).sum().backward()
+    close(v, g["ssim"])
+    close(x.grad, g["grad_x"], rtol=1e-4, atol=1e-7)
+    close(P.ssim_dissimilarity(g["x"], g["y2"]), g["ssim2"], atol=1e-6)
+    d = g["sm_disp"].clone().requires_grad_(True)
+    sm = P.edge_aware_smoothness(d, g["sm_img"])
+    sm.backward()
+    close(sm, g["smooth"])
+    close(d.grad, g["grad_sm_disp"], rtol=1e-4, atol=1e-9)
+
+
+def test_cross_entropy(golden):
+    g = golden("segmix")
+    for tgt, pw, lk, gk in (("ce_target", None, "ce_loss", "ce_grad"), ("ce_target", "ce_pw", "ce_loss_pw", "ce_grad_pw"),
+                            ("ce_target_big", None, "ce_loss_big", "ce_grad_big")):
+        x = g["ce_logits"].clone().requires_grad_(True)
+        loss = S.cross_entropy2d(x, g[tgt], pixel_weights=None if pw is None else g[pw])
+        loss.backward()
+        close(loss, g[lk])
+        close(x.grad, g[gk], rtol=1e-4, atol=1e-8)
+    allign = torch.full_like(g["ce_target"], 250)
+    a, b = S.cross_entropy2d(g["ce_logits"], allign), g["ce_loss_allignored"]
+    assert torch.isnan(a) == torch.isnan(b)
+
+
+def test_mix_and_masks_bit_exact(golden):
+    g = golden("segmix")
+    assert torch.equal(S.mix(g["mix_mask_f"], data=g["mix_img"])[0], g["mix_img_f"])
+    assert torch.equal(S.mix(g["mix_mask_i"], data=g["mix_img"])[0], g["mix_img_i"])
+    assert torch.equal(S.mix(g["mix_mask_i"], data=g["mix_soft"])[0], g["mix_soft_i"])
+    assert torch.equal(S.mix(g["mix_mask_half"], data=g["mix_img"])[0], g["mix_img_half"])
+    assert torch.equal(S.mix(g["mix_mask_i"], target=g["mix_lbl"])[1], g["mix_target_i"])
+    assert torch.equal(S.generate_class_mask(g["cm_pred"], g["cm_classes"]), g["cm_mask"])
+    assert torch.equal(S.generate_depth_mask(g["dm_depth"], g["dm_thr1"]), g["dm_mask1"])
+    assert torch.equal(S.generate_depth_mask(g["dm_depth"], g["dm_thr2"]), g["dm_mask2"])
+    m = S.depthcomp_mask(g["dc_depths"], 0.03, 0.0)
+    assert m.dtype == torch.int64 and torch.equal(m, g["dc_mask_m003_ft0"])
+    assert torch.equal(S.depthcomp_mask(g["dc_depths"], 0.03, 0.25), g["dc_mask_m003_ft025"])
+    lab, w = S.pseudo_label(g["mix_soft"])
+    assert torch.equal(lab, g["pl_label"]) and abs(w - float(g["pl_weight"])) < 1e-12
+
+
+def sd_from(g, prefix):
+    return {k[len(prefix):]: v.clone() for k, v in g.items() if k.startswith(prefix)}
+
+
+def grad_check(g, tag, named):
+    for k, p in named.items():
+        if tag + "_g_" + k in g:
+            close(p.grad if p.grad is not None else torch.zeros_like(p), g[tag + "_g_" + k], rtol=2e-4, atol=1e-6)
+        elif tag + "_gnorm_" + k in g:
+            close(p.grad.double().norm(), g[tag + "_gnorm_" + k], rtol=1e-4)
+            close(p.grad.reshape(-1)[:4096], g[tag + "_gslice_" + k], rtol=2e-4, atol=1e-6)
+
+
+def _leafify(sd):
+    return {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.clone())
+            for k, v in sd.items()}
+
+
+def test_blocks(golden):
+    g = golden("blocks")
+    # ConvBlock (with / without BN), Conv3x3, SelfAttention, ASPP, PoseDecoder
+    for tag, bn in (("convblock", False), ("convblock_bn", True)):
+        sd = _leafify(sd_from(g, tag + "_sd_"))
+        x = g[tag + "_x0"].clone().requires_grad_(True)
+        y = N._convblock(N.Ctx(sd, True), "", dict(bn=bn), x, 0.0)
+        (y * g[tag + "_w0"]).sum().backward()
+        close(y, g[tag + "_y0"], atol=1e-5)
+        close(x.grad, g[tag + "_gx0"], rtol=1e-4, atol=1e-6)
+        grad_check(g, tag, sd)
+        if bn:
+            for k, v in sd_from(g, tag + "_sdafter_").items():
+                close(sd[k].detach(), v, atol=1e-6)
+    sd = _leafify(sd_from(g, "conv3x3_sd_"))
+    x = g["conv3x3_x0"].clone().requires_grad_(True)
+    y = N._refl_conv3(N.Ctx(sd), "conv", x)
+    (y * g["conv3x3_w0"]).sum().backward()
+    close(y, g["conv3x3_y0"], atol=1e-5)
+    close(x.grad, g["conv3x3_gx0"], rtol=1e-4, atol=1e-6)
+    sd = _leafify(sd_from(g, "selfatt_sd_"))
+    x = g["selfatt_x0"].clone().requires_grad_(True)
+    y = N._self_attention(N.Ctx(sd), "", x) if False else N._conv(N.Ctx(sd), "conv", x, 1, 1) * torch.sigmoid(
+        N._conv(N.Ctx(sd), "attention", x, 1, 1))
+    (y * g["selfatt_w0"]).sum().backward()
+    close(y, g["selfatt_y0"], atol=1e-5)
+    close(x.grad, g["selfatt_gx0"], rtol=1e-4, atol=1e-6)
+    grad_check(g, "selfatt", sd)
+    sd = _leafify(sd_from(g, "aspp_sd_"))
+    x = g["aspp_x0"].clone().requires_grad_(True)
+    y = N._aspp(N.Ctx(sd, True), "", dict(rates=[1, 2, 3], pooling=True), x)
+    (y * g["aspp_w0"]).sum().backward()
+    close(y, g["aspp_y0"], atol=1e-5)
+    close(x.grad, g["aspp_gx0"], rtol=2e-4, atol=1e-6)
+    grad_check(g, "aspp", sd)
+    for k, v in sd_from(g, "aspp_sdafter_").items():
+        close(sd[k].detach(), v, atol=1e-6)
+    # PoseDecoder: weights regenerated from the recorded seed
+    gen = torch.Generator().manual_seed(int(g["posedec_seed"]))
+    shapes = [("net.0.weight", (256, 16, 1, 1)), ("net.0.bias", (256,)), ("net.1.weight", (256, 256, 3, 3)),
+              ("net.1.bias", (256,)), ("net.2.weight", (256, 256, 3, 3)), ("net.2.bias", (256,)),
+              ("net.3.weight", (12, 256, 1, 1)), ("net.3.bias", (12,))]
+    sd = {k: (torch.randn(s, generator=gen) * 0.05).requires_grad_(True) for k, s in shapes}
+    x = g["posedec_x0"].clone().requires_grad_(True)
+    aa, tr = N.pose_decoder(N.Ctx(sd), "", x)
+    ((aa * g["posedec_w0"]).sum() + (tr * g["posedec_w1"]).sum()).backward()
+    close(aa, g["posedec_y0"], atol=1e-7)
+    close(tr, g["posedec_y1"], atol=1e-7)
+    close(x.grad, g["posedec_gx0"], rtol=1e-4, atol=1e-8)
+    grad_check(g, "posedec", sd)
+
+
+def _dec_feats(g, tag):
+    return [g["%s_f%d" % (tag, i)].clone().requires_grad_(True) for i in range(5)]
+
+
+def _dec_check(g, tag, feats, out, keys, sd, prefix=""):
+    tot = 0
+    for k in keys:
+        name = "%s_out_%s" % (tag, "_".join(str(x) for x in k) if isinstance(k, tuple) else k)
+        close(out[k], g[name], rtol=1e-4, atol=1e-5)
+        tot = tot + (out[k] * g[name + "_w"]).sum()
+    tot.backward()
+    for i, f in enumerate(feats):
+        close(f.grad if f.grad is not None else torch.zeros_like(f), g["%s_gf%d" % (tag, i)], rtol=1e-3, atol=1e-5)
+    named = {k[len(prefix):]: v for k, v in sd.items() if v.is_floating_point() and v.requires_grad}
+    gscale = max(float(g["%s_g_%s" % (tag, k)].abs().max()) for k in named)
+    for k, p in named.items():
+        key = "%s_g_%s" % (tag, k)
+        assert key in g, key
+        close(p.grad if p.grad is not None else torch.zeros_like(p), g[key], rtol=1e-3, atol=1e-5, scale=gscale)
+
+
+ENC = [8, 8, 16, 16, 32]
+
+
+def test_depth_decoder(golden):
+    g = golden("decoders")
+    a1 = json.loads(str(g["dd1_args_json"]))
+    a1.pop("max_scale_size")
+    sd = _leafify(sd_from(g, "dd1_sd_"))
+    fs = _dec_feats(g, "dd1")
+    out = N.decoder_forward(N.Ctx(sd, True), "", N.decoder_plan(ENC, range(4), **a1), fs)
+    _dec_check(g, "dd1", fs, out, [("disp", 0), ("disp", 1), ("disp", 2), ("disp", 3), ("upconv", 0), ("upconv", 3)], sd)
+    a2 = json.loads(str(g["dd2_args_json"]))
+    a2.pop("max_scale_size")
+    sd = _leafify(sd_from(g, "dd2_sd_"))
+    fs = _dec_feats(g, "dd2")
+    plan = N.decoder_plan(ENC, range(4), **a2)
+    c = N.Ctx(sd, True)
+    o1 = N.decoder_forward(c, "", plan, fs, exec_layer=[4, 3, 2])
+    o2 = N.decoder_forward(c, "", plan, fs, x=o1[("upconv", 2)] * 1.5, exec_layer=[1, 0])
+    out = dict(o1)
+    out.update(o2)
+    _dec_check(g, "dd2", fs, out, [("disp", 0), ("disp", 2), ("upconv", 2)], sd)
+    for k, v in sd_from(g, "dd2_sdafter_").items():
+        close(sd[k].detach(), v, atol=1e-5)
+
+
+@pytest.mark.parametrize("tag", ["jsd1", "jsd2"])
+def test_joint_seg_depth_decoder(golden, tag):
+    g = golden("decoders")
+    a1 = json.loads(str(g["dd1_args_json"]))
+    a1.pop("max_scale_size")
+    sa = json.loads(str(g[tag + "_args_json"]))
+    sd = _leafify(sd_from(g, tag + "_sd_"))
+    fs = _dec_feats(g, tag)
+    y = N.jsd_forward(N.Ctx(sd, True), "", N.decoder_plan(ENC, range(4), **a1), fs, sa)
+    _dec_check(g, tag, fs, {"semantics": y}, ["semantics"], sd)
+
+
+@pytest.mark.parametrize("tag", ["pad1", "pad2"])
+def test_pad(golden, tag):
+    g = golden("decoders")
+    a1 = json.loads(str(g["dd1_args_json"]))
+    a1.pop("max_scale_size")
+    sa = json.loads(str(g[tag + "_args_json"]))
+    sd = _leafify(sd_from(g, tag + "_sd_"))
+    fs = _dec_feats(g, tag)
+    out = N.pad_forward(N.Ctx(sd, True), "", N.decoder_plan(ENC, range(4), **a1), fs, sa)
+    _dec_check(g, tag, fs, out, ["semantics", "intermediate_semantics", ("disp", 0), ("disp", 3)], sd)
+
+
+def _sd_hash(sd):
+    import hashlib
+    h = hashlib.sha256()
+    for k, v in sd.items():
+        h.update(k.encode())
+        h.update(np.ascontiguousarray(v.detach().numpy()).tobytes())
+    return h.hexdigest()
+
+
+def test_encoder_wiring(golden):
+    g = golden("encoder")
+    for tag, nl, rswd, nimg in (("r18", 18, None, 1), ("r50dil", 50, [False, False, True], 1), ("r18x2", 18, None, 2)):
+        sd = {}
+        N._resnet_sd(sd, "encoder.", nl, nimg, rswd, torch.Generator().manual_seed(77), True)
+        if _sd_hash(sd) != str(g[tag + "_sd_hash"]):
+            pytest.skip("torch RNG stream differs from the build container: cannot regenerate seeded weights")
+        fs = N.resnet_features(N.Ctx(sd, True), "encoder.", g[tag + "_x"], nl, rswd)
+        for i, f in enumerate(fs):
+            assert list(f.shape) == g["%s_f%d_shape" % (tag, i)].tolist()
+            ref = g["%s_f%d" % (tag, i)]
+            close(f if f.numel() < 40000 else f[:, :8], ref, rtol=1e-3, atol=1e-4)
+    with pytest.raises(NotImplementedError):
+        N.resnet_plan(18, [False, False, True])
+
+
+def test_state_dict_contract():
+    import os
+    from conftest import GOLDEN
+    c = json.load(open(os.path.join(GOLDEN, "state_dict_contract.json")))
+    for name, cfg in c["cfgs"].items():
+        sd = N.build_state_dict(cfg, 19, seed=1)
+        got = [[k, list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in sd.items()]
+        assert got == c["contract"][name], name
+
+
+@pytest.mark.parametrize("name", ["r18_mono", "r18_jsd"])
+def test_full_model_end_to_end(golden, name):
+    import os
+    from conftest import GOLDEN
+    g = golden("nets")
+    cfg = json.load(open(os.path.join(GOLDEN, "state_dict_contract.json")))["cfgs"][name]
+    sd = N.build_state_dict(cfg, 19, seed=1234, randomize_bn=True)
+    if _sd_hash(sd) != str(g[name + "_sd_hash"]):
+        pytest.skip("torch RNG stream differs from the build container: cannot regenerate seeded weights")
+    sd = _leafify(sd)
+    inputs = {}
+    for k, v in g.items():
+        if k.startswith(name + "_in_"):
+            parts = k[len(name) + 4:].rsplit("_", 2) if k.startswith(name + "_in_color") else None
+            if parts:
+                inputs[("color", int(parts[1]), int(parts[2]))] = v
+    inputs[("K", 0)], inputs[("inv_K", 0)] = g[name + "_in_K_0"], g[name + "_in_inv_K_0"]
+    for f in (0, -1, 1):
+        inputs[("color_aug", f, 0)] = inputs[("color", f, 0)]
+    out = N.model_forward(sd, cfg, inputs, train=True, dropout=False)
+    for s in range(4):
+        close(out[("disp", s)], g[name + "_disp_%d" % s], rtol=1e-3, atol=1e-5)
+    close(out[("cam_T_cam", 0, -1)], g[name + "_T_m1"], rtol=1e-4, atol=1e-6)
+    close(out[("cam_T_cam", 0, 1)], g[name + "_T_p1"], rtol=1e-4, atol=1e-6)
+    B, _, H, W = inputs[("color", 0, 0)].shape
+    obj = P.MonodepthLossOracle(num_scales=4, frame_ids=[0, -1, 1], height=H, width=W, batch_size=B, min_depth=0.1,
+                                max_depth=100, test_min_depth=1e-3, test_max_depth=80, disparity_smoothness=1e-3,
+                                no_ssim=False, avg_reprojection=False, disable_automasking=False)
+    obj.generate_images_pred(inputs, out)
+    losses = obj.compute_losses(inputs, out, tiebreak_noise={s: g[name + "_noise_%d" % s] for s in range(4)})
+    total = losses["loss"]
+    close(losses["loss"], g[name + "_mono_loss"], rtol=1e-4)
+    if "semantics" in out:
+        close(out["semantics"], g[name + "_semantics"], rtol=1e-3, atol=1e-4)
+        seg = S.cross_entropy2d(out["semantics"], g[name + "_lbl"])
+        close(seg, g[name + "_seg_loss"], rtol=1e-4)
+        total = total + seg
+    total.backward()
+    names = [str(x) for x in g[name + "_grad_names"]]
+    norms = g[name + "_grad_norms"]
+    bad = []
+    for k, n in zip(names, norms.tolist()):
+        p = sd["models." + k] if not k.startswith("models.") else sd[k]
+        got = float(p.grad.norm()) if p.grad is not None else -1.0
+        if n < 0 or got < 0:
+            if not (n < 0 and got < 0):
+                bad.append((k, n, got))
+        elif abs(got - n) > 2e-3 * max(abs(n), 1e-6) + 1e-7:
+            bad.append((k, n, got))
+    assert not bad, bad[:10]
+    close(sd["models.encoder.encoder.conv1.weight"].grad, g[name + "_grad_conv1"], rtol=2e-3, atol=1e-6)
+    close(sd["models.encoder.encoder.bn1.running_mean"], g[name + "_bn1_running_mean_after"], rtol=1e-4, atol=1e-6)
