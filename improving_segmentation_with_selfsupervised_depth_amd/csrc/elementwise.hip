@@ -1,0 +1,595 @@
+// HBM-bound NHWC kernels around the convolutions: BatchNorm (train / eval) forward + backward, activation
+// backward + bias gradient, max-pool, nearest-upsample adjoint, bilinear resize (+adjoint), global average
+// pool, SelfAttention gate, axpby, channel-slice copy and the NCHW<->NHWC edges.
+//
+// Design: every tensor is "M rows x C channels" with a pixel pitch ld.  Per-channel reductions use one thread
+// per channel inside a 64-channel slab (a wave reads one 256-byte row segment per instruction), double
+// accumulators per thread, a deterministic two-level tree (block partials -> finalize kernel): no atomics, so
+// results are run-to-run reproducible.  Pure elementwise kernels take a float4 path when C, the pitches and
+// the base pointers allow it.
+#include "segsde_common.h"
+
+namespace {
+
+constexpr int SLAB = 64;      // channels per block column
+constexpr int RLANES = 4;     // row lanes per block (256 threads = 64 channels x 4 rows)
+
+__host__ __device__ inline int red_blocks(long M) {
+  long nb = (M + 255) / 256;
+  return (int)(nb < 1 ? 1 : (nb > 512 ? 512 : nb));
+}
+
+// generic column reduction: Op::row(m, c, s0, s1) accumulates two sums for channel c over this block's rows
+template <class Op>
+__global__ __launch_bounds__(256) void colreduce_kernel(Op op, long M, int C, double* part) {
+  SEGSDE_SMEM;
+  double* sh = reinterpret_cast<double*>(segsde_smem);  // [2][RLANES][SLAB]
+  const int tx = threadIdx.x & (SLAB - 1), ty = threadIdx.x >> 6;
+  const int c = blockIdx.y * SLAB + tx;
+  const int nb = gridDim.x;
+  const long rows_per = (M + nb - 1) / nb;
+  const long r_begin = blockIdx.x * rows_per;
+  long r_end = r_begin + rows_per; if (r_end > M) r_end = M;
+  double s0 = 0.0, s1 = 0.0;
+  if (c < C)
+    for (long m = r_begin + ty; m < r_end; m += RLANES) op.row(m, c, s0, s1);
+  sh[ty * SLAB + tx] = s0;
+  sh[(RLANES + ty) * SLAB + tx] = s1;
+  __syncthreads();
+  if (ty == 0 && c < C) {
+    double a = 0.0, b = 0.0;
+#pragma unroll
+    for (int j = 0; j < RLANES; ++j) { a += sh[j * SLAB + tx]; b += sh[(RLANES + j) * SLAB + tx]; }
+    part[((long)blockIdx.x * 2 + 0) * C + c] = a;
+    part[((long)blockIdx.x * 2 + 1) * C + c] = b;
+  }
+}
+
+template <class Op>
+int launch_colreduce(Op op, long M, int C, double* part, hipStream_t s) {
+  const dim3 grid(red_blocks(M), (C + SLAB - 1) / SLAB);
+  hipLaunchKernelGGL((colreduce_kernel<Op>), grid, dim3(256), 2 * RLANES * SLAB * sizeof(double), s, op, M, C, part);
+  SEGSDE_CHECK_LAUNCH();
+  return 0;
+}
+
+size_t part_bytes(long M, int C) { return (size_t)red_blocks(M) * 2 * C * sizeof(double); }
+
+// ------------------------------------------------------------------ BatchNorm forward
+struct StatsOp {
+  const float* x; int ld;
+  __device__ void row(long m, int c, double& s0, double& s1) const {
+    const double v = (double)x[m * ld + c];
+    s0 += v; s1 += v * v;
+  }
+};
+
+__global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const double* part, int nb, long M, int C, float eps,
+                                                                float momentum, float* mean, float* invstd,
+                                                                float* running_mean, float* running_var) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0, q = 0.0;
+  for (int b = 0; b < nb; ++b) { s += part[((long)b * 2) * C + c]; q += part[((long)b * 2 + 1) * C + c]; }
+  const double mu = s / (double)M;
+  double var = q / (double)M - mu * mu;
+  if (var < 0.0) var = 0.0;
+  mean[c] = (float)mu;
+  invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+  if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mu;
+  if (running_var) {
+    const double unb = M > 1 ? var * (double)M / (double)(M - 1) : var;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_eval_stats_kernel(const float* rm, const float* rv, int C, float eps,
+                                                            float* mean, float* invstd) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  mean[c] = rm[c];
+  invstd[c] = 1.0f / sqrtf(rv[c] + eps);
+}
+
+template <int VW>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* x, int ldx, long M, int C, const float* mean,
+                                                       const float* invstd, const float* gamma, const float* beta,
+                                                       const float* res, int ldr, float* y, int ldy, int act,
+                                                       float drop_p, uint64_t seed) {
+  const int CV = C / VW;
+  const long total = M * CV;
+  const float keep_scale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+  for (long e = blockIdx.x * 256L + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const long m = e / CV; const int c = (int)(e - m * CV) * VW;
+    float v[VW], r[VW];
+    if (VW == 4) {
+      const float4 t = *reinterpret_cast<const float4*>(x + m * ldx + c);
+      v[0] = t.x; v[1 % VW] = t.y; v[2 % VW] = t.z; v[3 % VW] = t.w;
+      if (res) { const float4 q = *reinterpret_cast<const float4*>(res + m * ldr + c); r[0] = q.x; r[1 % VW] = q.y; r[2 % VW] = q.z; r[3 % VW] = q.w; }
+    } else {
+      v[0] = x[m * ldx + c];
+      if (res) r[0] = res[m * ldr + c];
+    }
+#pragma unroll
+    for (int j = 0; j < VW; ++j) {
+      float t = (v[j] - mean[c + j]) * invstd[c + j];
+      if (gamma) t = t * gamma[c + j] + beta[c + j];
+      if (res) t += r[j];
+      t = segsde_act(t, act);
+      if (drop_p > 0.f) t = segsde_uniform01(seed, (uint64_t)(m * C + c + j)) >= drop_p ? t * keep_scale : 0.f;
+      v[j] = t;
+    }
+    if (VW == 4) *reinterpret_cast<float4*>(y + m * ldy + c) = make_float4(v[0], v[1 % VW], v[2 % VW], v[3 % VW]);
+    else y[m * ldy + c] = v[0];
+  }
+}
+
+// ------------------------------------------------------------------ BatchNorm backward
+// dz = dy * dropout_mask * act'(y)
+__device__ __forceinline__ float bn_dz(float dy, float y, int act, float drop_p, uint64_t seed, uint64_t idx) {
+  float g = dy;
+  if (drop_p > 0.f) {
+    // y is the post-dropout value; the pre-dropout activation output is y*(1-p) where kept
+    const bool keep = segsde_uniform01(seed, idx) >= drop_p;
+    if (!keep) return 0.f;
+    const float ks = 1.f / (1.f - drop_p);
+    g *= ks;
+    y = y / ks;
+  }
+  return g * segsde_act_grad_from_out(y, act);
+}
+
+struct BnBwdOp {
+  const float* dy; int lddy; const float* y; int ldy; const float* x; int ldx; const float* mean; const float* invstd;
+  int act, C; float drop_p; uint64_t seed;
+  __device__ void row(long m, int c, double& s0, double& s1) const {
+    const float dz = bn_dz(dy[m * lddy + c], y[m * ldy + c], act, drop_p, seed, (uint64_t)(m * C + c));
+    const float xh = (x[m * ldx + c] - mean[c]) * invstd[c];
+    s0 += (double)dz * (double)xh; s1 += (double)dz;
+  }
+};
+
+__global__ __launch_bounds__(256) void pair_finalize_kernel(const double* part, int nb, int C, float* out0, float* out1) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  double a = 0.0, b = 0.0;
+  for (int i = 0; i < nb; ++i) { a += part[((long)i * 2) * C + c]; b += part[((long)i * 2 + 1) * C + c]; }
+  if (out0) out0[c] = (float)a;
+  if (out1) out1[c] = (float)b;
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* dy, int lddy, const float* y, int ldy,
+                                                           const float* x, int ldx, long M, int C, const float* mean,
+                                                           const float* invstd, const float* gamma, int act,
+                                                           float drop_p, uint64_t seed, int batch_stats,
+                                                           const float* dgamma, const float* dbeta, float* dx, int lddx,
+                                                           float* dres, int lddres) {
+  const long total = M * C;
+  const float invM = 1.f / (float)M;
+  for (long e = blockIdx.x * 256L + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const long m = e / C; const int c = (int)(e - m * C);
+    const float dz = bn_dz(dy[m * lddy + c], y[m * ldy + c], act, drop_p, seed, (uint64_t)e);
+    if (dres) dres[m * lddres + c] = dz;
+    if (dx) {
+      const float g = gamma ? gamma[c] : 1.f;
+      float v;
+      if (batch_stats) {
+        const float xh = (x[m * ldx + c] - mean[c]) * invstd[c];
+        v = g * invstd[c] * (dz - dbeta[c] * invM - xh * dgamma[c] * invM);
+      } else {
+        v = g * invstd[c] * dz;
+      }
+      dx[m * lddx + c] = v;
+    }
+  }
+}
+
+// ------------------------------------------------------------------ activation backward + bias gradient
+struct ActBwdOp {
+  const float* dy; int lddy; const float* y; int ldy; float* dz; int lddz; int act;
+  __device__ void row(long m, int c, double& s0, double& s1) const {
+    const float g = dy[m * lddy + c] * segsde_act_grad_from_out(y[m * ldy + c], act);
+    if (dz) dz[m * lddz + c] = g;
+    s0 += (double)g;
+  }
+};
+struct ColsumOp {
+  const float* x; int ld;
+  __device__ void row(long m, int c, double& s0, double& s1) const { s0 += (double)x[m * ld + c]; }
+};
+
+// ------------------------------------------------------------------ max-pool 3x3 s2 p1
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* x, int B, int H, int W, int C, int Ho, int Wo,
+                                                          float* y, uint8_t* idx) {
+  const long total = (long)B * Ho * Wo * C;
+  for (long e = blockIdx.x * 256L + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const int c = (int)(e % C); long t = e / C;
+    const int wo = (int)(t % Wo); t /= Wo;
+    const int ho = (int)(t % Ho); const int b = (int)(t / Ho);
+    float best = -INFINITY; int bi = 0; bool first = true;
+    for (int kh = 0; kh < 3; ++kh) {
+      const int h = 2 * ho - 1 + kh;
+      if (h < 0 || h >= H) continue;
+      for (int kw = 0; kw < 3; ++kw) {
+        const int w = 2 * wo - 1 + kw;
+        if (w < 0 || w >= W) continue;
+        const float v = x[((long)(b * H + h) * W + w) * C + c];
+        if (first || v > best || v != v) { best = v; bi = kh * 3 + kw; first = false; }
+      }
+    }
+    y[e] = best;
+    idx[e] = (uint8_t)bi;
+  }
+}
+
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* dy, const uint8_t* idx, int B, int H, int W, int C,
+                                                          int Ho, int Wo, float* dx) {
+  const long total = (long)B * H * W * C;
+  for (long e = blockIdx.x * 256L + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const int c = (int)(e % C); long t = e / C;
+    const int w = (int)(t % W); t /= W;
+    const int h = (int)(t % H); const int b = (int)(t / H);
+    float s = 0.f;
+    // output windows (ho, kh) with 2*ho - 1 + kh == h
+    for (int kh = 0; kh < 3; ++kh) {
+      const int hn = h + 1 - kh;
+      if (hn < 0 || (hn & 1)) continue;
+      const int ho = hn >> 1; if (ho >= Ho) continue;
+      for (int kw = 0; kw < 3; ++kw) {
+        const int wn = w + 1 - kw;
+        if (wn < 0 || (wn & 1)) continue;
+        const int wo = wn >> 1; if (wo >= Wo) continue;
+        const long o = ((long)(b * Ho + ho) * Wo + wo) * C + c;
+        if (idx[o] == kh * 3 + kw) s += dy[o];
+      }
+    }
+    dx[e] = s;
+  }
+}
+
+// ------------------------------------------------------------------ nearest x2 upsample adjoint
+__global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const float* dy, int lddy, int B, int h, int w, int C,
+                                                             float* dx, int lddx) {
+  const long total = (long)B * h * w * C;
+  const int W2 = 2 * w;
+  for (long e = blockIdx.x * 256L + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const int c = (int)(e % C); long t = e / C;
+    const int x = (int)(t % w); t /= w;
+    const int y = (int)(t % h); const int b = (int)(t / h);
+    const float* p = dy + ((long)(b * 2 * h + 2 * y) * W2 + 2 * x) * lddy + c;
+    const float s = (p[0] + p[lddy]) + (p[(long)W2 * lddy] + p[(long)W2 * lddy + lddy]);
+    dx[((long)(b * h + y) * w + x) * lddx + c] = s;
+  }
+}
+
+// ------------------------------------------------------------------ bilinear resize (ATen upsample_bilinear2d semantics)
+struct Lerp { int i0, i1; float l0, l1; };
+__device__ __forceinline__ Lerp lerp_src(int dst, int in, int out, int align_corners) {
+  float scale, src;
+  if (align_corners) { scale = out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f; src = scale * (float)dst; }
+  else { scale = (float)in / (float)out; src = scale * ((float)dst + 0.5f) - 0.5f; if (src < 0.f) src = 0.f; }
+  Lerp r;
+  r.i0 = (int)src; if (r.i0 > in - 1) r.i0 = in - 1;
+  r.i1 = r.i0 + (r.i0 < in - 1 ? 1 : 0);
+  r.l1 = src - (float)r.i0; r.l0 = 1.f - r.l1;
+  return r;
+}
+
+__global__ __launch_bounds__(256) void resize_fwd_kernel(const float* x, int ldx, int B, int Hi, int Wi, int C, float* y,
+                                                         int ldy, int Ho, int Wo, int ac) {
+  const long total = (long)B * Ho * Wo * C;
+  for (long e = blockIdx.x * 256L + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const int c = (int)(e % C); long t = e / C;
+    const int wo = (int)(t % Wo); t /= Wo;
+    const int ho = (int)(t % Ho); const int b = (int)(t / Ho);
+    const Lerp lh = lerp_src(ho, Hi, Ho, ac), lw = lerp_src(wo, Wi, Wo, ac);
+    const float* base = x + (long)b * Hi * Wi * ldx + c;
+    const float v00 = base[((long)lh.i0 * Wi + lw.i0) * ldx], v01 = base[((long)lh.i0 * Wi + lw.i1) * ldx];
+    const float v10 = base[((long)lh.i1 * Wi + lw.i0) * ldx], v11 = base[((long)lh.i1 * Wi + lw.i1) * ldx];
+    y[((long)(b * Ho + ho) * Wo + wo) * ldy + c] =
+        lh.l0 * (lw.l0 * v00 + lw.l1 * v01) + lh.l1 * (lw.l0 * v10 + lw.l1 * v11);
+  }
+}
+
+// adjoint as a deterministic gather: each input pixel visits the (conservatively bounded) destination range
+// that can reference it and re-derives the forward weights
+__device__ __forceinline__ void dst_range(int i, int in, int out, int ac, int& lo, int& hi) {
+  float inv;
+  if (ac) inv = in > 1 ? (float)(out - 1) / (float)(in - 1) : (float)out;
+  else inv = (float)out / (float)in;
+  lo = (int)floorf(((float)i - 1.5f) * inv) - 2;
+  hi = (int)ceilf(((float)i + 1.5f) * inv) + 2;
+  if (in == 1 || out == 1) { lo = 0; hi = out - 1; }
+  if (lo < 0) lo = 0;
+  if (hi > out - 1) hi = out - 1;
+}
+
+__global__ __launch_bounds__(256) void resize_bwd_kernel(const float* dy, int lddy, int B, int Hi, int Wi, int C,
+                                                         float* dx, int lddx, int Ho, int Wo, int ac) {
+  const long total = (long)B * Hi * Wi * C;
+  for (long e = blockIdx.x * 256L + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const int c = (int)(e % C); long t = e / C;
+    const int wi = (int)(t % Wi); t /= Wi;
+    const int hi = (int)(t % Hi); const int b = (int)(t / Hi);
+    int hlo, hhi, wlo, whi;
+    dst_range(hi, Hi, Ho, ac, hlo, hhi);
+    dst_range(wi, Wi, Wo, ac, wlo, whi);
+    float s = 0.f;
+    for (int ho = hlo; ho <= hhi; ++ho) {
+      const Lerp lh = lerp_src(ho, Hi, Ho, ac);
+      float wh = 0.f;
+      if (lh.i0 == hi) wh += lh.l0;
+      if (lh.i1 == hi) wh += lh.l1;
+      if (wh == 0.f) continue;
+      float rs = 0.f;
+      for (int wo = wlo; wo <= whi; ++wo) {
+        const Lerp lw = lerp_src(wo, Wi, Wo, ac);
+        float ww = 0.f;
+        if (lw.i0 == wi) ww += lw.l0;
+        if (lw.i1 == wi) ww += lw.l1;
+        if (ww != 0.f) rs += ww * dy[((long)(b * Ho + ho) * Wo + wo) * lddy + c];
+      }
+      s += wh * rs;
+    }
+    dx[((long)(b * Hi + hi) * Wi + wi) * lddx + c] = s;
+  }
+}
+
+// ------------------------------------------------------------------ global average pool
+__global__ __launch_bounds__(256) void gap_fwd_kernel(const float* x, int ldx, long HW, int C, float* y) {
+  // one block per (b, 64-channel slab); 4 row lanes
+  SEGSDE_SMEM;
+  double* sh = reinterpret_cast<double*>(segsde_smem);
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int c = blockIdx.y * SLAB + tx, b = blockIdx.x;
+  double s = 0.0;
+  if (c < C) for (long m = ty; m < HW; m += RLANES) s += (double)x[((long)b * HW + m) * ldx + c];
+  sh[ty * SLAB + tx] = s;
+  __syncthreads();
+  if (ty == 0 && c < C) y[(long)b * C + c] = (float)((sh[tx] + sh[SLAB + tx] + sh[2 * SLAB + tx] + sh[3 * SLAB + tx]) / (double)HW);
+}
+__global__ __launch_bounds__(256) void gap_bwd_kernel(const float* dy, int B, long HW, int C, float* dx, int lddx) {
+  const long total = (long)B * HW * C;
+  const float inv = 1.f / (float)HW;
+  for (long e = blockIdx.x * 256L + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const int c = (int)(e % C); const long m = e / C; const long b = m / HW;
+    dx[m * lddx + c] = dy[b * C + c] * inv;
+  }
+}
+
+// ------------------------------------------------------------------ small elementwise ops
+__global__ __launch_bounds__(256) void gate_fwd_kernel(const float* f, const float* a, long n, float* y) {
+  for (long e = blockIdx.x * 256L + threadIdx.x; e < n; e += (long)gridDim.x * 256)
+    y[e] = f[e] * (1.f / (1.f + expf(-a[e])));
+}
+__global__ __launch_bounds__(256) void gate_bwd_kernel(const float* dy, const float* f, const float* a, long n, float* df,
+                                                       float* da) {
+  for (long e = blockIdx.x * 256L + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
+    const float s = 1.f / (1.f + expf(-a[e]));
+    df[e] = dy[e] * s;
+    da[e] = dy[e] * f[e] * s * (1.f - s);
+  }
+}
+__global__ __launch_bounds__(256) void axpby_kernel(long n, float alpha, const float* x, float beta, const float* y,
+                                                    float* out) {
+  for (long e = blockIdx.x * 256L + threadIdx.x; e < n; e += (long)gridDim.x * 256)
+    out[e] = alpha * x[e] + (y ? beta * y[e] : 0.f);
+}
+template <int VW>
+__global__ __launch_bounds__(256) void copy_channels_kernel(const float* src, int lds, float* dst, int ldd, long M, int C) {
+  const int CV = C / VW;
+  const long total = M * CV;
+  for (long e = blockIdx.x * 256L + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const long m = e / CV; const int c = (int)(e - m * CV) * VW;
+    if (VW == 4) *reinterpret_cast<float4*>(dst + m * ldd + c) = *reinterpret_cast<const float4*>(src + m * lds + c);
+    else dst[m * ldd + c] = src[m * lds + c];
+  }
+}
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* x, int B, int C, int H, int W, float mean, float sd,
+                                                           float* y, int ldy) {
+  const long HW = (long)H * W, total = (long)B * HW * C;
+  for (long e = blockIdx.x * 256L + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const int c = (int)(e % C); const long m = e / C; const long b = m / HW, p = m - b * HW;
+    y[m * ldy + c] = (x[(b * C + c) * HW + p] - mean) / sd;
+  }
+}
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* x, int ldx, int B, int C, int H, int W, float* y) {
+  const long HW = (long)H * W, total = (long)B * HW * C;
+  for (long e = blockIdx.x * 256L + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const long p = e % HW; long t = e / HW; const int c = (int)(t % C); const long b = t / C;
+    y[e] = x[(b * HW + p) * ldx + c];
+  }
+}
+
+inline int ew_blocks(long total) { long nb = (total + 255) / 256; return (int)(nb < 1 ? 1 : (nb > 8192 ? 8192 : nb)); }
+inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+#define ST(s) static_cast<hipStream_t>(s)
+
+}  // namespace
+
+extern "C" size_t segsde_bn_stats_workspace(long M, int C) { return part_bytes(M, C); }
+extern "C" size_t segsde_bn_backward_workspace(long M, int C) { return part_bytes(M, C); }
+extern "C" size_t segsde_colsum_workspace(long M, int C) { return part_bytes(M, C); }
+
+extern "C" int segsde_bn_stats(const float* x, int ldx, long M, int C, float* mean, float* invstd, float* running_mean,
+                               float* running_var, float momentum, float eps, void* ws, size_t ws_bytes, void* stream) {
+  if (!x || !mean || !invstd || !ws) return SEGSDE_ERR_NULL;
+  if (M <= 0 || C <= 0 || ldx < C) return SEGSDE_ERR_SHAPE;
+  if (ws_bytes < part_bytes(M, C)) return SEGSDE_ERR_WORKSPACE;
+  StatsOp op{x, ldx};
+  if (int e = launch_colreduce(op, M, C, (double*)ws, ST(stream))) return e;
+  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, ST(stream), (const double*)ws,
+                     red_blocks(M), M, C, eps, momentum, mean, invstd, running_mean, running_var);
+  SEGSDE_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int segsde_bn_eval_stats(const float* rm, const float* rv, int C, float eps, float* mean, float* invstd,
+                                    void* stream) {
+  if (!rm || !rv || !mean || !invstd) return SEGSDE_ERR_NULL;
+  hipLaunchKernelGGL(bn_eval_stats_kernel, dim3((C + 255) / 256), dim3(256), 0, ST(stream), rm, rv, C, eps, mean, invstd);
+  SEGSDE_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int segsde_bn_apply(const float* x, int ldx, long M, int C, const float* mean, const float* invstd,
+                               const float* gamma, const float* beta, const float* residual, int ldr, float* y, int ldy,
+                               int act, float drop_p, uint64_t seed, void* stream) {
+  if (!x || !mean || !invstd || !y) return SEGSDE_ERR_NULL;
+  if ((gamma == nullptr) != (beta == nullptr)) return SEGSDE_ERR_NULL;
+  if (M <= 0 || C <= 0 || drop_p < 0.f || drop_p >= 1.f) return SEGSDE_ERR_SHAPE;
+  const bool v4 = (C % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) && al16(x) && al16(y) &&
+                  (!residual || ((ldr % 4 == 0) && al16(residual)));
+  if (v4)
+    hipLaunchKernelGGL(bn_apply_kernel<4>, dim3(ew_blocks(M * C / 4)), dim3(256), 0, ST(stream), x, ldx, M, C, mean,
+                       invstd, gamma, beta, residual, ldr, y, ldy, act, drop_p, seed);
+  else
+    hipLaunchKernelGGL(bn_apply_kernel<1>, dim3(ew_blocks(M * C)), dim3(256), 0, ST(stream), x, ldx, M, C, mean, invstd,
+                       gamma, beta, residual, ldr, y, ldy, act, drop_p, seed);
+  SEGSDE_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int segsde_bn_backward(const float* dy, int lddy, const float* y, int ldy, const float* x, int ldx, long M,
+                                  int C, const float* mean, const float* invstd, const float* gamma, int act,
+                                  float drop_p, uint64_t seed, int batch_stats, float* dgamma, float* dbeta, float* dx,
+                                  int lddx, float* dres, int lddres, void* ws, size_t ws_bytes, void* stream) {
+  if (!dy || !y || !x || !mean || !invstd || !dgamma || !dbeta || !ws) return SEGSDE_ERR_NULL;
+  if (M <= 0 || C <= 0) return SEGSDE_ERR_SHAPE;
+  if (ws_bytes < part_bytes(M, C)) return SEGSDE_ERR_WORKSPACE;
+  BnBwdOp op{dy, lddy, y, ldy, x, ldx, mean, invstd, act, C, drop_p, seed};
+  if (int e = launch_colreduce(op, M, C, (double*)ws, ST(stream))) return e;
+  hipLaunchKernelGGL(pair_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, ST(stream), (const double*)ws,
+                     red_blocks(M), C, dgamma, dbeta);
+  SEGSDE_CHECK_LAUNCH();
+  if (dx || dres) {
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_blocks(M * C)), dim3(256), 0, ST(stream), dy, lddy, y, ldy, x, ldx, M,
+                       C, mean, invstd, gamma, act, drop_p, seed, batch_stats, (const float*)dgamma,
+                       (const float*)dbeta, dx, lddx, dres, lddres);
+    SEGSDE_CHECK_LAUNCH();
+  }
+  return 0;
+}
+
+extern "C" int segsde_act_backward(const float* dy, int lddy, const float* y, int ldy, long M, int C, int act, float* dz,
+                                   int lddz, float* dbias, void* ws, size_t ws_bytes, void* stream) {
+  if (!dy || !y || !ws) return SEGSDE_ERR_NULL;
+  if (M <= 0 || C <= 0) return SEGSDE_ERR_SHAPE;
+  if (ws_bytes < part_bytes(M, C)) return SEGSDE_ERR_WORKSPACE;
+  ActBwdOp op{dy, lddy, y, ldy, dz, lddz, act};
+  if (int e = launch_colreduce(op, M, C, (double*)ws, ST(stream))) return e;
+  if (dbias) {
+    hipLaunchKernelGGL(pair_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, ST(stream), (const double*)ws,
+                       red_blocks(M), C, dbias, (float*)nullptr);
+    SEGSDE_CHECK_LAUNCH();
+  }
+  return 0;
+}
+
+extern "C" int segsde_colsum(const float* x, int ldx, long M, int C, float* out, void* ws, size_t ws_bytes, void* stream) {
+  if (!x || !out || !ws) return SEGSDE_ERR_NULL;
+  if (M <= 0 || C <= 0) return SEGSDE_ERR_SHAPE;
+  if (ws_bytes < part_bytes(M, C)) return SEGSDE_ERR_WORKSPACE;
+  ColsumOp op{x, ldx};
+  if (int e = launch_colreduce(op, M, C, (double*)ws, ST(stream))) return e;
+  hipLaunchKernelGGL(pair_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, ST(stream), (const double*)ws,
+                     red_blocks(M), C, out, (float*)nullptr);
+  SEGSDE_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int segsde_maxpool3x3s2_forward(const float* x, int B, int H, int W, int C, float* y, uint8_t* idx, void* stream) {
+  if (!x || !y || !idx) return SEGSDE_ERR_NULL;
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(ew_blocks((long)B * Ho * Wo * C)), dim3(256), 0, ST(stream), x, B, H, W, C,
+                     Ho, Wo, y, idx);
+  SEGSDE_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int segsde_maxpool3x3s2_backward(const float* dy, const uint8_t* idx, int B, int H, int W, int C, float* dx,
+                                            void* stream) {
+  if (!dy || !idx || !dx) return SEGSDE_ERR_NULL;
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(ew_blocks((long)B * H * W * C)), dim3(256), 0, ST(stream), dy, idx, B, H, W,
+                     C, Ho, Wo, dx);
+  SEGSDE_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int segsde_upsample2x_backward(const float* dy, int lddy, int B, int h, int w, int C, float* dx, int lddx,
+                                          void* stream) {
+  if (!dy || !dx) return SEGSDE_ERR_NULL;
+  hipLaunchKernelGGL(upsample2x_bwd_kernel, dim3(ew_blocks((long)B * h * w * C)), dim3(256), 0, ST(stream), dy, lddy, B, h,
+                     w, C, dx, lddx);
+  SEGSDE_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int segsde_resize_bilinear_forward(const float* x, int ldx, int B, int Hi, int Wi, int C, float* y, int ldy,
+                                              int Ho, int Wo, int ac, void* stream) {
+  if (!x || !y) return SEGSDE_ERR_NULL;
+  hipLaunchKernelGGL(resize_fwd_kernel, dim3(ew_blocks((long)B * Ho * Wo * C)), dim3(256), 0, ST(stream), x, ldx, B, Hi, Wi,
+                     C, y, ldy, Ho, Wo, ac);
+  SEGSDE_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int segsde_resize_bilinear_backward(const float* dy, int lddy, int B, int Hi, int Wi, int C, float* dx, int lddx,
+                                               int Ho, int Wo, int ac, void* stream) {
+  if (!dy || !dx) return SEGSDE_ERR_NULL;
+  hipLaunchKernelGGL(resize_bwd_kernel, dim3(ew_blocks((long)B * Hi * Wi * C)), dim3(256), 0, ST(stream), dy, lddy, B, Hi,
+                     Wi, C, dx, lddx, Ho, Wo, ac);
+  SEGSDE_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int segsde_global_avgpool_forward(const float* x, int ldx, int B, long HW, int C, float* y, void* stream) {
+  if (!x || !y) return SEGSDE_ERR_NULL;
+  hipLaunchKernelGGL(gap_fwd_kernel, dim3(B, (C + SLAB - 1) / SLAB), dim3(256), RLANES * SLAB * sizeof(double), ST(stream),
+                     x, ldx, HW, C, y);
+  SEGSDE_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int segsde_global_avgpool_backward(const float* dy, int B, long HW, int C, float* dx, int lddx, void* stream) {
+  if (!dy || !dx) return SEGSDE_ERR_NULL;
+  hipLaunchKernelGGL(gap_bwd_kernel, dim3(ew_blocks((long)B * HW * C)), dim3(256), 0, ST(stream), dy, B, HW, C, dx, lddx);
+  SEGSDE_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int segsde_gate_forward(const float* f, const float* a, long n, float* y, void* stream) {
+  if (!f || !a || !y) return SEGSDE_ERR_NULL;
+  hipLaunchKernelGGL(gate_fwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, ST(stream), f, a, n, y);
+  SEGSDE_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int segsde_gate_backward(const float* dy, const float* f, const float* a, long n, float* df, float* da,
+                                    void* stream) {
+  if (!dy || !f || !a || !df || !da) return SEGSDE_ERR_NULL;
+  hipLaunchKernelGGL(gate_bwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, ST(stream), dy, f, a, n, df, da);
+  SEGSDE_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int segsde_axpby(long n, float alpha, const float* x, float beta, const float* y, float* out, void* stream) {
+  if (!x || !out) return SEGSDE_ERR_NULL;
+  hipLaunchKernelGGL(axpby_kernel, dim3(ew_blocks(n)), dim3(256), 0, ST(stream), n, alpha, x, beta, y, out);
+  SEGSDE_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int segsde_copy_channels(const float* src, int lds, float* dst, int ldd, long M, int C, void* stream) {
+  if (!src || !dst) return SEGSDE_ERR_NULL;
+  const bool v4 = (C % 4 == 0) && (lds % 4 == 0) && (ldd % 4 == 0) && al16(src) && al16(dst);
+  if (v4) hipLaunchKernelGGL(copy_channels_kernel<4>, dim3(ew_blocks(M * C / 4)), dim3(256), 0, ST(stream), src, lds, dst, ldd, M, C);
+  else hipLaunchKernelGGL(copy_channels_kernel<1>, dim3(ew_blocks(M * C)), dim3(256), 0, ST(stream), src, lds, dst, ldd, M, C);
+  SEGSDE_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int segsde_nchw_to_nhwc(const float* x, int B, int C, int H, int W, float mean, float sd, float* y, int ldy,
+                                   void* stream) {
+  if (!x || !y) return SEGSDE_ERR_NULL;
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(ew_blocks((long)B * C * H * W)), dim3(256), 0, ST(stream), x, B, C, H, W,
+                     mean, sd, y, ldy);
+  SEGSDE_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int segsde_nhwc_to_nchw(const float* x, int ldx, int B, int C, int H, int W, float* y, void* stream) {
+  if (!x || !y) return SEGSDE_ERR_NULL;
+  hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(ew_blocks((long)B * C * H * W)), dim3(256), 0, ST(stream), x, ldx, B, C, H, W, y);
+  SEGSDE_CHECK_LAUNCH();
+  return 0;
+}

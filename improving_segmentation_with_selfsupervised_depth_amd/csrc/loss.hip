@@ -1,0 +1,589 @@
+// Monodepth photometric loss kernels (loss/monodepth_loss.py, models/monodepth_layers.py:18-27,145-254):
+// disparity upsample -> depth -> back-projection -> projection -> border-clamped bilinear warp, SSIM+L1
+// reprojection error, auto-masking min, edge-aware smoothness -- forward and hand-derived backward.
+// All tensors are NCHW planar fp32 exactly as the reference's loader hands them over (no layout copies).
+// HBM-bound: every kernel is one coalesced pass over pixel planes; cross-pixel reductions are two-level and
+// deterministic (block partials in double -> a finalize kernel), the pose-matrix gradient included.
+#include "segsde_common.h"
+
+namespace {
+#define ST(s) static_cast<hipStream_t>(s)
+
+struct Lerp { int i0, i1; float l0, l1; };
+// F.interpolate(..., mode="bilinear", align_corners=False) source coordinates (ATen area_pixel_compute_source_index)
+__device__ __forceinline__ Lerp lerp_half(int dst, int in, int out) {
+  const float scale = (float)in / (float)out;
+  float src = scale * ((float)dst + 0.5f) - 0.5f;
+  if (src < 0.f) src = 0.f;
+  Lerp r;
+  r.i0 = (int)src; if (r.i0 > in - 1) r.i0 = in - 1;
+  r.i1 = r.i0 + (r.i0 < in - 1 ? 1 : 0);
+  r.l1 = src - (float)r.i0; r.l0 = 1.f - r.l1;
+  return r;
+}
+
+struct Geo {  // per-pixel geometry shared by warp forward and backward
+  float depth, xn, yn, zn;   // depth and inv_K[:3,:3] * (u, v, 1)
+  float p0, p1, p2;          // P * [cam; 1]
+  float x, y;                // pixel coordinates in the source frame
+  float gx, gy;              // normalised grid as stored in outputs[("sample", f, s)]
+  float ix, iy;              // un-normalised + border-clamped sampling position
+  bool in_x, in_y;           // clamp inactive (gradient passes)
+};
+
+__device__ __forceinline__ Geo geometry(const float* disp_b, int hs, int ws, int H, int W, int h, int w,
+                                        const float* iK /*[16] inv_K*/, const float* P /*[12] (K*T)[:3]*/,
+                                        float min_disp, float max_disp) {
+  Geo g;
+  const Lerp lh = lerp_half(h, hs, H), lw = lerp_half(w, ws, W);
+  const float d = lh.l0 * (lw.l0 * disp_b[lh.i0 * ws + lw.i0] + lw.l1 * disp_b[lh.i0 * ws + lw.i1]) +
+                  lh.l1 * (lw.l0 * disp_b[lh.i1 * ws + lw.i0] + lw.l1 * disp_b[lh.i1 * ws + lw.i1]);
+  const float scaled = min_disp + (max_disp - min_disp) * d;       // monodepth_layers.py:23-26
+  g.depth = 1.f / scaled;
+  const float u = (float)w, v = (float)h;                            // :155-167 pixel-centre grid
+  g.xn = iK[0] * u + iK[1] * v + iK[2];
+  g.yn = iK[4] * u + iK[5] * v + iK[6];
+  g.zn = iK[8] * u + iK[9] * v + iK[10];
+  const float cx = g.depth * g.xn, cy = g.depth * g.yn, cz = g.depth * g.zn;   // :170-172
+  g.p0 = P[0] * cx + P[1] * cy + P[2] * cz + P[3];
+  g.p1 = P[4] * cx + P[5] * cy + P[6] * cz + P[7];
+  g.p2 = P[8] * cx + P[9] * cy + P[10] * cz + P[11];
+  const float den = g.p2 + 1e-7f;                                    // :193
+  g.x = g.p0 / den; g.y = g.p1 / den;
+  g.gx = (g.x / (float)(W - 1) - 0.5f) * 2.f;                         // :196-198
+  g.gy = (g.y / (float)(H - 1) - 0.5f) * 2.f;
+  // grid_sample(align_corners=True) un-normalisation and padding_mode="border" clamp
+  float ix = ((g.gx + 1.f) / 2.f) * (float)(W - 1);
+  float iy = ((g.gy + 1.f) / 2.f) * (float)(H - 1);
+  g.in_x = ix > 0.f && ix < (float)(W - 1);
+  g.in_y = iy > 0.f && iy < (float)(H - 1);
+  ix = fminf(fmaxf(ix, 0.f), (float)(W - 1));
+  iy = fminf(fmaxf(iy, 0.f), (float)(H - 1));
+  if (!(ix == ix)) ix = 0.f;   // NaN guard (ATen clamps NaN through fmin/fmax the same way: result max())
+  if (!(iy == iy)) iy = 0.f;
+  g.ix = ix; g.iy = iy;
+  return g;
+}
+
+// P = (K @ T)[:3, :]   (monodepth_layers.py:189), computed by 12 threads per block into LDS
+__device__ __forceinline__ void load_P(const float* K, const float* T, float* P, float* iKs, const float* inv_K) {
+  const int t = threadIdx.x;
+  if (t < 12) {
+    const int r = t >> 2, c = t & 3;
+    float s = 0.f;
+    for (int k = 0; k < 4; ++k) s += K[r * 4 + k] * T[k * 4 + c];
+    P[t] = s;
+  }
+  if (t >= 16 && t < 32) iKs[t - 16] = inv_K[t - 16];
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void warp_fwd_kernel(const float* disp, int hs, int ws, const float* inv_K,
+                                                       const float* K, const float* T, const float* src, int H, int W,
+                                                       float min_disp, float max_disp, float* color, float* grid,
+                                                       float* depth) {
+  SEGSDE_SMEM;
+  float* P = reinterpret_cast<float*>(segsde_smem);
+  float* iK = P + 16;
+  const int b = blockIdx.y;
+  load_P(K + b * 16, T + b * 16, P, iK, inv_K + b * 16);
+  const long HW = (long)H * W;
+  const float* disp_b = disp + (long)b * hs * ws;
+  const float* src_b = src + (long)b * 3 * HW;
+  for (long p = blockIdx.x * 256L + threadIdx.x; p < HW; p += (long)gridDim.x * 256) {
+    const int h = (int)(p / W), w = (int)(p - (long)h * W);
+    const Geo g = geometry(disp_b, hs, ws, H, W, h, w, iK, P, min_disp, max_disp);
+    if (depth) depth[b * HW + p] = g.depth;
+    if (grid) { grid[(b * HW + p) * 2] = g.gx; grid[(b * HW + p) * 2 + 1] = g.gy; }
+    const float fx = floorf(g.ix), fy = floorf(g.iy);
+    const int x0 = (int)fx, y0 = (int)fy, x1 = x0 + 1, y1 = y0 + 1;
+    const float wx1 = g.ix - fx, wx0 = (float)x1 - g.ix, wy1 = g.iy - fy, wy0 = (float)y1 - g.iy;
+    const float nw = wx0 * wy0, ne = wx1 * wy0, sw = wx0 * wy1, se = wx1 * wy1;
+    const bool vx1 = x1 <= W - 1, vy1 = y1 <= H - 1;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float* s = src_b + c * HW;
+      float v = s[(long)y0 * W + x0] * nw;
+      if (vx1) v += s[(long)y0 * W + x1] * ne;
+      if (vy1) v += s[(long)y1 * W + x0] * sw;
+      if (vx1 && vy1) v += s[(long)y1 * W + x1] * se;
+      color[(b * 3 + c) * HW + p] = v;
+    }
+  }
+}
+
+// adjoint: gcolor [B,3,H,W] -> g_disp_up [B,H,W] (+=) and per-block partial sums of dL/dP (3x4) per batch element
+__global__ __launch_bounds__(256) void warp_bwd_kernel(const float* gcolor, const float* disp, int hs, int ws,
+                                                       const float* inv_K, const float* K, const float* T,
+                                                       const float* src, int H, int W, float min_disp, float max_disp,
+                                                       float* g_disp_up, double* gP_part) {
+  SEGSDE_SMEM;
+  float* P = reinterpret_cast<float*>(segsde_smem);
+  float* iK = P + 16;
+  double* sh = reinterpret_cast<double*>(segsde_smem + 256);
+  const int b = blockIdx.y;
+  load_P(K + b * 16, T + b * 16, P, iK, inv_K + b * 16);
+  const long HW = (long)H * W;
+  const float* disp_b = disp + (long)b * hs * ws;
+  const float* src_b = src + (long)b * 3 * HW;
+  double acc[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) acc[i] = 0.0;
+  for (long p = blockIdx.x * 256L + threadIdx.x; p < HW; p += (long)gridDim.x * 256) {
+    const int h = (int)(p / W), w = (int)(p - (long)h * W);
+    const Geo g = geometry(disp_b, hs, ws, H, W, h, w, iK, P, min_disp, max_disp);
+    const float fx = floorf(g.ix), fy = floorf(g.iy);
+    const int x0 = (int)fx, y0 = (int)fy, x1 = x0 + 1, y1 = y0 + 1;
+    const bool vx1 = x1 <= W - 1, vy1 = y1 <= H - 1;
+    float gix = 0.f, giy = 0.f;   // ATen grid_sampler_2d_backward
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float* s = src_b + c * HW;
+      const float go = gcolor[(b * 3 + c) * HW + p];
+      const float vnw = s[(long)y0 * W + x0];
+      const float vne = vx1 ? s[(long)y0 * W + x1] : 0.f;
+      const float vsw = vy1 ? s[(long)y1 * W + x0] : 0.f;
+      const float vse = (vx1 && vy1) ? s[(long)y1 * W + x1] : 0.f;
+      gix -= vnw * ((float)y1 - g.iy) * go; giy -= vnw * ((float)x1 - g.ix) * go;
+      gix += vne * ((float)y1 - g.iy) * go; giy -= vne * (g.ix - (float)x0) * go;
+      gix -= vsw * (g.iy - (float)y0) * go; giy += vsw * ((float)x1 - g.ix) * go;
+      gix += vse * (g.iy - (float)y0) * go; giy += vse * (g.ix - (float)x0) * go;
+    }
+    // d ix / d x = ((W-1)/2) * (2/(W-1)) = 1 where the border clamp is inactive, else 0
+    const float g_x = g.in_x ? gix : 0.f, g_y = g.in_y ? giy : 0.f;
+    const float den = g.p2 + 1e-7f;
+    const float gp0 = g_x / den, gp1 = g_y / den, gp2 = -(g_x * g.x + g_y * g.y) / den;
+    const float cx = g.depth * g.xn, cy = g.depth * g.yn, cz = g.depth * g.zn;
+    acc[0] += gp0 * cx; acc[1] += gp0 * cy; acc[2] += gp0 * cz; acc[3] += gp0;
+    acc[4] += gp1 * cx; acc[5] += gp1 * cy; acc[6] += gp1 * cz; acc[7] += gp1;
+    acc[8] += gp2 * cx; acc[9] += gp2 * cy; acc[10] += gp2 * cz; acc[11] += gp2;
+    const float gcx = P[0] * gp0 + P[4] * gp1 + P[8] * gp2;
+    const float gcy = P[1] * gp0 + P[5] * gp1 + P[9] * gp2;
+    const float gcz = P[2] * gp0 + P[6] * gp1 + P[10] * gp2;
+    const float gdepth = gcx * g.xn + gcy * g.yn + gcz * g.zn;
+    const float gscaled = -gdepth * g.depth * g.depth;
+    g_disp_up[b * HW + p] += gscaled * (max_disp - min_disp);
+  }
+#pragma unroll
+  for (int i = 0; i < 12; ++i) {
+    const double r = segsde_block_sum(acc[i], sh);
+    if (threadIdx.x == 0) gP_part[((long)b * gridDim.x + blockIdx.x) * 12 + i] = r;
+  }
+}
+
+// gT[b] += K[b]^T (rows 0..2) * gP[b]
+__global__ __launch_bounds__(64) void warp_bwd_finalize_kernel(const double* gP_part, int nblk, const float* K, int B,
+                                                               float* gT) {
+  const int b = blockIdx.x, t = threadIdx.x;
+  if (t >= 16) return;
+  const int k = t >> 2, j = t & 3;
+  double s = 0.0;
+  for (int r = 0; r < 3; ++r) {
+    double gp = 0.0;
+    for (int i = 0; i < nblk; ++i) gp += gP_part[((long)b * nblk + i) * 12 + r * 4 + j];
+    s += (double)K[b * 16 + r * 4 + k] * gp;
+  }
+  gT[b * 16 + t] += (float)s;
+}
+
+// ---------------------------------------------------------------------------------------- SSIM + L1
+constexpr float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
+__device__ __forceinline__ int refl(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
+
+struct Stats { float mx, my, sxx, syy, sxy; };
+__device__ __forceinline__ Stats window_stats(const float* x, const float* y, int H, int W, int h, int w) {
+  float sx = 0.f, sy = 0.f, sxx = 0.f, syy = 0.f, sxy = 0.f;
+#pragma unroll
+  for (int dh = -1; dh <= 1; ++dh) {
+    const int hh = refl(h + dh, H);
+#pragma unroll
+    for (int dw = -1; dw <= 1; ++dw) {
+      const int ww = refl(w + dw, W);
+      const float a = x[(long)hh * W + ww], b = y[(long)hh * W + ww];
+      sx += a; sy += b; sxx += a * a; syy += b * b; sxy += a * b;
+    }
+  }
+  Stats s;
+  s.mx = sx / 9.f; s.my = sy / 9.f; s.sxx = sxx / 9.f; s.syy = syy / 9.f; s.sxy = sxy / 9.f;
+  return s;
+}
+
+__global__ __launch_bounds__(256) void reproj_err_fwd_kernel(const float* pred, const float* target, int H, int W,
+                                                             int no_ssim, float* err, long err_bs) {
+  const int b = blockIdx.y;
+  const long HW = (long)H * W;
+  for (long p = blockIdx.x * 256L + threadIdx.x; p < HW; p += (long)gridDim.x * 256) {
+    const int h = (int)(p / W), w = (int)(p - (long)h * W);
+    float l1 = 0.f, ss = 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float* x = pred + (b * 3 + c) * HW;
+      const float* y = target + (b * 3 + c) * HW;
+      l1 += fabsf(y[p] - x[p]);
+      if (!no_ssim) {
+        const Stats s = window_stats(x, y, H, W, h, w);
+        const float sig_x = s.sxx - s.mx * s.mx, sig_y = s.syy - s.my * s.my, sig_xy = s.sxy - s.mx * s.my;
+        const float n = (2.f * s.mx * s.my + C1) * (2.f * sig_xy + C2);
+        const float d = (s.mx * s.mx + s.my * s.my + C1) * (sig_x + sig_y + C2);
+        ss += fminf(fmaxf((1.f - n / d) / 2.f, 0.f), 1.f);
+      }
+    }
+    l1 = l1 / 3.f;
+    err[b * err_bs + p] = no_ssim ? l1 : (0.85f * (ss / 3.f) + 0.15f * l1);
+  }
+}
+
+// pass 1 of the backward: per window centre q and channel, coefficients (a, bx, by) such that
+// d err_q / d x_p = a + bx * x_p + by * y_p for every padded cell p of q's 3x3 window (already times gerr_q)
+__global__ __launch_bounds__(256) void ssim_coef_kernel(const float* pred, const float* target, const float* gerr,
+                                                        long gerr_bs, int H, int W, float* coef /*[B][3][3][H][W]*/) {
+  const int b = blockIdx.y;
+  const long HW = (long)H * W;
+  for (long p = blockIdx.x * 256L + threadIdx.x; p < HW; p += (long)gridDim.x * 256) {
+    const int h = (int)(p / W), w = (int)(p - (long)h * W);
+    const float gq = gerr[b * gerr_bs + p] * (0.85f / 3.f) * (-0.5f);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float* x = pred + (b * 3 + c) * HW;
+      const float* y = target + (b * 3 + c) * HW;
+      const Stats s = window_stats(x, y, H, W, h, w);
+      const float sig_x = s.sxx - s.mx * s.mx, sig_y = s.syy - s.my * s.my, sig_xy = s.sxy - s.mx * s.my;
+      const float A1 = 2.f * s.mx * s.my + C1, A2 = 2.f * sig_xy + C2;
+      const float B1 = s.mx * s.mx + s.my * s.my + C1, B2 = sig_x + sig_y + C2;
+      const float n = A1 * A2, d = B1 * B2, r = n / d;
+      const float raw = (1.f - r) / 2.f;
+      const float m = (raw >= 0.f && raw <= 1.f) ? gq / (9.f * d) : 0.f;   // clamp passes gradient on [0,1]
+      float* o = coef + ((long)(b * 3 + c) * 3) * HW + p;
+      o[0] = m * (2.f * s.my * A2 - 2.f * A1 * s.my - r * (2.f * s.mx * B2 - 2.f * B1 * s.mx));
+      o[HW] = m * (-r * 2.f * B1);
+      o[2 * HW] = m * (2.f * A1);
+    }
+  }
+}
+
+// pass 2: gather the coefficient maps over every (padded pre-image of p) x (window centre) pair, add the L1 term
+__global__ __launch_bounds__(256) void reproj_err_bwd_kernel(const float* pred, const float* target, const float* gerr,
+                                                             long gerr_bs, const float* coef, int H, int W, int no_ssim,
+                                                             float* gpred) {
+  const int b = blockIdx.y;
+  const long HW = (long)H * W;
+  for (long p = blockIdx.x * 256L + threadIdx.x; p < HW; p += (long)gridDim.x * 256) {
+    const int h = (int)(p / W), w = (int)(p - (long)h * W);
+    int hp[3], wp[3], nh = 0, nw = 0;
+    hp[nh++] = h; if (h == 1) hp[nh++] = -1; if (h == H - 2) hp[nh++] = H;
+    wp[nw++] = w; if (w == 1) wp[nw++] = -1; if (w == W - 2) wp[nw++] = W;
+    const float gl1 = gerr[b * gerr_bs + p] * (no_ssim ? (1.f / 3.f) : (0.15f / 3.f));
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float xv = pred[(b * 3 + c) * HW + p], yv = target[(b * 3 + c) * HW + p];
+      float g = 0.f;
+      if (!no_ssim) {
+        const float* o = coef + ((long)(b * 3 + c) * 3) * HW;
+        float sa = 0.f, sbx = 0.f, sby = 0.f;
+        for (int a = 0; a < nh; ++a)
+          for (int bb = 0; bb < nw; ++bb)
+            for (int dh = -1; dh <= 1; ++dh) {
+              const int qh = hp[a] + dh;
+              if (qh < 0 || qh >= H) continue;
+              for (int dw = -1; dw <= 1; ++dw) {
+                const int qw = wp[bb] + dw;
+                if (qw < 0 || qw >= W) continue;
+                const long q = (long)qh * W + qw;
+                sa += o[q]; sbx += o[HW + q]; sby += o[2 * HW + q];
+              }
+            }
+        g = sa + sbx * xv + sby * yv;
+      }
+      const float df = yv - xv;   // d|t - x|/dx = -sign(t - x)
+      g += gl1 * (df > 0.f ? -1.f : (df < 0.f ? 1.f : 0.f));
+      gpred[(b * 3 + c) * HW + p] = g;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------- auto-mask min
+__global__ __launch_bounds__(256) void automask_fwd_kernel(const float* ident, const float* noise, const float* reproj,
+                                                           int n_reproj, int avg, long total, long HW, uint8_t* sel,
+                                                           float* isel, double* part) {
+  SEGSDE_SMEM;
+  double* sh = reinterpret_cast<double*>(segsde_smem);
+  const int ni_in = ident ? 2 : 0;
+  const int ni = ident ? (avg ? 1 : 2) : 0;
+  double acc = 0.0;
+  for (long e = blockIdx.x * 256L + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const long b = e / HW, p = e - b * HW;
+    float v[4]; int n = 0;
+    if (ident) {
+      const float i0 = ident[(b * ni_in) * HW + p], i1 = ident[(b * ni_in + 1) * HW + p];
+      if (avg) { v[n] = (i0 + i1) / 2.f; if (noise) v[n] += noise[b * HW + p] * 0.00001f; ++n; }
+      else {
+        v[n] = i0; if (noise) v[n] += noise[(b * 2) * HW + p] * 0.00001f; ++n;
+        v[n] = i1; if (noise) v[n] += noise[(b * 2 + 1) * HW + p] * 0.00001f; ++n;
+      }
+    }
+    if (avg && n_reproj == 2) v[n++] = (reproj[(b * 2) * HW + p] + reproj[(b * 2 + 1) * HW + p]) / 2.f;
+    else for (int j = 0; j < n_reproj; ++j) v[n++] = reproj[(b * n_reproj + j) * HW + p];
+    float best = v[0]; int bi = 0;
+    for (int j = 1; j < n; ++j) if (v[j] < best) { best = v[j]; bi = j; }
+    sel[e] = (uint8_t)bi;
+    if (isel) isel[e] = bi > ni - 1 ? 1.f : 0.f;
+    acc += (double)best;
+  }
+  const double r = segsde_block_sum(acc, sh);
+  if (threadIdx.x == 0) part[blockIdx.x] = r;
+}
+
+__global__ __launch_bounds__(256) void sum_finalize_kernel(const double* part, int n, float* out, int out_idx, double scale) {
+  SEGSDE_SMEM;
+  double* sh = reinterpret_cast<double*>(segsde_smem);
+  double a = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) a += part[i];
+  const double r = segsde_block_sum(a, sh);
+  if (threadIdx.x == 0) out[out_idx] = (float)(r * scale);
+}
+
+__global__ __launch_bounds__(256) void automask_bwd_kernel(const uint8_t* sel, int ni, int n_reproj, int avg, long total,
+                                                           long HW, float scale, float* greproj) {
+  for (long e = blockIdx.x * 256L + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const long b = e / HW, p = e - b * HW;
+    const int s = sel[e];
+    if (avg && n_reproj == 2) {
+      const float g = (s == ni) ? 0.5f * scale : 0.f;
+      greproj[(b * 2) * HW + p] = g; greproj[(b * 2 + 1) * HW + p] = g;
+    } else {
+      for (int j = 0; j < n_reproj; ++j) greproj[(b * n_reproj + j) * HW + p] = (s == ni + j) ? scale : 0.f;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------- smoothness
+__global__ __launch_bounds__(256) void plane_sum_kernel(const float* x, long n, double* part) {
+  // grid (nblk, B): per-batch plane sums
+  SEGSDE_SMEM;
+  double* sh = reinterpret_cast<double*>(segsde_smem);
+  const float* xb = x + blockIdx.y * n;
+  double a = 0.0;
+  for (long e = blockIdx.x * 256L + threadIdx.x; e < n; e += (long)gridDim.x * 256) a += (double)xb[e];
+  const double r = segsde_block_sum(a, sh);
+  if (threadIdx.x == 0) part[(long)blockIdx.y * gridDim.x + blockIdx.x] = r;
+}
+__global__ __launch_bounds__(64) void plane_mean_finalize_kernel(const double* part, int nblk, double inv_n, float* out) {
+  if (threadIdx.x != 0) return;
+  double s = 0.0;
+  for (int i = 0; i < nblk; ++i) s += part[(long)blockIdx.x * nblk + i];
+  out[blockIdx.x] = (float)(s * inv_n);
+}
+
+__device__ __forceinline__ float edge_w(const float* img, long HW, long p, long q) {
+  const float g = (fabsf(img[p] - img[q]) + fabsf(img[HW + p] - img[HW + q]) + fabsf(img[2 * HW + p] - img[2 * HW + q])) / 3.f;
+  return expf(-g);
+}
+
+__global__ __launch_bounds__(256) void smooth_fwd_kernel(const float* disp, const float* img, const float* mean_disp,
+                                                         int h, int w, double* part /*[B][nblk][2]*/) {
+  SEGSDE_SMEM;
+  double* sh = reinterpret_cast<double*>(segsde_smem);
+  const int b = blockIdx.y;
+  const long HW = (long)h * w;
+  const float* d = disp + b * HW;
+  const float* im = img + (long)b * 3 * HW;
+  const float inv = mean_disp[b] + 1e-7f;
+  double ax = 0.0, ay = 0.0;
+  for (long p = blockIdx.x * 256L + threadIdx.x; p < HW; p += (long)gridDim.x * 256) {
+    const int y = (int)(p / w), x = (int)(p - (long)y * w);
+    const float dn = d[p] / inv;
+    if (x + 1 < w) ax += (double)(fabsf(dn - d[p + 1] / inv) * edge_w(im, HW, p, p + 1));
+    if (y + 1 < h) ay += (double)(fabsf(dn - d[p + w] / inv) * edge_w(im, HW, p, p + w));
+  }
+  const double rx = segsde_block_sum(ax, sh);
+  const double ry = segsde_block_sum(ay, sh);
+  if (threadIdx.x == 0) {
+    part[((long)b * gridDim.x + blockIdx.x) * 2] = rx;
+    part[((long)b * gridDim.x + blockIdx.x) * 2 + 1] = ry;
+  }
+}
+__global__ __launch_bounds__(64) void smooth_finalize_kernel(const double* part, int n, double inv_nx, double inv_ny,
+                                                             float* out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double sx = 0.0, sy = 0.0;
+  for (int i = 0; i < n; ++i) { sx += part[2 * i]; sy += part[2 * i + 1]; }
+  out[0] = (float)(sx * inv_nx) + (float)(sy * inv_ny);
+}
+
+__device__ __forceinline__ float sgn(float v) { return v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f); }
+
+// pass A: G = dL/d(normalised disparity) per pixel -> tmp, and per-block partials of sum(G * disp)
+__global__ __launch_bounds__(256) void smooth_bwd_a_kernel(const float* disp, const float* img, const float* mean_disp,
+                                                           int h, int w, float sx, float sy, float* tmp, double* part) {
+  SEGSDE_SMEM;
+  double* sh = reinterpret_cast<double*>(segsde_smem);
+  const int b = blockIdx.y;
+  const long HW = (long)h * w;
+  const float* d = disp + b * HW;
+  const float* im = img + (long)b * 3 * HW;
+  const float inv = mean_disp[b] + 1e-7f;
+  double acc = 0.0;
+  for (long p = blockIdx.x * 256L + threadIdx.x; p < HW; p += (long)gridDim.x * 256) {
+    const int y = (int)(p / w), x = (int)(p - (long)y * w);
+    const float dn = d[p] / inv;
+    float g = 0.f;
+    if (x + 1 < w) g += sx * sgn(dn - d[p + 1] / inv) * edge_w(im, HW, p, p + 1);
+    if (x > 0) g -= sx * sgn(d[p - 1] / inv - dn) * edge_w(im, HW, p - 1, p);
+    if (y + 1 < h) g += sy * sgn(dn - d[p + w] / inv) * edge_w(im, HW, p, p + w);
+    if (y > 0) g -= sy * sgn(d[p - w] / inv - dn) * edge_w(im, HW, p - w, p);
+    tmp[b * HW + p] = g;
+    acc += (double)g * (double)d[p];
+  }
+  const double r = segsde_block_sum(acc, sh);
+  if (threadIdx.x == 0) part[(long)b * gridDim.x + blockIdx.x] = r;
+}
+// pass B: gdisp += G/(m+eps) - S/((m+eps)^2 * n)
+__global__ __launch_bounds__(256) void smooth_bwd_b_kernel(const float* tmp, const float* mean_disp, const double* part,
+                                                           int nblk, long HW, float* gdisp) {
+  const int b = blockIdx.y;
+  double S = 0.0;
+  for (int i = 0; i < nblk; ++i) S += part[(long)b * nblk + i];
+  const float inv = mean_disp[b] + 1e-7f;
+  const float corr = (float)(S / ((double)inv * (double)inv * (double)HW));
+  for (long p = blockIdx.x * 256L + threadIdx.x; p < HW; p += (long)gridDim.x * 256)
+    gdisp[b * HW + p] += tmp[b * HW + p] / inv - corr;
+}
+
+inline int plane_blocks(long HW) { long nb = (HW + 255) / 256; return (int)(nb < 1 ? 1 : (nb > 512 ? 512 : nb)); }
+inline int flat_blocks(long n) { long nb = (n + 255) / 256; return (int)(nb < 1 ? 1 : (nb > 2048 ? 2048 : nb)); }
+
+}  // namespace
+
+extern "C" int segsde_warp_forward(const float* disp, int hs, int ws, const float* inv_K, const float* K, const float* T,
+                                   const float* src, int B, int H, int W, float min_depth, float max_depth, float* color,
+                                   float* grid, float* depth, void* stream) {
+  if (!disp || !inv_K || !K || !T || !src || !color) return SEGSDE_ERR_NULL;
+  if (B <= 0 || H < 2 || W < 2 || hs <= 0 || ws <= 0) return SEGSDE_ERR_SHAPE;
+  hipLaunchKernelGGL(warp_fwd_kernel, dim3(plane_blocks((long)H * W), B), dim3(256), 512, ST(stream), disp, hs, ws, inv_K, K,
+                     T, src, H, W, 1.f / max_depth, 1.f / min_depth, color, grid, depth);
+  SEGSDE_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" size_t segsde_warp_backward_workspace(int B, int H, int W) {
+  return (size_t)B * plane_blocks((long)H * W) * 12 * sizeof(double);
+}
+
+extern "C" int segsde_warp_backward(const float* gcolor, const float* disp, int hs, int ws, const float* inv_K,
+                                    const float* K, const float* T, const float* src, int B, int H, int W, float min_depth,
+                                    float max_depth, float* g_disp_up, float* gT, void* ws_, size_t ws_bytes, void* stream) {
+  if (!gcolor || !disp || !inv_K || !K || !T || !src || !g_disp_up || !gT || !ws_) return SEGSDE_ERR_NULL;
+  if (ws_bytes < segsde_warp_backward_workspace(B, H, W)) return SEGSDE_ERR_WORKSPACE;
+  const int nblk = plane_blocks((long)H * W);
+  hipLaunchKernelGGL(warp_bwd_kernel, dim3(nblk, B), dim3(256), 512, ST(stream), gcolor, disp, hs, ws, inv_K, K, T, src, H,
+                     W, 1.f / max_depth, 1.f / min_depth, g_disp_up, (double*)ws_);
+  SEGSDE_CHECK_LAUNCH();
+  hipLaunchKernelGGL(warp_bwd_finalize_kernel, dim3(B), dim3(64), 0, ST(stream), (const double*)ws_, nblk, K, B, gT);
+  SEGSDE_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int segsde_reprojection_error_forward(const float* pred, const float* target, int B, int H, int W, int no_ssim,
+                                                 float* err, long err_bstride, void* stream) {
+  if (!pred || !target || !err) return SEGSDE_ERR_NULL;
+  if (B <= 0 || H < 2 || W < 2) return SEGSDE_ERR_SHAPE;
+  hipLaunchKernelGGL(reproj_err_fwd_kernel, dim3(plane_blocks((long)H * W), B), dim3(256), 0, ST(stream), pred, target, H,
+                     W, no_ssim, err, err_bstride);
+  SEGSDE_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" size_t segsde_reprojection_error_backward_workspace(int B, int H, int W) {
+  return (size_t)B * 9 * H * W * sizeof(float);
+}
+
+extern "C" int segsde_reprojection_error_backward(const float* pred, const float* target, const float* gerr,
+                                                  long gerr_bstride, int B, int H, int W, int no_ssim, float* gpred,
+                                                  void* ws_, size_t ws_bytes, void* stream) {
+  if (!pred || !target || !gerr || !gpred) return SEGSDE_ERR_NULL;
+  if (B <= 0 || H < 2 || W < 2) return SEGSDE_ERR_SHAPE;
+  const dim3 grid(plane_blocks((long)H * W), B);
+  if (!no_ssim) {
+    if (!ws_) return SEGSDE_ERR_NULL;
+    if (ws_bytes < segsde_reprojection_error_backward_workspace(B, H, W)) return SEGSDE_ERR_WORKSPACE;
+    hipLaunchKernelGGL(ssim_coef_kernel, grid, dim3(256), 0, ST(stream), pred, target, gerr, gerr_bstride, H, W, (float*)ws_);
+    SEGSDE_CHECK_LAUNCH();
+  }
+  hipLaunchKernelGGL(reproj_err_bwd_kernel, grid, dim3(256), 0, ST(stream), pred, target, gerr, gerr_bstride,
+                     (const float*)ws_, H, W, no_ssim, gpred);
+  SEGSDE_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" size_t segsde_automask_workspace(int B, int H, int W) {
+  return (size_t)flat_blocks((long)B * H * W) * sizeof(double);
+}
+
+extern "C" int segsde_automask_min_forward(const float* ident, const float* noise, const float* reproj, int n_reproj,
+                                           int avg, int B, int H, int W, uint8_t* sel, float* identity_selection,
+                                           float* sum_out, void* ws_, size_t ws_bytes, void* stream) {
+  if (!reproj || !sel || !sum_out || !ws_) return SEGSDE_ERR_NULL;
+  if (n_reproj < 1 || n_reproj > 2) return SEGSDE_ERR_SHAPE;
+  if (ws_bytes < segsde_automask_workspace(B, H, W)) return SEGSDE_ERR_WORKSPACE;
+  const long total = (long)B * H * W;
+  const int nb = flat_blocks(total);
+  hipLaunchKernelGGL(automask_fwd_kernel, dim3(nb), dim3(256), 64, ST(stream), ident, noise, reproj, n_reproj, avg, total,
+                     (long)H * W, sel, identity_selection, (double*)ws_);
+  SEGSDE_CHECK_LAUNCH();
+  hipLaunchKernelGGL(sum_finalize_kernel, dim3(1), dim3(256), 64, ST(stream), (const double*)ws_, nb, sum_out, 0, 1.0);
+  SEGSDE_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int segsde_automask_min_backward(const uint8_t* sel, int n_ident, int n_reproj, int avg, int B, int H, int W,
+                                            float scale, float* greproj, void* stream) {
+  if (!sel || !greproj) return SEGSDE_ERR_NULL;
+  const long total = (long)B * H * W;
+  const int ni = n_ident ? (avg ? 1 : 2) : 0;
+  hipLaunchKernelGGL(automask_bwd_kernel, dim3(flat_blocks(total)), dim3(256), 0, ST(stream), sel, ni, n_reproj, avg, total,
+                     (long)H * W, scale, greproj);
+  SEGSDE_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" size_t segsde_smoothness_workspace(int B, int h, int w) {
+  return (size_t)B * plane_blocks((long)h * w) * 2 * sizeof(double) + (size_t)B * h * w * sizeof(float) + 64;
+}
+
+extern "C" int segsde_smoothness_forward(const float* disp, const float* img, int B, int h, int w, float* mean_disp,
+                                         float* out, void* ws_, size_t ws_bytes, void* stream) {
+  if (!disp || !img || !mean_disp || !out || !ws_) return SEGSDE_ERR_NULL;
+  if (B <= 0 || h < 2 || w < 2) return SEGSDE_ERR_SHAPE;
+  if (ws_bytes < segsde_smoothness_workspace(B, h, w)) return SEGSDE_ERR_WORKSPACE;
+  const long HW = (long)h * w;
+  const int nb = plane_blocks(HW);
+  double* part = (double*)ws_;
+  hipLaunchKernelGGL(plane_sum_kernel, dim3(nb, B), dim3(256), 64, ST(stream), disp, HW, part);
+  SEGSDE_CHECK_LAUNCH();
+  hipLaunchKernelGGL(plane_mean_finalize_kernel, dim3(B), dim3(64), 0, ST(stream), (const double*)part, nb, 1.0 / (double)HW,
+                     mean_disp);
+  SEGSDE_CHECK_LAUNCH();
+  hipLaunchKernelGGL(smooth_fwd_kernel, dim3(nb, B), dim3(256), 64, ST(stream), disp, img, (const float*)mean_disp, h, w, part);
+  SEGSDE_CHECK_LAUNCH();
+  hipLaunchKernelGGL(smooth_finalize_kernel, dim3(1), dim3(64), 0, ST(stream), (const double*)part, B * nb,
+                     1.0 / ((double)B * h * (w - 1)), 1.0 / ((double)B * (h - 1) * w), out);
+  SEGSDE_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int segsde_smoothness_backward(const float* disp, const float* img, const float* mean_disp, int B, int h, int w,
+                                          float scale, float* gdisp, void* ws_, size_t ws_bytes, void* stream) {
+  if (!disp || !img || !mean_disp || !gdisp || !ws_) return SEGSDE_ERR_NULL;
+  if (ws_bytes < segsde_smoothness_workspace(B, h, w)) return SEGSDE_ERR_WORKSPACE;
+  const long HW = (long)h * w;
+  const int nb = plane_blocks(HW);
+  double* part = (double*)ws_;
+  float* tmp = (float*)((char*)ws_ + (((size_t)B * nb * 2 * sizeof(double) + 63) / 64) * 64);
+  const float sx = scale / ((float)B * h * (w - 1)), sy = scale / ((float)B * (h - 1) * w);
+  hipLaunchKernelGGL(smooth_bwd_a_kernel, dim3(nb, B), dim3(256), 64, ST(stream), disp, img, mean_disp, h, w, sx, sy, tmp, part);
+  SEGSDE_CHECK_LAUNCH();
+  hipLaunchKernelGGL(smooth_bwd_b_kernel, dim3(nb, B), dim3(256), 0, ST(stream), (const float*)tmp, mean_disp,
+                     (const double*)part, nb, HW, gdisp);
+  SEGSDE_CHECK_LAUNCH();
+  return 0;
+}

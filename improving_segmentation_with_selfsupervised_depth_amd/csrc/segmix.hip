@@ -1,0 +1,192 @@
+// Segmentation cross-entropy (loss/loss.py:17-37) over NHWC logits, and the DepthMix / ClassMix mask +
+// composite kernels (loader/transformsgpu.py:33-47, loader/transformmasks.py:27-41, train.py:585-604).
+// Mask / composite arithmetic reproduces the reference's fp32 op sequence exactly (file is compiled with
+// -ffp-contract=off: m*x + (1-m)*y must not fuse), so outputs are bit-identical.
+#include "segsde_common.h"
+
+namespace {
+#define ST(s) static_cast<hipStream_t>(s)
+inline int flat_blocks(long n) { long nb = (n + 255) / 256; return (int)(nb < 1 ? 1 : (nb > 4096 ? 4096 : nb)); }
+inline int ce_blocks(long n) { long nb = (n + 255) / 256; return (int)(nb < 1 ? 1 : (nb > 1024 ? 1024 : nb)); }
+
+__global__ __launch_bounds__(256) void ce_fwd_kernel(const float* logits, int ld, long M, int C, const int64_t* target,
+                                                     int64_t ignore, const float* cw, const float* pw, double* part) {
+  SEGSDE_SMEM;
+  double* sh = reinterpret_cast<double*>(segsde_smem);
+  double num = 0.0, den = 0.0;
+  for (long m = blockIdx.x * 256L + threadIdx.x; m < M; m += (long)gridDim.x * 256) {
+    const int64_t t = target[m];
+    if (t == ignore) continue;
+    const float* x = logits + m * ld;
+    float mx = x[0];
+    for (int c = 1; c < C; ++c) mx = fmaxf(mx, x[c]);
+    float se = 0.f;
+    for (int c = 0; c < C; ++c) se += expf(x[c] - mx);
+    const float nll = (mx + logf(se)) - x[t];
+    float w = cw ? cw[t] : 1.f;
+    den += (double)w;
+    if (pw) w *= pw[m];
+    num += (double)(w * nll);
+  }
+  const double a = segsde_block_sum(num, sh);
+  const double b = segsde_block_sum(den, sh);
+  if (threadIdx.x == 0) { part[2 * blockIdx.x] = a; part[2 * blockIdx.x + 1] = b; }
+}
+__global__ __launch_bounds__(64) void ce_finalize_kernel(const double* part, int n, float* out) {
+  if (threadIdx.x != 0) return;
+  double a = 0.0, b = 0.0;
+  for (int i = 0; i < n; ++i) { a += part[2 * i]; b += part[2 * i + 1]; }
+  out[0] = (float)a; out[1] = (float)b;
+}
+__global__ __launch_bounds__(256) void ce_bwd_kernel(const float* logits, int ld, long M, int C, const int64_t* target,
+                                                     int64_t ignore, const float* cw, const float* pw,
+                                                     const float* scale, float* dl, int lddl) {
+  const float sc = scale[0];
+  for (long m = blockIdx.x * 256L + threadIdx.x; m < M; m += (long)gridDim.x * 256) {
+    const int64_t t = target[m];
+    float* o = dl + m * lddl;
+    if (t == ignore) { for (int c = 0; c < C; ++c) o[c] = 0.f; continue; }
+    const float* x = logits + m * ld;
+    float mx = x[0];
+    for (int c = 1; c < C; ++c) mx = fmaxf(mx, x[c]);
+    float se = 0.f;
+    for (int c = 0; c < C; ++c) se += expf(x[c] - mx);
+    float w = (cw ? cw[t] : 1.f) * sc;
+    if (pw) w *= pw[m];
+    const float inv = 1.f / se;
+    for (int c = 0; c < C; ++c) o[c] = w * (expf(x[c] - mx) * inv - (c == t ? 1.f : 0.f));
+  }
+}
+
+template <class MT>
+__global__ __launch_bounds__(256) void mix_kernel(const MT* mask, int Bm, const float* x, int B, int C, int H, int W,
+                                                  long sb, long sc, long sh, long sw, float* out) {
+  const long total = (long)B * C * H * W;
+  const bool half = (Bm != B);
+  for (long e = blockIdx.x * 256L + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    // enumerate in the memory order of x (smallest stride innermost) for coalescing: assume sw or sc is 1
+    int b, c, h, w;
+    if (sc == 1) { c = (int)(e % C); long t = e / C; w = (int)(t % W); t /= W; h = (int)(t % H); b = (int)(t / H); }
+    else { w = (int)(e % W); long t = e / W; h = (int)(t % H); t /= H; c = (int)(t % C); b = (int)(t / C); }
+    const long off = c * sc + h * sh + w * sw;
+    int ia, ib, mi; bool swap = false;
+    if (!half) { ia = b; ib = (b + 1) % B; mi = b; }
+    else { mi = b % Bm; ia = 2 * mi; ib = 2 * mi + 1; swap = b >= Bm; }
+    const MT m = mask[((long)mi * H + h) * W + w];
+    const float mf = (float)m, omf = (float)((MT)1 - m);
+    const float xa = x[ia * sb + off], xb = x[ib * sb + off];
+    float r;
+    if (!swap) { const float p = mf * xa, q = omf * xb; r = p + q; }
+    else { const float p = omf * xa, q = mf * xb; r = p + q; }
+    out[b * sb + off] = r;
+  }
+}
+__global__ __launch_bounds__(256) void mix_labels_kernel(const int64_t* mask, const int64_t* t, int B, long HW, int64_t* out) {
+  const long total = (long)B * HW;
+  for (long e = blockIdx.x * 256L + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const long b = e / HW, p = e - b * HW;
+    const int64_t m = mask[e];
+    out[e] = m * t[e] + (1 - m) * t[((b + 1) % B) * HW + p];
+  }
+}
+__global__ __launch_bounds__(256) void depthcomp_kernel(const float* d, int B, long HW, float margin, float ft, int64_t* mask) {
+  const long total = (long)B * HW;
+  for (long e = blockIdx.x * 256L + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const long b = e / HW, p = e - b * HW;
+    const float own = d[e], other = d[((b + 1) % B) * HW + p];
+    const float thr = other - margin;
+    const int64_t fg = own >= thr ? 1 : 0;
+    mask[e] = fg * (own >= ft ? 1 : 0);
+  }
+}
+__global__ __launch_bounds__(256) void depth_thr_kernel(const float* d, long n, float t1, float t2, int two, float* mask) {
+  for (long e = blockIdx.x * 256L + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
+    if (!two) mask[e] = d[e] >= t1 ? 1.f : 0.f;
+    else {
+      // reference: depth.ge(t1).le(t2).float() -- the boolean (0/1) of the first test is compared with t2
+      const float ge = d[e] >= t1 ? 1.f : 0.f;
+      mask[e] = ge <= t2 ? 1.f : 0.f;
+    }
+  }
+}
+__global__ __launch_bounds__(256) void class_mask_kernel(const int64_t* pred, long n, const int64_t* classes, int nc, int64_t* mask) {
+  for (long e = blockIdx.x * 256L + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
+    const int64_t v = pred[e];
+    int64_t s = 0;
+    for (int k = 0; k < nc; ++k) s += (v == classes[k]) ? 1 : 0;
+    mask[e] = s;
+  }
+}
+}  // namespace
+
+extern "C" size_t segsde_cross_entropy_workspace(long M) { return (size_t)ce_blocks(M) * 2 * sizeof(double); }
+
+extern "C" int segsde_cross_entropy_forward(const float* logits, int ld, long M, int C, const int64_t* target,
+                                            int64_t ignore_index, const float* class_weight, const float* pixel_weights,
+                                            float* out, void* ws, size_t ws_bytes, void* stream) {
+  if (!logits || !target || !out || !ws) return SEGSDE_ERR_NULL;
+  if (M <= 0 || C <= 0 || ld < C) return SEGSDE_ERR_SHAPE;
+  if (ws_bytes < segsde_cross_entropy_workspace(M)) return SEGSDE_ERR_WORKSPACE;
+  const int nb = ce_blocks(M);
+  hipLaunchKernelGGL(ce_fwd_kernel, dim3(nb), dim3(256), 64, ST(stream), logits, ld, M, C, target, ignore_index, class_weight,
+                     pixel_weights, (double*)ws);
+  SEGSDE_CHECK_LAUNCH();
+  hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(64), 0, ST(stream), (const double*)ws, nb, out);
+  SEGSDE_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int segsde_cross_entropy_backward(const float* logits, int ld, long M, int C, const int64_t* target,
+                                             int64_t ignore_index, const float* class_weight, const float* pixel_weights,
+                                             const float* scale, float* dlogits, int lddl, void* stream) {
+  if (!logits || !target || !scale || !dlogits) return SEGSDE_ERR_NULL;
+  if (M <= 0 || C <= 0 || ld < C || lddl < C) return SEGSDE_ERR_SHAPE;
+  hipLaunchKernelGGL(ce_bwd_kernel, dim3(ce_blocks(M)), dim3(256), 0, ST(stream), logits, ld, M, C, target, ignore_index,
+                     class_weight, pixel_weights, scale, dlogits, lddl);
+  SEGSDE_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int segsde_mix(const void* mask, int mask_is_int64, int Bm, const float* x, int B, int C, int H, int W, long sb,
+                          long sc, long sh, long sw, float* out, void* stream) {
+  if (!mask || !x || !out) return SEGSDE_ERR_NULL;
+  if (B <= 0 || C <= 0 || H <= 0 || W <= 0) return SEGSDE_ERR_SHAPE;
+  if (Bm != B && !(2 * Bm == B)) return SEGSDE_ERR_SHAPE;
+  if (sc != 1 && sw != 1) return SEGSDE_ERR_UNSUPPORTED;
+  const long total = (long)B * C * H * W;
+  if (mask_is_int64)
+    hipLaunchKernelGGL(mix_kernel<int64_t>, dim3(flat_blocks(total)), dim3(256), 0, ST(stream), (const int64_t*)mask, Bm, x, B,
+                       C, H, W, sb, sc, sh, sw, out);
+  else
+    hipLaunchKernelGGL(mix_kernel<float>, dim3(flat_blocks(total)), dim3(256), 0, ST(stream), (const float*)mask, Bm, x, B, C,
+                       H, W, sb, sc, sh, sw, out);
+  SEGSDE_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int segsde_mix_labels(const int64_t* mask, const int64_t* target, int B, int H, int W, int64_t* out, void* stream) {
+  if (!mask || !target || !out) return SEGSDE_ERR_NULL;
+  hipLaunchKernelGGL(mix_labels_kernel, dim3(flat_blocks((long)B * H * W)), dim3(256), 0, ST(stream), mask, target, B,
+                     (long)H * W, out);
+  SEGSDE_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int segsde_depthcomp_mask(const float* depths, int B, long HW, float margin, float fg_threshold, int64_t* mask,
+                                     void* stream) {
+  if (!depths || !mask) return SEGSDE_ERR_NULL;
+  if (B < 1 || HW <= 0) return SEGSDE_ERR_SHAPE;
+  hipLaunchKernelGGL(depthcomp_kernel, dim3(flat_blocks((long)B * HW)), dim3(256), 0, ST(stream), depths, B, HW, margin,
+                     fg_threshold, mask);
+  SEGSDE_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int segsde_depth_threshold_mask(const float* depth, long n, float t1, float t2, int two_thresholds, float* mask,
+                                           void* stream) {
+  if (!depth || !mask) return SEGSDE_ERR_NULL;
+  hipLaunchKernelGGL(depth_thr_kernel, dim3(flat_blocks(n)), dim3(256), 0, ST(stream), depth, n, t1, t2, two_thresholds, mask);
+  SEGSDE_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int segsde_class_mask(const int64_t* pred, long n, const int64_t* classes, int n_classes, int64_t* mask, void* stream) {
+  if (!pred || !classes || !mask) return SEGSDE_ERR_NULL;
+  hipLaunchKernelGGL(class_mask_kernel, dim3(flat_blocks(n)), dim3(256), 0, ST(stream), pred, n, classes, n_classes, mask);
+  SEGSDE_CHECK_LAUNCH();
+  return 0;
+}

@@ -1,0 +1,75 @@
+// Shared device helpers for the segsde gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/segsde_hip.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// all LDS lives in the dynamic region (16-byte aligned base, cdna_hip_programming.md G17)
+#ifndef SEGSDE_SMEM
+#define SEGSDE_SMEM extern __shared__ __attribute__((aligned(16))) unsigned char segsde_smem[]
+#endif
+
+#define SEGSDE_CHECK_LAUNCH()                       \
+  do {                                              \
+    hipError_t e_ = hipGetLastError();              \
+    if (e_ != hipSuccess) return (int)e_ ? (int)e_ : -1; \
+  } while (0)
+
+static inline int segsde_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// activation codes shared by conv epilogues, bn_apply and act_backward
+__device__ __forceinline__ float segsde_act(float v, int act) {
+  if (act == SEGSDE_ACT_RELU) return v > 0.f ? v : 0.f;
+  if (act == SEGSDE_ACT_ELU) return v > 0.f ? v : (expf(v) - 1.f);
+  if (act == SEGSDE_ACT_SIGMOID) return 1.f / (1.f + expf(-v));
+  return v;
+}
+// derivative expressed through the saved OUTPUT y (what the reference's in-place ELU/ReLU keep too)
+__device__ __forceinline__ float segsde_act_grad_from_out(float y, int act) {
+  if (act == SEGSDE_ACT_RELU) return y > 0.f ? 1.f : 0.f;
+  if (act == SEGSDE_ACT_ELU) return y > 0.f ? 1.f : (y + 1.f);
+  if (act == SEGSDE_ACT_SIGMOID) return y * (1.f - y);
+  return 1.f;
+}
+
+// counter-based RNG for dropout masks: the backward pass regenerates the mask from (seed, element index)
+__device__ __forceinline__ uint32_t segsde_hash32(uint64_t x) {
+  x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
+  return (uint32_t)x;
+}
+__device__ __forceinline__ float segsde_uniform01(uint64_t seed, uint64_t idx) {
+  return (segsde_hash32(seed * 0x9E3779B97F4A7C15ULL + idx) >> 8) * (1.0f / 16777216.0f);
+}
+
+// XCD-aware, bijective remap of a linear block id: hardware places block b on XCD b%8; give every XCD a
+// contiguous range of logical tiles so that neighbouring tiles (shared halo rows / weight panels) share an L2.
+__device__ __forceinline__ int segsde_xcd_remap(int bid, int nblk) {
+  const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+  const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + idx;
+}
+
+__device__ __forceinline__ float segsde_wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ double segsde_wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// block-wide sum (256-thread blocks); `sh` points at >= 4 doubles of LDS; result returned to every thread
+__device__ __forceinline__ double segsde_block_sum(double v, double* sh) {
+  v = segsde_wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double r = 0.0;
+  for (int i = 0; i < (int)(blockDim.x >> 6); ++i) r += sh[i];
+  return r;
+}

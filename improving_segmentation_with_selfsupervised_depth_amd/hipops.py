@@ -1,0 +1,508 @@
+"""Thin tensor-level wrappers over the C ABI (include/segsde_hip.h).
+
+PyTorch is used here for device memory (``torch.empty``), the current HIP stream and dtype/shape checks only;
+every arithmetic step is a call into libsegsde_hip.so.  Activations are NHWC fp32 tensors ``[B, H, W, C]`` whose
+last dimension is contiguous (a channel slice of a wider buffer is fine: its pixel pitch ``ld`` is passed on).
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import ConvDesc, check
+
+ACT = {"none": 0, "relu": 1, "elu": 2, "sigmoid": 3}
+PAD_ZERO, PAD_REFLECT = 0, 1
+
+
+def _stream(t):
+    if t.is_cuda:
+        return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+    if not _lib.HOST_POINTERS_OK:
+        raise RuntimeError("segsde HIP kernels need tensors on a ROCm device (got %s); there is no CPU path" % t.device)
+    return ctypes.c_void_p(0)
+
+
+def _p(t):
+    return ctypes.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _f32(t, name="tensor"):
+    if t.dtype != torch.float32:
+        raise TypeError("%s must be float32, got %s" % (name, t.dtype))
+    return t
+
+
+def nhwc_ld(t):
+    """pixel pitch of an NHWC tensor (validates that it is a dense-row channel slice)"""
+    B, H, W, C = t.shape
+    sb, sh, sw, sc = t.stride()
+    if C > 1 and sc != 1:
+        raise ValueError("NHWC tensor must be channel-contiguous")
+    ld = sw if W > 1 else (sh if H > 1 else (sb if B > 1 else C))
+    if W > 1 and H > 1 and sh != W * ld or (B > 1 and H * W > 1 and sb != H * W * ld) or ld < C:
+        raise ValueError("unsupported NHWC strides %s for shape %s" % (t.stride(), tuple(t.shape)))
+    return int(ld)
+
+
+def _ws(nbytes, like):
+    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=like.device)
+
+
+# ----------------------------------------------------------------------------------------------
+# convolution
+# ----------------------------------------------------------------------------------------------
+class ConvGeom:
+    """Static description of one convolution of the reference model (shared by fwd / dgrad / wgrad)."""
+
+    def __init__(self, C0, Cout, k, stride=1, dil=1, pad=0, reflect=False, C1=0, up0=False):
+        self.C0, self.C1, self.Cout, self.k = int(C0), int(C1), int(Cout), int(k)
+        self.stride, self.dil, self.pad, self.reflect, self.up0 = int(stride), int(dil), int(pad), bool(reflect), bool(up0)
+        if reflect and (self.k != 3 or self.stride != 1 or self.dil != 1 or self.pad != 1):
+            raise NotImplementedError("reflection padding is implemented for the reference's 3x3/s1/p1 Conv3x3 only")
+
+    @property
+    def Cin(self):
+        return self.C0 + self.C1
+
+    def out_hw(self, H, W):
+        e = self.dil * (self.k - 1) + 1
+        return (H + 2 * self.pad - e) // self.stride + 1, (W + 2 * self.pad - e) // self.stride + 1
+
+
+def pack_weight(w_oihw, for_dgrad=False):
+    """OIHW -> [O][KH][KW][I] (forward) or [I][KH][KW][O] flipped (data-gradient)."""
+    w = _f32(w_oihw.detach()).contiguous()
+    O, I, KH, KW = w.shape
+    out = torch.empty((I, KH, KW, O) if for_dgrad else (O, KH, KW, I), dtype=torch.float32, device=w.device)
+    check(_lib.lib().segsde_pack_weight(_p(w), _p(out), O, I, KH, KW, int(for_dgrad), _stream(w)), "pack_weight")
+    return out
+
+
+def conv_forward(g, x0, x1, wpack, bias, act="none"):
+    """y = act(conv(cat[up?(x0), x1]) + bias).  x0: [B,H0,W0,C0] (H0 = H/2 if g.up0), x1: [B,H,W,C1] or None."""
+    B, H0, W0, C0 = x0.shape
+    H, W = (2 * H0, 2 * W0) if g.up0 else (H0, W0)
+    assert C0 == g.C0 and (g.C1 == 0) == (x1 is None)
+    if x1 is not None:
+        assert tuple(x1.shape) == (B, H, W, g.C1), (tuple(x1.shape), (B, H, W, g.C1))
+    Ho, Wo = g.out_hw(H, W)
+    y = torch.empty((B, Ho, Wo, g.Cout), dtype=torch.float32, device=x0.device)
+    d = ConvDesc(B=B, H=H, W=W, C0=g.C0, C1=g.C1, ld0=nhwc_ld(x0), ld1=nhwc_ld(x1) if x1 is not None else 0,
+                 up0=int(g.up0), Ho=Ho, Wo=Wo, Cout=g.Cout, ldy=g.Cout, ldy2=0, nsplit=0, KH=g.k, KW=g.k,
+                 stride=g.stride, dil=g.dil, pad=g.pad, pad_mode=PAD_REFLECT if g.reflect else PAD_ZERO, in_div=1,
+                 act=ACT[act])
+    check(_lib.lib().segsde_conv2d_forward(ctypes.byref(d), _p(_f32(x0)), _p(x1), _p(wpack), _p(bias), _p(y), None,
+                                           _stream(x0)), "conv2d_forward")
+    return y
+
+
+def conv_dgrad(g, dy, wdpack, w_oihw, in_hw, need0=True, need1=True):
+    """Data gradient(s) of conv_forward w.r.t. (x0, x1).  dy: [B,Ho,Wo,Cout]; in_hw = (H, W) of the virtual input.
+    Returns (dx0, dx1); dx0 is at the *stored* resolution of x0 (2x2-summed when g.up0)."""
+    B, Ho, Wo, Cout = dy.shape
+    H, W = in_hw
+    assert Cout == g.Cout
+    full0 = torch.empty((B, H, W, g.C0), dtype=torch.float32, device=dy.device)
+    dx1 = torch.empty((B, H, W, g.C1), dtype=torch.float32, device=dy.device) if g.C1 else None
+    d = ConvDesc(B=B, H=Ho, W=Wo, C0=Cout, C1=0, ld0=nhwc_ld(dy), ld1=0, up0=0, Ho=H, Wo=W, Cout=g.Cin, ldy=g.C0,
+                 ldy2=g.C1, nsplit=g.C0, KH=g.k, KW=g.k, stride=1, dil=g.dil, pad=(g.k - 1) * g.dil - g.pad,
+                 pad_mode=PAD_ZERO, in_div=g.stride, act=0)
+    L = _lib.lib()
+    check(L.segsde_conv2d_forward(ctypes.byref(d), _p(_f32(dy)), None, _p(wdpack), None, _p(full0), _p(dx1),
+                                  _stream(dy)), "conv2d dgrad")
+    if g.reflect:
+        check(L.segsde_reflect_dgrad_fix(_p(dy), nhwc_ld(dy), _p(w_oihw), _p(full0), g.C0, _p(dx1), g.C1, g.C0, B, H, W,
+                                         g.Cin, Cout, _stream(dy)), "reflect_dgrad_fix")
+    if g.up0:
+        dx0 = torch.empty((B, H // 2, W // 2, g.C0), dtype=torch.float32, device=dy.device)
+        check(L.segsde_upsample2x_backward(_p(full0), g.C0, B, H // 2, W // 2, g.C0, _p(dx0), g.C0, _stream(dy)),
+              "upsample2x_backward")
+    else:
+        dx0 = full0
+    return dx0, dx1
+
+
+def conv_wgrad(g, x0, x1, dy):
+    """dW in OIHW layout."""
+    B, H0, W0, _ = x0.shape
+    H, W = (2 * H0, 2 * W0) if g.up0 else (H0, W0)
+    _, Ho, Wo, Cout = dy.shape
+    d = ConvDesc(B=B, H=H, W=W, C0=g.C0, C1=g.C1, ld0=nhwc_ld(x0), ld1=nhwc_ld(x1) if x1 is not None else 0,
+                 up0=int(g.up0), Ho=Ho, Wo=Wo, Cout=Cout, ldy=Cout, ldy2=0, nsplit=0, KH=g.k, KW=g.k, stride=g.stride,
+                 dil=g.dil, pad=g.pad, pad_mode=PAD_REFLECT if g.reflect else PAD_ZERO, in_div=1, act=0)
+    L = _lib.lib()
+    nbytes = L.segsde_conv2d_wgrad_workspace(ctypes.byref(d))
+    ws = _ws(nbytes, dy)
+    dw = torch.empty((Cout, g.Cin, g.k, g.k), dtype=torch.float32, device=dy.device)
+    check(L.segsde_conv2d_wgrad(ctypes.byref(d), _p(x0), _p(x1), _p(_f32(dy)), nhwc_ld(dy), _p(dw), _p(ws), nbytes,
+                                _stream(dy)), "conv2d_wgrad")
+    return dw
+
+
+# ----------------------------------------------------------------------------------------------
+# BatchNorm / activations / pooling / resampling
+# ----------------------------------------------------------------------------------------------
+def _rows(t):
+    """(M, C, ld) of an NHWC (or [M, C]) tensor"""
+    if t.dim() == 2:
+        return t.shape[0], t.shape[1], int(t.stride(0)) if t.shape[0] > 1 else t.shape[1]
+    B, H, W, C = t.shape
+    return B * H * W, C, nhwc_ld(t)
+
+
+def bn_stats(x, running_mean, running_var, momentum, eps, update_running=True):
+    M, C, ld = _rows(x)
+    L = _lib.lib()
+    mean = torch.empty(C, dtype=torch.float32, device=x.device)
+    invstd = torch.empty_like(mean)
+    nb = L.segsde_bn_stats_workspace(M, C)
+    ws = _ws(nb, x)
+    check(L.segsde_bn_stats(_p(_f32(x)), ld, M, C, _p(mean), _p(invstd), _p(running_mean if update_running else None),
+                            _p(running_var if update_running else None), float(momentum), float(eps), _p(ws), nb,
+                            _stream(x)), "bn_stats")
+    return mean, invstd
+
+
+def bn_eval_stats(running_mean, running_var, eps):
+    C = running_mean.numel()
+    mean = torch.empty(C, dtype=torch.float32, device=running_mean.device)
+    invstd = torch.empty_like(mean)
+    check(_lib.lib().segsde_bn_eval_stats(_p(running_mean), _p(running_var), C, float(eps), _p(mean), _p(invstd),
+                                          _stream(running_mean)), "bn_eval_stats")
+    return mean, invstd
+
+
+def bn_apply(x, mean, invstd, gamma, beta, residual=None, act="none", drop_p=0.0, seed=0, out=None):
+    M, C, ld = _rows(x)
+    y = torch.empty(x.shape, dtype=torch.float32, device=x.device) if out is None else out
+    ldr = _rows(residual)[2] if residual is not None else 0
+    check(_lib.lib().segsde_bn_apply(_p(x), ld, M, C, _p(mean), _p(invstd), _p(gamma), _p(beta), _p(residual), ldr, _p(y),
+                                     _rows(y)[2], ACT[act], float(drop_p), int(seed), _stream(x)), "bn_apply")
+    return y
+
+
+def bn_backward(dy, y, x, mean, invstd, gamma, act="none", drop_p=0.0, seed=0, batch_stats=True, need_dx=True,
+                need_dres=False):
+    M, C, ldx = _rows(x)
+    L = _lib.lib()
+    dgamma = torch.empty(C, dtype=torch.float32, device=x.device)
+    dbeta = torch.empty_like(dgamma)
+    dx = torch.empty(x.shape, dtype=torch.float32, device=x.device) if need_dx else None
+    dres = torch.empty(x.shape, dtype=torch.float32, device=x.device) if need_dres else None
+    nb = L.segsde_bn_backward_workspace(M, C)
+    ws = _ws(nb, x)
+    check(L.segsde_bn_backward(_p(_f32(dy)), _rows(dy)[2], _p(y), _rows(y)[2], _p(x), ldx, M, C, _p(mean), _p(invstd),
+                               _p(gamma), ACT[act], float(drop_p), int(seed), int(batch_stats), _p(dgamma), _p(dbeta),
+                               _p(dx), C, _p(dres), C, _p(ws), nb, _stream(x)), "bn_backward")
+    return dx, dres, dgamma, dbeta
+
+
+def act_backward(dy, y, act, need_dbias=False, need_dz=True):
+    M, C, ldy = _rows(y)
+    L = _lib.lib()
+    dz = torch.empty(y.shape, dtype=torch.float32, device=y.device) if need_dz else None
+    dbias = torch.empty(C, dtype=torch.float32, device=y.device) if need_dbias else None
+    nb = L.segsde_colsum_workspace(M, C)
+    ws = _ws(nb, y)
+    check(L.segsde_act_backward(_p(_f32(dy)), _rows(dy)[2], _p(y), ldy, M, C, ACT[act], _p(dz), C, _p(dbias), _p(ws), nb,
+                                _stream(y)), "act_backward")
+    return dz, dbias
+
+
+def colsum(x):
+    M, C, ld = _rows(x)
+    L = _lib.lib()
+    out = torch.empty(C, dtype=torch.float32, device=x.device)
+    nb = L.segsde_colsum_workspace(M, C)
+    ws = _ws(nb, x)
+    check(L.segsde_colsum(_p(_f32(x)), ld, M, C, _p(out), _p(ws), nb, _stream(x)), "colsum")
+    return out
+
+
+def maxpool_forward(x):
+    B, H, W, C = x.shape
+    x = x.contiguous()
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    y = torch.empty((B, Ho, Wo, C), dtype=torch.float32, device=x.device)
+    idx = torch.empty((B, Ho, Wo, C), dtype=torch.uint8, device=x.device)
+    check(_lib.lib().segsde_maxpool3x3s2_forward(_p(_f32(x)), B, H, W, C, _p(y), _p(idx), _stream(x)), "maxpool_fwd")
+    return y, idx
+
+
+def maxpool_backward(dy, idx, in_shape):
+    B, H, W, C = in_shape
+    dy = dy.contiguous()
+    dx = torch.empty(in_shape, dtype=torch.float32, device=dy.device)
+    check(_lib.lib().segsde_maxpool3x3s2_backward(_p(_f32(dy)), _p(idx), B, H, W, C, _p(dx), _stream(dy)), "maxpool_bwd")
+    return dx
+
+
+def resize_bilinear(x, out_hw, align_corners=False):
+    B, Hi, Wi, C = x.shape
+    Ho, Wo = out_hw
+    y = torch.empty((B, Ho, Wo, C), dtype=torch.float32, device=x.device)
+    check(_lib.lib().segsde_resize_bilinear_forward(_p(_f32(x)), nhwc_ld(x), B, Hi, Wi, C, _p(y), C, Ho, Wo,
+                                                    int(align_corners), _stream(x)), "resize_fwd")
+    return y
+
+
+def resize_bilinear_backward(dy, in_hw, align_corners=False):
+    B, Ho, Wo, C = dy.shape
+    Hi, Wi = in_hw
+    dx = torch.empty((B, Hi, Wi, C), dtype=torch.float32, device=dy.device)
+    check(_lib.lib().segsde_resize_bilinear_backward(_p(_f32(dy)), nhwc_ld(dy), B, Hi, Wi, C, _p(dx), C, Ho, Wo,
+                                                     int(align_corners), _stream(dy)), "resize_bwd")
+    return dx
+
+
+def global_avgpool(x):
+    B, H, W, C = x.shape
+    y = torch.empty((B, 1, 1, C), dtype=torch.float32, device=x.device)
+    check(_lib.lib().segsde_global_avgpool_forward(_p(_f32(x)), nhwc_ld(x), B, H * W, C, _p(y), _stream(x)), "gap_fwd")
+    return y
+
+
+def global_avgpool_backward(dy, in_shape):
+    B, H, W, C = in_shape
+    dy = dy.contiguous()
+    dx = torch.empty(in_shape, dtype=torch.float32, device=dy.device)
+    check(_lib.lib().segsde_global_avgpool_backward(_p(_f32(dy)), B, H * W, C, _p(dx), C, _stream(dy)), "gap_bwd")
+    return dx
+
+
+def gate_forward(f, a):
+    f, a = f.contiguous(), a.contiguous()
+    y = torch.empty_like(f)
+    check(_lib.lib().segsde_gate_forward(_p(_f32(f)), _p(_f32(a)), f.numel(), _p(y), _stream(f)), "gate_fwd")
+    return y
+
+
+def gate_backward(dy, f, a):
+    dy = dy.contiguous()
+    df, da = torch.empty_like(f), torch.empty_like(a)
+    check(_lib.lib().segsde_gate_backward(_p(_f32(dy)), _p(f), _p(a), f.numel(), _p(df), _p(da), _stream(f)), "gate_bwd")
+    return df, da
+
+
+def axpby(alpha, x, beta=0.0, y=None, out=None):
+    x = x.contiguous()
+    if y is not None:
+        y = y.contiguous()
+    out = torch.empty_like(x) if out is None else out
+    check(_lib.lib().segsde_axpby(x.numel(), float(alpha), _p(_f32(x)), float(beta), _p(y), _p(out), _stream(x)), "axpby")
+    return out
+
+
+def copy_channels(src, dst):
+    M, C, lds = _rows(src)
+    M2, C2, ldd = _rows(dst)
+    assert M == M2 and C == C2
+    check(_lib.lib().segsde_copy_channels(_p(_f32(src)), lds, _p(dst), ldd, M, C, _stream(src)), "copy_channels")
+    return dst
+
+
+def nchw_to_nhwc(x, mean=0.0, std=1.0):
+    x = _f32(x).contiguous()
+    B, C, H, W = x.shape
+    y = torch.empty((B, H, W, C), dtype=torch.float32, device=x.device)
+    check(_lib.lib().segsde_nchw_to_nhwc(_p(x), B, C, H, W, float(mean), float(std), _p(y), C, _stream(x)), "nchw_to_nhwc")
+    return y
+
+
+def nhwc_to_nchw(x):
+    B, H, W, C = x.shape
+    y = torch.empty((B, C, H, W), dtype=torch.float32, device=x.device)
+    check(_lib.lib().segsde_nhwc_to_nchw(_p(_f32(x)), nhwc_ld(x), B, C, H, W, _p(y), _stream(x)), "nhwc_to_nchw")
+    return y
+
+
+# ----------------------------------------------------------------------------------------------
+# pose
+# ----------------------------------------------------------------------------------------------
+def pose_matrix(axisangle, translation, invert):
+    """axisangle / translation: [B, F, 1, 3] network outputs; frame 0 is used (joint_segmentation_depth.py:48-49)."""
+    assert axisangle.is_contiguous() and translation.is_contiguous()
+    B = axisangle.shape[0]
+    stride = axisangle.stride(0) if B > 1 else axisangle[0].numel()
+    M = torch.empty((B, 4, 4), dtype=torch.float32, device=axisangle.device)
+    check(_lib.lib().segsde_pose_matrix_forward(_p(_f32(axisangle)), _p(_f32(translation)), B, int(stride), int(invert),
+                                                _p(M), _stream(axisangle)), "pose_fwd")
+    return M
+
+
+def pose_matrix_backward(axisangle, translation, dM, invert):
+    B = axisangle.shape[0]
+    stride = axisangle.stride(0) if B > 1 else axisangle[0].numel()
+    daa, dtr = torch.zeros_like(axisangle), torch.zeros_like(translation)
+    check(_lib.lib().segsde_pose_matrix_backward(_p(axisangle), _p(translation), _p(_f32(dM.contiguous())), B, int(stride),
+                                                 int(invert), _p(daa), _p(dtr), _stream(axisangle)), "pose_bwd")
+    return daa, dtr
+
+
+# ----------------------------------------------------------------------------------------------
+# monodepth loss
+# ----------------------------------------------------------------------------------------------
+def warp_forward(disp, inv_K, K, T, src, min_depth, max_depth, want_grid=False, want_depth=False):
+    B, _, hs, ws = disp.shape
+    _, _, H, W = src.shape
+    color = torch.empty((B, 3, H, W), dtype=torch.float32, device=src.device)
+    grid = torch.empty((B, H, W, 2), dtype=torch.float32, device=src.device) if want_grid else None
+    depth = torch.empty((B, 1, H, W), dtype=torch.float32, device=src.device) if want_depth else None
+    check(_lib.lib().segsde_warp_forward(_p(_f32(disp.contiguous())), hs, ws, _p(_f32(inv_K.contiguous())),
+                                         _p(_f32(K.contiguous())), _p(_f32(T.contiguous())), _p(_f32(src.contiguous())),
+                                         B, H, W, float(min_depth), float(max_depth), _p(color), _p(grid), _p(depth),
+                                         _stream(src)), "warp_fwd")
+    return color, grid, depth
+
+
+def warp_backward(gcolor, disp, inv_K, K, T, src, min_depth, max_depth, g_disp_up, gT):
+    """accumulates into g_disp_up [B,H,W] and gT [B,4,4]"""
+    B, _, hs, ws = disp.shape
+    _, _, H, W = src.shape
+    L = _lib.lib()
+    nb = L.segsde_warp_backward_workspace(B, H, W)
+    ws_ = _ws(nb, src)
+    check(L.segsde_warp_backward(_p(_f32(gcolor.contiguous())), _p(disp.contiguous()), hs, ws, _p(inv_K.contiguous()),
+                                 _p(K.contiguous()), _p(T.contiguous()), _p(src.contiguous()), B, H, W, float(min_depth),
+                                 float(max_depth), _p(g_disp_up), _p(gT), _p(ws_), nb, _stream(src)), "warp_bwd")
+
+
+def reprojection_error(pred, target, no_ssim, out_plane):
+    """out_plane: a [B,H,W] view (channel of a [B,n,H,W] tensor)"""
+    B, _, H, W = pred.shape
+    assert out_plane.stride(2) == 1 and out_plane.stride(1) == W
+    check(_lib.lib().segsde_reprojection_error_forward(_p(_f32(pred.contiguous())), _p(_f32(target.contiguous())), B, H, W,
+                                                       int(no_ssim), _p(out_plane), int(out_plane.stride(0)) if B > 1 else H * W,
+                                                       _stream(pred)), "reproj_err_fwd")
+
+
+def reprojection_error_backward(pred, target, gerr_plane, no_ssim):
+    B, _, H, W = pred.shape
+    L = _lib.lib()
+    nb = 0 if no_ssim else L.segsde_reprojection_error_backward_workspace(B, H, W)
+    ws_ = _ws(nb, pred) if nb else None
+    gpred = torch.empty_like(pred)
+    check(L.segsde_reprojection_error_backward(_p(pred.contiguous()), _p(target.contiguous()), _p(gerr_plane),
+                                               int(gerr_plane.stride(0)) if B > 1 else H * W, B, H, W, int(no_ssim),
+                                               _p(gpred), _p(ws_), nb, _stream(pred)), "reproj_err_bwd")
+    return gpred
+
+
+def automask_min(ident, noise, reproj, avg, want_selection=True):
+    B, nr, H, W = reproj.shape
+    L = _lib.lib()
+    sel = torch.empty((B, H, W), dtype=torch.uint8, device=reproj.device)
+    isel = torch.empty((B, H, W), dtype=torch.float32, device=reproj.device) if (want_selection and ident is not None) else None
+    out = torch.empty(1, dtype=torch.float32, device=reproj.device)
+    nb = L.segsde_automask_workspace(B, H, W)
+    ws_ = _ws(nb, reproj)
+    check(L.segsde_automask_min_forward(_p(ident), _p(noise), _p(_f32(reproj)), nr, int(avg), B, H, W, _p(sel), _p(isel),
+                                        _p(out), _p(ws_), nb, _stream(reproj)), "automask_fwd")
+    return out, sel, isel
+
+
+def automask_min_backward(sel, has_ident, n_reproj, avg, scale):
+    B, H, W = sel.shape
+    g = torch.empty((B, n_reproj, H, W), dtype=torch.float32, device=sel.device)
+    check(_lib.lib().segsde_automask_min_backward(_p(sel), 2 if has_ident else 0, n_reproj, int(avg), B, H, W, float(scale),
+                                                  _p(g), _stream(sel)), "automask_bwd")
+    return g
+
+
+def smoothness_forward(disp, img):
+    B, _, h, w = disp.shape
+    L = _lib.lib()
+    mean = torch.empty(B, dtype=torch.float32, device=disp.device)
+    out = torch.empty(1, dtype=torch.float32, device=disp.device)
+    nb = L.segsde_smoothness_workspace(B, h, w)
+    ws_ = _ws(nb, disp)
+    check(L.segsde_smoothness_forward(_p(_f32(disp.contiguous())), _p(_f32(img.contiguous())), B, h, w, _p(mean), _p(out),
+                                      _p(ws_), nb, _stream(disp)), "smooth_fwd")
+    return out, mean
+
+
+def smoothness_backward(disp, img, mean, scale, gdisp):
+    """accumulates into gdisp [B,1,h,w]"""
+    B, _, h, w = disp.shape
+    L = _lib.lib()
+    nb = L.segsde_smoothness_workspace(B, h, w)
+    ws_ = _ws(nb, disp)
+    check(L.segsde_smoothness_backward(_p(disp.contiguous()), _p(img.contiguous()), _p(mean), B, h, w, float(scale),
+                                       _p(gdisp), _p(ws_), nb, _stream(disp)), "smooth_bwd")
+
+
+# ----------------------------------------------------------------------------------------------
+# segmentation loss, mix, masks
+# ----------------------------------------------------------------------------------------------
+def cross_entropy_forward(logits_nhwc, target, ignore_index, class_weight=None, pixel_weights=None):
+    M, C, ld = _rows(logits_nhwc)
+    L = _lib.lib()
+    out = torch.empty(2, dtype=torch.float32, device=logits_nhwc.device)
+    nb = L.segsde_cross_entropy_workspace(M)
+    ws_ = _ws(nb, logits_nhwc)
+    assert target.dtype == torch.int64 and target.is_contiguous() and target.numel() == M
+    check(L.segsde_cross_entropy_forward(_p(_f32(logits_nhwc)), ld, M, C, _p(target), int(ignore_index), _p(class_weight),
+                                         _p(pixel_weights), _p(out), _p(ws_), nb, _stream(logits_nhwc)), "ce_fwd")
+    return out
+
+
+def cross_entropy_backward(logits_nhwc, target, ignore_index, scale, class_weight=None, pixel_weights=None):
+    M, C, ld = _rows(logits_nhwc)
+    dl = torch.empty(logits_nhwc.shape, dtype=torch.float32, device=logits_nhwc.device)
+    check(_lib.lib().segsde_cross_entropy_backward(_p(logits_nhwc), ld, M, C, _p(target), int(ignore_index),
+                                                   _p(class_weight), _p(pixel_weights), _p(_f32(scale)), _p(dl), C,
+                                                   _stream(logits_nhwc)), "ce_bwd")
+    return dl
+
+
+def mix(mask, x):
+    """x: [B,C,H,W] fp32, NCHW-contiguous or channels-last; mask [Bm,H,W] int64 / float32"""
+    B, C, H, W = x.shape
+    if not (x.stride(3) == 1 or x.stride(1) == 1):
+        x = x.contiguous()
+    out = torch.empty_strided(x.shape, x.stride(), dtype=torch.float32, device=x.device)
+    if mask.dtype == torch.int64:
+        is64 = 1
+    elif mask.dtype == torch.float32:
+        is64 = 0
+    else:
+        raise TypeError("mask must be int64 or float32")
+    mask = mask.contiguous()
+    sb = x.stride(0) if B > 1 else C * H * W
+    check(_lib.lib().segsde_mix(_p(mask), is64, mask.shape[0], _p(_f32(x)), B, C, H, W, int(sb), int(x.stride(1)),
+                                int(x.stride(2)), int(x.stride(3)), _p(out), _stream(x)), "mix")
+    return out
+
+
+def mix_labels(mask, target):
+    B, H, W = target.shape
+    out = torch.empty_like(target)
+    check(_lib.lib().segsde_mix_labels(_p(mask.contiguous()), _p(target.contiguous()), B, H, W, _p(out), _stream(target)),
+          "mix_labels")
+    return out
+
+
+def depthcomp_mask(depths, margin, fg_threshold):
+    B = depths.shape[0]
+    HW = depths[0].numel()
+    mask = torch.empty((B,) + tuple(depths.shape[-2:]), dtype=torch.int64, device=depths.device)
+    check(_lib.lib().segsde_depthcomp_mask(_p(_f32(depths.contiguous())), B, HW, float(margin), float(fg_threshold), _p(mask),
+                                           _stream(depths)), "depthcomp_mask")
+    return mask
+
+
+def depth_threshold_mask(depth, t1, t2=0.0, two=False):
+    depth = depth.contiguous()
+    mask = torch.empty_like(depth)
+    check(_lib.lib().segsde_depth_threshold_mask(_p(_f32(depth)), depth.numel(), float(t1), float(t2), int(two), _p(mask),
+                                                 _stream(depth)), "depth_threshold_mask")
+    return mask
+
+
+def class_mask(pred, classes):
+    pred, classes = pred.contiguous(), classes.contiguous().to(torch.int64)
+    mask = torch.empty_like(pred)
+    check(_lib.lib().segsde_class_mask(_p(pred), pred.numel(), _p(classes), classes.numel(), _p(mask), _stream(pred)),
+          "class_mask")
+    return mask

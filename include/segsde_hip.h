@@ -1,0 +1,210 @@
+/* segsde_hip.h -- C ABI of libsegsde_hip.so: hand-written gfx950 (MI355X) kernels for the joint
+ * segmentation + self-supervised-depth training hot path of
+ * lhoyer/improving_segmentation_with_selfsupervised_depth.
+ *
+ * Boundary rules
+ *   - plain pointers + sizes; every pointer is DEVICE memory (the caller -- PyTorch-ROCm in the Python host
+ *     layer -- owns allocation); no torch types; `stream` is a hipStream_t passed as void*; nothing syncs.
+ *   - return 0 on success, a SEGSDE_ERR_* code (<0) for bad arguments, or a positive hipError_t.
+ *   - activations are NHWC fp32 ("rows" = pixels, `ld*` = floats between consecutive pixels, which lets a
+ *     tensor be a channel slice of a wider buffer); images / disparities of the loss path are NCHW planar
+ *     fp32 exactly as the reference's data loader hands them over.
+ *   - workspaces are caller-provided; `*_workspace()` return the bytes needed.
+ *
+ * The reference is pure Python on torch.nn; it has no FFI.  Each entry point therefore cites the reference
+ * call site(s) whose ATen op sequence it replaces (paths relative to /root/reference).  The ctypes binding a
+ * maintainer would add is shown in INTEGRATION.md and shipped in
+ * improving_segmentation_with_selfsupervised_depth_amd/_lib.py.
+ */
+#ifndef SEGSDE_HIP_H
+#define SEGSDE_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SEGSDE_ABI_VERSION 1
+
+enum { SEGSDE_ERR_NULL = -1, SEGSDE_ERR_SHAPE = -2, SEGSDE_ERR_WORKSPACE = -3, SEGSDE_ERR_UNSUPPORTED = -4 };
+enum { SEGSDE_ACT_NONE = 0, SEGSDE_ACT_RELU = 1, SEGSDE_ACT_ELU = 2, SEGSDE_ACT_SIGMOID = 3 };
+enum { SEGSDE_PAD_ZERO = 0, SEGSDE_PAD_REFLECT = 1 };
+
+int segsde_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------------ *
+ * Convolutions (implicit GEMM on v_mfma_f32_32x32x2_f32)                                           *
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct segsde_conv_desc {
+  int B, H, W;      /* batch; spatial size of the (virtual) conv input: after the optional x2 upsample, before padding */
+  int C0, C1;       /* channels of source 0 / source 1 (C1 = 0: single source); the conv sees [src0 | src1]           */
+  int ld0, ld1;     /* pixel pitch (floats) of the two sources                                                          */
+  int up0;          /* 1: source 0 is stored at (H/2, W/2) and nearest-upsampled x2 on the fly (depth_decoder.py:93-94) */
+  int Ho, Wo, Cout; /* output size                                                                                       */
+  int ldy, ldy2, nsplit; /* output pitch; optional second destination receiving channels >= nsplit (concat dgrad)       */
+  int KH, KW, stride, dil, pad;
+  int pad_mode;     /* SEGSDE_PAD_ZERO | SEGSDE_PAD_REFLECT (monodepth_layers.py:133-136)                               */
+  int in_div;       /* 1; >1 only for data-gradients of strided convs: input coordinate must divide by in_div          */
+  int act;          /* fused epilogue activation applied after the bias: SEGSDE_ACT_*                                    */
+} segsde_conv_desc;
+
+/* y[b,ho,wo,n] = act(bias[n] + sum_{kh,kw,c} x[b, ho*stride-pad+kh*dil, wo*stride-pad+kw*dil, c] * wpack[n][kh][kw][c])
+ * Replaces: every nn.Conv2d on the path -- torchvision ResNet convs reached from models/resnet_encoder.py:93-99,
+ * Conv3x3 (ReflectionPad2d+Conv2d, models/monodepth_layers.py:127-142) incl. the upsample+torch.cat in front of it
+ * (models/depth_decoder.py:93-101), ASPP convs (models/model_parts.py:9-25), SelfAttention convs (:38-39),
+ * segmentation heads (models/joint_segmentation_depth_decoder.py:35-53,111-116), PoseDecoder convs
+ * (models/pose_decoder.py:29-33).  Run on dgrad-packed weights (segsde_pack_weight(for_dgrad=1)) with
+ * pad' = (K-1)*dil - pad, stride 1 and in_div = stride it is the data-gradient of the same convolution. */
+int segsde_conv2d_forward(const segsde_conv_desc* d, const float* x0, const float* x1, const float* wpack,
+                          const float* bias, float* y, float* y2, void* stream);
+
+/* dW (OIHW, the state_dict layout) of the convolution described by d, given dy [B,Ho,Wo,Cout] (pitch lddy). */
+size_t segsde_conv2d_wgrad_workspace(const segsde_conv_desc* d);
+int segsde_conv2d_wgrad(const segsde_conv_desc* d, const float* x0, const float* x1, const float* dy, int lddy,
+                        float* dw_oihw, float* workspace, size_t workspace_bytes, void* stream);
+
+/* OIHW -> [O][KH][KW][I] (for_dgrad=0) or [I][KH][KW][O] spatially flipped (for_dgrad=1). */
+int segsde_pack_weight(const float* w_oihw, float* out, int O, int I, int KH, int KW, int for_dgrad, void* stream);
+
+/* Adds to dx the gradient that entered the mirrored padding cells of a reflection-padded 3x3 stride-1 conv
+ * (autograd of nn.ReflectionPad2d(1), models/monodepth_layers.py:134,140). */
+int segsde_reflect_dgrad_fix(const float* dy, int lddy, const float* w_oihw, float* dx, int lddx, float* dx2, int lddx2,
+                             int nsplit, int B, int H, int W, int Cin, int Cout, void* stream);
+
+/* ------------------------------------------------------------------------------------------------ *
+ * BatchNorm / activations / pooling / resampling (HBM-bound, NHWC)                                 *
+ * ------------------------------------------------------------------------------------------------ */
+/* Training-mode batch statistics over M rows (nn.BatchNorm2d.forward in train(), every BN on the path):
+ * mean[c], invstd[c] = 1/sqrt(biased var + eps); running stats updated with `momentum` using the unbiased var. */
+size_t segsde_bn_stats_workspace(long M, int C);
+int segsde_bn_stats(const float* x, int ldx, long M, int C, float* mean, float* invstd, float* running_mean,
+                    float* running_var, float momentum, float eps, void* workspace, size_t workspace_bytes, void* stream);
+/* Eval mode: mean = running_mean, invstd = 1/sqrt(running_var + eps). */
+int segsde_bn_eval_stats(const float* running_mean, const float* running_var, int C, float eps, float* mean,
+                         float* invstd, void* stream);
+/* y = dropout(act(gamma*(x-mean)*invstd + beta + residual)); dropout keeps with prob 1-p and scales by 1/(1-p)
+ * (nn.Dropout(0.5) in ASPP.project, models/model_parts.py:21-25), mask = hash(seed, element). */
+int segsde_bn_apply(const float* x, int ldx, long M, int C, const float* mean, const float* invstd, const float* gamma,
+                    const float* beta, const float* residual, int ldr, float* y, int ldy, int act, float drop_p,
+                    uint64_t seed, void* stream);
+/* Backward of segsde_bn_apply + batch statistics.  Phase 1 reduces dgamma/dbeta (sums[0..C) = sum dz*xhat,
+ * sums[C..2C) = sum dz) where dz = dy * dropout_mask * act'(y); phase 2 writes dx (and dres = dz if non-null).
+ * batch_stats=0 (eval-mode BN): dx = gamma*invstd*dz. */
+size_t segsde_bn_backward_workspace(long M, int C);
+int segsde_bn_backward(const float* dy, int lddy, const float* y, int ldy, const float* x, int ldx, long M, int C,
+                       const float* mean, const float* invstd, const float* gamma, int act, float drop_p, uint64_t seed,
+                       int batch_stats, float* dgamma, float* dbeta, float* dx, int lddx, float* dres, int lddres,
+                       void* workspace, size_t workspace_bytes, void* stream);
+/* dz = dy * act'(y) (ELU / ReLU / sigmoid via the saved output, as the reference's in-place ops do);
+ * dbias[c] = sum_rows dz (nullable).  Replaces autograd of nn.ELU / nn.ReLU / torch.sigmoid + conv bias grad. */
+size_t segsde_colsum_workspace(long M, int C);
+int segsde_act_backward(const float* dy, int lddy, const float* y, int ldy, long M, int C, int act, float* dz, int lddz,
+                        float* dbias, void* workspace, size_t workspace_bytes, void* stream);
+int segsde_colsum(const float* x, int ldx, long M, int C, float* out, void* workspace, size_t workspace_bytes,
+                  void* stream);
+
+/* nn.MaxPool2d(3, 2, 1) (models/resnet_encoder.py:96); idx keeps the winning tap (first max in scan order). */
+int segsde_maxpool3x3s2_forward(const float* x, int B, int H, int W, int C, float* y, uint8_t* idx, void* stream);
+int segsde_maxpool3x3s2_backward(const float* dy, const uint8_t* idx, int B, int H, int W, int C, float* dx, void* stream);
+/* adjoint of the nearest x2 upsample (models/monodepth_layers.py:202-205): dx[h,w] = sum of the 2x2 block of dy */
+int segsde_upsample2x_backward(const float* dy, int lddy, int B, int h, int w, int C, float* dx, int lddx, void* stream);
+/* F.interpolate(mode="bilinear") and its adjoint, NHWC (joint_segmentation_depth_decoder.py:64-65,72-73,173-180;
+ * torchvision ASPPPooling; loss/loss.py:22-23 with align_corners=1; loss/monodepth_loss.py:72-73 with C=1). */
+int segsde_resize_bilinear_forward(const float* x, int ldx, int B, int Hi, int Wi, int C, float* y, int ldy, int Ho, int Wo,
+                                   int align_corners, void* stream);
+int segsde_resize_bilinear_backward(const float* dy, int lddy, int B, int Hi, int Wi, int C, float* dx, int lddx, int Ho,
+                                    int Wo, int align_corners, void* stream);
+/* nn.AdaptiveAvgPool2d(1) / out.mean(3).mean(2) (pose_decoder.py:49) and adjoint */
+int segsde_global_avgpool_forward(const float* x, int ldx, int B, long HW, int C, float* y, void* stream);
+int segsde_global_avgpool_backward(const float* dy, int B, long HW, int C, float* dx, int lddx, void* stream);
+/* SelfAttention gate y = f * sigmoid(a) (models/model_parts.py:44-46) and adjoint */
+int segsde_gate_forward(const float* f, const float* a, long n, float* y, void* stream);
+int segsde_gate_backward(const float* dy, const float* f, const float* a, long n, float* df, float* da, void* stream);
+/* out = alpha*x + beta*y over n contiguous floats (PAD feature merge :160-161; EMA update train.py:346-358) */
+int segsde_axpby(long n, float alpha, const float* x, float beta, const float* y, float* out, void* stream);
+/* channel-slice copy dst[m, 0..C) = src[m, 0..C) (torch.cat of the ASPP branches, models/model_parts.py:31) */
+int segsde_copy_channels(const float* src, int lds, float* dst, int ldd, long M, int C, void* stream);
+/* NCHW image -> NHWC with the encoder's input normalisation (x - mean) / std (models/resnet_encoder.py:92);
+ * mean = 0, std = 1 gives a plain layout change.  nhwc_to_nchw is the inverse layout change. */
+int segsde_nchw_to_nhwc(const float* x, int B, int C, int H, int W, float mean, float std, float* y, int ldy, void* stream);
+int segsde_nhwc_to_nchw(const float* x, int ldx, int B, int C, int H, int W, float* y, void* stream);
+
+/* ------------------------------------------------------------------------------------------------ *
+ * Pose: axis-angle + translation -> 4x4 (models/monodepth_layers.py:30-105)                         *
+ * ------------------------------------------------------------------------------------------------ */
+int segsde_pose_matrix_forward(const float* axisangle, const float* translation, int B, int stride, int invert, float* M,
+                               void* stream);
+int segsde_pose_matrix_backward(const float* axisangle, const float* translation, const float* dM, int B, int stride,
+                                int invert, float* daxisangle, float* dtranslation, void* stream);
+
+/* ------------------------------------------------------------------------------------------------ *
+ * Monodepth photometric loss (loss/monodepth_loss.py, models/monodepth_layers.py:18-27,145-254)     *
+ * ------------------------------------------------------------------------------------------------ */
+/* generate_images_pred for one (scale, frame): bilinear-upsample disp_s (align_corners=False) -> depth ->
+ * backproject with inv_K -> project with K*T -> grid_sample(src, bilinear, border, align_corners=True).
+ * color: [B,3,H,W]; optional outputs grid [B,H,W,2] (normalised, as outputs[("sample",f,s)]) and depth [B,1,H,W]. */
+int segsde_warp_forward(const float* disp, int hs, int ws, const float* inv_K, const float* K, const float* T,
+                        const float* src, int B, int H, int W, float min_depth, float max_depth, float* color,
+                        float* grid, float* depth, void* stream);
+/* adjoint w.r.t. the upsampled disparity (g_disp_up [B,H,W], accumulated +=) and T (gT [B,4,4], accumulated +=). */
+size_t segsde_warp_backward_workspace(int B, int H, int W);
+int segsde_warp_backward(const float* gcolor, const float* disp, int hs, int ws, const float* inv_K, const float* K,
+                         const float* T, const float* src, int B, int H, int W, float min_depth, float max_depth,
+                         float* g_disp_up, float* gT, void* workspace, size_t workspace_bytes, void* stream);
+/* compute_reprojection_loss: err[b,h,w] = 0.85*mean_c SSIM(pred,target) + 0.15*mean_c|target-pred| (or L1 only).
+ * err / gerr are [B,H,W] planes with `bstride` floats between batches (a channel of a [B,n,H,W] tensor). */
+int segsde_reprojection_error_forward(const float* pred, const float* target, int B, int H, int W, int no_ssim,
+                                      float* err, long err_bstride, void* stream);
+size_t segsde_reprojection_error_backward_workspace(int B, int H, int W);
+int segsde_reprojection_error_backward(const float* pred, const float* target, const float* gerr, long gerr_bstride, int B,
+                                       int H, int W, int no_ssim, float* gpred, void* workspace, size_t workspace_bytes,
+                                       void* stream);
+/* per-pixel min over [identity(+1e-5*noise) | reprojection] channels (monodepth_loss.py:147-177).
+ * ident/noise may be NULL (disable_automasking); avg=1 averages the two channels of each group first.
+ * Outputs: sel [B,H,W] uint8 = argmin index in the combined order, identity_selection [B,H,W] float (nullable),
+ * sum_out[0] = sum of the minima (the caller divides by B*H*W). */
+size_t segsde_automask_workspace(int B, int H, int W);
+int segsde_automask_min_forward(const float* ident, const float* noise, const float* reproj, int n_reproj, int avg, int B,
+                                int H, int W, uint8_t* sel, float* identity_selection, float* sum_out, void* workspace,
+                                size_t workspace_bytes, void* stream);
+int segsde_automask_min_backward(const uint8_t* sel, int n_ident, int n_reproj, int avg, int B, int H, int W, float scale,
+                                 float* greproj, void* stream);
+/* edge-aware smoothness of the mean-normalised disparity (monodepth_loss.py:182-186, monodepth_layers.py:208-221):
+ * out[0] = mean|dx d^|e^{-|dx I|} + mean|dy d^|e^{-|dy I|};  mean_disp [B] is kept for the backward. */
+size_t segsde_smoothness_workspace(int B, int h, int w);
+int segsde_smoothness_forward(const float* disp, const float* img, int B, int h, int w, float* mean_disp, float* out,
+                              void* workspace, size_t workspace_bytes, void* stream);
+int segsde_smoothness_backward(const float* disp, const float* img, const float* mean_disp, int B, int h, int w,
+                               float scale, float* gdisp, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------ *
+ * Segmentation loss and DepthMix / ClassMix (loss/loss.py:17-37, loader/transformsgpu.py:33-47,     *
+ * loader/transformmasks.py:27-41, train.py:585-604)                                                 *
+ * ------------------------------------------------------------------------------------------------ */
+/* F.cross_entropy over NHWC logits (pitch ld) with ignore_index; out[0] = sum_i w_i*nll_i, out[1] = sum_i w_i over
+ * non-ignored pixels (w_i = class_weight[t_i] or 1; times pixel_weights[i] if given). */
+size_t segsde_cross_entropy_workspace(long M);
+int segsde_cross_entropy_forward(const float* logits, int ld, long M, int C, const int64_t* target, int64_t ignore_index,
+                                 const float* class_weight, const float* pixel_weights, float* out, void* workspace,
+                                 size_t workspace_bytes, void* stream);
+/* dlogits[i,c] = scale * w_i * (softmax_c - [c == t_i]) (0 for ignored pixels) */
+int segsde_cross_entropy_backward(const float* logits, int ld, long M, int C, const int64_t* target, int64_t ignore_index,
+                                  const float* class_weight, const float* pixel_weights, const float* scale,
+                                  float* dlogits, int lddl, void* stream);
+/* out_i = m_i*x_i + (1-m_i)*x_{(i+1)%B}; mask is int64 or float32 [Bm,H,W] (Bm = B, or B/2: paired-halves branch);
+ * element strides let x be NCHW or channels-last.  Bit-exact with the reference's fp32 op sequence. */
+int segsde_mix(const void* mask, int mask_is_int64, int Bm, const float* x, int B, int C, int H, int W, long sb, long sc,
+               long sh, long sw, float* out, void* stream);
+int segsde_mix_labels(const int64_t* mask, const int64_t* target, int B, int H, int W, int64_t* out, void* stream);
+/* depthcomp: m_i = (d_i >= d_{(i+1)%B} - margin) * (d_i >= ft) -> int64 [B,H,W] (train.py:585-604, generalised partner) */
+int segsde_depthcomp_mask(const float* depths, int B, long HW, float margin, float fg_threshold, int64_t* mask, void* stream);
+/* generate_depth_mask: depth >= thr (one threshold), or (depth >= min(t)) <= max(t) as the reference writes it */
+int segsde_depth_threshold_mask(const float* depth, long n, float t1, float t2, int two_thresholds, float* mask, void* stream);
+/* generate_class_mask: N[h,w] = #{k : pred[h,w] == classes[k]} */
+int segsde_class_mask(const int64_t* pred, long n, const int64_t* classes, int n_classes, int64_t* mask, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SEGSDE_HIP_H */

@@ -1,0 +1,190 @@
+// TEST INFRASTRUCTURE ONLY -- a tiny single-threaded *interpreter* for HIP kernels.
+//
+// The build container has no GPU.  To check index math, LDS staging, barriers
+// and MFMA/shuffle lane layouts of the real kernel sources (csrc/*.hip) BEFORE
+// spending GPU minutes, tests compile those same sources for the host with
+// `clang++ -x c++ -I tests/hipemu` so that `#include <hip/hip_runtime.h>`
+// resolves to this file.  Every HIP thread of a block becomes a ucontext fiber;
+// __syncthreads / wave shuffles / MFMA are rendezvous points between fibers.
+// Nothing here is part of the product: the shipped library is built by hipcc
+// from the unmodified sources, and the package never loads the emulated .so
+// (tests inject it explicitly).
+#pragma once
+#include <ucontext.h>
+#include <sys/mman.h>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <vector>
+#include <algorithm>
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#define __shared__
+#define __launch_bounds__(...)
+#define __restrict__
+#define warpSize 64
+using std::min;
+using std::max;
+
+typedef int hipError_t;
+typedef void* hipStream_t;
+static const int hipSuccess = 0;
+static const int hipErrorInvalidValue = 1;
+enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+inline hipError_t hipGetLastError() { return 0; }
+inline const char* hipGetErrorString(hipError_t) { return "emu"; }
+inline hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return 0; }
+inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return 0; }
+enum hipMemcpyKind { hipMemcpyDeviceToDevice = 3 };
+inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memmove(d, s, n); return 0; }
+
+struct dim3 { unsigned x, y, z; dim3(unsigned a = 1, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {} };
+struct float2 { float x, y; };
+struct alignas(16) float4 { float x, y, z, w; };
+struct int2 { int x, y; };
+struct alignas(16) int4 { int x, y, z, w; };
+inline float4 make_float4(float a, float b, float c, float d) { return float4{a, b, c, d}; }
+inline float2 make_float2(float a, float b) { return float2{a, b}; }
+
+namespace emu {
+struct Barrier { int count = 0; unsigned gen = 0; int expected = 0; };
+struct Fiber {
+  ucontext_t ctx; void* stack = nullptr; bool done = false; dim3 tid; int lin = 0;
+  Barrier* wait = nullptr; unsigned wait_gen = 0;
+};
+struct State {
+  ucontext_t sched; std::vector<Fiber> fibers; Fiber* cur = nullptr; dim3 bid, bdim, gdim;
+  Barrier block_bar; std::vector<Barrier> wave_bar; std::function<void()> body;
+  // rendezvous scratch per wave
+  std::vector<float> xa, xb; std::vector<double> xd; std::vector<long long> xi;
+};
+inline State& S() { static State s; return s; }
+static const size_t STACK = 256 * 1024;
+inline void yield() { State& s = S(); swapcontext(&s.cur->ctx, &s.sched); }
+inline void barrier_wait(Barrier* b) {
+  State& s = S(); Fiber* f = s.cur; unsigned g = b->gen;
+  if (++b->count == b->expected) { b->count = 0; b->gen++; return; }
+  f->wait = b; f->wait_gen = g;
+  while (b->gen == g) yield();
+  f->wait = nullptr;
+}
+inline void trampoline() { State& s = S(); s.body(); s.cur->done = true; swapcontext(&s.cur->ctx, &s.sched); }
+inline void run_block(int nthreads) {
+  State& s = S();
+  if ((int)s.fibers.size() < nthreads) {
+    size_t old = s.fibers.size(); s.fibers.resize(nthreads);
+    for (size_t i = old; i < s.fibers.size(); ++i)
+      s.fibers[i].stack = mmap(nullptr, STACK, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+  }
+  int nw = (nthreads + 63) / 64;
+  s.wave_bar.assign(nw, Barrier());
+  for (int w = 0; w < nw; ++w) s.wave_bar[w].expected = std::min(64, nthreads - 64 * w);
+  s.block_bar = Barrier(); s.block_bar.expected = nthreads;
+  s.xa.assign(nw * 64, 0.f); s.xb.assign(nw * 64, 0.f); s.xd.assign(nw * 64, 0.0); s.xi.assign(nw * 64, 0);
+  for (int i = 0; i < nthreads; ++i) {
+    Fiber& f = s.fibers[i]; f.done = false; f.wait = nullptr; f.lin = i;
+    f.tid = dim3(i % s.bdim.x, (i / s.bdim.x) % s.bdim.y, i / (s.bdim.x * s.bdim.y));
+    getcontext(&f.ctx); f.ctx.uc_stack.ss_sp = f.stack; f.ctx.uc_stack.ss_size = STACK; f.ctx.uc_link = nullptr;
+    makecontext(&f.ctx, (void (*)())trampoline, 0);
+  }
+  int alive = nthreads; long idle_rounds = 0;
+  while (alive > 0) {
+    bool progressed = false;
+    for (int i = 0; i < nthreads; ++i) {
+      Fiber& f = s.fibers[i];
+      if (f.done) continue;
+      if (f.wait && f.wait->gen == f.wait_gen) continue;  // still blocked
+      s.cur = &f; swapcontext(&s.sched, &f.ctx); progressed = true;
+      if (f.done) --alive;
+    }
+    if (!progressed && ++idle_rounds > 4) { fprintf(stderr, "hipemu: deadlock (divergent barrier?)\n"); abort(); }
+    if (progressed) idle_rounds = 0;
+  }
+}
+template <class K, class... A>
+inline void launch(K kernel, dim3 grid, dim3 block, size_t smem, hipStream_t, A... args) {
+  State& s = S(); s.gdim = grid; s.bdim = block;
+  if (smem > 160 * 1024) { fprintf(stderr, "hipemu: %zu B of LDS requested\n", smem); abort(); }
+  int nthreads = block.x * block.y * block.z;
+  s.body = [=]() { kernel(args...); };
+  for (unsigned z = 0; z < grid.z; ++z) for (unsigned y = 0; y < grid.y; ++y) for (unsigned x = 0; x < grid.x; ++x) {
+    s.bid = dim3(x, y, z); run_block(nthreads);
+  }
+}
+inline int lane() { return S().cur->lin & 63; }
+inline int wave() { return S().cur->lin >> 6; }
+inline Barrier* wbar() { return &S().wave_bar[wave()]; }
+template <class T> inline std::vector<T>& scratch();
+template <> inline std::vector<float>& scratch<float>() { return S().xa; }
+template <> inline std::vector<double>& scratch<double>() { return S().xd; }
+template <> inline std::vector<long long>& scratch<long long>() { return S().xi; }
+template <class T, class U> inline T shfl_idx(T v, U srcf) {
+  auto& x = scratch<T>(); int base = wave() * 64; x[base + lane()] = v;
+  barrier_wait(wbar()); int src = srcf(lane());
+  T r = (src >= 0 && src < S().wave_bar[wave()].expected) ? x[base + src] : v;
+  barrier_wait(wbar()); return r;
+}
+}  // namespace emu
+
+#define threadIdx (emu::S().cur->tid)
+#define blockIdx (emu::S().bid)
+#define blockDim (emu::S().bdim)
+#define gridDim (emu::S().gdim)
+#define hipLaunchKernelGGL(kernel, grid, block, smem, stream, ...) emu::launch(kernel, dim3(grid), dim3(block), smem, stream, ##__VA_ARGS__)
+
+alignas(16) inline unsigned char emu_lds[160 * 1024];
+#define SEGSDE_SMEM unsigned char* const segsde_smem = ::emu_lds
+
+inline void __syncthreads() { emu::barrier_wait(&emu::S().block_bar); }
+inline float __shfl_xor(float v, int m, int = 64) { return emu::shfl_idx<float>(v, [m](int l) { return l ^ m; }); }
+inline float __shfl_down(float v, int d, int = 64) { return emu::shfl_idx<float>(v, [d](int l) { return l + d; }); }
+inline float __shfl(float v, int s, int = 64) { return emu::shfl_idx<float>(v, [s](int) { return s; }); }
+inline double __shfl_xor(double v, int m, int = 64) { return emu::shfl_idx<double>(v, [m](int l) { return l ^ m; }); }
+inline double __shfl_down(double v, int d, int = 64) { return emu::shfl_idx<double>(v, [d](int l) { return l + d; }); }
+inline int __shfl_xor(int v, int m, int = 64) { return (int)emu::shfl_idx<long long>(v, [m](int l) { return l ^ m; }); }
+inline int __shfl_down(int v, int d, int = 64) { return (int)emu::shfl_idx<long long>(v, [d](int l) { return l + d; }); }
+inline float atomicAdd(float* p, float v) { float o = *p; *p = o + v; return o; }
+inline double atomicAdd(double* p, double v) { double o = *p; *p = o + v; return o; }
+inline int atomicAdd(int* p, int v) { int o = *p; *p = o + v; return o; }
+inline unsigned atomicAdd(unsigned* p, unsigned v) { unsigned o = *p; *p = o + v; return o; }
+inline float __expf(float x) { return expf(x); }
+inline float __frcp_rn(float x) { return 1.0f / x; }
+inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
+inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
+
+typedef float emu_f32x16 __attribute__((ext_vector_type(16)));
+typedef float emu_f32x4 __attribute__((ext_vector_type(4)));
+// v_mfma_f32_32x32x2_f32: lane l supplies A[i=l&31][k=l>>5], B[k=l>>5][j=l&31];
+// D reg r of lane l is row (r&3)+8*(r>>2)+4*(l>>5), col l&31 (cdna_hip_programming.md section 3).
+inline emu_f32x16 emu_mfma_32x32x2(float a, float b, emu_f32x16 c, int, int, int) {
+  using namespace emu; State& s = S(); int base = wave() * 64, l = lane();
+  s.xa[base + l] = a; s.xb[base + l] = b; barrier_wait(wbar());
+  emu_f32x16 d = c; int col = l & 31;
+  for (int r = 0; r < 16; ++r) {
+    int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+    float acc = c[r];
+    for (int k = 0; k < 2; ++k) acc = fmaf(s.xa[base + row + 32 * k], s.xb[base + col + 32 * k], acc);
+    d[r] = acc;
+  }
+  barrier_wait(wbar()); return d;
+}
+// v_mfma_f32_16x16x4_f32: A[i=l&15][k=l>>4], B[k=l>>4][j=l&15]; D reg r: row 4*(l>>4)+r, col l&15.
+inline emu_f32x4 emu_mfma_16x16x4(float a, float b, emu_f32x4 c, int, int, int) {
+  using namespace emu; State& s = S(); int base = wave() * 64, l = lane();
+  s.xa[base + l] = a; s.xb[base + l] = b; barrier_wait(wbar());
+  emu_f32x4 d = c; int col = l & 15;
+  for (int r = 0; r < 4; ++r) {
+    int row = 4 * (l >> 4) + r; float acc = c[r];
+    for (int k = 0; k < 4; ++k) acc = fmaf(s.xa[base + row + 16 * k], s.xb[base + col + 16 * k], acc);
+    d[r] = acc;
+  }
+  barrier_wait(wbar()); return d;
+}
+#define __builtin_amdgcn_mfma_f32_32x32x2f32 emu_mfma_32x32x2
+#define __builtin_amdgcn_mfma_f32_16x16x4f32 emu_mfma_16x16x4
