@@ -98,3 +98,286 @@ def run_conv_case(case, device, seed=0):
         bb = b.clone().requires_grad_(True)
         conv_reference(case, x0, x1, w, bb).backward(gy)
         assert_close(dbias, bb.grad, rtol=2e-3, what=name + " dbias")
+
+
+# ---------------------------------------------------------------------------------------------
+# BatchNorm / activation / pooling / resize
+# ---------------------------------------------------------------------------------------------
+def run_bn_case(device, C=24, act="relu", residual=True, train=True, drop_p=0.0, seed=0):
+    gen = torch.Generator().manual_seed(seed)
+    B, Hh, W = 3, 5, 7
+    x = torch.randn(B, C, Hh, W, generator=gen) * 2 + 0.5
+    res = torch.randn(B, C, Hh, W, generator=gen) if residual else None
+    gamma = torch.rand(C, generator=gen) + 0.5
+    beta = torch.randn(C, generator=gen)
+    rm, rv = torch.randn(C, generator=gen) * 0.1, torch.rand(C, generator=gen) + 0.5
+    xr = x.clone().requires_grad_(True)
+    rr = res.clone().requires_grad_(True) if residual else None
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    y = F.batch_norm(xr, rm_ref, rv_ref, gr, br, training=train, momentum=0.1, eps=1e-5)
+    if residual:
+        y = y + rr
+    y = {"none": lambda t: t, "relu": F.relu, "elu": F.elu}[act](y)
+    gy = torch.randn(y.shape, generator=gen)
+    y.backward(gy)
+
+    d = lambda t: None if t is None else t.to(device)
+    xn, rn = d(nhwc(x)), d(nhwc(res)) if residual else None
+    rm_d, rv_d = d(rm.clone()), d(rv.clone())
+    if train:
+        mean, invstd = H.bn_stats(xn, rm_d, rv_d, 0.1, 1e-5)
+        assert_close(rm_d, rm_ref, what="running_mean")
+        assert_close(rv_d, rv_ref, what="running_var")
+    else:
+        mean, invstd = H.bn_eval_stats(rm_d, rv_d, 1e-5)
+    out = H.bn_apply(xn, mean, invstd, d(gamma), d(beta), rn, act)
+    assert_close(nchw(out), y, what="bn fwd")
+    dx, dres, dgamma, dbeta = H.bn_backward(d(nhwc(gy)), out, xn, mean, invstd, d(gamma), act, batch_stats=train,
+                                            need_dres=residual)
+    assert_close(nchw(dx), xr.grad, what="bn dx", rtol=2e-3, atol=2e-5)
+    assert_close(dgamma, gr.grad, rtol=2e-3, what="bn dgamma")
+    assert_close(dbeta, br.grad, rtol=2e-3, what="bn dbeta")
+    if residual:
+        assert_close(nchw(dres), rr.grad, what="bn dres")
+
+
+def run_dropout_case(device):
+    """dropout inside bn_apply: keep fraction, scaling, and backward consistency with the regenerated mask"""
+    gen = torch.Generator().manual_seed(3)
+    x = torch.randn(4, 16, 16, 32, generator=gen).to(device)
+    mean, invstd = torch.zeros(32).to(device), torch.ones(32).to(device)
+    y0 = H.bn_apply(x, mean, invstd, None, None, None, "relu", 0.0)
+    y = H.bn_apply(x, mean, invstd, None, None, None, "relu", 0.5, seed=1234)
+    kept = (y != 0) | (y0 == 0)
+    frac = float(((y != 0) & (y0 != 0)).sum()) / float((y0 != 0).sum())
+    assert 0.45 < frac < 0.55, frac
+    assert_close(y[kept], (2.0 * y0)[kept], what="dropout scale")
+    gy = torch.ones_like(y)
+    dx, _, _, _ = H.bn_backward(gy, y, x, mean, invstd, None, "relu", 0.5, seed=1234, batch_stats=False)
+    assert_close(dx, 2.0 * (y != 0).float(), what="dropout bwd")
+    y2 = H.bn_apply(x, mean, invstd, None, None, None, "relu", 0.5, seed=99)
+    assert not torch.equal(y, y2)
+
+
+def run_misc_cases(device):
+    gen = torch.Generator().manual_seed(5)
+    d = lambda t: t.to(device)
+    # max pool (ties: post-ReLU zeros)
+    x = F.relu(torch.randn(2, 12, 9, 11, generator=gen)).requires_grad_(True)
+    y = F.max_pool2d(x, 3, 2, 1)
+    gy = torch.randn(y.shape, generator=gen)
+    y.backward(gy)
+    yo, idx = H.maxpool_forward(d(nhwc(x.detach())))
+    assert torch.equal(nchw(yo).cpu(), y.detach())
+    dx = H.maxpool_backward(d(nhwc(gy)), idx, (2, 9, 11, 12))
+    assert_close(nchw(dx), x.grad, what="maxpool bwd")
+    # bilinear resize, both conventions, up and down, and 1x1 -> HxW (ASPP pooling)
+    for (hi, wi, ho, wo, ac) in [(5, 7, 10, 14, False), (5, 7, 11, 13, True), (8, 12, 4, 6, False), (1, 1, 6, 9, False),
+                                 (4, 8, 32, 64, False), (6, 6, 6, 6, False)]:
+        x = torch.randn(2, 5, hi, wi, generator=gen).requires_grad_(True)
+        y = F.interpolate(x, size=(ho, wo), mode="bilinear", align_corners=ac)
+        gy = torch.randn(y.shape, generator=gen)
+        y.backward(gy)
+        yo = H.resize_bilinear(d(nhwc(x.detach())), (ho, wo), ac)
+        assert_close(nchw(yo), y, what="resize fwd %s" % ((hi, wi, ho, wo, ac),))
+        dx = H.resize_bilinear_backward(d(nhwc(gy)), (hi, wi), ac)
+        assert_close(nchw(dx), x.grad, what="resize bwd %s" % ((hi, wi, ho, wo, ac),))
+    # global average pool
+    x = torch.randn(3, 70, 5, 6, generator=gen).requires_grad_(True)
+    y = x.mean((2, 3), keepdim=True)
+    gy = torch.randn(y.shape, generator=gen)
+    y.backward(gy)
+    yo = H.global_avgpool(d(nhwc(x.detach())))
+    assert_close(nchw(yo), y, what="gap fwd")
+    assert_close(nchw(H.global_avgpool_backward(d(nhwc(gy)), (3, 5, 6, 70))), x.grad, what="gap bwd")
+    # gate
+    f = torch.randn(2, 4, 5, 8, generator=gen).requires_grad_(True)
+    a = torch.randn(2, 4, 5, 8, generator=gen).requires_grad_(True)
+    y = f * torch.sigmoid(a)
+    gy = torch.randn(y.shape, generator=gen)
+    y.backward(gy)
+    assert_close(H.gate_forward(d(f.detach()), d(a.detach())), y, what="gate fwd")
+    df, da = H.gate_backward(d(gy), d(f.detach()), d(a.detach()))
+    assert_close(df, f.grad, what="gate df")
+    assert_close(da, a.grad, what="gate da")
+    # axpby / copy_channels / layout edges / upsample adjoint
+    x, y = torch.randn(1000, generator=gen), torch.randn(1000, generator=gen)
+    assert_close(H.axpby(0.99, d(x), 0.01, d(y)), 0.99 * x + 0.01 * y, what="axpby")
+    buf = torch.zeros(2, 3, 4, 20).to(device)
+    src = torch.randn(2, 3, 4, 8, generator=gen)
+    H.copy_channels(d(src), buf[..., 4:12])
+    assert torch.equal(buf[..., 4:12].cpu(), src) and float(buf[..., :4].abs().sum()) == 0
+    img = torch.rand(2, 3, 6, 10, generator=gen)
+    assert_close(nchw(H.nchw_to_nhwc(d(img), 0.45, 0.225)), (img - 0.45) / 0.225, rtol=1e-6, atol=1e-6, what="img norm")
+    t = torch.randn(2, 6, 10, 7, generator=gen)
+    assert torch.equal(H.nhwc_to_nchw(d(t)).cpu(), nchw(t))
+    assert torch.equal(H.nchw_to_nhwc(d(nchw(t))).cpu(), t)
+    # colsum with a pitch
+    wide = torch.randn(50, 40, generator=gen).to(device)
+    assert_close(H.colsum(wide[:, 8:24]), wide[:, 8:24].cpu().sum(0), what="colsum")
+
+
+# ---------------------------------------------------------------------------------------------
+# pose
+# ---------------------------------------------------------------------------------------------
+def run_pose_case(device, golden):
+    g = golden("geom")
+    from oracle import geometry as G
+    for inv, tag in ((False, "fwd"), (True, "inv")):
+        aa4 = torch.zeros(3, 2, 1, 3)
+        tr4 = torch.zeros(3, 2, 1, 3)
+        aa4[:, 0] = g["axisangle"]
+        tr4[:, 0] = g["translation"]
+        aa4[:, 1] = 7.0  # frame 1 must be ignored
+        M = H.pose_matrix(aa4.to(device), tr4.to(device), inv)
+        assert_close(M, g["M_" + tag], rtol=1e-5, atol=1e-6, what="pose M")
+        daa, dtr = H.pose_matrix_backward(aa4.to(device), tr4.to(device), g["M_weight"].to(device), inv)
+        assert_close(daa[:, 0], g["grad_aa_" + tag], rtol=1e-4, atol=1e-6, what="pose daa")
+        assert_close(dtr[:, 0], g["grad_tr_" + tag], rtol=1e-4, atol=1e-6, what="pose dtr")
+        assert float(daa[:, 1].abs().sum()) == 0
+    M0 = H.pose_matrix(torch.zeros(1, 2, 1, 3).to(device), torch.ones(1, 2, 1, 3).to(device), False)
+    assert_close(M0, g["M_zero"], what="pose zero angle")
+    daa, _ = H.pose_matrix_backward(torch.zeros(1, 2, 1, 3).to(device), torch.ones(1, 2, 1, 3).to(device),
+                                    torch.ones(1, 4, 4).to(device), False)
+    assert bool(torch.isfinite(daa).all())
+
+
+# ---------------------------------------------------------------------------------------------
+# segmentation loss / mix / masks  (bit-exact where the reference is integer / mask arithmetic)
+# ---------------------------------------------------------------------------------------------
+def run_segmix_cases(device, golden):
+    g = golden("segmix")
+    d = lambda t: t.to(device)
+    logits = d(nhwc(g["ce_logits"]))
+    tgt = d(g["ce_target"])
+    M = tgt.numel()
+    out = H.cross_entropy_forward(logits, tgt, 250)
+    assert_close(out[0] / out[1], g["ce_loss"], rtol=1e-5, what="ce loss")
+    scale = (1.0 / out[1]).reshape(1)
+    dl = H.cross_entropy_backward(logits, tgt, 250, scale)
+    assert_close(nchw(dl), g["ce_grad"], rtol=1e-4, atol=1e-7, what="ce grad")
+    pw = d(g["ce_pw"].contiguous())
+    out = H.cross_entropy_forward(logits, tgt, 250, pixel_weights=pw)
+    assert_close(out[0] / M, g["ce_loss_pw"], rtol=1e-5, what="ce pw loss")
+    dl = H.cross_entropy_backward(logits, tgt, 250, torch.full((1,), 1.0 / M).to(device), pixel_weights=pw)
+    assert_close(nchw(dl), g["ce_grad_pw"], rtol=1e-4, atol=1e-7, what="ce pw grad")
+    # logits as a padded-pitch slice
+    wide = torch.zeros(logits.shape[:3] + (24,)).to(device)
+    wide[..., :19] = logits
+    out2 = H.cross_entropy_forward(wide[..., :19], tgt, 250)
+    assert torch.equal(out2.cpu(), H.cross_entropy_forward(logits, tgt, 250).cpu())
+    # all-ignored -> 0/0 = nan like the reference
+    oi = H.cross_entropy_forward(logits, torch.full_like(tgt, 250), 250)
+    assert float(oi[1]) == 0.0 and bool(torch.isnan(g["ce_loss_allignored"]))
+    # mix (bit exact): NCHW and channels-last inputs, int64 / float masks, half-batch branch, labels
+    for mk, xk, ok in (("mix_mask_f", "mix_img", "mix_img_f"), ("mix_mask_i", "mix_img", "mix_img_i"),
+                       ("mix_mask_i", "mix_soft", "mix_soft_i"), ("mix_mask_half", "mix_img", "mix_img_half")):
+        assert torch.equal(H.mix(d(g[mk]), d(g[xk])).cpu(), g[ok]), ok
+        cl = d(g[xk]).contiguous(memory_format=torch.channels_last)
+        o = H.mix(d(g[mk]), cl)
+        assert o.stride() == cl.stride() and torch.equal(o.cpu(), g[ok]), ok + " channels_last"
+    assert torch.equal(H.mix_labels(d(g["mix_mask_i"]), d(g["mix_lbl"])).cpu(), g["mix_target_i"])
+    # masks (bit exact)
+    m = H.depthcomp_mask(d(g["dc_depths"]), 0.03, 0.0)
+    assert m.dtype == torch.int64 and torch.equal(m.cpu(), g["dc_mask_m003_ft0"])
+    assert torch.equal(H.depthcomp_mask(d(g["dc_depths"]), 0.03, 0.25).cpu(), g["dc_mask_m003_ft025"])
+    assert torch.equal(H.depth_threshold_mask(d(g["dm_depth"]), float(g["dm_thr1"][0])).cpu(), g["dm_mask1"])
+    t2 = g["dm_thr2"]
+    assert torch.equal(H.depth_threshold_mask(d(g["dm_depth"]), float(t2.min()), float(t2.max()), True).cpu(), g["dm_mask2"])
+    assert torch.equal(H.class_mask(d(g["cm_pred"]), d(g["cm_classes"])).cpu(), g["cm_mask"])
+
+
+# ---------------------------------------------------------------------------------------------
+# loss kernels one by one against torch autograd / the golden vectors
+# ---------------------------------------------------------------------------------------------
+def run_loss_kernel_cases(device, golden):
+    from oracle import photometric as P, geometry as G
+    d = lambda t: t.to(device)
+    g = golden("ssim_smooth")
+    # reprojection error fwd / bwd (SSIM + L1)
+    for no_ssim in (False, True):
+        x = g["x"].clone().requires_grad_(True)
+        err = P.reprojection_error(x, g["y"], no_ssim)
+        gen = torch.Generator().manual_seed(1)
+        ge = torch.randn(err.shape, generator=gen)
+        err.backward(ge)
+        B, _, Hh, W = g["x"].shape
+        buf = torch.zeros(B, 2, Hh, W).to(device)
+        H.reprojection_error(d(g["x"]), d(g["y"]), no_ssim, buf[:, 1])
+        assert_close(buf[:, 1:2], err, rtol=1e-4, atol=1e-6, what="reproj err")
+        assert float(buf[:, 0].abs().sum()) == 0
+        gbuf = torch.zeros(B, 2, Hh, W)
+        gbuf[:, 1] = ge[:, 0]
+        gp = H.reprojection_error_backward(d(g["x"]), d(g["y"]), d(gbuf)[:, 1], no_ssim)
+        assert_close(gp, x.grad, rtol=2e-3, atol=2e-5, what="reproj err bwd no_ssim=%s" % no_ssim)
+    # clamp branch (near-identical images)
+    B, _, Hh, W = g["x"].shape
+    e2 = torch.zeros(B, 1, Hh, W).to(device)
+    H.reprojection_error(d(g["x"]), d(g["y2"]), False, e2[:, 0])
+    assert_close(e2, P.reprojection_error(g["x"], g["y2"]), rtol=1e-4, atol=1e-6, what="reproj err clamp")
+    # smoothness
+    disp = g["sm_disp"].clone().requires_grad_(True)
+    mean_disp = disp.mean(2, True).mean(3, True)
+    sm = P.edge_aware_smoothness(disp / (mean_disp + 1e-7), g["sm_img"])
+    sm.backward()
+    out, mean = H.smoothness_forward(d(g["sm_disp"]), d(g["sm_img"]))
+    assert_close(out, sm.reshape(1), rtol=1e-4, what="smooth fwd")
+    gd = torch.zeros_like(g["sm_disp"]).to(device)
+    H.smoothness_backward(d(g["sm_disp"]), d(g["sm_img"]), mean, 1.0, gd)
+    assert_close(gd, disp.grad, rtol=2e-3, atol=1e-6, what="smooth bwd")
+    # warp fwd / bwd at two scales against the reference's own vectors + torch autograd of the oracle
+    gl = golden("loss_default")
+    inv_K, K = gl["in_inv_K_0"], gl["in_K_0"]
+    for s in (0, 2):
+        for f, tag in ((-1, "m1"), (1, "p1")):
+            src = gl["in_color_%d_0" % f]
+            color, grid, depth = H.warp_forward(d(gl["disp_%d" % s]), d(inv_K), d(K), d(gl["T_" + tag]), d(src), 0.1, 100,
+                                                True, True)
+            assert_close(depth, gl["depth_%d" % s], rtol=1e-5, what="depth")
+            assert_close(grid, gl["sample_%s_%d" % (tag, s)], rtol=1e-4, atol=1e-5, what="grid")
+            assert_close(color, gl["color_%s_%d" % (tag, s)], rtol=1e-3, atol=1e-4, what="warped color")
+            # backward vs autograd through the oracle
+            disp = gl["disp_%d" % s].clone().requires_grad_(True)
+            T = gl["T_" + tag].clone().requires_grad_(True)
+            Bq, _, Hh, W = src.shape
+            up = F.interpolate(disp, [Hh, W], mode="bilinear", align_corners=False)
+            up.retain_grad()
+            dep = G.disp_to_depth(up, 0.1, 100)[1]
+            col = G.warp(src, G.project(G.backproject(dep, inv_K), K, T, Hh, W))
+            gen = torch.Generator().manual_seed(2)
+            gc = torch.randn(col.shape, generator=gen)
+            col.backward(gc)
+            gup = torch.zeros(Bq, Hh, W).to(device)
+            gT = torch.zeros(Bq, 4, 4).to(device)
+            H.warp_backward(d(gc), d(gl["disp_%d" % s]), d(inv_K), d(K), d(gl["T_" + tag]), d(src), 0.1, 100, gup, gT)
+            assert_close(gup, up.grad[:, 0], rtol=5e-3, atol=1e-5, what="warp bwd disp s=%d" % s)
+            assert_close(gT, T.grad, rtol=5e-3, atol=1e-5, what="warp bwd T")
+    # automask min fwd / bwd
+    gen = torch.Generator().manual_seed(4)
+    ident, reproj = torch.rand(2, 2, 6, 9, generator=gen), torch.rand(2, 2, 6, 9, generator=gen)
+    noise = torch.randn(2, 2, 6, 9, generator=gen)
+    for avg in (False, True):
+        for use_ident in (True, False):
+            i_, r_ = ident, reproj
+            nz = noise[:, :1].contiguous() if avg else noise
+            if avg:
+                i_c, r_c = ident.mean(1, keepdim=True), reproj.mean(1, keepdim=True)
+            else:
+                i_c, r_c = ident, reproj
+            comb = torch.cat([i_c + nz * 0.00001, r_c], 1) if use_ident else r_c
+            if comb.shape[1] == 1:
+                mn, ix = comb[:, 0], torch.zeros_like(comb[:, 0], dtype=torch.long)
+            else:
+                mn, ix = torch.min(comb, 1)
+            out, sel, isel = H.automask_min(d(i_) if use_ident else None, d(nz) if use_ident else None, d(r_), avg)
+            assert_close(out, mn.sum().reshape(1), rtol=1e-5, what="automask sum")
+            assert torch.equal(sel.cpu().long(), ix)
+            if use_ident:
+                assert torch.equal(isel.cpu(), (ix > i_c.shape[1] - 1).float())
+            gr = H.automask_min_backward(sel, use_ident, 2, avg, 0.25)
+            r2 = reproj.clone().requires_grad_(True)
+            r2c = r2.mean(1, keepdim=True) if avg else r2
+            comb2 = torch.cat([(i_c + nz * 0.00001), r2c], 1) if use_ident else r2c
+            (comb2.min(1)[0].sum() * 0.25 if comb2.shape[1] > 1 else comb2.sum() * 0.25).backward()
+            assert_close(gr, r2.grad, what="automask bwd")

@@ -16,3 +16,31 @@ def _emu():
 @pytest.mark.parametrize("case", KC.CONV_CASES, ids=[c[0] for c in KC.CONV_CASES])
 def test_conv(case):
     KC.run_conv_case(case, "cpu")
+
+
+@pytest.mark.parametrize("cfg", [dict(C=24, act="relu", residual=True, train=True),
+                                 dict(C=70, act="none", residual=False, train=True),
+                                 dict(C=8, act="elu", residual=False, train=True),
+                                 dict(C=16, act="relu", residual=True, train=False)])
+def test_batchnorm(cfg):
+    KC.run_bn_case("cpu", **cfg)
+
+
+def test_dropout():
+    KC.run_dropout_case("cpu")
+
+
+def test_misc_kernels():
+    KC.run_misc_cases("cpu")
+
+
+def test_pose(golden):
+    KC.run_pose_case("cpu", golden)
+
+
+def test_segmix(golden):
+    KC.run_segmix_cases("cpu", golden)
+
+
+def test_loss_kernels(golden):
+    KC.run_loss_kernel_cases("cpu", golden)
