@@ -52,6 +52,7 @@ _SIGS = {
     "segsde_gate_forward": (c_int, [P, P, c_long, P, P]),
     "segsde_gate_backward": (c_int, [P, P, P, c_long, P, P, P]),
     "segsde_axpby": (c_int, [c_long, c_float, P, c_float, P, P, P]),
+    "segsde_axpby_dev": (c_int, [c_long, P, P, P, P, P, P]),
     "segsde_copy_channels": (c_int, [P, c_int, P, c_int, c_long, c_int, P]),
     "segsde_nchw_to_nhwc": (c_int, [P, c_int, c_int, c_int, c_int, c_float, c_float, P, c_int, P]),
     "segsde_nhwc_to_nchw": (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, P]),

@@ -375,6 +375,12 @@ __global__ __launch_bounds__(256) void axpby_kernel(long n, float alpha, const f
   for (long e = blockIdx.x * 256L + threadIdx.x; e < n; e += (long)gridDim.x * 256)
     out[e] = alpha * x[e] + (y ? beta * y[e] : 0.f);
 }
+__global__ __launch_bounds__(256) void axpby_dev_kernel(long n, const float* alpha, const float* x, const float* beta,
+                                                        const float* y, float* out) {
+  const float a = alpha[0], b = y ? beta[0] : 0.f;
+  for (long e = blockIdx.x * 256L + threadIdx.x; e < n; e += (long)gridDim.x * 256)
+    out[e] = a * x[e] + (y ? b * y[e] : 0.f);
+}
 template <int VW>
 __global__ __launch_bounds__(256) void copy_channels_kernel(const float* src, int lds, float* dst, int ldd, long M, int C) {
   const int CV = C / VW;
@@ -568,6 +574,13 @@ extern "C" int segsde_gate_backward(const float* dy, const float* f, const float
 extern "C" int segsde_axpby(long n, float alpha, const float* x, float beta, const float* y, float* out, void* stream) {
   if (!x || !out) return SEGSDE_ERR_NULL;
   hipLaunchKernelGGL(axpby_kernel, dim3(ew_blocks(n)), dim3(256), 0, ST(stream), n, alpha, x, beta, y, out);
+  SEGSDE_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int segsde_axpby_dev(long n, const float* alpha, const float* x, const float* beta, const float* y, float* out,
+                                void* stream) {
+  if (!alpha || !x || !out || (y && !beta)) return SEGSDE_ERR_NULL;
+  hipLaunchKernelGGL(axpby_dev_kernel, dim3(ew_blocks(n)), dim3(256), 0, ST(stream), n, alpha, x, beta, y, out);
   SEGSDE_CHECK_LAUNCH();
   return 0;
 }

@@ -1,0 +1,253 @@
+"""autograd glue: each class wraps one fused HIP op pair (forward + hand-written backward) from hipops.
+
+All activations flowing between these Functions are NHWC fp32 tensors.  Module-level APIs of the reference speak
+NCHW; ``to_nhwc`` / ``to_nchw`` convert at that edge for free when the tensor is already channels-last in memory
+(which is what every module of this package returns), and with a HIP layout kernel otherwise.
+"""
+import torch
+from torch.autograd import Function
+
+from . import hipops as H
+
+
+def _c(t):
+    """dense NHWC tensor (grad tensors produced by our kernels already are)"""
+    if t.is_contiguous():
+        return t
+    if t.dim() == 4 and t.stride(3) == 1:
+        try:
+            H.nhwc_ld(t)     # a channel slice of a wider NHWC buffer: kernels take its pixel pitch
+            return t
+        except ValueError:
+            pass
+    if t.dim() == 4 and t.permute(0, 3, 1, 2).is_contiguous():   # an NCHW-contiguous grad seen through an NHWC view
+        return H.nchw_to_nhwc(t.permute(0, 3, 1, 2))
+    return t.contiguous()
+
+
+class _ToNHWC(Function):
+    @staticmethod
+    def forward(ctx, x, mean, std):
+        ctx.std = std
+        return H.nchw_to_nhwc(x, mean, std)
+
+    @staticmethod
+    def backward(ctx, g):
+        gx = H.nhwc_to_nchw(_c(g))
+        if ctx.std != 1.0:
+            gx = H.axpby(1.0 / ctx.std, gx)
+        return gx, None, None
+
+
+class _ToNCHWDense(Function):
+    @staticmethod
+    def forward(ctx, x):
+        return H.nhwc_to_nchw(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return H.nchw_to_nhwc(g.contiguous())
+
+
+def to_nhwc(x, mean=0.0, std=1.0):
+    """NCHW-logical tensor -> NHWC tensor (zero-copy when x is channels-last in memory and no normalisation)."""
+    if mean == 0.0 and std == 1.0:
+        v = x.permute(0, 2, 3, 1)
+        if v.is_contiguous():
+            return v
+    return _ToNHWC.apply(x, mean, std)
+
+
+def to_nchw(x_nhwc):
+    """NHWC tensor -> NCHW-logical view (channels-last memory format; what the package's modules return)."""
+    return x_nhwc.permute(0, 3, 1, 2)
+
+
+def to_nchw_dense(x_nhwc):
+    return _ToNCHWDense.apply(x_nhwc)
+
+
+class ConvFn(Function):
+    """y = act(conv([up2x?(x0) | x1], weight) + bias); geometry in ``g`` (hipops.ConvGeom)."""
+
+    @staticmethod
+    def forward(ctx, x0, x1, weight, bias, g, act):
+        x0 = _c(x0) if x0.stride(-1) != 1 else x0
+        wp = H.pack_weight(weight, False)
+        y = H.conv_forward(g, x0, x1, wp, bias, act)
+        ctx.g, ctx.act = g, act
+        ctx.in_hw = (x0.shape[1] * (2 if g.up0 else 1), x0.shape[2] * (2 if g.up0 else 1))
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(x0, x1, weight, y if act != "none" else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x0, x1, weight, y = ctx.saved_tensors
+        g = ctx.g
+        dy = _c(dy)
+        need_b = ctx.has_bias and ctx.needs_input_grad[3]
+        if ctx.act != "none":
+            dz, dbias = H.act_backward(dy, y, ctx.act, need_dbias=need_b)
+        else:
+            dz, dbias = dy, (H.colsum(dy) if need_b else None)
+        dx0 = dx1 = dw = None
+        if ctx.needs_input_grad[0] or (x1 is not None and ctx.needs_input_grad[1]):
+            wd = H.pack_weight(weight, True)
+            dx0, dx1 = H.conv_dgrad(g, dz, wd, weight.detach(), ctx.in_hw)
+            if not ctx.needs_input_grad[0]:
+                dx0 = None
+            if x1 is None or not ctx.needs_input_grad[1]:
+                dx1 = None
+        if ctx.needs_input_grad[2]:
+            dw = H.conv_wgrad(g, x0, x1, dz)
+        return dx0, dx1, dw, dbias, None, None
+
+
+class BNActFn(Function):
+    """y = dropout(act(BN(x) + residual)); training=True uses batch statistics and updates the running buffers."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, residual, running_mean, running_var, training, momentum, eps, act, drop_p, seed):
+        x = _c(x)
+        if training:
+            mean, invstd = H.bn_stats(x, running_mean, running_var, momentum, eps, update_running=running_mean is not None)
+        else:
+            mean, invstd = H.bn_eval_stats(running_mean, running_var, eps)
+        y = H.bn_apply(x, mean, invstd, gamma, beta, residual, act, drop_p, seed)
+        ctx.cfg = (act, drop_p, seed, training, residual is not None)
+        ctx.save_for_backward(x, gamma, mean, invstd, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, mean, invstd, y = ctx.saved_tensors
+        act, drop_p, seed, training, has_res = ctx.cfg
+        dx, dres, dgamma, dbeta = H.bn_backward(_c(dy), y, x, mean, invstd, gamma, act, drop_p, seed, batch_stats=training,
+                                                need_dx=ctx.needs_input_grad[0],
+                                                need_dres=has_res and ctx.needs_input_grad[3])
+        if gamma is None or not ctx.needs_input_grad[1]:
+            dgamma = dbeta = None
+        return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None, None
+
+
+class MaxPoolFn(Function):
+    @staticmethod
+    def forward(ctx, x):
+        y, idx = H.maxpool_forward(_c(x))
+        ctx.shape = tuple(x.shape)
+        ctx.save_for_backward(idx)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (idx,) = ctx.saved_tensors
+        return H.maxpool_backward(_c(dy), idx, ctx.shape)
+
+
+class ResizeFn(Function):
+    @staticmethod
+    def forward(ctx, x, out_hw, align_corners):
+        ctx.in_hw, ctx.ac = (x.shape[1], x.shape[2]), align_corners
+        return H.resize_bilinear(x, out_hw, align_corners)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return H.resize_bilinear_backward(_c(dy), ctx.in_hw, ctx.ac), None, None
+
+
+def resize_bilinear(x_nhwc, out_hw, align_corners=False):
+    out_hw = (int(out_hw[0]), int(out_hw[1]))
+    if not align_corners and out_hw == (x_nhwc.shape[1], x_nhwc.shape[2]):
+        return x_nhwc          # F.interpolate to the same size with align_corners=False is the identity
+    return ResizeFn.apply(x_nhwc, out_hw, align_corners)
+
+
+class GlobalAvgPoolFn(Function):
+    @staticmethod
+    def forward(ctx, x):
+        ctx.shape = tuple(x.shape)
+        return H.global_avgpool(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return H.global_avgpool_backward(_c(dy), ctx.shape)
+
+
+class GateFn(Function):
+    """SelfAttention gate: f * sigmoid(a)"""
+
+    @staticmethod
+    def forward(ctx, f, a):
+        f, a = _c(f), _c(a)
+        ctx.save_for_backward(f, a)
+        return H.gate_forward(f, a)
+
+    @staticmethod
+    def backward(ctx, dy):
+        f, a = ctx.saved_tensors
+        return H.gate_backward(_c(dy), f, a)
+
+
+class AddFn(Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        return H.axpby(1.0, _c(a), 1.0, _c(b))
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, g
+
+
+class ConcatFn(Function):
+    """channel concat of NHWC tensors (ASPP branches, models/model_parts.py:31)"""
+
+    @staticmethod
+    def forward(ctx, *xs):
+        B, Hh, W, _ = xs[0].shape
+        ctx.sizes = [x.shape[3] for x in xs]
+        out = torch.empty((B, Hh, W, sum(ctx.sizes)), dtype=torch.float32, device=xs[0].device)
+        o = 0
+        for x, c in zip(xs, ctx.sizes):
+            H.copy_channels(x, out[..., o:o + c])
+            o += c
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _c(g)
+        outs, o = [], 0
+        for c in ctx.sizes:
+            outs.append(g[..., o:o + c])   # pitch-aware consumers read the slice in place
+            o += c
+        return tuple(outs)
+
+
+class PoseMatrixFn(Function):
+    """transformation_from_parameters(axisangle[:, 0], translation[:, 0], invert) on the [B,F,1,3] network outputs"""
+
+    @staticmethod
+    def forward(ctx, axisangle, translation, invert):
+        axisangle, translation = axisangle.contiguous(), translation.contiguous()
+        ctx.invert = invert
+        ctx.save_for_backward(axisangle, translation)
+        return H.pose_matrix(axisangle, translation, invert)
+
+    @staticmethod
+    def backward(ctx, dM):
+        aa, tr = ctx.saved_tensors
+        daa, dtr = H.pose_matrix_backward(aa, tr, dM, ctx.invert)
+        return daa, dtr, None
+
+
+class ScaleSliceFn(Function):
+    """out = alpha * x  (PoseDecoder's 0.01 factor, pose_decoder.py:51)"""
+
+    @staticmethod
+    def forward(ctx, x, alpha):
+        ctx.alpha = alpha
+        return H.axpby(alpha, x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return H.axpby(ctx.alpha, g), None

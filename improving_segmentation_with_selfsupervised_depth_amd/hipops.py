@@ -294,6 +294,17 @@ def axpby(alpha, x, beta=0.0, y=None, out=None):
     return out
 
 
+def axpby_dev(alpha_t, x, beta_t=None, y=None, out=None):
+    """out = alpha_t[0]*x (+ beta_t[0]*y) with 1-element DEVICE tensors as scalars (no host sync)"""
+    x = x.contiguous()
+    if y is not None:
+        y = y.contiguous()
+    out = torch.empty_like(x) if out is None else out
+    check(_lib.lib().segsde_axpby_dev(x.numel(), _p(_f32(alpha_t)), _p(_f32(x)), _p(beta_t), _p(y), _p(out), _stream(x)),
+          "axpby_dev")
+    return out
+
+
 def copy_channels(src, dst):
     M, C, lds = _rows(src)
     M2, C2, ldd = _rows(dst)

@@ -1,0 +1,166 @@
+"""Mirror of loss/monodepth_loss.py (same constructor kwargs and method protocol) on the HIP loss kernels.
+
+``generate_images_pred`` fills ``outputs`` with the reference's API-visible tensors (("depth",0,s), ("sample",f,s),
+("color",f,s), ("color_identity",f,s)); ``compute_losses`` evaluates the photometric + smoothness loss through ONE
+autograd node whose backward is the hand-written kernel chain (SSIM/L1 -> auto-mask -> warp -> disparity upsample),
+so nothing of the reference's ~2000-op graph (1 GB/img of saved intermediates) is recorded.
+Gradients flow to ("disp", s) and ("cam_T_cam", 0, f) exactly as in the reference."""
+import torch
+from torch.autograd import Function
+
+from .. import hipops as H
+
+_ONES = {}
+
+
+def _one(dev):
+    if dev not in _ONES:
+        _ONES[dev] = torch.ones(1, dtype=torch.float32, device=dev)
+    return _ONES[dev]
+
+
+class _MonoLossFn(Function):
+    @staticmethod
+    def forward(ctx, obj, inputs, cache, outputs, *tensors):
+        S, frames = obj.num_scales, list(obj.frame_ids[1:])
+        disps = [t.detach().contiguous() for t in tensors[:S]]
+        Ts = [t.detach().contiguous() for t in tensors[S:]]
+        target = inputs[("color", 0, 0)].contiguous()
+        B, _, Hh, W = target.shape
+        dev = target.device
+        automask = not obj.disable_automasking
+        avg = bool(obj.avg_reprojection)
+        nf = len(frames)
+        assert nf == 2, "the auto-mask kernel is written for the reference's two source frames"
+        srcs = [inputs[("color", f, 0)].contiguous() for f in frames]
+        inv_K, K = inputs[("inv_K", 0)].contiguous(), inputs[("K", 0)].contiguous()
+        ident = None
+        if automask:   # identical for every scale (reference recomputes it 4x, monodepth_loss.py:139-147)
+            ident = torch.empty((B, nf, Hh, W), dtype=torch.float32, device=dev)
+            for j in range(nf):
+                H.reprojection_error(srcs[j], target, obj.no_ssim, ident[:, j])
+        losses, saved = [], []
+        for s in range(S):
+            reproj = torch.empty((B, nf, Hh, W), dtype=torch.float32, device=dev)
+            colors = []
+            for j, f in enumerate(frames):
+                col = cache.get(("color", f, s)) if cache is not None else None
+                if col is None:
+                    col, _, _ = H.warp_forward(disps[s], inv_K, K, Ts[j], srcs[j], obj.min_depth, obj.max_depth)
+                colors.append(col)
+                H.reprojection_error(col, target, obj.no_ssim, reproj[:, j])
+            noise = None
+            if automask:
+                if obj.tiebreak_noise is not None:
+                    noise = obj.tiebreak_noise[s].to(dev).float().contiguous()
+                else:
+                    noise = torch.randn((B, 1 if avg else nf, Hh, W), device=dev)
+            ssum, sel, isel = H.automask_min(ident, noise, reproj, avg)
+            if automask:
+                outputs["identity_selection/{}".format(s)] = isel
+            color_s = inputs[("color", 0, s)].contiguous()
+            smooth, mean_disp = H.smoothness_forward(disps[s], color_s)
+            loss_s = ssum[0] / float(B * Hh * W) + smooth[0] * (obj.disparity_smoothness / (2 ** s))
+            losses.append(loss_s)
+            saved.append((sel, colors, mean_disp, color_s))
+        total = losses[0]
+        for l in losses[1:]:
+            total = total + l
+        total = total / S
+        ctx.obj, ctx.saved, ctx.disps, ctx.Ts, ctx.srcs, ctx.target = obj, saved, disps, Ts, srcs, target
+        ctx.geo = (inv_K, K)
+        ctx.automask, ctx.avg = automask, avg
+        return (total,) + tuple(losses)
+
+    @staticmethod
+    def backward(ctx, g_total, *g_scales):
+        obj, S = ctx.obj, ctx.obj.num_scales
+        inv_K, K = ctx.geo
+        target = ctx.target
+        B, _, Hh, W = target.shape
+        dev = target.device
+        gd_out, gT_acc = [], [None, None]
+        for s in range(S):
+            sel, colors, mean_disp, color_s = ctx.saved[s]
+            w_s = (g_total / S + g_scales[s]).reshape(1).contiguous()    # upstream weight of loss/s (device scalar)
+            greproj = H.automask_min_backward(sel, ctx.automask, 2, ctx.avg, 1.0 / float(B * Hh * W))
+            gup = torch.zeros((B, Hh, W), dtype=torch.float32, device=dev)
+            for j in range(2):
+                gpred = H.reprojection_error_backward(colors[j], target, greproj[:, j], obj.no_ssim)
+                gT = torch.zeros((B, 4, 4), dtype=torch.float32, device=dev)
+                H.warp_backward(gpred, ctx.disps[s], inv_K, K, ctx.Ts[j], ctx.srcs[j], obj.min_depth, obj.max_depth, gup, gT)
+                gT_acc[j] = H.axpby_dev(w_s, gT) if gT_acc[j] is None else H.axpby_dev(w_s, gT, _one(dev), gT_acc[j])
+            hs, ws = ctx.disps[s].shape[-2:]
+            gdisp = H.resize_bilinear_backward(gup.reshape(B, Hh, W, 1), (hs, ws), False).reshape(B, 1, hs, ws)
+            H.smoothness_backward(ctx.disps[s], color_s, mean_disp, obj.disparity_smoothness / (2 ** s), gdisp)
+            gd_out.append(H.axpby_dev(w_s, gdisp))
+        return (None, None, None, None) + tuple(gd_out) + tuple(gT_acc)
+
+
+class MonodepthLoss:
+    def __init__(self, num_scales, frame_ids, height, width, batch_size, min_depth, max_depth, test_min_depth,
+                 test_max_depth, disparity_smoothness, no_ssim, avg_reprojection, disable_automasking, crop_h=None,
+                 crop_w=None, is_train=True):
+        self.num_scales = num_scales
+        self.scales = list(range(self.num_scales))
+        self.height = height if crop_h is None or not is_train else crop_h      # reference :22-23
+        self.width = width if crop_w is None or not is_train else crop_w
+        self.batch_size = batch_size
+        self.frame_ids = list(frame_ids)
+        self.min_depth, self.max_depth = min_depth, max_depth
+        self.test_min_depth, self.test_max_depth = test_min_depth, test_max_depth
+        self.disparity_smoothness = disparity_smoothness
+        self.no_ssim = no_ssim
+        self.avg_reprojection = avg_reprojection
+        self.disable_automasking = disable_automasking
+        self.device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
+        self.depth_metric_names = ["abs_rel", "sq_rel", "rms", "log_rms", "a1", "a2", "a3"]
+        if any(f == "s" for f in self.frame_ids):
+            raise NotImplementedError("stereo frame id 's' is not used by the reference's configs")
+        self.tiebreak_noise = None    # tests: dict scale -> tensor replacing the fresh randn of reference :163-164
+        self._cache = None
+
+    def generate_depth_test_pred(self, outputs):
+        """reference :54-62 (eval only)"""
+        assert tuple(outputs[("disp", 0)].shape[-2:]) == (self.height, self.width), outputs[("disp", 0)].shape[-2:]
+        for s in self.scales:
+            d = outputs[("disp", s)].detach().contiguous()
+            B, _, hs, ws = d.shape
+            up = H.resize_bilinear(d.reshape(B, hs, ws, 1), (self.height, self.width), False)
+            up = up.reshape(B, 1, self.height, self.width)
+            lo, hi = 1.0 / self.test_max_depth, 1.0 / self.test_min_depth
+            outputs[("depth", 0, s)] = 1.0 / (lo + (hi - lo) * up)
+
+    def generate_images_pred(self, inputs, outputs):
+        """reference :64-102; tensors written to ``outputs`` are detached (the differentiable path is compute_losses)"""
+        assert tuple(outputs[("disp", 0)].shape[-2:]) == (self.height, self.width), \
+            f'{outputs[("disp", 0)].shape[-2:]} should be {(self.height, self.width)} '
+        cache = {}
+        for s in self.scales:
+            disp = outputs[("disp", s)].detach().contiguous()
+            for i, f in enumerate(self.frame_ids[1:]):
+                T = outputs[("cam_T_cam", 0, f)].detach().float().contiguous()
+                color, grid, depth = H.warp_forward(disp, inputs[("inv_K", 0)], inputs[("K", 0)], T,
+                                                    inputs[("color", f, 0)], self.min_depth, self.max_depth,
+                                                    want_grid=True, want_depth=(i == 0))
+                if i == 0:
+                    outputs[("depth", 0, s)] = depth
+                outputs[("sample", f, s)] = grid
+                outputs[("color", f, s)] = color
+                cache[("color", f, s)] = color
+                if not self.disable_automasking:
+                    outputs[("color_identity", f, s)] = inputs[("color", f, 0)]
+        self._cache = (cache, [outputs[("disp", s)] for s in self.scales])
+
+    def compute_losses(self, inputs, outputs):
+        """reference :118-192 -> {"loss/0".."loss/3", "loss"}"""
+        disps = [outputs[("disp", s)] for s in self.scales]
+        Ts = [outputs[("cam_T_cam", 0, f)].float() for f in self.frame_ids[1:]]
+        cache = None
+        if self._cache is not None and all(a is b for a, b in zip(self._cache[1], disps)):
+            cache = self._cache[0]           # warped frames from generate_images_pred for these very tensors
+        self._cache = None
+        res = _MonoLossFn.apply(self, inputs, cache, outputs, *disps, *Ts)
+        losses = {"loss/{}".format(s): res[1 + s] for s in self.scales}
+        losses["loss"] = res[0]
+        return losses

@@ -1,0 +1,47 @@
+"""HIP-backed building blocks shared by the model mirror: Conv2d / BatchNorm2d subclasses that keep torch.nn's
+parameter names, shapes and default initialisation (so reference checkpoints load and ``isinstance(m,
+nn.BatchNorm2d)`` checks in the reference's train.py keep working) but run on NHWC tensors through the HIP ops."""
+import torch
+from torch import nn
+
+from .. import functional as Fn
+from ..hipops import ConvGeom
+
+
+def _seed():
+    # CPU generator: no device sync; the dropout mask itself is generated in-kernel from this counter seed
+    return int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+
+
+class Conv2d(nn.Conv2d):
+    """nn.Conv2d state, HIP implicit-GEMM compute.  ``forward(x_nhwc, skip=None, up=False, act="none")``:
+    ``skip`` is an optional second NHWC source concatenated after x along channels, ``up`` nearest-upsamples x by 2
+    inside the kernel's tile loader (models/depth_decoder.py:93-100 without materialising either)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, bias=True, reflect=False):
+        super().__init__(int(in_channels), int(out_channels), kernel_size, stride, padding, dilation, bias=bias)
+        self.reflect = reflect
+        k = self.kernel_size[0]
+        assert self.kernel_size[0] == self.kernel_size[1] and self.stride[0] == self.stride[1]
+
+    def forward(self, x, skip=None, up=False, act="none"):
+        c0 = x.shape[3]
+        c1 = 0 if skip is None else skip.shape[3]
+        assert c0 + c1 == self.in_channels, (c0, c1, self.in_channels)
+        g = ConvGeom(c0, self.out_channels, self.kernel_size[0], self.stride[0], self.dilation[0], self.padding[0],
+                     self.reflect, c1, up)
+        return Fn.ConvFn.apply(x, skip, self.weight, self.bias, g, act)
+
+
+class BatchNorm2d(nn.BatchNorm2d):
+    """nn.BatchNorm2d state; ``forward(x_nhwc, residual=None, act="none", drop_p=0.0)`` fuses the residual add,
+    the activation and (for ASPP.project) the dropout into the normalisation pass."""
+
+    def forward(self, x, residual=None, act="none", drop_p=0.0):
+        training = self.training or (self.running_mean is None)
+        if self.training and self.track_running_stats and self.num_batches_tracked is not None:
+            self.num_batches_tracked.add_(1)
+        momentum = 0.1 if self.momentum is None else self.momentum
+        seed = _seed() if drop_p > 0 else 0
+        return Fn.BNActFn.apply(x, self.weight, self.bias, residual, self.running_mean, self.running_var, training,
+                                momentum, self.eps, act, drop_p, seed)

@@ -123,6 +123,8 @@ int segsde_gate_forward(const float* f, const float* a, long n, float* y, void* 
 int segsde_gate_backward(const float* dy, const float* f, const float* a, long n, float* df, float* da, void* stream);
 /* out = alpha*x + beta*y over n contiguous floats (PAD feature merge :160-161; EMA update train.py:346-358) */
 int segsde_axpby(long n, float alpha, const float* x, float beta, const float* y, float* out, void* stream);
+/* same with the scalars read from device memory (gradient scaling by upstream 0-dim tensors without a host sync) */
+int segsde_axpby_dev(long n, const float* alpha, const float* x, const float* beta, const float* y, float* out, void* stream);
 /* channel-slice copy dst[m, 0..C) = src[m, 0..C) (torch.cat of the ASPP branches, models/model_parts.py:31) */
 int segsde_copy_channels(const float* src, int lds, float* dst, int ldd, long M, int C, void* stream);
 /* NCHW image -> NHWC with the encoder's input normalisation (x - mean) / std (models/resnet_encoder.py:92);

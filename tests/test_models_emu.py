@@ -1,0 +1,39 @@
+"""CPU: product modules (autograd glue + real kernel sources under the interpreter) vs the reference's golden vectors."""
+import json
+
+import pytest
+import torch
+
+import emu
+import model_cases as MC
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _emu():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: the -m gpu suite exercises the real library instead")
+    emu.install()
+
+
+def test_state_dict_contract():
+    """key names, shapes, dtypes AND order of every benchmark model == what the reference's get_model builds"""
+    from improving_segmentation_with_selfsupervised_depth_amd.models import get_model
+    c = MC.contract_cfgs()
+    for name, cfg in c["cfgs"].items():
+        m = get_model(cfg, 19)
+        got = [[k, list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in m.state_dict().items()]
+        assert got == c["contract"][name], name
+        assert [k for k, p in m.named_parameters() if p.requires_grad] == c["contract"][name + "__trainable"]
+
+
+def test_blocks(golden):
+    MC.run_blocks("cpu", golden)
+
+
+@pytest.mark.parametrize("which", ["dd1", "dd2", "jsd1", "jsd2", "pad1", "pad2"])
+def test_decoders(golden, which):
+    MC.run_decoders("cpu", golden, (which,))
+
+
+def test_encoder_r18(golden):
+    MC.run_encoder("cpu", golden, ("r18",))
