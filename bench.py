@@ -1,0 +1,251 @@
+#!/usr/bin/env python
+"""Training-throughput benchmark of the hot path.
+
+    python bench.py --gpus N --steps K --warmup W            (N>1: launched by torch.distributed.run, one rank per GPU)
+
+A "step" re-enacts the reference's Trainer.train_step (train.py:442-549) on synthetic, device-resident inputs:
+model forward -> monodepth loss -> segmentation loss -> backward -> gradient all-reduce (N>1) -> clip_grad_norm ->
+optimiser step.  Default workload = BASELINE.json configs[2]: cityscapes_joint.yml + decoder_variant(dec=6) ResNet-101
+joint_seg_depth_dec, 512x1024, per-GPU batch 16, SGD (experiments.py:32-48,139-145).  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# algorithmic GFLOP per image (conv + matmul, 2*MAC), measured on the reference model
+GFLOP_PER_IMG = {"cfg1": 216.8, "cfg2": 1423.6, "cfg3": 2467.2, "cfg3pad": 2569.4}
+PEAK_FP32_MATRIX_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, no TF32 on gfx950
+
+
+def model_cfg(workload, H, W):
+    mono = dict(frame_ids=[0, -1, 1], num_scales=4, height=H, width=W)
+    common = dict(arch="joint_segmentation_depth", pose_model_input="pairs", provide_uncropped_for_pose=False,
+                  backbone_pretraining="none", depth_pretraining="none", pose_pretraining="none", freeze_backbone=False,
+                  freeze_depth=False, freeze_pose=False, freeze_segmentation=False, disable_monodepth=False,
+                  disable_pose=False, enable_imnet_encoder=False, **mono)
+    dec = dict(intermediate_aspp=True, aspp_rates=[6, 12, 18], num_ch_dec=[64, 128, 128, 256, 256], max_scale_size=[H, W])
+    jsd = dict(weights="none", layers=[9], head_inter_channels=64, layer_out_channels=64, head_dropout=0.1,
+               layer_dropout=0, head_inter=False, output_stride=1)
+    pad = dict(weights="none", output_stride=1, distillation_layer=7, side_output=True, final_layer=9)
+    if workload == "cfg1":
+        return dict(common, backbone_name="resnet18", replace_stride_with_dilation=None, segmentation_name=None,
+                    segmentation_args=None, depth_args=dec)
+    if workload == "cfg2":
+        return dict(common, backbone_name="resnet50", replace_stride_with_dilation=[False, False, True],
+                    segmentation_name=None, segmentation_args=None, depth_args=dec)
+    if workload == "cfg3":
+        return dict(common, backbone_name="resnet101", replace_stride_with_dilation=[False, False, True],
+                    segmentation_name="joint_seg_depth_dec", segmentation_args=jsd, depth_args=dec)
+    if workload == "cfg3pad":
+        return dict(common, backbone_name="resnet101", replace_stride_with_dilation=[False, False, True],
+                    segmentation_name="mtl_pad", segmentation_args=pad, depth_args=dec)
+    raise KeyError(workload)
+
+
+WORKLOADS = {  # name -> (H, W, per-GPU batch, optimiser, description)
+    "cfg1": (256, 512, 2, "adam", "ResNet-18 monodepth dec5, 256x512, batch 2 (BASELINE configs[0])"),
+    "cfg2": (512, 1024, 8, "adam", "ResNet-50 monodepth dec5, 512x1024, batch 8 (BASELINE configs[1])"),
+    "cfg3": (512, 1024, 16, "sgd", "ResNet-101 joint_seg_depth_dec seg+depth, 512x1024, batch 16/GPU (BASELINE configs[2])"),
+    "cfg3pad": (512, 1024, 16, "sgd", "ResNet-101 mtl_pad seg+depth, 512x1024, batch 16/GPU"),
+}
+
+
+def synthetic_inputs(B, H, W, device, seed, with_labels=True):
+    """SURVEY.md 8d 'Synthetic inputs': U[0,1) frames, Cityscapes intrinsics (not rescaled, as the reference), labels
+    with ~5 % ignore."""
+    g = torch.Generator().manual_seed(seed)
+    inp = {}
+    for f in (0, -1, 1):
+        inp[("color", f, 0)] = torch.rand(B, 3, H, W, generator=g)
+        inp[("color_aug", f, 0)] = inp[("color", f, 0)]
+    for s in range(1, 4):
+        inp[("color", 0, s)] = torch.rand(B, 3, H // 2 ** s, W // 2 ** s, generator=g)
+    K = np.array([[2262.52, 0, 1096.98, 0], [0, 2265.3017905988554, 513.137, 0], [0, 0, 1, 0], [0, 0, 0, 1]], dtype=np.float32)
+    inp[("K", 0)] = torch.from_numpy(K).unsqueeze(0).repeat(B, 1, 1)
+    inp[("inv_K", 0)] = torch.from_numpy(np.linalg.pinv(K)).unsqueeze(0).repeat(B, 1, 1)
+    if with_labels:
+        lbl = torch.randint(0, 19, (B, H, W), generator=g)
+        lbl[torch.rand(B, H, W, generator=g) < 0.05] = 250
+        inp["lbl"] = lbl
+    return {k: v.to(device) for k, v in inp.items()}
+
+
+def loss_cfg(B, H, W):
+    return {"training": {"batch_size": B, "monodepth_loss": dict(
+        num_scales=4, frame_ids=[0, -1, 1], height=H, width=W, min_depth=0.1, max_depth=100, test_min_depth=1e-3,
+        test_max_depth=80, disparity_smoothness=1e-3, no_ssim=False, avg_reprojection=False, disable_automasking=False)}}
+
+
+def param_groups(model, opt):
+    """train.py:67-101 with experiments.py:32-48: backbone lr 1e-3, everything else 1e-2 (sgd); adam 1e-4"""
+    if opt == "adam":
+        return torch.optim.Adam(model.parameters(), lr=1e-4)
+    enc = list(model.models["encoder"].parameters())
+    ids = {id(p) for p in enc}
+    rest = [p for p in model.parameters() if id(p) not in ids]
+    return torch.optim.SGD([{"params": enc, "lr": 1e-3}, {"params": rest}], lr=1e-2, momentum=0.9, weight_decay=5e-4)
+
+
+def cpu_baseline(workload, H, W, budget_s):
+    """The oracle (CPU torch restatement of the reference path) timed on this box's host cores on a bounded sample:
+    one full train step (fwd + mono loss + seg loss + bwd) at batch 2."""
+    from oracle import nets as N, photometric as P, segmix as S
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cfg = model_cfg(workload, H, W)
+    B = 2
+    sd = N.build_state_dict(cfg, 19, seed=0)
+    sd = {k: (v.requires_grad_(True) if v.is_floating_point() and "running" not in k else v) for k, v in sd.items()}
+    inp = synthetic_inputs(B, H, W, "cpu", 99, with_labels=cfg.get("segmentation_name") is not None)
+    t0 = time.time()
+    out = N.model_forward(sd, cfg, inp, train=True, dropout=True)
+    lo = P.MonodepthLossOracle(**loss_cfg(B, H, W)["training"]["monodepth_loss"], batch_size=B)
+    lo.generate_images_pred(inp, out)
+    total = lo.compute_losses(inp, out)["loss"]
+    if "semantics" in out:
+        total = total + S.cross_entropy2d(out["semantics"], inp["lbl"])
+        if "intermediate_semantics" in out:
+            total = total + S.cross_entropy2d(out["intermediate_semantics"], inp["lbl"])
+    total.backward()
+    dt = time.time() - t0
+    return {"value": B / dt, "unit": "img/s", "cores": cores, "kind": "port",
+            "sample": "oracle (CPU PyTorch restatement, validated against the reference): 1 train step fwd+loss+bwd, "
+                      "%s at batch %d, %.1f s, torch %s" % (workload, B, dt, torch.__version__)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the workload's)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus or (args.gpus == 1 and world == 1), "--gpus must equal WORLD_SIZE"
+    torch.cuda.set_device(local_rank)     # before constructing anything (SURVEY.md 8b device quirk)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    import __graft_entry__ as ge
+    if not os.path.exists(ge.LIB):
+        ge.build()
+    from improving_segmentation_with_selfsupervised_depth_amd import hipops as H
+    from improving_segmentation_with_selfsupervised_depth_amd.models import get_model
+    from improving_segmentation_with_selfsupervised_depth_amd.loss import get_monodepth_loss
+    from improving_segmentation_with_selfsupervised_depth_amd.loss.loss import cross_entropy2d
+    from improving_segmentation_with_selfsupervised_depth_amd.ddp import GradAllReducer
+
+    Hh, W, B, opt_name, desc = WORKLOADS[args.workload]
+    if args.batch:
+        B = args.batch
+    torch.manual_seed(42)
+    cfg = model_cfg(args.workload, Hh, W)
+    model = get_model(cfg, 19).to(dev).train()
+    optimizer = param_groups(model, opt_name)
+    loss_obj = get_monodepth_loss(loss_cfg(B, Hh, W), is_train=True)
+    reducer = GradAllReducer(model) if world > 1 else None
+    inputs = synthetic_inputs(B, Hh, W, dev, 1234 + rank, with_labels=cfg.get("segmentation_name") is not None)
+    clip = 10.0 if opt_name == "sgd" else None
+
+    def step():
+        optimizer.zero_grad(set_to_none=True)
+        out = model(inputs)
+        loss_obj.generate_images_pred(inputs, out)
+        total = loss_obj.compute_losses(inputs, out)["loss"]
+        if "semantics" in out:
+            seg = cross_entropy2d(out["semantics"], inputs["lbl"])
+            if "intermediate_semantics" in out:
+                seg = (seg + cross_entropy2d(out["intermediate_semantics"], inputs["lbl"])) / 2
+            total = total + seg
+        total.backward()
+        if reducer is not None:
+            reducer.finish()
+        if clip is not None:
+            torch.nn.utils.clip_grad_norm_(model.parameters(), clip)
+        optimizer.step()
+        return total
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    prof = None if args.no_kernel_timing else []
+    H.PROFILE = prof
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        last = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    H.PROFILE = None
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t[0])
+    loss_val = float(last)
+
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        value = B * world * args.steps / dt
+        res = {"metric": "train images/sec, ResNet-101 joint seg+depth @512x1024" if args.workload.startswith("cfg3")
+               else "train images/sec (%s)" % args.workload,
+               "value": value, "unit": "img/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+               "data": "synthetic", "config": {"workload": desc, "per_gpu_batch": B, "global_batch": B * world,
+                                               "height": Hh, "width": W, "optimizer": opt_name,
+                                               "parallelism": "dp%d" % world, "final_loss": loss_val}}
+        gflop_img = GFLOP_PER_IMG[args.workload]
+        res["step_tflops"] = value * gflop_img / 1e3 / world
+        roof = {"bound": "mfma", "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s", "traffic": None,
+                "kernel": "conv_igemm_kernel (implicit-GEMM forward + data-gradient, v_mfma_f32_32x32x2_f32)"}
+        if prof:
+            agg = {}
+            for kind, flops, s, e in prof:
+                a = agg.setdefault(kind, [0.0, 0.0, 0])
+                a[0] += flops
+                a[1] += s.elapsed_time(e) * 1e-3
+                a[2] += 1
+            fl = sum(agg[k][0] for k in ("conv_fwd", "conv_dgrad") if k in agg)
+            tt = sum(agg[k][1] for k in ("conv_fwd", "conv_dgrad") if k in agg)
+            nl = sum(agg[k][2] for k in ("conv_fwd", "conv_dgrad") if k in agg)
+            roof.update(achieved=fl / tt / 1e12, frac=fl / tt / 1e12 / PEAK_FP32_MATRIX_TFLOPS, launches=nl,
+                        avg_launch_ms=tt / nl * 1e3, avg_launch_gflop=fl / nl / 1e9,
+                        share_of_step=tt / dt)
+            res["kernels"] = {k: {"tflops": v[0] / v[1] / 1e12, "seconds": v[1], "launches": v[2],
+                                  "share_of_step": v[1] / dt} for k, v in agg.items()}
+        else:
+            roof.update(achieved=res["step_tflops"], frac=res["step_tflops"] / PEAK_FP32_MATRIX_TFLOPS)
+        res["roofline"] = roof
+        if not args.no_cpu_baseline and world == 1:
+            try:
+                res["cpu_baseline"] = cpu_baseline(args.workload, Hh, W, 30)
+            except Exception as ex:  # the baseline is reported, never required for the GPU number
+                res["cpu_baseline"] = {"value": None, "unit": "img/s", "cores": os.cpu_count(), "kind": "port",
+                                       "sample": "failed: %r" % (ex,)}
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

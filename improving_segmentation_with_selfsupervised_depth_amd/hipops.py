@@ -12,6 +12,21 @@ from . import _lib
 from ._lib import ConvDesc, check
 
 ACT = {"none": 0, "relu": 1, "elu": 2, "sigmoid": 3}
+
+# Optional live kernel timing (bench.py): when set to a list, every implicit-GEMM launch is bracketed by HIP events
+# recorded on the stream the kernel is launched on; entries are (kind, algorithmic_flops, start_event, end_event).
+PROFILE = None
+
+
+def _timed(kind, flops, like, launch):
+    if PROFILE is None or not like.is_cuda:
+        return launch()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    r = launch()
+    e.record()
+    PROFILE.append((kind, flops, s, e))
+    return r
 PAD_ZERO, PAD_REFLECT = 0, 1
 
 
@@ -92,8 +107,9 @@ def conv_forward(g, x0, x1, wpack, bias, act="none"):
                  up0=int(g.up0), Ho=Ho, Wo=Wo, Cout=g.Cout, ldy=g.Cout, ldy2=0, nsplit=0, KH=g.k, KW=g.k,
                  stride=g.stride, dil=g.dil, pad=g.pad, pad_mode=PAD_REFLECT if g.reflect else PAD_ZERO, in_div=1,
                  act=ACT[act])
-    check(_lib.lib().segsde_conv2d_forward(ctypes.byref(d), _p(_f32(x0)), _p(x1), _p(wpack), _p(bias), _p(y), None,
-                                           _stream(x0)), "conv2d_forward")
+    flops = 2.0 * B * Ho * Wo * g.Cout * g.Cin * g.k * g.k
+    _timed("conv_fwd", flops, x0, lambda: check(_lib.lib().segsde_conv2d_forward(
+        ctypes.byref(d), _p(_f32(x0)), _p(x1), _p(wpack), _p(bias), _p(y), None, _stream(x0)), "conv2d_forward"))
     return y
 
 
@@ -109,8 +125,9 @@ def conv_dgrad(g, dy, wdpack, w_oihw, in_hw, need0=True, need1=True):
                  ldy2=g.C1, nsplit=g.C0, KH=g.k, KW=g.k, stride=1, dil=g.dil, pad=(g.k - 1) * g.dil - g.pad,
                  pad_mode=PAD_ZERO, in_div=g.stride, act=0)
     L = _lib.lib()
-    check(L.segsde_conv2d_forward(ctypes.byref(d), _p(_f32(dy)), None, _p(wdpack), None, _p(full0), _p(dx1),
-                                  _stream(dy)), "conv2d dgrad")
+    flops = 2.0 * B * Ho * Wo * Cout * g.Cin * g.k * g.k
+    _timed("conv_dgrad", flops, dy, lambda: check(L.segsde_conv2d_forward(
+        ctypes.byref(d), _p(_f32(dy)), None, _p(wdpack), None, _p(full0), _p(dx1), _stream(dy)), "conv2d dgrad"))
     if g.reflect:
         check(L.segsde_reflect_dgrad_fix(_p(dy), nhwc_ld(dy), _p(w_oihw), _p(full0), g.C0, _p(dx1), g.C1, g.C0, B, H, W,
                                          g.Cin, Cout, _stream(dy)), "reflect_dgrad_fix")
@@ -135,8 +152,9 @@ def conv_wgrad(g, x0, x1, dy):
     nbytes = L.segsde_conv2d_wgrad_workspace(ctypes.byref(d))
     ws = _ws(nbytes, dy)
     dw = torch.empty((Cout, g.Cin, g.k, g.k), dtype=torch.float32, device=dy.device)
-    check(L.segsde_conv2d_wgrad(ctypes.byref(d), _p(x0), _p(x1), _p(_f32(dy)), nhwc_ld(dy), _p(dw), _p(ws), nbytes,
-                                _stream(dy)), "conv2d_wgrad")
+    flops = 2.0 * B * Ho * Wo * Cout * g.Cin * g.k * g.k
+    _timed("conv_wgrad", flops, dy, lambda: check(L.segsde_conv2d_wgrad(
+        ctypes.byref(d), _p(x0), _p(x1), _p(_f32(dy)), nhwc_ld(dy), _p(dw), _p(ws), nbytes, _stream(dy)), "conv2d_wgrad"))
     return dw
 
 
