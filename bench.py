@@ -98,7 +98,11 @@ def cpu_baseline(workload, H, W, budget_s):
     """The oracle (CPU torch restatement of the reference path) timed on this box's host cores on a bounded sample:
     one full train step (fwd + mono loss + seg loss + bwd) at batch 2."""
     from oracle import nets as N, photometric as P, segmix as S
-    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 64))
     torch.set_num_threads(cores)
     cfg = model_cfg(workload, H, W)
     B = 2
@@ -130,7 +134,13 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-baseline-timeout", type=float, default=170.0)
     args = ap.parse_args()
+    if args.cpu_baseline_only:
+        Hh, W = WORKLOADS[args.workload][:2]
+        print(json.dumps(cpu_baseline(args.workload, Hh, W, 30)))
+        return
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -202,7 +212,7 @@ def main():
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t[0])
-    loss_val = float(last)
+    loss_val = float(last.detach())
 
     if rank == 0:
         ms = dt / args.steps * 1e3
@@ -236,13 +246,19 @@ def main():
         else:
             roof.update(achieved=res["step_tflops"], frac=res["step_tflops"] / PEAK_FP32_MATRIX_TFLOPS)
         res["roofline"] = roof
+        print("gpu result:", json.dumps(res), file=sys.stderr, flush=True)
         if not args.no_cpu_baseline and world == 1:
+            # separate process + hard time limit: the baseline is reported, never allowed to stall the GPU number
+            import subprocess
             try:
-                res["cpu_baseline"] = cpu_baseline(args.workload, Hh, W, 30)
-            except Exception as ex:  # the baseline is reported, never required for the GPU number
+                cp = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--workload",
+                                     args.workload], capture_output=True, text=True, timeout=args.cpu_baseline_timeout,
+                                    env=dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES=""))
+                res["cpu_baseline"] = json.loads(cp.stdout.strip().splitlines()[-1])
+            except Exception as ex:
                 res["cpu_baseline"] = {"value": None, "unit": "img/s", "cores": os.cpu_count(), "kind": "port",
-                                       "sample": "failed: %r" % (ex,)}
-        print(json.dumps(res))
+                                       "sample": "not measured: %r" % (ex,)}
+        print(json.dumps(res), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

@@ -13,7 +13,7 @@ ABI_VERSION = 1
 
 _LIB = None
 # Set only by the test-suite when it injects the host-interpreted build of the same kernel sources
-# (tests/hipemu); the product never sets it.
+# (see tests/emu.py); the product never sets it.
 HOST_POINTERS_OK = False
 
 

@@ -128,8 +128,48 @@ constexpr int LDT = 36;   // LDS row pitch in floats (BK + 4): conflict-free ds_
 // ---------------------------------------------------------------------------------------------------
 // forward / data-gradient kernel
 // ---------------------------------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN, bool VEC>
+// Uniform per-chunk tap state of the FAST path: when Ctot % 32 == 0 (and C0 % 32 == 0 for two sources) a 32-wide
+// reduction chunk lies inside ONE tap of ONE source, so tap / source / channel base are wave-uniform scalars that
+// advance incrementally (no per-element integer division) and the tile loads become straight-line code:
+// clamped (always valid) addresses + a select, instead of the branchy generic gather.
+struct ChunkState {
+  int c0, kh, kw;   // channel offset inside the concatenated input, tap coordinates
+  __device__ __forceinline__ void advance(const ConvP& p) {
+    c0 += 32;
+    if (c0 == p.Ctot) { c0 = 0; if (++kw == p.KW) { kw = 0; ++kh; } }
+  }
+};
+
+struct SrcSel { const float* src; unsigned ld, Ws, bstride; int shift, cc; };
+__device__ __forceinline__ SrcSel select_src(const ConvP& p, int c) {
+  SrcSel s;
+  if (c < p.C0) { s.src = p.x0; s.ld = p.ld0; s.cc = c; s.shift = p.up0; }
+  else { s.src = p.x1; s.ld = p.ld1; s.cc = c - p.C0; s.shift = 0; }
+  s.Ws = (unsigned)(p.W >> s.shift);
+  s.bstride = (unsigned)(p.H >> s.shift) * s.Ws * s.ld;
+  return s;
+}
+
+__device__ __forceinline__ float4 fast_fetch(const ConvP& p, const SrcSel& s, int b, int hi, int wi, bool ok, int cq) {
+  if (p.pad_mode == SEGSDE_PAD_REFLECT) {
+    hi = hi < 0 ? -hi : (hi >= p.H ? 2 * p.H - 2 - hi : hi);
+    wi = wi < 0 ? -wi : (wi >= p.W ? 2 * p.W - 2 - wi : wi);
+  } else {
+    ok = ok && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+  }
+  hi = ok ? hi : 0; wi = ok ? wi : 0;
+  const unsigned off = (unsigned)b * s.bstride + ((unsigned)(hi >> s.shift) * s.Ws + (unsigned)(wi >> s.shift)) * s.ld +
+                       (unsigned)(s.cc + cq);
+  float4 v = *reinterpret_cast<const float4*>(s.src + off);
+  if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+  return v;
+}
+
+// MODE 0: generic scalar gather, 1: generic float4 gather, 2: FAST (uniform tap per chunk, branch-free loads)
+template <int BM, int BN, int WM, int WN, int MODE>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
+  constexpr bool VEC = MODE >= 1;
+  constexpr bool FAST = MODE == 2;
   constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
   constexpr int AR = BM / 32, BR = BN / 32;
   constexpr int STAGE = (BM + BN) * LDT;
@@ -151,6 +191,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
   bool rok[AR];
 #pragma unroll
   for (int i = 0; i < AR; ++i) decode_m(p, m0 + r0 + 32 * i, rb[i], rh[i], rw[i], rok[i]);
+  // FAST: weight-row bases (clamped) and validity
+  const float* wrow[BR];
+  bool nok[BR];
+#pragma unroll
+  for (int i = 0; i < BR; ++i) {
+    const int n = n0 + r0 + 32 * i;
+    nok[i] = n < p.N;
+    wrow[i] = p.w + (long)(nok[i] ? n : 0) * p.Ktot + 4 * kq;
+  }
+  ChunkState cs; cs.c0 = 0; cs.kh = 0; cs.kw = 0;
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -164,11 +214,25 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
   const int nchunks = (p.Ktot + BK - 1) / BK;
 
   auto gload = [&](int kc) {
-    const int k = kc * BK + 4 * kq;
+    if (FAST) {
+      const SrcSel s = select_src(p, cs.c0);
+      const int dh = cs.kh * p.dil - p.pad, dw = cs.kw * p.dil - p.pad;
 #pragma unroll
-    for (int i = 0; i < AR; ++i) ra[i] = fetch_a4<VEC>(p, k, rb[i], rh[i], rw[i], rok[i]);
+      for (int i = 0; i < AR; ++i) ra[i] = fast_fetch(p, s, rb[i], rh[i] + dh, rw[i] + dw, rok[i], 4 * kq);
 #pragma unroll
-    for (int i = 0; i < BR; ++i) rbv[i] = fetch_w4<VEC>(p, n0 + r0 + 32 * i, k);
+      for (int i = 0; i < BR; ++i) {
+        float4 v = *reinterpret_cast<const float4*>(wrow[i] + kc * BK);
+        if (!nok[i]) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        rbv[i] = v;
+      }
+      cs.advance(p);
+    } else {
+      const int k = kc * BK + 4 * kq;
+#pragma unroll
+      for (int i = 0; i < AR; ++i) ra[i] = fetch_a4<VEC>(p, k, rb[i], rh[i], rw[i], rok[i]);
+#pragma unroll
+      for (int i = 0; i < BR; ++i) rbv[i] = fetch_w4<VEC>(p, n0 + r0 + 32 * i, k);
+    }
   };
   auto lstore = [&](int buf) {
     float* As = smem + buf * STAGE;
@@ -197,15 +261,23 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
         for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const float4*>(Ap + i * 32 * LDT + 8 * g);
 #pragma unroll
         for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const float4*>(Bp + j * 32 * LDT + 8 * g);
+        // k-step outermost: consecutive MFMAs target different accumulators
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int j = 0; j < TN; ++j) {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
-          }
+          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
       }
     }
     if (more) lstore((kc + 1) & 1);
@@ -238,9 +310,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
 // ---------------------------------------------------------------------------------------------------
 constexpr int BP = 32;  // pixels per staged chunk
 
-template <int BKT, int BN, int WM, int WN, bool VEC>
+template <int BKT, int BN, int WM, int WN, int MODE>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvP p, const float* dy, int lddy, float* part,
                                                          int chunks_per_split) {
+  constexpr bool VEC = MODE >= 1;
+  constexpr bool FAST = MODE == 2;
   constexpr int TM = BKT / (WM * 32), TN = BN / (WN * 32);
   constexpr int AQ = BKT / 4, DQ = BN / 4;             // float4 columns per tile row
   constexpr int AI = (BP * AQ) / 256, DI = (BP * DQ) / 256;
@@ -265,8 +339,48 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvP p, const float* d
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  // FAST: this thread's reduction column (tap, source, channel) is fixed for the whole kernel; its AI pixel rows
+  // advance by BP pixels per chunk with carries instead of divisions; loads are clamped + selected (branch-free)
+  const int fk = k0 + 4 * (tid % AQ);
+  const bool fk_ok = fk < p.Ktot;
+  SrcSel fs; int fdh = 0, fdw = 0;
+  int fb[AI], fh[AI], fw[AI], fm[AI];
+  if (FAST) {
+    const int kk = fk_ok ? fk : 0;
+    const int tap = kk / p.Ctot, c = kk - tap * p.Ctot;
+    const int kh = tap / p.KW, kw = tap - kh * p.KW;
+    fs = select_src(p, c);
+    fdh = kh * p.dil - p.pad; fdw = kw * p.dil - p.pad;
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+      bool ok;
+      fm[i] = c_begin * BP + (tid + 256 * i) / AQ;
+      decode_m(p, fm[i], fb[i], fh[i], fw[i], ok);   // fh/fw are ho*stride, wo*stride
+    }
+  }
+  const int wstep = BP * p.stride, wlim = p.Wo * p.stride, hlim = p.Ho * p.stride;
+
   float4 ra[AI], rd[DI];
   auto gload = [&](int c) {
+    if (FAST) {
+#pragma unroll
+      for (int i = 0; i < AI; ++i) {
+        ra[i] = fast_fetch(p, fs, fb[i], fh[i] + fdh, fw[i] + fdw, fk_ok && fm[i] < p.M, 0);
+        fm[i] += BP; fw[i] += wstep;
+        while (fw[i] >= wlim) { fw[i] -= wlim; fh[i] += p.stride; }
+        while (fh[i] >= hlim) { fh[i] -= hlim; ++fb[i]; }
+      }
+#pragma unroll
+      for (int i = 0; i < DI; ++i) {
+        const int e = tid + 256 * i, row = e / DQ, nq = e - row * DQ;
+        const int m = c * BP + row, n = n0 + 4 * nq;
+        const bool ok = m < p.M && n < p.N;
+        float4 v = *reinterpret_cast<const float4*>(dy + (long)(ok ? m : 0) * lddy + (ok ? n : 0));
+        if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        rd[i] = v;
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
       const int e = tid + 256 * i, row = e / AQ, kq = e - row * AQ;
@@ -463,21 +577,30 @@ int validate(const segsde_conv_desc* d) {
   return 0;
 }
 
-template <int BM, int BN, int WM, int WN>
-int launch_igemm(const ConvP& p, hipStream_t stream) {
+bool fast_ok(const ConvP& p) {
+  // uniform-tap chunks + 32-bit element offsets
+  const long e0 = (long)p.B * (p.H >> p.up0) * (p.W >> p.up0) * p.ld0;
+  const long e1 = (long)p.B * p.H * p.W * p.ld1;
+  return vec_ok(p) && (p.Ctot % 32 == 0) && (p.C1 == 0 || p.C0 % 32 == 0) && p.in_div == 1 && e0 < (1L << 31) &&
+         e1 < (1L << 31);
+}
+
+template <int BM, int BN, int WM, int WN, int MODE>
+int launch_igemm_mode(const ConvP& p, hipStream_t stream) {
   const int nblk = segsde_cdiv(p.M, BM) * segsde_cdiv(p.N, BN);
   const size_t smem = 2 * (size_t)(BM + BN) * LDT * sizeof(float);
-  if (vec_ok(p)) {
-    auto k = conv_igemm_kernel<BM, BN, WM, WN, true>;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    hipLaunchKernelGGL(k, dim3(nblk), dim3(256), smem, stream, p);
-  } else {
-    auto k = conv_igemm_kernel<BM, BN, WM, WN, false>;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    hipLaunchKernelGGL(k, dim3(nblk), dim3(256), smem, stream, p);
-  }
+  auto k = conv_igemm_kernel<BM, BN, WM, WN, MODE>;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  hipLaunchKernelGGL(k, dim3(nblk), dim3(256), smem, stream, p);
   SEGSDE_CHECK_LAUNCH();
   return 0;
+}
+
+template <int BM, int BN, int WM, int WN>
+int launch_igemm(const ConvP& p, hipStream_t stream) {
+  if (fast_ok(p)) return launch_igemm_mode<BM, BN, WM, WN, 2>(p, stream);
+  if (vec_ok(p)) return launch_igemm_mode<BM, BN, WM, WN, 1>(p, stream);
+  return launch_igemm_mode<BM, BN, WM, WN, 0>(p, stream);
 }
 
 }  // namespace
@@ -494,22 +617,25 @@ extern "C" int segsde_conv2d_forward(const segsde_conv_desc* d, const float* x0,
 }
 
 namespace {
-template <int BKT, int BN, int WM, int WN>
-int launch_wgrad(const ConvP& p, const float* dy, int lddy, float* ws, int splits, int cps, hipStream_t stream) {
+template <int BKT, int BN, int WM, int WN, int MODE>
+int launch_wgrad_mode(const ConvP& p, const float* dy, int lddy, float* ws, int splits, int cps, hipStream_t stream) {
   const dim3 grid(segsde_cdiv(p.Ktot, BKT), segsde_cdiv(p.N, BN), splits);
   const size_t smem = 2 * (size_t)BP * (BKT + BN) * sizeof(float);
-  const bool vec = vec_ok(p) && (p.N % 4 == 0) && (lddy % 4 == 0) && aligned16(dy);
-  if (vec) {
-    auto k = conv_wgrad_kernel<BKT, BN, WM, WN, true>;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    hipLaunchKernelGGL(k, grid, dim3(256), smem, stream, p, dy, lddy, ws, cps);
-  } else {
-    auto k = conv_wgrad_kernel<BKT, BN, WM, WN, false>;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    hipLaunchKernelGGL(k, grid, dim3(256), smem, stream, p, dy, lddy, ws, cps);
-  }
+  auto k = conv_wgrad_kernel<BKT, BN, WM, WN, MODE>;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  hipLaunchKernelGGL(k, grid, dim3(256), smem, stream, p, dy, lddy, ws, cps);
   SEGSDE_CHECK_LAUNCH();
   return 0;
+}
+
+template <int BKT, int BN, int WM, int WN>
+int launch_wgrad(const ConvP& p, const float* dy, int lddy, float* ws, int splits, int cps, hipStream_t stream) {
+  const bool vec = vec_ok(p) && (p.N % 4 == 0) && (lddy % 4 == 0) && aligned16(dy);
+  const long e0 = (long)p.B * (p.H >> p.up0) * (p.W >> p.up0) * p.ld0, e1 = (long)p.B * p.H * p.W * p.ld1;
+  const bool fast = vec && e0 < (1L << 31) && e1 < (1L << 31);
+  if (fast) return launch_wgrad_mode<BKT, BN, WM, WN, 2>(p, dy, lddy, ws, splits, cps, stream);
+  if (vec) return launch_wgrad_mode<BKT, BN, WM, WN, 1>(p, dy, lddy, ws, splits, cps, stream);
+  return launch_wgrad_mode<BKT, BN, WM, WN, 0>(p, dy, lddy, ws, splits, cps, stream);
 }
 
 void wgrad_plan(const segsde_conv_desc* d, int& bkt, int& bn, int& splits, int& cps) {

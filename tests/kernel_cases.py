@@ -39,6 +39,14 @@ CONV_CASES = [
     ("1x1_cout19", 1, 7, 9, 16, 0, False, 19, 1, 1, 1, 0, False, True, "none"),
     ("3x3_big_n", 1, 6, 6, 8, 0, False, 136, 3, 1, 1, 1, False, False, "none"),
     ("refl_tiny_h3", 1, 3, 4, 4, 0, False, 4, 3, 1, 1, 1, True, False, "none"),
+    # channel counts that are multiples of 32 take the FAST (uniform-tap, branch-free) loader path
+    ("fast_3x3", 2, 9, 11, 32, 0, False, 64, 3, 1, 1, 1, False, True, "relu"),
+    ("fast_refl_up_cat", 2, 8, 12, 32, 64, True, 32, 3, 1, 1, 1, True, True, "elu"),
+    ("fast_refl_cat", 1, 5, 6, 64, 32, False, 64, 3, 1, 1, 1, True, False, "none"),
+    ("fast_dil3", 1, 12, 10, 64, 0, False, 32, 3, 1, 3, 3, False, False, "none"),
+    ("fast_s2", 2, 11, 14, 32, 0, False, 64, 3, 2, 1, 1, False, False, "none"),
+    ("fast_1x1", 2, 7, 9, 96, 0, False, 160, 1, 1, 1, 0, False, True, "none"),
+    ("fast_1x1_s2", 1, 8, 10, 64, 0, False, 32, 1, 2, 1, 0, False, False, "none"),
 ]
 
 
