@@ -19,48 +19,71 @@ __host__ __device__ inline int red_blocks(long M) {
   return (int)(nb < 1 ? 1 : (nb > 512 ? 512 : nb));
 }
 
-// generic column reduction: Op::row(m, c, s0, s1) accumulates two sums for channel c over this block's rows
-template <class Op>
+// generic column reduction: Op::row(m, c, s0, s1) accumulates two sums for channel c over this block's rows.
+// VW = 4: each thread owns 4 consecutive channels (16-byte loads; 16 channel-quads x 16 row lanes per block),
+// VW = 1: one channel per thread (64 channels x 4 row lanes) for odd channel counts / unaligned pitches.
+template <class Op, int VW>
 __global__ __launch_bounds__(256) void colreduce_kernel(Op op, long M, int C, double* part) {
+  constexpr int TX = SLAB / VW, TY = 256 / TX;
   SEGSDE_SMEM;
-  double* sh = reinterpret_cast<double*>(segsde_smem);  // [2][RLANES][SLAB]
-  const int tx = threadIdx.x & (SLAB - 1), ty = threadIdx.x >> 6;
-  const int c = blockIdx.y * SLAB + tx;
+  double* sh = reinterpret_cast<double*>(segsde_smem);  // [2][TY][SLAB]
+  const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+  const int c = blockIdx.y * SLAB + tx * VW;
   const int nb = gridDim.x;
   const long rows_per = (M + nb - 1) / nb;
   const long r_begin = blockIdx.x * rows_per;
   long r_end = r_begin + rows_per; if (r_end > M) r_end = M;
-  double s0 = 0.0, s1 = 0.0;
-  if (c < C)
-    for (long m = r_begin + ty; m < r_end; m += RLANES) op.row(m, c, s0, s1);
-  sh[ty * SLAB + tx] = s0;
-  sh[(RLANES + ty) * SLAB + tx] = s1;
-  __syncthreads();
-  if (ty == 0 && c < C) {
-    double a = 0.0, b = 0.0;
+  double s0[VW], s1[VW];
 #pragma unroll
-    for (int j = 0; j < RLANES; ++j) { a += sh[j * SLAB + tx]; b += sh[(RLANES + j) * SLAB + tx]; }
-    part[((long)blockIdx.x * 2 + 0) * C + c] = a;
-    part[((long)blockIdx.x * 2 + 1) * C + c] = b;
+  for (int j = 0; j < VW; ++j) { s0[j] = 0.0; s1[j] = 0.0; }
+  if (c < C)
+    for (long m = r_begin + ty; m < r_end; m += TY) op.template row<VW>(m, c, s0, s1);
+#pragma unroll
+  for (int j = 0; j < VW; ++j) {
+    sh[ty * SLAB + tx * VW + j] = s0[j];
+    sh[(TY + ty) * SLAB + tx * VW + j] = s1[j];
+  }
+  __syncthreads();
+  const int cc = threadIdx.x;   // first 64 threads finish one channel each
+  if (cc < SLAB && blockIdx.y * SLAB + cc < C) {
+    double a = 0.0, b2 = 0.0;
+    for (int j = 0; j < TY; ++j) { a += sh[j * SLAB + cc]; b2 += sh[(TY + j) * SLAB + cc]; }
+    part[((long)blockIdx.x * 2 + 0) * C + blockIdx.y * SLAB + cc] = a;
+    part[((long)blockIdx.x * 2 + 1) * C + blockIdx.y * SLAB + cc] = b2;
   }
 }
 
 template <class Op>
-int launch_colreduce(Op op, long M, int C, double* part, hipStream_t s) {
+int launch_colreduce(Op op, long M, int C, double* part, bool vec, hipStream_t s) {
   const dim3 grid(red_blocks(M), (C + SLAB - 1) / SLAB);
-  hipLaunchKernelGGL((colreduce_kernel<Op>), grid, dim3(256), 2 * RLANES * SLAB * sizeof(double), s, op, M, C, part);
+  if (vec) hipLaunchKernelGGL((colreduce_kernel<Op, 4>), grid, dim3(256), 2 * 16 * SLAB * sizeof(double), s, op, M, C, part);
+  else hipLaunchKernelGGL((colreduce_kernel<Op, 1>), grid, dim3(256), 2 * 4 * SLAB * sizeof(double), s, op, M, C, part);
   SEGSDE_CHECK_LAUNCH();
   return 0;
 }
+
+template <int VW> struct VecF { float v[VW]; };
+template <int VW> __device__ __forceinline__ VecF<VW> ldv(const float* p) {
+  VecF<VW> r;
+  if (VW == 4) { const float4 t = *reinterpret_cast<const float4*>(p); r.v[0] = t.x; r.v[1 % VW] = t.y; r.v[2 % VW] = t.z; r.v[3 % VW] = t.w; }
+  else r.v[0] = p[0];
+  return r;
+}
+template <int VW> __device__ __forceinline__ void stv(float* p, const VecF<VW>& r) {
+  if (VW == 4) *reinterpret_cast<float4*>(p) = make_float4(r.v[0], r.v[1 % VW], r.v[2 % VW], r.v[3 % VW]);
+  else p[0] = r.v[0];
+}
+inline bool al16p(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 size_t part_bytes(long M, int C) { return (size_t)red_blocks(M) * 2 * C * sizeof(double); }
 
 // ------------------------------------------------------------------ BatchNorm forward
 struct StatsOp {
   const float* x; int ld;
-  __device__ void row(long m, int c, double& s0, double& s1) const {
-    const double v = (double)x[m * ld + c];
-    s0 += v; s1 += v * v;
+  template <int VW> __device__ void row(long m, int c, double* s0, double* s1) const {
+    const VecF<VW> t = ldv<VW>(x + m * ld + c);
+#pragma unroll
+    for (int j = 0; j < VW; ++j) { const double v = (double)t.v[j]; s0[j] += v; s1[j] += v * v; }
   }
 };
 
@@ -142,10 +165,14 @@ __device__ __forceinline__ float bn_dz(float dy, float y, int act, float drop_p,
 struct BnBwdOp {
   const float* dy; int lddy; const float* y; int ldy; const float* x; int ldx; const float* mean; const float* invstd;
   int act, C; float drop_p; uint64_t seed;
-  __device__ void row(long m, int c, double& s0, double& s1) const {
-    const float dz = bn_dz(dy[m * lddy + c], y[m * ldy + c], act, drop_p, seed, (uint64_t)(m * C + c));
-    const float xh = (x[m * ldx + c] - mean[c]) * invstd[c];
-    s0 += (double)dz * (double)xh; s1 += (double)dz;
+  template <int VW> __device__ void row(long m, int c, double* s0, double* s1) const {
+    const VecF<VW> g = ldv<VW>(dy + m * lddy + c), yy = ldv<VW>(y + m * ldy + c), xx = ldv<VW>(x + m * ldx + c);
+#pragma unroll
+    for (int j = 0; j < VW; ++j) {
+      const float dz = bn_dz(g.v[j], yy.v[j], act, drop_p, seed, (uint64_t)(m * C + c + j));
+      const float xh = (xx.v[j] - mean[c + j]) * invstd[c + j];
+      s0[j] += (double)dz * (double)xh; s1[j] += (double)dz;
+    }
   }
 };
 
@@ -158,44 +185,58 @@ __global__ __launch_bounds__(256) void pair_finalize_kernel(const double* part, 
   if (out1) out1[c] = (float)b;
 }
 
+template <int VW>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* dy, int lddy, const float* y, int ldy,
                                                            const float* x, int ldx, long M, int C, const float* mean,
                                                            const float* invstd, const float* gamma, int act,
                                                            float drop_p, uint64_t seed, int batch_stats,
                                                            const float* dgamma, const float* dbeta, float* dx, int lddx,
                                                            float* dres, int lddres) {
-  const long total = M * C;
+  const int CV = C / VW;
+  const long total = M * CV;
   const float invM = 1.f / (float)M;
   for (long e = blockIdx.x * 256L + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
-    const long m = e / C; const int c = (int)(e - m * C);
-    const float dz = bn_dz(dy[m * lddy + c], y[m * ldy + c], act, drop_p, seed, (uint64_t)e);
-    if (dres) dres[m * lddres + c] = dz;
-    if (dx) {
-      const float g = gamma ? gamma[c] : 1.f;
-      float v;
-      if (batch_stats) {
-        const float xh = (x[m * ldx + c] - mean[c]) * invstd[c];
-        v = g * invstd[c] * (dz - dbeta[c] * invM - xh * dgamma[c] * invM);
-      } else {
-        v = g * invstd[c] * dz;
+    const long m = e / CV; const int c = (int)(e - m * CV) * VW;
+    const VecF<VW> g = ldv<VW>(dy + m * lddy + c), yy = ldv<VW>(y + m * ldy + c);
+    VecF<VW> xx;
+    if (dx && batch_stats) xx = ldv<VW>(x + m * ldx + c);
+    VecF<VW> dz, o;
+#pragma unroll
+    for (int j = 0; j < VW; ++j) {
+      dz.v[j] = bn_dz(g.v[j], yy.v[j], act, drop_p, seed, (uint64_t)(m * C + c + j));
+      if (dx) {
+        const float gm = gamma ? gamma[c + j] : 1.f;
+        if (batch_stats) {
+          const float xh = (xx.v[j] - mean[c + j]) * invstd[c + j];
+          o.v[j] = gm * invstd[c + j] * (dz.v[j] - dbeta[c + j] * invM - xh * dgamma[c + j] * invM);
+        } else {
+          o.v[j] = gm * invstd[c + j] * dz.v[j];
+        }
       }
-      dx[m * lddx + c] = v;
     }
+    if (dres) stv<VW>(dres + m * lddres + c, dz);
+    if (dx) stv<VW>(dx + m * lddx + c, o);
   }
 }
 
 // ------------------------------------------------------------------ activation backward + bias gradient
 struct ActBwdOp {
   const float* dy; int lddy; const float* y; int ldy; float* dz; int lddz; int act;
-  __device__ void row(long m, int c, double& s0, double& s1) const {
-    const float g = dy[m * lddy + c] * segsde_act_grad_from_out(y[m * ldy + c], act);
-    if (dz) dz[m * lddz + c] = g;
-    s0 += (double)g;
+  template <int VW> __device__ void row(long m, int c, double* s0, double* s1) const {
+    const VecF<VW> g = ldv<VW>(dy + m * lddy + c), yy = ldv<VW>(y + m * ldy + c);
+    VecF<VW> o;
+#pragma unroll
+    for (int j = 0; j < VW; ++j) { o.v[j] = g.v[j] * segsde_act_grad_from_out(yy.v[j], act); s0[j] += (double)o.v[j]; }
+    if (dz) stv<VW>(dz + m * lddz + c, o);
   }
 };
 struct ColsumOp {
   const float* x; int ld;
-  __device__ void row(long m, int c, double& s0, double& s1) const { s0 += (double)x[m * ld + c]; }
+  template <int VW> __device__ void row(long m, int c, double* s0, double* s1) const {
+    const VecF<VW> t = ldv<VW>(x + m * ld + c);
+#pragma unroll
+    for (int j = 0; j < VW; ++j) s0[j] += (double)t.v[j];
+  }
 };
 
 // ------------------------------------------------------------------ max-pool 3x3 s2 p1
@@ -423,7 +464,8 @@ extern "C" int segsde_bn_stats(const float* x, int ldx, long M, int C, float* me
   if (M <= 0 || C <= 0 || ldx < C) return SEGSDE_ERR_SHAPE;
   if (ws_bytes < part_bytes(M, C)) return SEGSDE_ERR_WORKSPACE;
   StatsOp op{x, ldx};
-  if (int e = launch_colreduce(op, M, C, (double*)ws, ST(stream))) return e;
+  const bool vec = (C % 4 == 0) && (ldx % 4 == 0) && al16p(x);
+  if (int e = launch_colreduce(op, M, C, (double*)ws, vec, ST(stream))) return e;
   hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, ST(stream), (const double*)ws,
                      red_blocks(M), M, C, eps, momentum, mean, invstd, running_mean, running_var);
   SEGSDE_CHECK_LAUNCH();
@@ -464,14 +506,21 @@ extern "C" int segsde_bn_backward(const float* dy, int lddy, const float* y, int
   if (M <= 0 || C <= 0) return SEGSDE_ERR_SHAPE;
   if (ws_bytes < part_bytes(M, C)) return SEGSDE_ERR_WORKSPACE;
   BnBwdOp op{dy, lddy, y, ldy, x, ldx, mean, invstd, act, C, drop_p, seed};
-  if (int e = launch_colreduce(op, M, C, (double*)ws, ST(stream))) return e;
+  const bool vec = (C % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) && (lddy % 4 == 0) && al16p(x) && al16p(y) && al16p(dy);
+  if (int e = launch_colreduce(op, M, C, (double*)ws, vec, ST(stream))) return e;
   hipLaunchKernelGGL(pair_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, ST(stream), (const double*)ws,
                      red_blocks(M), C, dgamma, dbeta);
   SEGSDE_CHECK_LAUNCH();
   if (dx || dres) {
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_blocks(M * C)), dim3(256), 0, ST(stream), dy, lddy, y, ldy, x, ldx, M,
-                       C, mean, invstd, gamma, act, drop_p, seed, batch_stats, (const float*)dgamma,
-                       (const float*)dbeta, dx, lddx, dres, lddres);
+    const bool v4 = vec && (!dx || ((lddx % 4 == 0) && al16p(dx))) && (!dres || ((lddres % 4 == 0) && al16p(dres)));
+    if (v4)
+      hipLaunchKernelGGL(bn_bwd_apply_kernel<4>, dim3(ew_blocks(M * C / 4)), dim3(256), 0, ST(stream), dy, lddy, y, ldy, x,
+                         ldx, M, C, mean, invstd, gamma, act, drop_p, seed, batch_stats, (const float*)dgamma,
+                         (const float*)dbeta, dx, lddx, dres, lddres);
+    else
+      hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, dim3(ew_blocks(M * C)), dim3(256), 0, ST(stream), dy, lddy, y, ldy, x, ldx,
+                         M, C, mean, invstd, gamma, act, drop_p, seed, batch_stats, (const float*)dgamma,
+                         (const float*)dbeta, dx, lddx, dres, lddres);
     SEGSDE_CHECK_LAUNCH();
   }
   return 0;
@@ -483,7 +532,9 @@ extern "C" int segsde_act_backward(const float* dy, int lddy, const float* y, in
   if (M <= 0 || C <= 0) return SEGSDE_ERR_SHAPE;
   if (ws_bytes < part_bytes(M, C)) return SEGSDE_ERR_WORKSPACE;
   ActBwdOp op{dy, lddy, y, ldy, dz, lddz, act};
-  if (int e = launch_colreduce(op, M, C, (double*)ws, ST(stream))) return e;
+  const bool vec = (C % 4 == 0) && (ldy % 4 == 0) && (lddy % 4 == 0) && al16p(y) && al16p(dy) &&
+                   (!dz || ((lddz % 4 == 0) && al16p(dz)));
+  if (int e = launch_colreduce(op, M, C, (double*)ws, vec, ST(stream))) return e;
   if (dbias) {
     hipLaunchKernelGGL(pair_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, ST(stream), (const double*)ws,
                        red_blocks(M), C, dbias, (float*)nullptr);
@@ -497,7 +548,8 @@ extern "C" int segsde_colsum(const float* x, int ldx, long M, int C, float* out,
   if (M <= 0 || C <= 0) return SEGSDE_ERR_SHAPE;
   if (ws_bytes < part_bytes(M, C)) return SEGSDE_ERR_WORKSPACE;
   ColsumOp op{x, ldx};
-  if (int e = launch_colreduce(op, M, C, (double*)ws, ST(stream))) return e;
+  const bool vec = (C % 4 == 0) && (ldx % 4 == 0) && al16p(x);
+  if (int e = launch_colreduce(op, M, C, (double*)ws, vec, ST(stream))) return e;
   hipLaunchKernelGGL(pair_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, ST(stream), (const double*)ws,
                      red_blocks(M), C, out, (float*)nullptr);
   SEGSDE_CHECK_LAUNCH();

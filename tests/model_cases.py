@@ -252,7 +252,7 @@ def run_full_model(device, golden, name):
         if n < 0 or got < 0:
             if not (n < 0 and got < 0):
                 bad.append((k, n, got))
-        elif abs(got - n) > 5e-2 * abs(n) + 1e-6:
+        elif abs(got - n) > 5e-2 * abs(n) + 1e-5:
             bad.append((k, n, got))
         elif abs(got - n) > 5e-3 * abs(n) + 1e-6:
             loose += 1
@@ -262,3 +262,47 @@ def run_full_model(device, golden, name):
                  what="conv1 grad")
     assert_close(model.models["encoder"].encoder.bn1.running_mean, g[name + "_bn1_running_mean_after"], rtol=1e-3,
                  atol=1e-5, what="bn1 running mean")
+
+
+def run_loss_vs_reference(device, golden):
+    """product MonodepthLoss (one fused autograd node on the HIP loss kernels) vs the reference's own loss values,
+    auto-mask selections (bit-exact) and gradients w.r.t. disparities and poses, all four flag variants"""
+    from improving_segmentation_with_selfsupervised_depth_amd.loss import MonodepthLoss
+    for variant in ["default", "no_ssim", "avg_reprojection", "disable_automasking"]:
+        g = golden("loss_" + variant)
+        cfg = json.loads(str(g["cfg_json"]))
+        inputs = {}
+        for f, t in ((0, "0"), (-1, "-1"), (1, "1")):
+            inputs[("color", f, 0)] = g["in_color_%s_0" % t].to(device)
+        for s in range(1, 4):
+            inputs[("color", 0, s)] = g["in_color_0_%d" % s].to(device)
+        inputs[("K", 0)], inputs[("inv_K", 0)] = g["in_K_0"].to(device), g["in_inv_K_0"].to(device)
+        obj = MonodepthLoss(**cfg)
+        out = {}
+        disps = {s: g["disp_%d" % s].clone().to(device).requires_grad_(True) for s in range(4)}
+        Ts = {f: g["T_" + t].clone().to(device).requires_grad_(True) for f, t in ((-1, "m1"), (1, "p1"))}
+        for s in range(4):
+            out[("disp", s)] = disps[s]
+        for f in (-1, 1):
+            out[("cam_T_cam", 0, f)] = Ts[f]
+        if not cfg["disable_automasking"]:
+            obj.tiebreak_noise = {s: g["noise_%d" % s] for s in range(4)}
+        obj.generate_images_pred(inputs, out)
+        losses = obj.compute_losses(inputs, out)
+        losses["loss"].backward()
+        assert_close(losses["loss"], g["loss"], rtol=1e-5, atol=1e-7, what=variant + " loss")
+        for s in range(4):
+            assert_close(losses["loss/%d" % s], g["loss_%d" % s], rtol=1e-5, atol=1e-7, what=variant + " loss/%d" % s)
+            assert_close(out[("depth", 0, s)], g["depth_%d" % s], rtol=1e-5, what="depth")
+            gscale = float(g["grad_disp_%d" % s].abs().max())
+            err = float((disps[s].grad.cpu() - g["grad_disp_%d" % s]).abs().max())
+            assert err <= 1e-3 * gscale, (variant, s, err, gscale)
+            if not cfg["disable_automasking"]:
+                assert torch.equal(out["identity_selection/%d" % s].cpu(), g["identity_selection_%d" % s]), (variant, s)
+        for f, t in ((-1, "m1"), (1, "p1")):
+            gs = float(g["grad_T_" + t].abs().max())
+            err = float((Ts[f].grad.cpu() - g["grad_T_" + t]).abs().max())
+            assert err <= 1e-3 * gs, (variant, t, err, gs)
+            for s in (0, 2):
+                assert_close(out[("sample", f, s)], g["sample_%s_%d" % (t, s)], rtol=1e-4, atol=1e-5, what="sample")
+                assert_close(out[("color", f, s)], g["color_%s_%d" % (t, s)], rtol=1e-3, atol=1e-4, what="color")

@@ -37,3 +37,7 @@ def test_decoders(golden, which):
 
 def test_encoder_r18(golden):
     MC.run_encoder("cpu", golden, ("r18",))
+
+
+def test_monodepth_loss_vs_reference(golden):
+    MC.run_loss_vs_reference("cpu", golden)
