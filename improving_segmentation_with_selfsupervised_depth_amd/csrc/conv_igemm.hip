@@ -22,6 +22,8 @@
 // MFMA operand order inside a 8-wide k group is permuted (lane half h, step s) -> k = 4h + s so that each
 // lane fetches its 4 A (and 4 B) values with ONE 16-byte LDS read.
 #include "segsde_common.h"
+#include <cstdlib>
+#include <cstring>
 
 namespace {
 
@@ -31,7 +33,7 @@ struct ConvP {
   int B, H, W, C0, C1, ld0, ld1, up0;
   int Ho, Wo, N, ldy, ldy2, nsplit;
   int KH, KW, stride, dil, pad, pad_mode, in_div;
-  int Ctot, Ktot, M, act;
+  int Ctot, Ktot, M, act, stagger;
 };
 
 struct KInfo {  // decoded reduction index k -> tap + channel + source
@@ -122,8 +124,7 @@ __device__ __forceinline__ float4 fetch_w4(const ConvP& p, int n, int k) {
   return v;
 }
 
-constexpr int BK = 32;    // reduction elements per staged chunk
-constexpr int LDT = 36;   // LDS row pitch in floats (BK + 4): conflict-free ds_read_b128 fragments
+// reduction elements per staged chunk: template parameter BK (32, or 64 on the FAST path when channels allow)
 
 // ---------------------------------------------------------------------------------------------------
 // forward / data-gradient kernel
@@ -134,8 +135,8 @@ constexpr int LDT = 36;   // LDS row pitch in floats (BK + 4): conflict-free ds_
 // clamped (always valid) addresses + a select, instead of the branchy generic gather.
 struct ChunkState {
   int c0, kh, kw;   // channel offset inside the concatenated input, tap coordinates
-  __device__ __forceinline__ void advance(const ConvP& p) {
-    c0 += 32;
+  __device__ __forceinline__ void advance(const ConvP& p, int bk) {
+    c0 += bk;
     if (c0 == p.Ctot) { c0 = 0; if (++kw == p.KW) { kw = 0; ++kh; } }
   }
 };
@@ -150,28 +151,51 @@ __device__ __forceinline__ SrcSel select_src(const ConvP& p, int c) {
   return s;
 }
 
-__device__ __forceinline__ float4 fast_fetch(const ConvP& p, const SrcSel& s, int b, int hi, int wi, bool ok, int cq) {
+__device__ __forceinline__ float4 ld4_at(const SrcSel& s, int b, int hi, int wi, int cq) {
+  const unsigned off = (unsigned)b * s.bstride + ((unsigned)(hi >> s.shift) * s.Ws + (unsigned)(wi >> s.shift)) * s.ld +
+                       (unsigned)(s.cc + cq);
+  return *reinterpret_cast<const float4*>(s.src + off);
+}
+
+// (hi, wi) = output pixel + tap offset (dh, dw)
+__device__ __forceinline__ float4 fast_fetch(const ConvP& p, const SrcSel& s, int b, int hi, int wi, bool ok, int cq,
+                                             int dh, int dw) {
   if (p.pad_mode == SEGSDE_PAD_REFLECT) {
     hi = hi < 0 ? -hi : (hi >= p.H ? 2 * p.H - 2 - hi : hi);
     wi = wi < 0 ? -wi : (wi >= p.W ? 2 * p.W - 2 - wi : wi);
-  } else {
-    ok = ok && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+    hi = ok ? hi : 0; wi = ok ? wi : 0;
+    float4 v = ld4_at(s, b, hi, wi, cq);
+    if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+    return v;
   }
-  hi = ok ? hi : 0; wi = ok ? wi : 0;
-  const unsigned off = (unsigned)b * s.bstride + ((unsigned)(hi >> s.shift) * s.Ws + (unsigned)(wi >> s.shift)) * s.ld +
-                       (unsigned)(s.cc + cq);
-  float4 v = *reinterpret_cast<const float4*>(s.src + off);
-  if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+  const bool hin = (unsigned)hi < (unsigned)p.H, win = (unsigned)wi < (unsigned)p.W;
+  const bool okp = ok && hin && win;
+  float4 v = ld4_at(s, b, okp ? hi : 0, okp ? wi : 0, cq);
+  if (!okp) v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (p.pad_mode == SEGSDE_PAD_REFLECT_ADJOINT && ok) {
+    // data-gradient of a reflection-padded 3x3/s1 conv: a pixel in row 1 (H-2) also collects what flowed into the
+    // mirrored padding row -1 (H); that pre-image is reachable only through the tap with dh = +1 (-1).  Same for columns.
+    const int ho = hi - dh, wo = wi - dw;
+    const int eh = (ho == 1 && dh == 1) ? 0 : ((ho == p.H - 2 && dh == -1) ? p.H - 1 : -1);
+    const int ew = (wo == 1 && dw == 1) ? 0 : ((wo == p.W - 2 && dw == -1) ? p.W - 1 : -1);
+    if (eh >= 0 || ew >= 0) {
+      if (eh >= 0 && win) { const float4 t = ld4_at(s, b, eh, wi, cq); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+      if (ew >= 0 && hin) { const float4 t = ld4_at(s, b, hi, ew, cq); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+      if (eh >= 0 && ew >= 0) { const float4 t = ld4_at(s, b, eh, ew, cq); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+    }
+  }
   return v;
 }
 
 // MODE 0: generic scalar gather, 1: generic float4 gather, 2: FAST (uniform tap per chunk, branch-free loads)
-template <int BM, int BN, int WM, int WN, int MODE>
+template <int BM, int BN, int WM, int WN, int MODE, int BK>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
   constexpr bool VEC = MODE >= 1;
   constexpr bool FAST = MODE == 2;
+  constexpr int LDT = BK + 4;               // LDS row pitch (floats): conflict-free ds_read_b128 fragments
+  constexpr int KQ = BK / 4, RP = 256 / KQ; // float4 columns per tile row, tile rows staged per pass
   constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
-  constexpr int AR = BM / 32, BR = BN / 32;
+  constexpr int AR = BM / RP, BR = BN / RP;
   constexpr int STAGE = (BM + BN) * LDT;
   static_assert(WM * WN == 4, "4 waves per workgroup");
   SEGSDE_SMEM;
@@ -185,18 +209,20 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave - wm * WN;
-  const int kq = tid & 7, r0 = tid >> 3;
+  const int kq = tid % KQ, r0 = tid / KQ;
+  if (p.stagger && ((blockIdx.x >> 8) & 1))   // experiment: de-phase the two co-resident workgroups of a CU
+    for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(8);
 
   int rb[AR], rh[AR], rw[AR];
   bool rok[AR];
 #pragma unroll
-  for (int i = 0; i < AR; ++i) decode_m(p, m0 + r0 + 32 * i, rb[i], rh[i], rw[i], rok[i]);
+  for (int i = 0; i < AR; ++i) decode_m(p, m0 + r0 + RP * i, rb[i], rh[i], rw[i], rok[i]);
   // FAST: weight-row bases (clamped) and validity
   const float* wrow[BR];
   bool nok[BR];
 #pragma unroll
   for (int i = 0; i < BR; ++i) {
-    const int n = n0 + r0 + 32 * i;
+    const int n = n0 + r0 + RP * i;
     nok[i] = n < p.N;
     wrow[i] = p.w + (long)(nok[i] ? n : 0) * p.Ktot + 4 * kq;
   }
@@ -218,29 +244,29 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
       const SrcSel s = select_src(p, cs.c0);
       const int dh = cs.kh * p.dil - p.pad, dw = cs.kw * p.dil - p.pad;
 #pragma unroll
-      for (int i = 0; i < AR; ++i) ra[i] = fast_fetch(p, s, rb[i], rh[i] + dh, rw[i] + dw, rok[i], 4 * kq);
+      for (int i = 0; i < AR; ++i) ra[i] = fast_fetch(p, s, rb[i], rh[i] + dh, rw[i] + dw, rok[i], 4 * kq, dh, dw);
 #pragma unroll
       for (int i = 0; i < BR; ++i) {
         float4 v = *reinterpret_cast<const float4*>(wrow[i] + kc * BK);
         if (!nok[i]) v = make_float4(0.f, 0.f, 0.f, 0.f);
         rbv[i] = v;
       }
-      cs.advance(p);
+      cs.advance(p, BK);
     } else {
       const int k = kc * BK + 4 * kq;
 #pragma unroll
       for (int i = 0; i < AR; ++i) ra[i] = fetch_a4<VEC>(p, k, rb[i], rh[i], rw[i], rok[i]);
 #pragma unroll
-      for (int i = 0; i < BR; ++i) rbv[i] = fetch_w4<VEC>(p, n0 + r0 + 32 * i, k);
+      for (int i = 0; i < BR; ++i) rbv[i] = fetch_w4<VEC>(p, n0 + r0 + RP * i, k);
     }
   };
   auto lstore = [&](int buf) {
     float* As = smem + buf * STAGE;
     float* Bs = As + BM * LDT;
 #pragma unroll
-    for (int i = 0; i < AR; ++i) *reinterpret_cast<float4*>(As + (r0 + 32 * i) * LDT + 4 * kq) = ra[i];
+    for (int i = 0; i < AR; ++i) *reinterpret_cast<float4*>(As + (r0 + RP * i) * LDT + 4 * kq) = ra[i];
 #pragma unroll
-    for (int i = 0; i < BR; ++i) *reinterpret_cast<float4*>(Bs + (r0 + 32 * i) * LDT + 4 * kq) = rbv[i];
+    for (int i = 0; i < BR; ++i) *reinterpret_cast<float4*>(Bs + (r0 + RP * i) * LDT + 4 * kq) = rbv[i];
   };
 
   gload(0);
@@ -255,7 +281,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
       const float* Ap = As + (wm * TM * 32 + (lane & 31)) * LDT + 4 * (lane >> 5);
       const float* Bp = Bs + (wn * TN * 32 + (lane & 31)) * LDT + 4 * (lane >> 5);
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
+      for (int g = 0; g < BK / 8; ++g) {
         float4 a[TM], b[TN];
 #pragma unroll
         for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const float4*>(Ap + i * 32 * LDT + 8 * g);
@@ -365,7 +391,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvP p, const float* d
     if (FAST) {
 #pragma unroll
       for (int i = 0; i < AI; ++i) {
-        ra[i] = fast_fetch(p, fs, fb[i], fh[i] + fdh, fw[i] + fdw, fk_ok && fm[i] < p.M, 0);
+        ra[i] = fast_fetch(p, fs, fb[i], fh[i] + fdh, fw[i] + fdw, fk_ok && fm[i] < p.M, 0, fdh, fdw);
         fm[i] += BP; fw[i] += wstep;
         while (fw[i] >= wlim) { fw[i] -= wlim; fh[i] += p.stride; }
         while (fh[i] >= hlim) { fh[i] -= hlim; ++fb[i]; }
@@ -506,7 +532,7 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float* w, float*
 // The main dgrad GEMM treats the padding as zeros; pixels whose row is 1 or H-2 (col 1 or W-2) additionally
 // receive the gradient that flowed into the mirrored padding cells.  dx[b,h,w,c] += sum over extra padded
 // pre-images (hp,wp) of (h,w), taps (kh,kw), o:  w[o][c][kh][kw] * dy[b, hp-kh+1, wp-kw+1, o].
-__global__ __launch_bounds__(256) void reflect_dgrad_fix_kernel(const float* dy, int lddy, const float* w_oihw,
+__global__ __launch_bounds__(256) void reflect_dgrad_fix_kernel(const float* dy, int lddy, const float* wd /*[Cin][3][3][Cout] flipped*/,
                                                                 float* dx, int lddx, float* dx2, int lddx2,
                                                                 int nsplit, int B, int H, int W, int Cin, int Cout) {
   // candidate border pixels: 4 lines per image (row 1, row H-2, col 1, col W-2); a pixel that lies on several
@@ -537,8 +563,8 @@ __global__ __launch_bounds__(256) void reflect_dgrad_fix_kernel(const float* dy,
             const int yw = wp[bb] - kw + 1;
             if (yw < 0 || yw >= W) continue;
             const float* dyp = dy + ((long)(b * H + yh) * W + yw) * lddy;
-            const float* wq = w_oihw + ((long)c * 9 + kh * 3 + kw);
-            for (int o = 0; o < Cout; ++o) s += dyp[o] * wq[(long)o * Cin * 9];
+            const float* wq = wd + (((long)c * 3 + (2 - kh)) * 3 + (2 - kw)) * Cout;   // = w_oihw[o][c][kh][kw]
+            for (int o = 0; o < Cout; ++o) s += dyp[o] * wq[o];
           }
         }
       }
@@ -546,6 +572,20 @@ __global__ __launch_bounds__(256) void reflect_dgrad_fix_kernel(const float* dy,
     if (c < nsplit) dx[pix * lddx + c] += s;
     else dx2[pix * lddx2 + (c - nsplit)] += s;
   }
+}
+
+// experiment knobs (environment SEGSDE_TUNE="bk64=1,stagger=32"), read once
+struct Tune { int bk64 = 0, stagger = 0; };
+const Tune& tune() {
+  static Tune t = [] {
+    Tune r;
+    if (const char* e = getenv("SEGSDE_TUNE")) {
+      if (const char* q = strstr(e, "bk64=")) r.bk64 = atoi(q + 5);
+      if (const char* q = strstr(e, "stagger=")) r.stagger = atoi(q + 8);
+    }
+    return r;
+  }();
+  return t;
 }
 
 ConvP make_params(const segsde_conv_desc* d, const float* x0, const float* x1, const float* w, const float* bias,
@@ -558,6 +598,7 @@ ConvP make_params(const segsde_conv_desc* d, const float* x0, const float* x1, c
   p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.dil = d->dil; p.pad = d->pad; p.pad_mode = d->pad_mode;
   p.in_div = d->in_div < 1 ? 1 : d->in_div;
   p.Ctot = d->C0 + d->C1; p.Ktot = d->KH * d->KW * p.Ctot; p.M = d->B * d->Ho * d->Wo; p.act = d->act;
+  p.stagger = tune().stagger;
   return p;
 }
 
@@ -573,6 +614,10 @@ int validate(const segsde_conv_desc* d) {
   if (d->KH <= 0 || d->KW <= 0 || d->stride <= 0 || d->dil <= 0 || d->pad < 0) return SEGSDE_ERR_SHAPE;
   if (d->up0 && ((d->H & 1) || (d->W & 1))) return SEGSDE_ERR_SHAPE;
   if (d->pad_mode == SEGSDE_PAD_REFLECT && (d->pad >= d->H || d->pad >= d->W)) return SEGSDE_ERR_SHAPE;
+  if (d->pad_mode == SEGSDE_PAD_REFLECT_ADJOINT &&
+      (d->KH != 3 || d->KW != 3 || d->stride != 1 || d->dil != 1 || d->pad != 1 || d->in_div > 1 || d->C1 != 0 ||
+       d->H != d->Ho || d->W != d->Wo || d->H < 2 || d->W < 2))
+    return SEGSDE_ERR_SHAPE;
   if (d->ld0 < d->C0 || (d->C1 && d->ld1 < d->C1) || d->ldy <= 0) return SEGSDE_ERR_SHAPE;
   return 0;
 }
@@ -584,12 +629,13 @@ bool fast_ok(const ConvP& p) {
   return vec_ok(p) && (p.Ctot % 32 == 0) && (p.C1 == 0 || p.C0 % 32 == 0) && p.in_div == 1 && e0 < (1L << 31) &&
          e1 < (1L << 31);
 }
+bool bk64_ok(const ConvP& p) { return fast_ok(p) && (p.Ctot % 64 == 0) && (p.C1 == 0 || p.C0 % 64 == 0); }
 
-template <int BM, int BN, int WM, int WN, int MODE>
+template <int BM, int BN, int WM, int WN, int MODE, int BK>
 int launch_igemm_mode(const ConvP& p, hipStream_t stream) {
   const int nblk = segsde_cdiv(p.M, BM) * segsde_cdiv(p.N, BN);
-  const size_t smem = 2 * (size_t)(BM + BN) * LDT * sizeof(float);
-  auto k = conv_igemm_kernel<BM, BN, WM, WN, MODE>;
+  const size_t smem = 2 * (size_t)(BM + BN) * (BK + 4) * sizeof(float);
+  auto k = conv_igemm_kernel<BM, BN, WM, WN, MODE, BK>;
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   hipLaunchKernelGGL(k, dim3(nblk), dim3(256), smem, stream, p);
   SEGSDE_CHECK_LAUNCH();
@@ -598,11 +644,21 @@ int launch_igemm_mode(const ConvP& p, hipStream_t stream) {
 
 template <int BM, int BN, int WM, int WN>
 int launch_igemm(const ConvP& p, hipStream_t stream) {
-  if (fast_ok(p)) return launch_igemm_mode<BM, BN, WM, WN, 2>(p, stream);
-  if (vec_ok(p)) return launch_igemm_mode<BM, BN, WM, WN, 1>(p, stream);
-  return launch_igemm_mode<BM, BN, WM, WN, 0>(p, stream);
+  if (tune().bk64 && bk64_ok(p)) return launch_igemm_mode<BM, BN, WM, WN, 2, 64>(p, stream);
+  if (fast_ok(p)) return launch_igemm_mode<BM, BN, WM, WN, 2, 32>(p, stream);
+  if (vec_ok(p)) return launch_igemm_mode<BM, BN, WM, WN, 1, 32>(p, stream);
+  return launch_igemm_mode<BM, BN, WM, WN, 0, 32>(p, stream);
 }
 
+int launch_reflect_fix(const float* dy, int lddy, const float* wd, float* dx, int lddx, float* dx2, int lddx2, int nsplit,
+                       int B, int H, int W, int Cin, int Cout, hipStream_t s) {
+  if (!dx2) { dx2 = dx; lddx2 = lddx; nsplit = Cin; }
+  const long total = (long)B * (2 * W + 2 * H) * Cin;
+  hipLaunchKernelGGL(reflect_dgrad_fix_kernel, dim3(min(4096, segsde_cdiv(total, 256))), dim3(256), 0, s, dy, lddy, wd, dx,
+                     lddx, dx2, lddx2, nsplit, B, H, W, Cin, Cout);
+  SEGSDE_CHECK_LAUNCH();
+  return 0;
+}
 }  // namespace
 
 extern "C" int segsde_conv2d_forward(const segsde_conv_desc* d, const float* x0, const float* x1, const float* wpack,
@@ -611,9 +667,15 @@ extern "C" int segsde_conv2d_forward(const segsde_conv_desc* d, const float* x0,
   if (!x0 || !wpack || !y || (d->C1 && !x1)) return SEGSDE_ERR_NULL;
   const ConvP p = make_params(d, x0, x1, wpack, bias, y, y2);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (p.N <= 32) return launch_igemm<128, 32, 4, 1>(p, s);
-  if (p.N <= 64) return launch_igemm<128, 64, 2, 2>(p, s);
-  return launch_igemm<128, 128, 2, 2>(p, s);
+  int e;
+  if (p.N <= 32) e = launch_igemm<128, 32, 4, 1>(p, s);
+  else if (p.N <= 64) e = launch_igemm<128, 64, 2, 2>(p, s);
+  else e = launch_igemm<128, 128, 2, 2>(p, s);
+  if (e) return e;
+  if (d->pad_mode == SEGSDE_PAD_REFLECT_ADJOINT && !fast_ok(p))
+    // the generic gathers treat the padding as zeros; add the mirrored-padding contributions on the border pixels
+    return launch_reflect_fix(x0, p.ld0, wpack, y, p.ldy, y2, p.ldy2, p.nsplit, p.B, p.H, p.W, p.N, p.C0, s);
+  return 0;
 }
 
 namespace {
@@ -693,15 +755,10 @@ extern "C" int segsde_pack_weight(const float* w_oihw, float* out, int O, int I,
   return 0;
 }
 
-extern "C" int segsde_reflect_dgrad_fix(const float* dy, int lddy, const float* w_oihw, float* dx, int lddx, float* dx2,
+extern "C" int segsde_reflect_dgrad_fix(const float* dy, int lddy, const float* wdpack, float* dx, int lddx, float* dx2,
                                         int lddx2, int nsplit, int B, int H, int W, int Cin, int Cout, void* stream) {
-  if (!dy || !w_oihw || !dx) return SEGSDE_ERR_NULL;
+  if (!dy || !wdpack || !dx) return SEGSDE_ERR_NULL;
   if (H < 2 || W < 2) return SEGSDE_ERR_SHAPE;
-  if (!dx2) { dx2 = dx; lddx2 = lddx; nsplit = Cin; }
-  const long total = (long)B * (2 * W + 2 * H) * Cin;
-  hipLaunchKernelGGL(reflect_dgrad_fix_kernel, dim3(min(4096, segsde_cdiv(total, 256))), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), dy, lddy, w_oihw, dx, lddx, dx2, lddx2, nsplit, B, H, W, Cin,
-                     Cout);
-  SEGSDE_CHECK_LAUNCH();
-  return 0;
+  return launch_reflect_fix(dy, lddy, wdpack, dx, lddx, dx2, lddx2, nsplit, B, H, W, Cin, Cout,
+                            static_cast<hipStream_t>(stream));
 }

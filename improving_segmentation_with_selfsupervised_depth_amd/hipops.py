@@ -27,7 +27,7 @@ def _timed(kind, flops, like, launch):
     e.record()
     PROFILE.append((kind, flops, s, e))
     return r
-PAD_ZERO, PAD_REFLECT = 0, 1
+PAD_ZERO, PAD_REFLECT, PAD_REFLECT_ADJOINT = 0, 1, 2
 
 
 def _stream(t):
@@ -123,14 +123,11 @@ def conv_dgrad(g, dy, wdpack, w_oihw, in_hw, need0=True, need1=True):
     dx1 = torch.empty((B, H, W, g.C1), dtype=torch.float32, device=dy.device) if g.C1 else None
     d = ConvDesc(B=B, H=Ho, W=Wo, C0=Cout, C1=0, ld0=nhwc_ld(dy), ld1=0, up0=0, Ho=H, Wo=W, Cout=g.Cin, ldy=g.C0,
                  ldy2=g.C1, nsplit=g.C0, KH=g.k, KW=g.k, stride=1, dil=g.dil, pad=(g.k - 1) * g.dil - g.pad,
-                 pad_mode=PAD_ZERO, in_div=g.stride, act=0)
+                 pad_mode=PAD_REFLECT_ADJOINT if g.reflect else PAD_ZERO, in_div=g.stride, act=0)
     L = _lib.lib()
     flops = 2.0 * B * Ho * Wo * Cout * g.Cin * g.k * g.k
     _timed("conv_dgrad", flops, dy, lambda: check(L.segsde_conv2d_forward(
         ctypes.byref(d), _p(_f32(dy)), None, _p(wdpack), None, _p(full0), _p(dx1), _stream(dy)), "conv2d dgrad"))
-    if g.reflect:
-        check(L.segsde_reflect_dgrad_fix(_p(dy), nhwc_ld(dy), _p(w_oihw), _p(full0), g.C0, _p(dx1), g.C1, g.C0, B, H, W,
-                                         g.Cin, Cout, _stream(dy)), "reflect_dgrad_fix")
     if g.up0:
         dx0 = torch.empty((B, H // 2, W // 2, g.C0), dtype=torch.float32, device=dy.device)
         check(L.segsde_upsample2x_backward(_p(full0), g.C0, B, H // 2, W // 2, g.C0, _p(dx0), g.C0, _stream(dy)),

@@ -29,7 +29,7 @@ extern "C" {
 
 enum { SEGSDE_ERR_NULL = -1, SEGSDE_ERR_SHAPE = -2, SEGSDE_ERR_WORKSPACE = -3, SEGSDE_ERR_UNSUPPORTED = -4 };
 enum { SEGSDE_ACT_NONE = 0, SEGSDE_ACT_RELU = 1, SEGSDE_ACT_ELU = 2, SEGSDE_ACT_SIGMOID = 3 };
-enum { SEGSDE_PAD_ZERO = 0, SEGSDE_PAD_REFLECT = 1 };
+enum { SEGSDE_PAD_ZERO = 0, SEGSDE_PAD_REFLECT = 1, SEGSDE_PAD_REFLECT_ADJOINT = 2 };
 
 int segsde_abi_version(void);
 
@@ -44,7 +44,8 @@ typedef struct segsde_conv_desc {
   int Ho, Wo, Cout; /* output size                                                                                       */
   int ldy, ldy2, nsplit; /* output pitch; optional second destination receiving channels >= nsplit (concat dgrad)       */
   int KH, KW, stride, dil, pad;
-  int pad_mode;     /* SEGSDE_PAD_ZERO | SEGSDE_PAD_REFLECT (monodepth_layers.py:133-136)                               */
+  int pad_mode;     /* SEGSDE_PAD_ZERO | SEGSDE_PAD_REFLECT (monodepth_layers.py:133-136) | SEGSDE_PAD_REFLECT_ADJOINT:
+                       data-gradient of a reflection-padded 3x3/s1/p1 conv (x0 = dy, dgrad-packed weights, pad = 1)       */
   int in_div;       /* 1; >1 only for data-gradients of strided convs: input coordinate must divide by in_div          */
   int act;          /* fused epilogue activation applied after the bias: SEGSDE_ACT_*                                    */
 } segsde_conv_desc;
@@ -68,8 +69,9 @@ int segsde_conv2d_wgrad(const segsde_conv_desc* d, const float* x0, const float*
 int segsde_pack_weight(const float* w_oihw, float* out, int O, int I, int KH, int KW, int for_dgrad, void* stream);
 
 /* Adds to dx the gradient that entered the mirrored padding cells of a reflection-padded 3x3 stride-1 conv
- * (autograd of nn.ReflectionPad2d(1), models/monodepth_layers.py:134,140). */
-int segsde_reflect_dgrad_fix(const float* dy, int lddy, const float* w_oihw, float* dx, int lddx, float* dx2, int lddx2,
+ * (autograd of nn.ReflectionPad2d(1), models/monodepth_layers.py:134,140); wdpack = segsde_pack_weight(for_dgrad=1).
+ * segsde_conv2d_forward(pad_mode = SEGSDE_PAD_REFLECT_ADJOINT) already includes it. */
+int segsde_reflect_dgrad_fix(const float* dy, int lddy, const float* wdpack, float* dx, int lddx, float* dx2, int lddx2,
                              int nsplit, int B, int H, int W, int Cin, int Cout, void* stream);
 
 /* ------------------------------------------------------------------------------------------------ *

@@ -63,6 +63,8 @@ def main():
         print("%-44s %8.1f GF  fwd %7.3f ms %6.1f TF | dgrad %7.3f ms %6.1f TF | wgrad %7.3f ms %6.1f TF" % (
             name, row["gflop"], t_f, row["fwd_tflops"], t_d, row["dgrad_tflops"], t_w, row["wgrad_tflops"]), flush=True)
         del x0, x1, y, dy
+    if os.environ.get("BENCH_ONLY_CONV"):
+        return
     # HBM-bound kernels
     x = torch.randn(B, 128, 256, 256, device=dev)
     rm, rv = torch.zeros(256, device=dev), torch.ones(256, device=dev)
