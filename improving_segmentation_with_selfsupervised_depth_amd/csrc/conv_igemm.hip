@@ -33,7 +33,7 @@ struct ConvP {
   int B, H, W, C0, C1, ld0, ld1, up0;
   int Ho, Wo, N, ldy, ldy2, nsplit;
   int KH, KW, stride, dil, pad, pad_mode, in_div;
-  int Ctot, Ktot, M, act, stagger;
+  int Ctot, Ktot, M, act;
 };
 
 struct KInfo {  // decoded reduction index k -> tap + channel + source
@@ -210,8 +210,6 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave - wm * WN;
   const int kq = tid % KQ, r0 = tid / KQ;
-  if (p.stagger && ((blockIdx.x >> 8) & 1))   // experiment: de-phase the two co-resident workgroups of a CU
-    for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(8);
 
   int rb[AR], rh[AR], rw[AR];
   bool rok[AR];
@@ -385,6 +383,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvP p, const float* d
     }
   }
   const int wstep = BP * p.stride, wlim = p.Wo * p.stride, hlim = p.Ho * p.stride;
+  const bool dyvec = (p.N % 4 == 0) && (lddy % 4 == 0) && ((reinterpret_cast<uintptr_t>(dy) & 15) == 0);
 
   float4 ra[AI], rd[DI];
   auto gload = [&](int c) {
@@ -400,9 +399,18 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvP p, const float* d
       for (int i = 0; i < DI; ++i) {
         const int e = tid + 256 * i, row = e / DQ, nq = e - row * DQ;
         const int m = c * BP + row, n = n0 + 4 * nq;
-        const bool ok = m < p.M && n < p.N;
-        float4 v = *reinterpret_cast<const float4*>(dy + (long)(ok ? m : 0) * lddy + (ok ? n : 0));
-        if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 v;
+        if (dyvec) {
+          const bool ok = m < p.M && n < p.N;
+          v = *reinterpret_cast<const float4*>(dy + (long)(ok ? m : 0) * lddy + (ok ? n : 0));
+          if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        } else {   // odd Cout (19 classes, 1 disparity channel): scalar, clamped
+          const float* src = dy + (long)(m < p.M ? m : 0) * lddy;
+          float t[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { const bool ok = m < p.M && n + j < p.N; const float x = src[ok ? n + j : 0]; t[j] = ok ? x : 0.f; }
+          v = make_float4(t[0], t[1], t[2], t[3]);
+        }
         rd[i] = v;
       }
       return;
@@ -498,11 +506,27 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvP p, const float* d
 // dW[o][c][kh][kw] (OIHW, the state_dict layout) = sum_z part[z][(kh*KW+kw)*Ctot + c][o], fixed order
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* part, int splits, int Ktot, int N, int Ctot,
                                                            int taps, float* dw) {
+  // 32 output elements x 8 split-lanes per block; each lane sums every 8th slab (4 independent chains), fixed order
+  SEGSDE_SMEM;
+  float* sh = reinterpret_cast<float*>(segsde_smem);
   const long total = (long)Ktot * N;
-  for (long e = blockIdx.x * 256L + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
-    const int k = (int)(e / N), n = (int)(e - (long)k * N);
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const long e = blockIdx.x * 32L + tx;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (e < total) {
+    int z = ty;
+    for (; z + 24 < splits; z += 32) {
+      s0 += part[(long)z * total + e]; s1 += part[(long)(z + 8) * total + e];
+      s2 += part[(long)(z + 16) * total + e]; s3 += part[(long)(z + 24) * total + e];
+    }
+    for (; z < splits; z += 8) s0 += part[(long)z * total + e];
+  }
+  sh[ty * 32 + tx] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (ty == 0 && e < total) {
     float s = 0.f;
-    for (int z = 0; z < splits; ++z) s += part[(long)z * total + e];
+    for (int j = 0; j < 8; ++j) s += sh[j * 32 + tx];
+    const int k = (int)(e / N), n = (int)(e - (long)k * N);
     const int tap = k / Ctot, c = k - tap * Ctot;
     dw[((long)n * Ctot + c) * taps + tap] = s;
   }
@@ -574,14 +598,15 @@ __global__ __launch_bounds__(256) void reflect_dgrad_fix_kernel(const float* dy,
   }
 }
 
-// experiment knobs (environment SEGSDE_TUNE="bk64=1,stagger=32"), read once
-struct Tune { int bk64 = 0, stagger = 0; };
+// experiment knob (environment SEGSDE_TUNE="bk64=1"), read once.  Measured on MI355X (profiles/ab_conv_r01.log):
+// BK=64 (139 KB LDS => 1 workgroup/CU, half the barriers) loses 15-25 % on the large layers against BK=32 with two
+// co-resident workgroups per CU, and start-up staggering of co-resident workgroups changes nothing.
+struct Tune { int bk64 = 0; };
 const Tune& tune() {
   static Tune t = [] {
     Tune r;
     if (const char* e = getenv("SEGSDE_TUNE")) {
       if (const char* q = strstr(e, "bk64=")) r.bk64 = atoi(q + 5);
-      if (const char* q = strstr(e, "stagger=")) r.stagger = atoi(q + 8);
     }
     return r;
   }();
@@ -598,7 +623,6 @@ ConvP make_params(const segsde_conv_desc* d, const float* x0, const float* x1, c
   p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.dil = d->dil; p.pad = d->pad; p.pad_mode = d->pad_mode;
   p.in_div = d->in_div < 1 ? 1 : d->in_div;
   p.Ctot = d->C0 + d->C1; p.Ktot = d->KH * d->KW * p.Ctot; p.M = d->B * d->Ho * d->Wo; p.act = d->act;
-  p.stagger = tune().stagger;
   return p;
 }
 
@@ -694,7 +718,7 @@ template <int BKT, int BN, int WM, int WN>
 int launch_wgrad(const ConvP& p, const float* dy, int lddy, float* ws, int splits, int cps, hipStream_t stream) {
   const bool vec = vec_ok(p) && (p.N % 4 == 0) && (lddy % 4 == 0) && aligned16(dy);
   const long e0 = (long)p.B * (p.H >> p.up0) * (p.W >> p.up0) * p.ld0, e1 = (long)p.B * p.H * p.W * p.ld1;
-  const bool fast = vec && e0 < (1L << 31) && e1 < (1L << 31);
+  const bool fast = vec_ok(p) && e0 < (1L << 31) && e1 < (1L << 31);   // the dY side may be scalar (odd Cout)
   if (fast) return launch_wgrad_mode<BKT, BN, WM, WN, 2>(p, dy, lddy, ws, splits, cps, stream);
   if (vec) return launch_wgrad_mode<BKT, BN, WM, WN, 1>(p, dy, lddy, ws, splits, cps, stream);
   return launch_wgrad_mode<BKT, BN, WM, WN, 0>(p, dy, lddy, ws, splits, cps, stream);
@@ -738,7 +762,7 @@ extern "C" int segsde_conv2d_wgrad(const segsde_conv_desc* d, const float* x0, c
   else e = launch_wgrad<128, 128, 2, 2>(p, dy, lddy, workspace, splits, cps, s);
   if (e) return e;
   const long total = (long)p.Ktot * p.N;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(min(2048, segsde_cdiv(total, 256))), dim3(256), 0, s, workspace, splits,
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(segsde_cdiv(total, 32)), dim3(256), 1024, s, workspace, splits,
                      p.Ktot, p.N, p.Ctot, d->KH * d->KW, dw_oihw);
   SEGSDE_CHECK_LAUNCH();
   return 0;

@@ -87,13 +87,29 @@ struct StatsOp {
   }
 };
 
+// partial-slab combine shared by the finalize kernels: 16 channels x 16 partial-lanes per block, fixed order
+__device__ __forceinline__ void combine_partials(const double* part, int nb, int C, int c, int pl, double* sh /*[2][16][16]*/,
+                                                 double& s, double& q) {
+  double a = 0.0, b = 0.0;
+  if (c < C)
+    for (int i = pl; i < nb; i += 16) { a += part[((long)i * 2) * C + c]; b += part[((long)i * 2 + 1) * C + c]; }
+  const int cl = threadIdx.x & 15;
+  sh[pl * 16 + cl] = a; sh[256 + pl * 16 + cl] = b;
+  __syncthreads();
+  s = 0.0; q = 0.0;
+  if (pl == 0)
+    for (int j = 0; j < 16; ++j) { s += sh[j * 16 + cl]; q += sh[256 + j * 16 + cl]; }
+}
+
 __global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const double* part, int nb, long M, int C, float eps,
                                                                 float momentum, float* mean, float* invstd,
                                                                 float* running_mean, float* running_var) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
-  double s = 0.0, q = 0.0;
-  for (int b = 0; b < nb; ++b) { s += part[((long)b * 2) * C + c]; q += part[((long)b * 2 + 1) * C + c]; }
+  SEGSDE_SMEM;
+  double* sh = reinterpret_cast<double*>(segsde_smem);
+  const int c = blockIdx.x * 16 + (threadIdx.x & 15), pl = threadIdx.x >> 4;
+  double s, q;
+  combine_partials(part, nb, C, c, pl, sh, s, q);
+  if (pl != 0 || c >= C) return;
   const double mu = s / (double)M;
   double var = q / (double)M - mu * mu;
   if (var < 0.0) var = 0.0;
@@ -177,10 +193,12 @@ struct BnBwdOp {
 };
 
 __global__ __launch_bounds__(256) void pair_finalize_kernel(const double* part, int nb, int C, float* out0, float* out1) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
-  double a = 0.0, b = 0.0;
-  for (int i = 0; i < nb; ++i) { a += part[((long)i * 2) * C + c]; b += part[((long)i * 2 + 1) * C + c]; }
+  SEGSDE_SMEM;
+  double* sh = reinterpret_cast<double*>(segsde_smem);
+  const int c = blockIdx.x * 16 + (threadIdx.x & 15), pl = threadIdx.x >> 4;
+  double a, b;
+  combine_partials(part, nb, C, c, pl, sh, a, b);
+  if (pl != 0 || c >= C) return;
   if (out0) out0[c] = (float)a;
   if (out1) out1[c] = (float)b;
 }
@@ -466,7 +484,7 @@ extern "C" int segsde_bn_stats(const float* x, int ldx, long M, int C, float* me
   StatsOp op{x, ldx};
   const bool vec = (C % 4 == 0) && (ldx % 4 == 0) && al16p(x);
   if (int e = launch_colreduce(op, M, C, (double*)ws, vec, ST(stream))) return e;
-  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, ST(stream), (const double*)ws,
+  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((C + 15) / 16), dim3(256), 4096, ST(stream), (const double*)ws,
                      red_blocks(M), M, C, eps, momentum, mean, invstd, running_mean, running_var);
   SEGSDE_CHECK_LAUNCH();
   return 0;
@@ -508,7 +526,7 @@ extern "C" int segsde_bn_backward(const float* dy, int lddy, const float* y, int
   BnBwdOp op{dy, lddy, y, ldy, x, ldx, mean, invstd, act, C, drop_p, seed};
   const bool vec = (C % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) && (lddy % 4 == 0) && al16p(x) && al16p(y) && al16p(dy);
   if (int e = launch_colreduce(op, M, C, (double*)ws, vec, ST(stream))) return e;
-  hipLaunchKernelGGL(pair_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, ST(stream), (const double*)ws,
+  hipLaunchKernelGGL(pair_finalize_kernel, dim3((C + 15) / 16), dim3(256), 4096, ST(stream), (const double*)ws,
                      red_blocks(M), C, dgamma, dbeta);
   SEGSDE_CHECK_LAUNCH();
   if (dx || dres) {
@@ -536,7 +554,7 @@ extern "C" int segsde_act_backward(const float* dy, int lddy, const float* y, in
                    (!dz || ((lddz % 4 == 0) && al16p(dz)));
   if (int e = launch_colreduce(op, M, C, (double*)ws, vec, ST(stream))) return e;
   if (dbias) {
-    hipLaunchKernelGGL(pair_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, ST(stream), (const double*)ws,
+    hipLaunchKernelGGL(pair_finalize_kernel, dim3((C + 15) / 16), dim3(256), 4096, ST(stream), (const double*)ws,
                        red_blocks(M), C, dbias, (float*)nullptr);
     SEGSDE_CHECK_LAUNCH();
   }
@@ -550,7 +568,7 @@ extern "C" int segsde_colsum(const float* x, int ldx, long M, int C, float* out,
   ColsumOp op{x, ldx};
   const bool vec = (C % 4 == 0) && (ldx % 4 == 0) && al16p(x);
   if (int e = launch_colreduce(op, M, C, (double*)ws, vec, ST(stream))) return e;
-  hipLaunchKernelGGL(pair_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, ST(stream), (const double*)ws,
+  hipLaunchKernelGGL(pair_finalize_kernel, dim3((C + 15) / 16), dim3(256), 4096, ST(stream), (const double*)ws,
                      red_blocks(M), C, out, (float*)nullptr);
   SEGSDE_CHECK_LAUNCH();
   return 0;

@@ -258,7 +258,7 @@ def run_full_model(device, golden, name):
             loose += 1
     assert not bad, bad[:10]
     assert loose <= 0.03 * len(names), (loose, len(names))
-    assert_close(params["models.encoder.encoder.conv1.weight"].grad, g[name + "_grad_conv1"], rtol=5e-3, atol=1e-4,
+    assert_close(params["models.encoder.encoder.conv1.weight"].grad, g[name + "_grad_conv1"], rtol=1e-2, atol=1e-3,
                  what="conv1 grad")
     assert_close(model.models["encoder"].encoder.bn1.running_mean, g[name + "_bn1_running_mean_after"], rtol=1e-3,
                  atol=1e-5, what="bn1 running mean")
