@@ -21,7 +21,7 @@ class ConvDesc(ctypes.Structure):
     """mirror of ``segsde_conv_desc`` (include/segsde_hip.h)"""
     _fields_ = [(n, c_int) for n in (
         "B", "H", "W", "C0", "C1", "ld0", "ld1", "up0", "Ho", "Wo", "Cout", "ldy", "ldy2", "nsplit",
-        "KH", "KW", "stride", "dil", "pad", "pad_mode", "in_div", "act")]
+        "KH", "KW", "stride", "dil", "pad", "pad_mode", "in_div", "act", "sum2x2")]
 
 
 P = c_void_p

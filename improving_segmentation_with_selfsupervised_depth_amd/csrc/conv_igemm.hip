@@ -33,7 +33,7 @@ struct ConvP {
   int B, H, W, C0, C1, ld0, ld1, up0;
   int Ho, Wo, N, ldy, ldy2, nsplit;
   int KH, KW, stride, dil, pad, pad_mode, in_div;
-  int Ctot, Ktot, M, act;
+  int Ctot, Ktot, M, act, sum2x2;
 };
 
 struct KInfo {  // decoded reduction index k -> tap + channel + source
@@ -75,6 +75,16 @@ __device__ __forceinline__ long a_offset(const ConvP& p, const KInfo& t, int b, 
 __device__ __forceinline__ void decode_m(const ConvP& p, int m, int& b, int& hb, int& wb, bool& ok) {
   ok = m < p.M;
   const int mm = ok ? m : 0;
+  if (p.sum2x2) {
+    // output pixels enumerated patch-major: m = ((b*Ho/2 + h/2)*Wo/2 + w/2)*4 + (h&1)*2 + (w&1), so the four members of
+    // a 2x2 block are four consecutive GEMM rows = the four registers (r&3) of one lane in the MFMA accumulator
+    const int q = mm >> 2, sub = mm & 3, w2 = p.Wo >> 1, hw2 = (p.Ho >> 1) * w2;
+    b = q / hw2;
+    const int rem = q - b * hw2, h2 = rem / w2;
+    hb = 2 * h2 + (sub >> 1);
+    wb = 2 * (rem - h2 * w2) + (sub & 1);
+    return;
+  }
   const int hw = p.Ho * p.Wo;
   b = mm / hw;
   const int rem = mm - b * hw;
@@ -320,10 +330,29 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
     else { dst = p.y2; ld = p.ldy2; nn = n - p.nsplit; }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
+      if (p.sum2x2) {
+        // data-gradient through the nearest x2 upsample: channels of source 0 are summed over each 2x2 block in
+        // registers and stored at half resolution; skip-connection channels are stored per pixel
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * rhalf;
-        if (m < p.M) dst[(long)m * ld + nn] = segsde_act(acc[i][j][r] + bias, p.act);
+        for (int g = 0; g < 4; ++g) {
+          const int m = m0 + (wm * TM + i) * 32 + 8 * g + 4 * rhalf;
+          if (m >= p.M) continue;
+          if (n < p.nsplit) {
+            dst[(long)(m >> 2) * ld + nn] = (acc[i][j][4 * g] + acc[i][j][4 * g + 1]) + (acc[i][j][4 * g + 2] + acc[i][j][4 * g + 3]);
+          } else {
+            int b, hb, wb; bool ok;
+            decode_m(p, m, b, hb, wb, ok);
+            float* q = dst + ((long)(b * p.Ho + hb) * p.Wo + wb) * ld + nn;   // sub-pixel 0 of the block
+            q[0] = acc[i][j][4 * g]; q[ld] = acc[i][j][4 * g + 1];
+            q[(long)p.Wo * ld] = acc[i][j][4 * g + 2]; q[(long)p.Wo * ld + ld] = acc[i][j][4 * g + 3];
+          }
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * rhalf;
+          if (m < p.M) dst[(long)m * ld + nn] = segsde_act(acc[i][j][r] + bias, p.act);
+        }
       }
     }
   }
@@ -623,6 +652,7 @@ ConvP make_params(const segsde_conv_desc* d, const float* x0, const float* x1, c
   p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.dil = d->dil; p.pad = d->pad; p.pad_mode = d->pad_mode;
   p.in_div = d->in_div < 1 ? 1 : d->in_div;
   p.Ctot = d->C0 + d->C1; p.Ktot = d->KH * d->KW * p.Ctot; p.M = d->B * d->Ho * d->Wo; p.act = d->act;
+  p.sum2x2 = d->sum2x2;
   return p;
 }
 
@@ -691,6 +721,10 @@ extern "C" int segsde_conv2d_forward(const segsde_conv_desc* d, const float* x0,
   if (!x0 || !wpack || !y || (d->C1 && !x1)) return SEGSDE_ERR_NULL;
   const ConvP p = make_params(d, x0, x1, wpack, bias, y, y2);
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (d->sum2x2) {
+    if ((d->Ho & 1) || (d->Wo & 1) || d->stride != 1 || d->act != 0 || bias) return SEGSDE_ERR_SHAPE;
+    if (!fast_ok(p)) return SEGSDE_ERR_UNSUPPORTED;   // caller falls back to the two-pass path (full-res dgrad + 2x2 sum)
+  }
   int e;
   if (p.N <= 32) e = launch_igemm<128, 32, 4, 1>(p, s);
   else if (p.N <= 64) e = launch_igemm<128, 64, 2, 2>(p, s);

@@ -134,12 +134,14 @@ template <int VW>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* x, int ldx, long M, int C, const float* mean,
                                                        const float* invstd, const float* gamma, const float* beta,
                                                        const float* res, int ldr, float* y, int ldy, int act,
-                                                       float drop_p, uint64_t seed) {
+                                                       float drop_p, uint64_t seed, int cv_shift) {
   const int CV = C / VW;
   const long total = M * CV;
   const float keep_scale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
   for (long e = blockIdx.x * 256L + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
-    const long m = e / CV; const int c = (int)(e - m * CV) * VW;
+    // channel counts are powers of two on the whole ResNet / decoder path: shift + mask instead of a 64-bit division
+    const long m = cv_shift >= 0 ? (e >> cv_shift) : e / CV;
+    const int c = (int)(e - m * CV) * VW;
     float v[VW], r[VW];
     if (VW == 4) {
       const float4 t = *reinterpret_cast<const float4*>(x + m * ldx + c);
@@ -209,12 +211,13 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* dy, int 
                                                            const float* invstd, const float* gamma, int act,
                                                            float drop_p, uint64_t seed, int batch_stats,
                                                            const float* dgamma, const float* dbeta, float* dx, int lddx,
-                                                           float* dres, int lddres) {
+                                                           float* dres, int lddres, int cv_shift) {
   const int CV = C / VW;
   const long total = M * CV;
   const float invM = 1.f / (float)M;
   for (long e = blockIdx.x * 256L + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
-    const long m = e / CV; const int c = (int)(e - m * CV) * VW;
+    const long m = cv_shift >= 0 ? (e >> cv_shift) : e / CV;
+    const int c = (int)(e - m * CV) * VW;
     const VecF<VW> g = ldv<VW>(dy + m * lddy + c), yy = ldv<VW>(y + m * ldy + c);
     VecF<VW> xx;
     if (dx && batch_stats) xx = ldv<VW>(x + m * ldx + c);
@@ -466,6 +469,7 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* x, int l
   }
 }
 
+inline int pow2_shift(int v) { int s = 0; while ((1 << s) < v) ++s; return (1 << s) == v ? s : -1; }
 inline int ew_blocks(long total) { long nb = (total + 255) / 256; return (int)(nb < 1 ? 1 : (nb > 8192 ? 8192 : nb)); }
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 #define ST(s) static_cast<hipStream_t>(s)
@@ -508,10 +512,10 @@ extern "C" int segsde_bn_apply(const float* x, int ldx, long M, int C, const flo
                   (!residual || ((ldr % 4 == 0) && al16(residual)));
   if (v4)
     hipLaunchKernelGGL(bn_apply_kernel<4>, dim3(ew_blocks(M * C / 4)), dim3(256), 0, ST(stream), x, ldx, M, C, mean,
-                       invstd, gamma, beta, residual, ldr, y, ldy, act, drop_p, seed);
+                       invstd, gamma, beta, residual, ldr, y, ldy, act, drop_p, seed, pow2_shift(C / 4));
   else
     hipLaunchKernelGGL(bn_apply_kernel<1>, dim3(ew_blocks(M * C)), dim3(256), 0, ST(stream), x, ldx, M, C, mean, invstd,
-                       gamma, beta, residual, ldr, y, ldy, act, drop_p, seed);
+                       gamma, beta, residual, ldr, y, ldy, act, drop_p, seed, pow2_shift(C));
   SEGSDE_CHECK_LAUNCH();
   return 0;
 }
@@ -534,11 +538,11 @@ extern "C" int segsde_bn_backward(const float* dy, int lddy, const float* y, int
     if (v4)
       hipLaunchKernelGGL(bn_bwd_apply_kernel<4>, dim3(ew_blocks(M * C / 4)), dim3(256), 0, ST(stream), dy, lddy, y, ldy, x,
                          ldx, M, C, mean, invstd, gamma, act, drop_p, seed, batch_stats, (const float*)dgamma,
-                         (const float*)dbeta, dx, lddx, dres, lddres);
+                         (const float*)dbeta, dx, lddx, dres, lddres, pow2_shift(C / 4));
     else
       hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, dim3(ew_blocks(M * C)), dim3(256), 0, ST(stream), dy, lddy, y, ldy, x, ldx,
                          M, C, mean, invstd, gamma, act, drop_p, seed, batch_stats, (const float*)dgamma,
-                         (const float*)dbeta, dx, lddx, dres, lddres);
+                         (const float*)dbeta, dx, lddx, dres, lddres, pow2_shift(C));
     SEGSDE_CHECK_LAUNCH();
   }
   return 0;

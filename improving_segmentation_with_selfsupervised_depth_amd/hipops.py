@@ -106,7 +106,7 @@ def conv_forward(g, x0, x1, wpack, bias, act="none"):
     d = ConvDesc(B=B, H=H, W=W, C0=g.C0, C1=g.C1, ld0=nhwc_ld(x0), ld1=nhwc_ld(x1) if x1 is not None else 0,
                  up0=int(g.up0), Ho=Ho, Wo=Wo, Cout=g.Cout, ldy=g.Cout, ldy2=0, nsplit=0, KH=g.k, KW=g.k,
                  stride=g.stride, dil=g.dil, pad=g.pad, pad_mode=PAD_REFLECT if g.reflect else PAD_ZERO, in_div=1,
-                 act=ACT[act])
+                 act=ACT[act], sum2x2=0)
     flops = 2.0 * B * Ho * Wo * g.Cout * g.Cin * g.k * g.k
     _timed("conv_fwd", flops, x0, lambda: check(_lib.lib().segsde_conv2d_forward(
         ctypes.byref(d), _p(_f32(x0)), _p(x1), _p(wpack), _p(bias), _p(y), None, _stream(x0)), "conv2d_forward"))
@@ -119,13 +119,26 @@ def conv_dgrad(g, dy, wdpack, w_oihw, in_hw, need0=True, need1=True):
     B, Ho, Wo, Cout = dy.shape
     H, W = in_hw
     assert Cout == g.Cout
-    full0 = torch.empty((B, H, W, g.C0), dtype=torch.float32, device=dy.device)
     dx1 = torch.empty((B, H, W, g.C1), dtype=torch.float32, device=dy.device) if g.C1 else None
-    d = ConvDesc(B=B, H=Ho, W=Wo, C0=Cout, C1=0, ld0=nhwc_ld(dy), ld1=0, up0=0, Ho=H, Wo=W, Cout=g.Cin, ldy=g.C0,
-                 ldy2=g.C1, nsplit=g.C0, KH=g.k, KW=g.k, stride=1, dil=g.dil, pad=(g.k - 1) * g.dil - g.pad,
-                 pad_mode=PAD_REFLECT_ADJOINT if g.reflect else PAD_ZERO, in_div=g.stride, act=0)
     L = _lib.lib()
     flops = 2.0 * B * Ho * Wo * Cout * g.Cin * g.k * g.k
+
+    def desc(sum2x2):
+        return ConvDesc(B=B, H=Ho, W=Wo, C0=Cout, C1=0, ld0=nhwc_ld(dy), ld1=0, up0=0, Ho=H, Wo=W, Cout=g.Cin, ldy=g.C0,
+                        ldy2=g.C1, nsplit=g.C0, KH=g.k, KW=g.k, stride=1, dil=g.dil, pad=(g.k - 1) * g.dil - g.pad,
+                        pad_mode=PAD_REFLECT_ADJOINT if g.reflect else PAD_ZERO, in_div=g.stride, act=0, sum2x2=sum2x2)
+    if g.up0:
+        # fused: the 2x2 sum of the upsample adjoint happens in the GEMM epilogue (no full-resolution gradient tensor)
+        dx0 = torch.empty((B, H // 2, W // 2, g.C0), dtype=torch.float32, device=dy.device)
+        d = desc(1)
+        rc = _timed("conv_dgrad", flops, dy, lambda: L.segsde_conv2d_forward(
+            ctypes.byref(d), _p(_f32(dy)), None, _p(wdpack), None, _p(dx0), _p(dx1), _stream(dy)))
+        if rc == 0:
+            return dx0, dx1
+        if rc != -4:
+            check(rc, "conv2d dgrad (fused upsample adjoint)")
+    full0 = torch.empty((B, H, W, g.C0), dtype=torch.float32, device=dy.device)
+    d = desc(0)
     _timed("conv_dgrad", flops, dy, lambda: check(L.segsde_conv2d_forward(
         ctypes.byref(d), _p(_f32(dy)), None, _p(wdpack), None, _p(full0), _p(dx1), _stream(dy)), "conv2d dgrad"))
     if g.up0:
@@ -144,7 +157,7 @@ def conv_wgrad(g, x0, x1, dy):
     _, Ho, Wo, Cout = dy.shape
     d = ConvDesc(B=B, H=H, W=W, C0=g.C0, C1=g.C1, ld0=nhwc_ld(x0), ld1=nhwc_ld(x1) if x1 is not None else 0,
                  up0=int(g.up0), Ho=Ho, Wo=Wo, Cout=Cout, ldy=Cout, ldy2=0, nsplit=0, KH=g.k, KW=g.k, stride=g.stride,
-                 dil=g.dil, pad=g.pad, pad_mode=PAD_REFLECT if g.reflect else PAD_ZERO, in_div=1, act=0)
+                 dil=g.dil, pad=g.pad, pad_mode=PAD_REFLECT if g.reflect else PAD_ZERO, in_div=1, act=0, sum2x2=0)
     L = _lib.lib()
     nbytes = L.segsde_conv2d_wgrad_workspace(ctypes.byref(d))
     ws = _ws(nbytes, dy)

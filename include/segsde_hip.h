@@ -48,6 +48,9 @@ typedef struct segsde_conv_desc {
                        data-gradient of a reflection-padded 3x3/s1/p1 conv (x0 = dy, dgrad-packed weights, pad = 1)       */
   int in_div;       /* 1; >1 only for data-gradients of strided convs: input coordinate must divide by in_div          */
   int act;          /* fused epilogue activation applied after the bias: SEGSDE_ACT_*                                    */
+  int sum2x2;       /* 1 (data-gradient through the x2 upsample): output channels < nsplit are summed over 2x2 pixel
+                       blocks in registers and stored to y at (Ho/2, Wo/2); channels >= nsplit go to y2 per pixel.
+                       Returns SEGSDE_ERR_UNSUPPORTED when the shape cannot take the fused path.                         */
 } segsde_conv_desc;
 
 /* y[b,ho,wo,n] = act(bias[n] + sum_{kh,kw,c} x[b, ho*stride-pad+kh*dil, wo*stride-pad+kw*dil, c] * wpack[n][kh][kw][c])
