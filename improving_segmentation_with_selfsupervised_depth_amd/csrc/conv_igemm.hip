@@ -161,47 +161,55 @@ __device__ __forceinline__ SrcSel select_src(const ConvP& p, int c) {
   return s;
 }
 
-__device__ __forceinline__ float4 ld4_at(const SrcSel& s, int b, int hi, int wi, int cq) {
-  const unsigned off = (unsigned)b * s.bstride + ((unsigned)(hi >> s.shift) * s.Ws + (unsigned)(wi >> s.shift)) * s.ld +
-                       (unsigned)(s.cc + cq);
-  return *reinterpret_cast<const float4*>(s.src + off);
+// Loads that fall on zero padding / past the tile edge read this page instead of being zeroed after the fact: a select on
+// a loaded value would force an s_waitcnt right behind every load and serialise the eight tile loads of a chunk.
+__device__ float segsde_zero_page[64];
+
+__device__ __forceinline__ unsigned off_at(const SrcSel& s, int b, int hi, int wi, int cq) {
+  return (unsigned)b * s.bstride + ((unsigned)(hi >> s.shift) * s.Ws + (unsigned)(wi >> s.shift)) * s.ld +
+         (unsigned)(s.cc + cq);
 }
 
-// (hi, wi) = output pixel + tap offset (dh, dw)
-__device__ __forceinline__ float4 fast_fetch(const ConvP& p, const SrcSel& s, int b, int hi, int wi, bool ok, int cq,
-                                             int dh, int dw) {
-  if (p.pad_mode == SEGSDE_PAD_REFLECT) {
-    hi = hi < 0 ? -hi : (hi >= p.H ? 2 * p.H - 2 - hi : hi);
-    wi = wi < 0 ? -wi : (wi >= p.W ? 2 * p.W - 2 - wi : wi);
-    hi = ok ? hi : 0; wi = ok ? wi : 0;
-    float4 v = ld4_at(s, b, hi, wi, cq);
-    if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
-    return v;
-  }
-  const bool hin = (unsigned)hi < (unsigned)p.H, win = (unsigned)wi < (unsigned)p.W;
-  const bool okp = ok && hin && win;
-  float4 v = ld4_at(s, b, okp ? hi : 0, okp ? wi : 0, cq);
-  if (!okp) v = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (p.pad_mode == SEGSDE_PAD_REFLECT_ADJOINT && ok) {
-    // data-gradient of a reflection-padded 3x3/s1 conv: a pixel in row 1 (H-2) also collects what flowed into the
-    // mirrored padding row -1 (H); that pre-image is reachable only through the tap with dh = +1 (-1).  Same for columns.
-    const int ho = hi - dh, wo = wi - dw;
-    const int eh = (ho == 1 && dh == 1) ? 0 : ((ho == p.H - 2 && dh == -1) ? p.H - 1 : -1);
-    const int ew = (wo == 1 && dw == 1) ? 0 : ((wo == p.W - 2 && dw == -1) ? p.W - 1 : -1);
-    if (eh >= 0 || ew >= 0) {
-      if (eh >= 0 && win) { const float4 t = ld4_at(s, b, eh, wi, cq); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
-      if (ew >= 0 && hin) { const float4 t = ld4_at(s, b, hi, ew, cq); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
-      if (eh >= 0 && ew >= 0) { const float4 t = ld4_at(s, b, eh, ew, cq); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
-    }
+// (hi, wi) = output pixel + tap offset.  Straight-line on purpose (selects, no branches): the address is always formed
+// from clamped coordinates and swapped for the zero page when the tap is out of range.
+__device__ __forceinline__ float4 fast_fetch(const ConvP& p, const SrcSel& s, int b, int hi, int wi, bool ok, int cq) {
+  const bool refl = p.pad_mode == SEGSDE_PAD_REFLECT;
+  const int hr = hi < 0 ? -hi : (hi >= p.H ? 2 * p.H - 2 - hi : hi);
+  const int wr = wi < 0 ? -wi : (wi >= p.W ? 2 * p.W - 2 - wi : wi);
+  const bool inb = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+  ok = ok && (refl || inb);
+  hi = ok ? (refl ? hr : hi) : 0;
+  wi = ok ? (refl ? wr : wi) : 0;
+  const float* ptr = s.src + off_at(s, b, hi, wi, cq);
+  ptr = ok ? ptr : segsde_zero_page;
+  return *reinterpret_cast<const float4*>(ptr);
+}
+
+// SEGSDE_PAD_REFLECT_ADJOINT (data-gradient of a reflection-padded 3x3/s1 conv): a pixel in row 1 (H-2) also collects
+// what flowed into the mirrored padding row -1 (H); that pre-image is reachable only through the tap with dh = +1 (-1);
+// same for columns.  Returns the sum of the (at most three) extra contributions; the common case loads nothing.
+__device__ __forceinline__ float4 adjoint_extras(const ConvP& p, const SrcSel& s, int b, int ho, int wo, bool ok, int cq,
+                                                 int dh, int dw) {
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int eh = (ho == 1 && dh == 1) ? 0 : ((ho == p.H - 2 && dh == -1) ? p.H - 1 : -1);
+  const int ew = (wo == 1 && dw == 1) ? 0 : ((wo == p.W - 2 && dw == -1) ? p.W - 1 : -1);
+  if (ok && (eh >= 0 || ew >= 0)) {
+    const int hi = ho + dh, wi = wo + dw;
+    const bool hin = (unsigned)hi < (unsigned)p.H, win = (unsigned)wi < (unsigned)p.W;
+    if (eh >= 0 && win) { const float4 t = *reinterpret_cast<const float4*>(s.src + off_at(s, b, eh, wi, cq)); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+    if (ew >= 0 && hin) { const float4 t = *reinterpret_cast<const float4*>(s.src + off_at(s, b, hi, ew, cq)); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+    if (eh >= 0 && ew >= 0) { const float4 t = *reinterpret_cast<const float4*>(s.src + off_at(s, b, eh, ew, cq)); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
   }
   return v;
 }
 
-// MODE 0: generic scalar gather, 1: generic float4 gather, 2: FAST (uniform tap per chunk, branch-free loads)
+// MODE 0: generic scalar gather, 1: generic float4 gather, 2: FAST (uniform tap per chunk, branch-free loads),
+// 3: FAST + reflection-pad adjoint extras
 template <int BM, int BN, int WM, int WN, int MODE, int BK>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
   constexpr bool VEC = MODE >= 1;
-  constexpr bool FAST = MODE == 2;
+  constexpr bool FAST = MODE >= 2;
+  constexpr bool ADJ = MODE == 3;
   constexpr int LDT = BK + 4;               // LDS row pitch (floats): conflict-free ds_read_b128 fragments
   constexpr int KQ = BK / 4, RP = 256 / KQ; // float4 columns per tile row, tile rows staged per pass
   constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
@@ -227,12 +235,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
   for (int i = 0; i < AR; ++i) decode_m(p, m0 + r0 + RP * i, rb[i], rh[i], rw[i], rok[i]);
   // FAST: weight-row bases (clamped) and validity
   const float* wrow[BR];
-  bool nok[BR];
+  int wstep[BR];
 #pragma unroll
   for (int i = 0; i < BR; ++i) {
     const int n = n0 + r0 + RP * i;
-    nok[i] = n < p.N;
-    wrow[i] = p.w + (long)(nok[i] ? n : 0) * p.Ktot + 4 * kq;
+    wrow[i] = n < p.N ? p.w + (long)n * p.Ktot + 4 * kq : segsde_zero_page;   // rows past Cout read zeros
+    wstep[i] = n < p.N ? BK : 0;
   }
   ChunkState cs; cs.c0 = 0; cs.kh = 0; cs.kw = 0;
 
@@ -244,24 +252,27 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  float4 ra[AR], rbv[BR];
+  float4 ra[AR], rbv[BR], rex[ADJ ? AR : 1];
   const int nchunks = (p.Ktot + BK - 1) / BK;
 
   auto gload = [&](int kc) {
+    // chunks past the end are loaded from clamped (valid) addresses and discarded: the K loop stays branch-free
+    const bool live = kc < nchunks;
+    const int kcl = live ? kc : nchunks - 1;
     if (FAST) {
       const SrcSel s = select_src(p, cs.c0);
       const int dh = cs.kh * p.dil - p.pad, dw = cs.kw * p.dil - p.pad;
 #pragma unroll
-      for (int i = 0; i < AR; ++i) ra[i] = fast_fetch(p, s, rb[i], rh[i] + dh, rw[i] + dw, rok[i], 4 * kq, dh, dw);
+      for (int i = 0; i < AR; ++i) ra[i] = fast_fetch(p, s, rb[i], rh[i] + dh, rw[i] + dw, rok[i] && live, 4 * kq);
 #pragma unroll
-      for (int i = 0; i < BR; ++i) {
-        float4 v = *reinterpret_cast<const float4*>(wrow[i] + kc * BK);
-        if (!nok[i]) v = make_float4(0.f, 0.f, 0.f, 0.f);
-        rbv[i] = v;
+      for (int i = 0; i < BR; ++i) rbv[i] = *reinterpret_cast<const float4*>(wrow[i] + kcl * wstep[i]);
+      if (ADJ) {
+#pragma unroll
+        for (int i = 0; i < AR; ++i) rex[i] = adjoint_extras(p, s, rb[i], rh[i], rw[i], rok[i] && live, 4 * kq, dh, dw);
       }
-      cs.advance(p, BK);
+      if (live) cs.advance(p, BK);
     } else {
-      const int k = kc * BK + 4 * kq;
+      const int k = kcl * BK + 4 * kq;
 #pragma unroll
       for (int i = 0; i < AR; ++i) ra[i] = fetch_a4<VEC>(p, k, rb[i], rh[i], rw[i], rok[i]);
 #pragma unroll
@@ -272,49 +283,61 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
     float* As = smem + buf * STAGE;
     float* Bs = As + BM * LDT;
 #pragma unroll
-    for (int i = 0; i < AR; ++i) *reinterpret_cast<float4*>(As + (r0 + RP * i) * LDT + 4 * kq) = ra[i];
+    for (int i = 0; i < AR; ++i) {
+      float4 v = ra[i];
+      if (ADJ) { v.x += rex[i].x; v.y += rex[i].y; v.z += rex[i].z; v.w += rex[i].w; }
+      *reinterpret_cast<float4*>(As + (r0 + RP * i) * LDT + 4 * kq) = v;
+    }
 #pragma unroll
     for (int i = 0; i < BR; ++i) *reinterpret_cast<float4*>(Bs + (r0 + RP * i) * LDT + 4 * kq) = rbv[i];
   };
+  auto mma_groups = [&](int buf, int g0, int g1) {
+    const float* As = smem + buf * STAGE;
+    const float* Bs = As + BM * LDT;
+    const float* Ap = As + (wm * TM * 32 + (lane & 31)) * LDT + 4 * (lane >> 5);
+    const float* Bp = Bs + (wn * TN * 32 + (lane & 31)) * LDT + 4 * (lane >> 5);
+#pragma unroll
+    for (int g = g0; g < g1; ++g) {
+      float4 a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const float4*>(Ap + i * 32 * LDT + 8 * g);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const float4*>(Bp + j * 32 * LDT + 8 * g);
+      // k-step outermost: consecutive MFMAs target different accumulators
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
+    }
+  };
 
+  // Software pipeline (one barrier per chunk, nothing but the barrier at the chunk boundary):
+  //   registers hold chunk kc+1 (loaded during the previous iteration); first half of chunk kc's MFMAs; the
+  //   registers go to the other LDS buffer (free since the barrier that ended iteration kc-1); the loads of chunk
+  //   kc+2 are issued; second half of the MFMAs.  LDS writes and the address arithmetic of the loads sit in the
+  //   middle of the MFMA stream of the same wave instead of serialising in front of the barrier.
+  constexpr int NG = BK / 8;
   gload(0);
   lstore(0);
+  gload(1);
   __syncthreads();
   for (int kc = 0; kc < nchunks; ++kc) {
-    const bool more = kc + 1 < nchunks;
-    if (more) gload(kc + 1);
-    {
-      const float* As = smem + (kc & 1) * STAGE;
-      const float* Bs = As + BM * LDT;
-      const float* Ap = As + (wm * TM * 32 + (lane & 31)) * LDT + 4 * (lane >> 5);
-      const float* Bp = Bs + (wn * TN * 32 + (lane & 31)) * LDT + 4 * (lane >> 5);
-#pragma unroll
-      for (int g = 0; g < BK / 8; ++g) {
-        float4 a[TM], b[TN];
-#pragma unroll
-        for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const float4*>(Ap + i * 32 * LDT + 8 * g);
-#pragma unroll
-        for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const float4*>(Bp + j * 32 * LDT + 8 * g);
-        // k-step outermost: consecutive MFMAs target different accumulators
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
-      }
-    }
-    if (more) lstore((kc + 1) & 1);
+    mma_groups(kc & 1, 0, NG / 2);
+    lstore((kc + 1) & 1);
+    gload(kc + 2);
+    mma_groups(kc & 1, NG / 2, NG);
     __syncthreads();
   }
 
@@ -415,14 +438,23 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvP p, const float* d
   const bool dyvec = (p.N % 4 == 0) && (lddy % 4 == 0) && ((reinterpret_cast<uintptr_t>(dy) & 15) == 0);
 
   float4 ra[AI], rd[DI];
+  const bool wide = p.Wo >= BP;   // a 32-pixel step wraps at most one image row: carries instead of divisions
   auto gload = [&](int c) {
     if (FAST) {
 #pragma unroll
       for (int i = 0; i < AI; ++i) {
-        ra[i] = fast_fetch(p, fs, fb[i], fh[i] + fdh, fw[i] + fdw, fk_ok && fm[i] < p.M, 0, fdh, fdw);
-        fm[i] += BP; fw[i] += wstep;
-        while (fw[i] >= wlim) { fw[i] -= wlim; fh[i] += p.stride; }
-        while (fh[i] >= hlim) { fh[i] -= hlim; ++fb[i]; }
+        ra[i] = fast_fetch(p, fs, fb[i], fh[i] + fdh, fw[i] + fdw, fk_ok && fm[i] < p.M, 0);
+        fm[i] += BP;
+        if (wide) {
+          fw[i] += wstep;
+          const bool cw = fw[i] >= wlim;
+          fw[i] -= cw ? wlim : 0; fh[i] += cw ? p.stride : 0;
+          const bool ch = fh[i] >= hlim;
+          fh[i] -= ch ? hlim : 0; fb[i] += ch ? 1 : 0;
+        } else {
+          bool ok;
+          decode_m(p, fm[i], fb[i], fh[i], fw[i], ok);
+        }
       }
 #pragma unroll
       for (int i = 0; i < DI; ++i) {
@@ -431,8 +463,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvP p, const float* d
         float4 v;
         if (dyvec) {
           const bool ok = m < p.M && n < p.N;
-          v = *reinterpret_cast<const float4*>(dy + (long)(ok ? m : 0) * lddy + (ok ? n : 0));
-          if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+          v = *reinterpret_cast<const float4*>(ok ? dy + (long)m * lddy + n : segsde_zero_page);
         } else {   // odd Cout (19 classes, 1 disparity channel): scalar, clamped
           const float* src = dy + (long)(m < p.M ? m : 0) * lddy;
           float t[4];
@@ -484,35 +515,37 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvP p, const float* d
     }
   };
 
-  if (c_begin < c_end) {
-    gload(c_begin);
-    lstore(0);
-  }
+  auto mma_steps = [&](int buf, int s0, int s1) {
+    const float* At = smem + buf * STAGE;
+    const float* Dt = At + BP * BKT;
+    const float* Ap = At + (lane >> 5) * BKT + wm * TM * 32 + (lane & 31);
+    const float* Dp = Dt + (lane >> 5) * BN + wn * TN * 32 + (lane & 31);
+#pragma unroll
+    for (int s = s0; s < s1; ++s) {
+      float a[TM], d[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = Ap[2 * s * BKT + i * 32];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) d[j] = Dp[2 * s * BN + j * 32];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], d[j], acc[i][j], 0, 0, 0);
+    }
+  };
+  // same software pipeline as the forward kernel: LDS stores + the loads of chunk c+2 sit between the two halves of
+  // chunk c's MFMAs; rows past M load the zero page, so running one or two chunks past c_end is harmless
+  gload(c_begin);
+  lstore(0);
+  gload(c_begin + 1);
   __syncthreads();
   for (int c = c_begin; c < c_end; ++c) {
-    const bool more = c + 1 < c_end;
     const int buf = (c - c_begin) & 1;
-    if (more) gload(c + 1);
-    {
-      const float* At = smem + buf * STAGE;
-      const float* Dt = At + BP * BKT;
-      const float* Ap = At + (lane >> 5) * BKT + wm * TM * 32 + (lane & 31);
-      const float* Dp = Dt + (lane >> 5) * BN + wn * TN * 32 + (lane & 31);
-#pragma unroll 4
-      for (int s = 0; s < BP / 2; ++s) {
-        float a[TM], d[TN];
-#pragma unroll
-        for (int i = 0; i < TM; ++i) a[i] = Ap[2 * s * BKT + i * 32];
-#pragma unroll
-        for (int j = 0; j < TN; ++j) d[j] = Dp[2 * s * BN + j * 32];
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], d[j], acc[i][j], 0, 0, 0);
-      }
-    }
-    if (more) lstore(buf ^ 1);
+    mma_steps(buf, 0, BP / 4);
+    lstore(buf ^ 1);
+    gload(c + 2);
+    mma_steps(buf, BP / 4, BP / 2);
     __syncthreads();
   }
 
@@ -698,6 +731,7 @@ int launch_igemm_mode(const ConvP& p, hipStream_t stream) {
 
 template <int BM, int BN, int WM, int WN>
 int launch_igemm(const ConvP& p, hipStream_t stream) {
+  if (fast_ok(p) && p.pad_mode == SEGSDE_PAD_REFLECT_ADJOINT) return launch_igemm_mode<BM, BN, WM, WN, 3, 32>(p, stream);
   if (tune().bk64 && bk64_ok(p)) return launch_igemm_mode<BM, BN, WM, WN, 2, 64>(p, stream);
   if (fast_ok(p)) return launch_igemm_mode<BM, BN, WM, WN, 2, 32>(p, stream);
   if (vec_ok(p)) return launch_igemm_mode<BM, BN, WM, WN, 1, 32>(p, stream);
