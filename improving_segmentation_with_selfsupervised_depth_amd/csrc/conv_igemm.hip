@@ -34,6 +34,7 @@ struct ConvP {
   int Ho, Wo, N, ldy, ldy2, nsplit;
   int KH, KW, stride, dil, pad, pad_mode, in_div;
   int Ctot, Ktot, M, act, sum2x2;
+  const float* zero;   // 256 bytes of zeros: target of out-of-range tile loads
 };
 
 struct KInfo {  // decoded reduction index k -> tap + channel + source
@@ -181,7 +182,7 @@ __device__ __forceinline__ float4 fast_fetch(const ConvP& p, const SrcSel& s, in
   hi = ok ? (refl ? hr : hi) : 0;
   wi = ok ? (refl ? wr : wi) : 0;
   const float* ptr = s.src + off_at(s, b, hi, wi, cq);
-  ptr = ok ? ptr : segsde_zero_page;
+  ptr = ok ? ptr : p.zero;
   return *reinterpret_cast<const float4*>(ptr);
 }
 
@@ -206,7 +207,7 @@ __device__ __forceinline__ float4 adjoint_extras(const ConvP& p, const SrcSel& s
 // MODE 0: generic scalar gather, 1: generic float4 gather, 2: FAST (uniform tap per chunk, branch-free loads),
 // 3: FAST + reflection-pad adjoint extras
 template <int BM, int BN, int WM, int WN, int MODE, int BK>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
+__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
   constexpr bool VEC = MODE >= 1;
   constexpr bool FAST = MODE >= 2;
   constexpr bool ADJ = MODE == 3;
@@ -239,7 +240,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
 #pragma unroll
   for (int i = 0; i < BR; ++i) {
     const int n = n0 + r0 + RP * i;
-    wrow[i] = n < p.N ? p.w + (long)n * p.Ktot + 4 * kq : segsde_zero_page;   // rows past Cout read zeros
+    wrow[i] = n < p.N ? p.w + (long)n * p.Ktot + 4 * kq : p.zero;   // rows past Cout read zeros
     wstep[i] = n < p.N ? BK : 0;
   }
   ChunkState cs; cs.c0 = 0; cs.kh = 0; cs.kw = 0;
@@ -252,21 +253,24 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  float4 ra[AR], rbv[BR], rex[ADJ ? AR : 1];
+  float4 ra[AR], rbv[BR], rex[AR];
   const int nchunks = (p.Ktot + BK - 1) / BK;
 
   auto gload = [&](int kc) {
     // chunks past the end are loaded from clamped (valid) addresses and discarded: the K loop stays branch-free
     const bool live = kc < nchunks;
     const int kcl = live ? kc : nchunks - 1;
-    if (FAST) {
+    if constexpr (FAST) {
       const SrcSel s = select_src(p, cs.c0);
       const int dh = cs.kh * p.dil - p.pad, dw = cs.kw * p.dil - p.pad;
 #pragma unroll
       for (int i = 0; i < AR; ++i) ra[i] = fast_fetch(p, s, rb[i], rh[i] + dh, rw[i] + dw, rok[i] && live, 4 * kq);
 #pragma unroll
-      for (int i = 0; i < BR; ++i) rbv[i] = *reinterpret_cast<const float4*>(wrow[i] + kcl * wstep[i]);
-      if (ADJ) {
+      for (int i = 0; i < BR; ++i) {
+        const float4 v = *reinterpret_cast<const float4*>(wrow[i] + kcl * wstep[i]);
+        rbv[i] = make_float4(v.x, v.y, v.z, v.w);
+      }
+      if constexpr (ADJ) {
 #pragma unroll
         for (int i = 0; i < AR; ++i) rex[i] = adjoint_extras(p, s, rb[i], rh[i], rw[i], rok[i] && live, 4 * kq, dh, dw);
       }
@@ -285,7 +289,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
       float4 v = ra[i];
-      if (ADJ) { v.x += rex[i].x; v.y += rex[i].y; v.z += rex[i].z; v.w += rex[i].w; }
+      if constexpr (ADJ) { v.x += rex[i].x; v.y += rex[i].y; v.z += rex[i].z; v.w += rex[i].w; }
       *reinterpret_cast<float4*>(As + (r0 + RP * i) * LDT + 4 * kq) = v;
     }
 #pragma unroll
@@ -387,7 +391,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
 constexpr int BP = 32;  // pixels per staged chunk
 
 template <int BKT, int BN, int WM, int WN, int MODE>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvP p, const float* dy, int lddy, float* part,
+__global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(ConvP p, const float* dy, int lddy, float* part,
                                                          int chunks_per_split) {
   constexpr bool VEC = MODE >= 1;
   constexpr bool FAST = MODE == 2;
@@ -463,7 +467,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvP p, const float* d
         float4 v;
         if (dyvec) {
           const bool ok = m < p.M && n < p.N;
-          v = *reinterpret_cast<const float4*>(ok ? dy + (long)m * lddy + n : segsde_zero_page);
+          v = *reinterpret_cast<const float4*>(ok ? dy + (long)m * lddy + n : p.zero);
         } else {   // odd Cout (19 classes, 1 disparity channel): scalar, clamped
           const float* src = dy + (long)(m < p.M ? m : 0) * lddy;
           float t[4];
@@ -675,6 +679,15 @@ const Tune& tune() {
   return t;
 }
 
+const float* zero_page() {
+  static const float* z = [] {
+    void* q = nullptr;
+    (void)hipGetSymbolAddress(&q, HIP_SYMBOL(segsde_zero_page));
+    return static_cast<const float*>(q);
+  }();
+  return z;
+}
+
 ConvP make_params(const segsde_conv_desc* d, const float* x0, const float* x1, const float* w, const float* bias,
                   float* y, float* y2) {
   ConvP p;
@@ -686,6 +699,7 @@ ConvP make_params(const segsde_conv_desc* d, const float* x0, const float* x1, c
   p.in_div = d->in_div < 1 ? 1 : d->in_div;
   p.Ctot = d->C0 + d->C1; p.Ktot = d->KH * d->KW * p.Ctot; p.M = d->B * d->Ho * d->Wo; p.act = d->act;
   p.sum2x2 = d->sum2x2;
+  p.zero = zero_page();
   return p;
 }
 
