@@ -34,6 +34,7 @@ struct ConvP {
   int Ho, Wo, N, ldy, ldy2, nsplit;
   int KH, KW, stride, dil, pad, pad_mode, in_div;
   int Ctot, Ktot, M, act, sum2x2;
+  int nb, ne;          // output-channel range [nb, ne) handled by this launch (tile-shape mixing for Cout % 128 == 64)
   const float* zero;   // 256 bytes of zeros: target of out-of-range tile loads
 };
 
@@ -122,7 +123,7 @@ __device__ __forceinline__ float4 fetch_a4(const ConvP& p, int k, int b, int hb,
 template <bool VEC>
 __device__ __forceinline__ float4 fetch_w4(const ConvP& p, int n, int k) {
   float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (n >= p.N) return v;
+  if (n >= p.ne) return v;
   const float* row = p.w + (long)n * p.Ktot;
   if (VEC) {
     if (k < p.Ktot) v = *reinterpret_cast<const float4*>(row + k);
@@ -211,8 +212,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
   constexpr bool VEC = MODE >= 1;
   constexpr bool FAST = MODE >= 2;
   constexpr bool ADJ = MODE == 3;
-  constexpr int LDT = BK + 4;               // LDS row pitch (floats): conflict-free ds_read_b128 fragments
+  // LDS rows are unpadded (BK floats); the 16-byte column groups of a row are XOR-swizzled with the row index so that
+  // the 16 lanes of every ds_read_b128 lane group hit 16 distinct 16-byte slots of the 256-byte bank row (conflict-free)
+  // -- no padding means 48 KB instead of 54 KB for the 128x64 tile, i.e. THREE workgroups per CU instead of two.
+  constexpr int LDT = BK;
   constexpr int KQ = BK / 4, RP = 256 / KQ; // float4 columns per tile row, tile rows staged per pass
+  constexpr int RPS = 16 / KQ;              // tile rows per 256-byte LDS bank row
+  auto swz = [](int row) { return (row / RPS) & (KQ - 1); };
   constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
   constexpr int AR = BM / RP, BR = BN / RP;
   constexpr int STAGE = (BM + BN) * LDT;
@@ -220,11 +226,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
   SEGSDE_SMEM;
   float* smem = reinterpret_cast<float*>(segsde_smem);
 
-  const int ntn = (p.N + BN - 1) / BN;
+  const int ntn = (p.ne - p.nb + BN - 1) / BN;
   const int ntm = (p.M + BM - 1) / BM;
   const int tile = segsde_xcd_remap(blockIdx.x, ntm * ntn);
   const int mt = tile / ntn, nt = tile - mt * ntn;
-  const int m0 = mt * BM, n0 = nt * BN;
+  const int m0 = mt * BM, n0 = p.nb + nt * BN;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave - wm * WN;
@@ -240,8 +246,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
 #pragma unroll
   for (int i = 0; i < BR; ++i) {
     const int n = n0 + r0 + RP * i;
-    wrow[i] = n < p.N ? p.w + (long)n * p.Ktot + 4 * kq : p.zero;   // rows past Cout read zeros
-    wstep[i] = n < p.N ? BK : 0;
+    wrow[i] = n < p.ne ? p.w + (long)n * p.Ktot + 4 * kq : p.zero;   // rows past Cout read zeros
+    wstep[i] = n < p.ne ? BK : 0;
   }
   ChunkState cs; cs.c0 = 0; cs.kh = 0; cs.kw = 0;
 
@@ -290,23 +296,29 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
     for (int i = 0; i < AR; ++i) {
       float4 v = ra[i];
       if constexpr (ADJ) { v.x += rex[i].x; v.y += rex[i].y; v.z += rex[i].z; v.w += rex[i].w; }
-      *reinterpret_cast<float4*>(As + (r0 + RP * i) * LDT + 4 * kq) = v;
+      const int row = r0 + RP * i;
+      *reinterpret_cast<float4*>(As + row * LDT + 4 * (kq ^ swz(row))) = v;
     }
 #pragma unroll
-    for (int i = 0; i < BR; ++i) *reinterpret_cast<float4*>(Bs + (r0 + RP * i) * LDT + 4 * kq) = rbv[i];
+    for (int i = 0; i < BR; ++i) {
+      const int row = r0 + RP * i;
+      *reinterpret_cast<float4*>(Bs + row * LDT + 4 * (kq ^ swz(row))) = rbv[i];
+    }
   };
   auto mma_groups = [&](int buf, int g0, int g1) {
     const float* As = smem + buf * STAGE;
     const float* Bs = As + BM * LDT;
-    const float* Ap = As + (wm * TM * 32 + (lane & 31)) * LDT + 4 * (lane >> 5);
-    const float* Bp = Bs + (wn * TN * 32 + (lane & 31)) * LDT + 4 * (lane >> 5);
+    const int arow = wm * TM * 32 + (lane & 31), brow = wn * TN * 32 + (lane & 31), h = lane >> 5;
+    const float* Ap = As + arow * LDT;
+    const float* Bp = Bs + brow * LDT;
+    const int sa = swz(arow), sb = swz(brow);   // rows 32 apart share the swizzle (32 / RPS is a multiple of KQ)
 #pragma unroll
     for (int g = g0; g < g1; ++g) {
       float4 a[TM], b[TN];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const float4*>(Ap + i * 32 * LDT + 8 * g);
+      for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const float4*>(Ap + i * 32 * LDT + 4 * ((2 * g + h) ^ sa));
 #pragma unroll
-      for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const float4*>(Bp + j * 32 * LDT + 8 * g);
+      for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const float4*>(Bp + j * 32 * LDT + 4 * ((2 * g + h) ^ sb));
       // k-step outermost: consecutive MFMAs target different accumulators
 #pragma unroll
       for (int i = 0; i < TM; ++i)
@@ -350,7 +362,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int n = n0 + (wn * TN + j) * 32 + col;
-    if (n >= p.N) continue;
+    if (n >= p.ne) continue;
     const float bias = p.bias ? p.bias[n] : 0.f;
     float* dst; long ld; int nn;
     if (n < p.nsplit) { dst = p.y; ld = p.ldy; nn = n; }
@@ -699,6 +711,7 @@ ConvP make_params(const segsde_conv_desc* d, const float* x0, const float* x1, c
   p.in_div = d->in_div < 1 ? 1 : d->in_div;
   p.Ctot = d->C0 + d->C1; p.Ktot = d->KH * d->KW * p.Ctot; p.M = d->B * d->Ho * d->Wo; p.act = d->act;
   p.sum2x2 = d->sum2x2;
+  p.nb = 0; p.ne = p.N;
   p.zero = zero_page();
   return p;
 }
@@ -734,8 +747,8 @@ bool bk64_ok(const ConvP& p) { return fast_ok(p) && (p.Ctot % 64 == 0) && (p.C1 
 
 template <int BM, int BN, int WM, int WN, int MODE, int BK>
 int launch_igemm_mode(const ConvP& p, hipStream_t stream) {
-  const int nblk = segsde_cdiv(p.M, BM) * segsde_cdiv(p.N, BN);
-  const size_t smem = 2 * (size_t)(BM + BN) * (BK + 4) * sizeof(float);
+  const int nblk = segsde_cdiv(p.M, BM) * segsde_cdiv(p.ne - p.nb, BN);
+  const size_t smem = 2 * (size_t)(BM + BN) * BK * sizeof(float);
   auto k = conv_igemm_kernel<BM, BN, WM, WN, MODE, BK>;
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   hipLaunchKernelGGL(k, dim3(nblk), dim3(256), smem, stream, p);
@@ -776,7 +789,13 @@ extern "C" int segsde_conv2d_forward(const segsde_conv_desc* d, const float* x0,
   int e;
   if (p.N <= 32) e = launch_igemm<128, 32, 4, 1>(p, s);
   else if (p.N <= 64) e = launch_igemm<128, 64, 2, 2>(p, s);
-  else e = launch_igemm<128, 128, 2, 2>(p, s);
+  else if (p.N % 128 > 0 && p.N % 128 <= 64) {
+    // e.g. the 192-channel concat data-gradient: 128-wide tiles for the bulk, 64-wide tiles for the 64-channel tail
+    ConvP a = p, b = p;
+    a.ne = p.N - p.N % 128; b.nb = a.ne;
+    e = launch_igemm<128, 128, 2, 2>(a, s);
+    if (!e) e = (b.ne - b.nb <= 32) ? launch_igemm<128, 32, 4, 1>(b, s) : launch_igemm<128, 64, 2, 2>(b, s);
+  } else e = launch_igemm<128, 128, 2, 2>(p, s);
   if (e) return e;
   if (d->pad_mode == SEGSDE_PAD_REFLECT_ADJOINT && !fast_ok(p))
     // the generic gathers treat the padding as zeros; add the mirrored-padding contributions on the border pixels
@@ -813,8 +832,8 @@ void wgrad_plan(const segsde_conv_desc* d, int& bkt, int& bn, int& splits, int& 
   bkt = 128;
   const long tiles = (long)segsde_cdiv(Ktot, bkt) * segsde_cdiv(d->Cout, bn);
   const int nchunks = segsde_cdiv(M, BP);
-  long want = (1536 + tiles - 1) / tiles;          // ~6 workgroups per CU overall
-  if (want > nchunks / 4) want = nchunks / 4;      // at least 4 chunks (128 pixels) per split
+  long want = (1024 + tiles - 1) / tiles;          // ~4 workgroups per CU overall (2 resident)
+  if (want > nchunks / 8) want = nchunks / 8;      // at least 8 chunks (256 pixels) per split: amortise prologue/epilogue
   if (want < 1) want = 1;
   if (want > 1024) want = 1024;
   cps = segsde_cdiv(nchunks, want);
