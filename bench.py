@@ -149,8 +149,10 @@ def main():
     torch.cuda.set_device(local_rank)     # before constructing anything (SURVEY.md 8b device quirk)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
-    if world > 1:
+    force_reducer = bool(os.environ.get("SEGSDE_FORCE_REDUCER"))   # exercise the RCCL all-reduce path on one GPU
+    if world > 1 or force_reducer:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world)
 
     import __graft_entry__ as ge
@@ -170,7 +172,7 @@ def main():
     model = get_model(cfg, 19).to(dev).train()
     optimizer = param_groups(model, opt_name)
     loss_obj = get_monodepth_loss(loss_cfg(B, Hh, W), is_train=True)
-    reducer = GradAllReducer(model) if world > 1 else None
+    reducer = GradAllReducer(model, always=force_reducer) if (world > 1 or force_reducer) else None
     inputs = synthetic_inputs(B, Hh, W, dev, 1234 + rank, with_labels=cfg.get("segmentation_name") is not None)
     clip = 10.0 if opt_name == "sgd" else None
 
@@ -259,7 +261,7 @@ def main():
                 res["cpu_baseline"] = {"value": None, "unit": "img/s", "cores": os.cpu_count(), "kind": "port",
                                        "sample": "not measured: %r" % (ex,)}
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if world > 1 or force_reducer:
         dist.destroy_process_group()
 
 

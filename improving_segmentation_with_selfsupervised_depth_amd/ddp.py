@@ -28,10 +28,11 @@ class _Bucket:
 
 
 class GradAllReducer:
-    def __init__(self, module, bucket_mb=32.0, process_group=None, overlap=True):
+    def __init__(self, module, bucket_mb=32.0, process_group=None, overlap=True, always=False):
         self.module = module
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.always = always       # run the bucket / hook / collective machinery even with a single rank (self-test)
         self.bucket_bytes = int(bucket_mb * 1024 * 1024)
         self.overlap = overlap
         self.buckets = None
@@ -40,7 +41,7 @@ class GradAllReducer:
         self.broadcast_parameters()
 
     def broadcast_parameters(self):
-        if self.world == 1:
+        if self.world == 1 and not self.always:
             return
         with torch.no_grad():
             for t in list(self.module.parameters()) + list(self.module.buffers()):
@@ -75,7 +76,7 @@ class GradAllReducer:
 
     def finish(self):
         """call after backward(), before clipping / the optimizer step"""
-        if self.world == 1:
+        if self.world == 1 and not self.always:
             return
         if self.buckets is None:
             # first step: learn which parameters actually receive gradients, reduce them unbucketed-overlap
