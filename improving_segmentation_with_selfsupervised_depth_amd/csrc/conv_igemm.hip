@@ -405,8 +405,11 @@ constexpr int BP = 32;  // pixels per staged chunk
 template <int BKT, int BN, int WM, int WN, int MODE>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(ConvP p, const float* dy, int lddy, float* part,
                                                          int chunks_per_split) {
+  // MODE 0: scalar gather, 1: float4 gather, 2: FAST A side + vector dY + rows at least 32 pixels wide (straight-line
+  // loop), 3: FAST A side with the general row walk / scalar dY (odd Cout, tiny feature maps)
   constexpr bool VEC = MODE >= 1;
-  constexpr bool FAST = MODE == 2;
+  constexpr bool FAST = MODE >= 2;
+  constexpr bool SIMPLE = MODE == 2;
   constexpr int TM = BKT / (WM * 32), TN = BN / (WN * 32);
   constexpr int AQ = BKT / 4, DQ = BN / 4;             // float4 columns per tile row
   constexpr int AI = (BP * AQ) / 256, DI = (BP * DQ) / 256;
@@ -451,12 +454,12 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(ConvP p, const float
     }
   }
   const int wstep = BP * p.stride, wlim = p.Wo * p.stride, hlim = p.Ho * p.stride;
-  const bool dyvec = (p.N % 4 == 0) && (lddy % 4 == 0) && ((reinterpret_cast<uintptr_t>(dy) & 15) == 0);
+  const bool dyvec = SIMPLE || ((p.N % 4 == 0) && (lddy % 4 == 0) && ((reinterpret_cast<uintptr_t>(dy) & 15) == 0));
 
   float4 ra[AI], rd[DI];
-  const bool wide = p.Wo >= BP;   // a 32-pixel step wraps at most one image row: carries instead of divisions
+  const bool wide = SIMPLE || p.Wo >= BP;   // a 32-pixel step wraps at most one image row: carries, not divisions
   auto gload = [&](int c) {
-    if (FAST) {
+    if constexpr (FAST) {
 #pragma unroll
       for (int i = 0; i < AI; ++i) {
         ra[i] = fast_fetch(p, fs, fb[i], fh[i] + fdh, fw[i] + fdw, fk_ok && fm[i] < p.M, 0);
@@ -536,18 +539,26 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(ConvP p, const float
     const float* Dt = At + BP * BKT;
     const float* Ap = At + (lane >> 5) * BKT + wm * TM * 32 + (lane & 31);
     const float* Dp = Dt + (lane >> 5) * BN + wn * TN * 32 + (lane & 31);
+    // fetch the fragments of 4 k-steps at a time ahead of their MFMAs (counted lgkmcnt waits) instead of read-wait-use
+    // per step, which exposed the LDS latency every four MFMAs
 #pragma unroll
-    for (int s = s0; s < s1; ++s) {
-      float a[TM], d[TN];
+    for (int sb = s0; sb < s1; sb += 4) {
+      float a[4][TM], d[4][TN];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) a[i] = Ap[2 * s * BKT + i * 32];
+      for (int u = 0; u < 4; ++u) {
 #pragma unroll
-      for (int j = 0; j < TN; ++j) d[j] = Dp[2 * s * BN + j * 32];
+        for (int i = 0; i < TM; ++i) a[u][i] = Ap[2 * (sb + u) * BKT + i * 32];
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+        for (int j = 0; j < TN; ++j) d[u][j] = Dp[2 * (sb + u) * BN + j * 32];
+      }
+      __builtin_amdgcn_sched_barrier(0);   // keep the read batch ahead of the MFMAs (the scheduler sinks it otherwise)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], d[j], acc[i][j], 0, 0, 0);
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][i], d[u][j], acc[i][j], 0, 0, 0);
     }
   };
   // same software pipeline as the forward kernel: LDS stores + the loads of chunk c+2 sit between the two halves of
@@ -820,7 +831,8 @@ int launch_wgrad(const ConvP& p, const float* dy, int lddy, float* ws, int split
   const bool vec = vec_ok(p) && (p.N % 4 == 0) && (lddy % 4 == 0) && aligned16(dy);
   const long e0 = (long)p.B * (p.H >> p.up0) * (p.W >> p.up0) * p.ld0, e1 = (long)p.B * p.H * p.W * p.ld1;
   const bool fast = vec_ok(p) && e0 < (1L << 31) && e1 < (1L << 31);   // the dY side may be scalar (odd Cout)
-  if (fast) return launch_wgrad_mode<BKT, BN, WM, WN, 2>(p, dy, lddy, ws, splits, cps, stream);
+  if (fast && vec && p.Wo >= BP) return launch_wgrad_mode<BKT, BN, WM, WN, 2>(p, dy, lddy, ws, splits, cps, stream);
+  if (fast) return launch_wgrad_mode<BKT, BN, WM, WN, 3>(p, dy, lddy, ws, splits, cps, stream);
   if (vec) return launch_wgrad_mode<BKT, BN, WM, WN, 1>(p, dy, lddy, ws, splits, cps, stream);
   return launch_wgrad_mode<BKT, BN, WM, WN, 0>(p, dy, lddy, ws, splits, cps, stream);
 }
@@ -832,8 +844,11 @@ void wgrad_plan(const segsde_conv_desc* d, int& bkt, int& bn, int& splits, int& 
   bkt = 128;
   const long tiles = (long)segsde_cdiv(Ktot, bkt) * segsde_cdiv(d->Cout, bn);
   const int nchunks = segsde_cdiv(M, BP);
-  long want = (1024 + tiles - 1) / tiles;          // ~4 workgroups per CU overall (2 resident)
-  if (want > nchunks / 8) want = nchunks / 8;      // at least 8 chunks (256 pixels) per split: amortise prologue/epilogue
+  long want = (1536 + tiles - 1) / tiles;          // ~6 workgroups per CU overall (2 resident): measured best for long loops
+  if (nchunks / want < 64) {                       // short reductions: fewer, longer splits amortise prologue/epilogue
+    want = (1024 + tiles - 1) / tiles;
+    if (want > nchunks / 8) want = nchunks / 8;
+  }
   if (want < 1) want = 1;
   if (want > 1024) want = 1024;
   cps = segsde_cdiv(nchunks, want);

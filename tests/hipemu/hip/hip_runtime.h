@@ -190,3 +190,4 @@ inline emu_f32x4 emu_mfma_16x16x4(float a, float b, emu_f32x4 c, int, int, int) 
 #define __builtin_amdgcn_mfma_f32_16x16x4f32 emu_mfma_16x16x4
 #define HIP_SYMBOL(x) (&x)
 inline hipError_t hipGetSymbolAddress(void** p, const void* sym) { *p = const_cast<void*>(sym); return 0; }
+inline void __builtin_amdgcn_sched_barrier(int) {}
