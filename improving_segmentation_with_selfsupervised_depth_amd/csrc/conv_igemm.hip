@@ -34,6 +34,7 @@ struct ConvP {
   int Ho, Wo, N, ldy, ldy2, nsplit;
   int KH, KW, stride, dil, pad, pad_mode, in_div;
   int Ctot, Ktot, M, act, sum2x2;
+  int vecout;          // outputs allow 16-byte stores (pitches, split point and bases multiples of 4 floats / 16 B)
   int nb, ne;          // output-channel range [nb, ne) handled by this launch (tile-shape mixing for Cout % 128 == 64)
   const float* zero;   // 256 bytes of zeros: target of out-of-range tile loads
 };
@@ -355,6 +356,42 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
     gload(kc + 2);
     mma_groups(kc & 1, NG / 2, NG);
     __syncthreads();
+  }
+
+  // epilogue, staged variant: the accumulator tile goes through LDS (free after the K loop) so that every output row
+  // leaves as 16-byte stores covering whole 512-byte (BN*4) row segments, instead of 4-byte stores per lane -- the
+  // short-K layers (1x1 bottleneck convs and their gradients) are bound by exactly this store stream.
+  if (p.vecout && !p.sum2x2) {
+    float* Ct = smem;                      // [BM][BN] floats = 2 stages of (BM+BN)*BK only when BN <= 2*BK... checked on host
+    const int col = lane & 31, rhalf = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int nl = (wn * TN + j) * 32 + col;
+      const int n = n0 + nl;
+      const float bias = (p.bias && n < p.ne) ? p.bias[n] : 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int ml = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * rhalf;
+          Ct[ml * BN + nl] = segsde_act(acc[i][j][r] + bias, p.act);
+        }
+    }
+    __syncthreads();
+    constexpr int CQ = BN / 4, RPP = 256 / CQ;    // float4 columns per row, rows per pass
+    const int cq = tid % CQ, rr = tid / CQ;
+    const int n = n0 + 4 * cq;
+    if (n < p.ne) {
+      float* dst; long ld; int nn;
+      if (n < p.nsplit) { dst = p.y; ld = p.ldy; nn = n; }
+      else { dst = p.y2; ld = p.ldy2; nn = n - p.nsplit; }
+#pragma unroll 4
+      for (int ml = rr; ml < BM; ml += RPP) {
+        const int m = m0 + ml;
+        if (m < p.M) *reinterpret_cast<float4*>(dst + (long)m * ld + nn) = *reinterpret_cast<const float4*>(Ct + ml * BN + 4 * cq);
+      }
+    }
+    return;
   }
 
   // epilogue: bias + activation, channel-split store (concat data-gradients go to two tensors)
@@ -702,6 +739,8 @@ const Tune& tune() {
   return t;
 }
 
+bool aligned16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
+
 const float* zero_page() {
   static const float* z = [] {
     void* q = nullptr;
@@ -723,11 +762,12 @@ ConvP make_params(const segsde_conv_desc* d, const float* x0, const float* x1, c
   p.Ctot = d->C0 + d->C1; p.Ktot = d->KH * d->KW * p.Ctot; p.M = d->B * d->Ho * d->Wo; p.act = d->act;
   p.sum2x2 = d->sum2x2;
   p.nb = 0; p.ne = p.N;
+  p.vecout = (p.N % 4 == 0) && (p.ldy % 4 == 0) && (p.ldy2 % 4 == 0) && (p.nsplit % 4 == 0) && aligned16(p.y) &&
+             aligned16(p.y2);
   p.zero = zero_page();
   return p;
 }
 
-bool aligned16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
 
 bool vec_ok(const ConvP& p) {
   return (p.Ctot % 4 == 0) && (p.C0 % 4 == 0) && (p.ld0 % 4 == 0) && (p.ld1 % 4 == 0) && aligned16(p.x0) &&
