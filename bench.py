@@ -232,11 +232,23 @@ def main():
                 "kernel": "conv_igemm_kernel (implicit-GEMM forward + data-gradient, v_mfma_f32_32x32x2_f32)"}
         if prof:
             agg = {}
-            for kind, flops, s, e in prof:
+            layers = {}
+            for kind, flops, s, e, tag in prof:
+                t = s.elapsed_time(e) * 1e-3
                 a = agg.setdefault(kind, [0.0, 0.0, 0])
                 a[0] += flops
-                a[1] += s.elapsed_time(e) * 1e-3
+                a[1] += t
                 a[2] += 1
+                b = layers.setdefault((kind, tag), [0.0, 0.0, 0])
+                b[0] += flops
+                b[1] += t
+                b[2] += 1
+            if os.environ.get("SEGSDE_BENCH_LAYERS"):
+                with open(os.environ["SEGSDE_BENCH_LAYERS"], "w") as f:
+                    f.write("# per-layer conv launches over %d timed steps (HIP events on the launch stream)\n" % args.steps)
+                    for (kind, tag), v in sorted(layers.items(), key=lambda kv: -kv[1][1]):
+                        f.write("%-11s %-40s n=%4d  %8.2f ms/step  %6.1f TF  %5.2f%% of step\n" % (
+                            kind, tag, v[2], v[1] / args.steps * 1e3, v[0] / v[1] / 1e12, 100 * v[1] / dt))
             fl = sum(agg[k][0] for k in ("conv_fwd", "conv_dgrad") if k in agg)
             tt = sum(agg[k][1] for k in ("conv_fwd", "conv_dgrad") if k in agg)
             nl = sum(agg[k][2] for k in ("conv_fwd", "conv_dgrad") if k in agg)

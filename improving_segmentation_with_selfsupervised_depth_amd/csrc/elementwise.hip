@@ -11,6 +11,18 @@
 
 namespace {
 
+template <int VW> struct VecF { float v[VW]; };
+template <int VW> __device__ __forceinline__ VecF<VW> ldv(const float* p) {
+  VecF<VW> r;
+  if (VW == 4) { const float4 t = *reinterpret_cast<const float4*>(p); r.v[0] = t.x; r.v[1 % VW] = t.y; r.v[2 % VW] = t.z; r.v[3 % VW] = t.w; }
+  else r.v[0] = p[0];
+  return r;
+}
+template <int VW> __device__ __forceinline__ void stv(float* p, const VecF<VW>& r) {
+  if (VW == 4) *reinterpret_cast<float4*>(p) = make_float4(r.v[0], r.v[1 % VW], r.v[2 % VW], r.v[3 % VW]);
+  else p[0] = r.v[0];
+}
+
 constexpr int SLAB = 64;      // channels per block column
 constexpr int RLANES = 4;     // row lanes per block (256 threads = 64 channels x 4 rows)
 
@@ -62,17 +74,6 @@ int launch_colreduce(Op op, long M, int C, double* part, bool vec, hipStream_t s
   return 0;
 }
 
-template <int VW> struct VecF { float v[VW]; };
-template <int VW> __device__ __forceinline__ VecF<VW> ldv(const float* p) {
-  VecF<VW> r;
-  if (VW == 4) { const float4 t = *reinterpret_cast<const float4*>(p); r.v[0] = t.x; r.v[1 % VW] = t.y; r.v[2 % VW] = t.z; r.v[3 % VW] = t.w; }
-  else r.v[0] = p[0];
-  return r;
-}
-template <int VW> __device__ __forceinline__ void stv(float* p, const VecF<VW>& r) {
-  if (VW == 4) *reinterpret_cast<float4*>(p) = make_float4(r.v[0], r.v[1 % VW], r.v[2 % VW], r.v[3 % VW]);
-  else p[0] = r.v[0];
-}
 inline bool al16p(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 size_t part_bytes(long M, int C) { return (size_t)red_blocks(M) * 2 * C * sizeof(double); }
@@ -142,26 +143,21 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* x, int ldx, 
     // channel counts are powers of two on the whole ResNet / decoder path: shift + mask instead of a 64-bit division
     const long m = cv_shift >= 0 ? (e >> cv_shift) : e / CV;
     const int c = (int)(e - m * CV) * VW;
-    float v[VW], r[VW];
-    if (VW == 4) {
-      const float4 t = *reinterpret_cast<const float4*>(x + m * ldx + c);
-      v[0] = t.x; v[1 % VW] = t.y; v[2 % VW] = t.z; v[3 % VW] = t.w;
-      if (res) { const float4 q = *reinterpret_cast<const float4*>(res + m * ldr + c); r[0] = q.x; r[1 % VW] = q.y; r[2 % VW] = q.z; r[3 % VW] = q.w; }
-    } else {
-      v[0] = x[m * ldx + c];
-      if (res) r[0] = res[m * ldr + c];
-    }
+    // per-channel parameters as one 16-byte load each (they were 16 scalar loads per float4 of data before)
+    const VecF<VW> xv = ldv<VW>(x + m * ldx + c), mu = ldv<VW>(mean + c), is = ldv<VW>(invstd + c);
+    VecF<VW> ga, be, rv, o;
+    if (gamma) { ga = ldv<VW>(gamma + c); be = ldv<VW>(beta + c); }
+    if (res) rv = ldv<VW>(res + m * ldr + c);
 #pragma unroll
     for (int j = 0; j < VW; ++j) {
-      float t = (v[j] - mean[c + j]) * invstd[c + j];
-      if (gamma) t = t * gamma[c + j] + beta[c + j];
-      if (res) t += r[j];
+      float t = (xv.v[j] - mu.v[j]) * is.v[j];
+      if (gamma) t = t * ga.v[j] + be.v[j];
+      if (res) t += rv.v[j];
       t = segsde_act(t, act);
       if (drop_p > 0.f) t = segsde_uniform01(seed, (uint64_t)(m * C + c + j)) >= drop_p ? t * keep_scale : 0.f;
-      v[j] = t;
+      o.v[j] = t;
     }
-    if (VW == 4) *reinterpret_cast<float4*>(y + m * ldy + c) = make_float4(v[0], v[1 % VW], v[2 % VW], v[3 % VW]);
-    else y[m * ldy + c] = v[0];
+    stv<VW>(y + m * ldy + c, o);
   }
 }
 
@@ -221,17 +217,22 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* dy, int 
     const VecF<VW> g = ldv<VW>(dy + m * lddy + c), yy = ldv<VW>(y + m * ldy + c);
     VecF<VW> xx;
     if (dx && batch_stats) xx = ldv<VW>(x + m * ldx + c);
-    VecF<VW> dz, o;
+    VecF<VW> dz, o, ga, mu, is, dg, db;
+    if (dx) {
+      is = ldv<VW>(invstd + c);
+      if (gamma) ga = ldv<VW>(gamma + c);
+      if (batch_stats) { mu = ldv<VW>(mean + c); dg = ldv<VW>(dgamma + c); db = ldv<VW>(dbeta + c); }
+    }
 #pragma unroll
     for (int j = 0; j < VW; ++j) {
       dz.v[j] = bn_dz(g.v[j], yy.v[j], act, drop_p, seed, (uint64_t)(m * C + c + j));
       if (dx) {
-        const float gm = gamma ? gamma[c + j] : 1.f;
+        const float gm = gamma ? ga.v[j] : 1.f;
         if (batch_stats) {
-          const float xh = (xx.v[j] - mean[c + j]) * invstd[c + j];
-          o.v[j] = gm * invstd[c + j] * (dz.v[j] - dbeta[c + j] * invM - xh * dgamma[c + j] * invM);
+          const float xh = (xx.v[j] - mu.v[j]) * is.v[j];
+          o.v[j] = gm * is.v[j] * (dz.v[j] - db.v[j] * invM - xh * dg.v[j] * invM);
         } else {
-          o.v[j] = gm * invstd[c + j] * dz.v[j];
+          o.v[j] = gm * is.v[j] * dz.v[j];
         }
       }
     }

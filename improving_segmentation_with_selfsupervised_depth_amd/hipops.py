@@ -18,15 +18,20 @@ ACT = {"none": 0, "relu": 1, "elu": 2, "sigmoid": 3}
 PROFILE = None
 
 
-def _timed(kind, flops, like, launch):
+def _timed(kind, flops, like, launch, tag=""):
     if PROFILE is None or not like.is_cuda:
         return launch()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
     r = launch()
     e.record()
-    PROFILE.append((kind, flops, s, e))
+    PROFILE.append((kind, flops, s, e, tag))
     return r
+
+
+def _tag(g, H, W):
+    return "%d+%d->%d k%d s%d d%d %dx%d%s%s" % (g.C0, g.C1, g.Cout, g.k, g.stride, g.dil, H, W, " up" if g.up0 else "",
+                                                " refl" if g.reflect else "")
 PAD_ZERO, PAD_REFLECT, PAD_REFLECT_ADJOINT = 0, 1, 2
 
 
@@ -109,7 +114,8 @@ def conv_forward(g, x0, x1, wpack, bias, act="none"):
                  act=ACT[act], sum2x2=0)
     flops = 2.0 * B * Ho * Wo * g.Cout * g.Cin * g.k * g.k
     _timed("conv_fwd", flops, x0, lambda: check(_lib.lib().segsde_conv2d_forward(
-        ctypes.byref(d), _p(_f32(x0)), _p(x1), _p(wpack), _p(bias), _p(y), None, _stream(x0)), "conv2d_forward"))
+        ctypes.byref(d), _p(_f32(x0)), _p(x1), _p(wpack), _p(bias), _p(y), None, _stream(x0)), "conv2d_forward"),
+        _tag(g, H, W))
     return y
 
 
@@ -132,7 +138,7 @@ def conv_dgrad(g, dy, wdpack, w_oihw, in_hw, need0=True, need1=True):
         dx0 = torch.empty((B, H // 2, W // 2, g.C0), dtype=torch.float32, device=dy.device)
         d = desc(1)
         rc = _timed("conv_dgrad", flops, dy, lambda: L.segsde_conv2d_forward(
-            ctypes.byref(d), _p(_f32(dy)), None, _p(wdpack), None, _p(dx0), _p(dx1), _stream(dy)))
+            ctypes.byref(d), _p(_f32(dy)), None, _p(wdpack), None, _p(dx0), _p(dx1), _stream(dy)), _tag(g, H, W))
         if rc == 0:
             return dx0, dx1
         if rc != -4:
@@ -140,7 +146,8 @@ def conv_dgrad(g, dy, wdpack, w_oihw, in_hw, need0=True, need1=True):
     full0 = torch.empty((B, H, W, g.C0), dtype=torch.float32, device=dy.device)
     d = desc(0)
     _timed("conv_dgrad", flops, dy, lambda: check(L.segsde_conv2d_forward(
-        ctypes.byref(d), _p(_f32(dy)), None, _p(wdpack), None, _p(full0), _p(dx1), _stream(dy)), "conv2d dgrad"))
+        ctypes.byref(d), _p(_f32(dy)), None, _p(wdpack), None, _p(full0), _p(dx1), _stream(dy)), "conv2d dgrad"),
+        _tag(g, H, W))
     if g.up0:
         dx0 = torch.empty((B, H // 2, W // 2, g.C0), dtype=torch.float32, device=dy.device)
         check(L.segsde_upsample2x_backward(_p(full0), g.C0, B, H // 2, W // 2, g.C0, _p(dx0), g.C0, _stream(dy)),
@@ -164,7 +171,8 @@ def conv_wgrad(g, x0, x1, dy):
     dw = torch.empty((Cout, g.Cin, g.k, g.k), dtype=torch.float32, device=dy.device)
     flops = 2.0 * B * Ho * Wo * Cout * g.Cin * g.k * g.k
     _timed("conv_wgrad", flops, dy, lambda: check(L.segsde_conv2d_wgrad(
-        ctypes.byref(d), _p(x0), _p(x1), _p(_f32(dy)), nhwc_ld(dy), _p(dw), _p(ws), nbytes, _stream(dy)), "conv2d_wgrad"))
+        ctypes.byref(d), _p(x0), _p(x1), _p(_f32(dy)), nhwc_ld(dy), _p(dw), _p(ws), nbytes, _stream(dy)), "conv2d_wgrad"),
+        _tag(g, H, W))
     return dw
 
 
