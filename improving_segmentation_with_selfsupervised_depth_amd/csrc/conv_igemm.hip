@@ -22,6 +22,7 @@
 // MFMA operand order inside a 8-wide k group is permuted (lane half h, step s) -> k = 4h + s so that each
 // lane fetches its 4 A (and 4 B) values with ONE 16-byte LDS read.
 #include "segsde_common.h"
+#include "conv_small.h"
 #include <cstdlib>
 #include <cstring>
 
@@ -176,6 +177,10 @@ __device__ __forceinline__ unsigned off_at(const SrcSel& s, int b, int hi, int w
 // (hi, wi) = output pixel + tap offset.  Straight-line on purpose (selects, no branches): the address is always formed
 // from clamped coordinates and swapped for the zero page when the tap is out of range.
 __device__ __forceinline__ float4 fast_fetch(const ConvP& p, const SrcSel& s, int b, int hi, int wi, bool ok, int cq) {
+  if (p.in_div == 2) {   // data-gradient of a stride-2 conv: only even coordinates carry a value
+    ok = ok && (((hi | wi) & 1) == 0);
+    hi >>= 1; wi >>= 1;
+  }
   const bool refl = p.pad_mode == SEGSDE_PAD_REFLECT;
   const int hr = hi < 0 ? -hi : (hi >= p.H ? 2 * p.H - 2 - hi : hi);
   const int wr = wi < 0 ? -wi : (wi >= p.W ? 2 * p.W - 2 - wi : wi);
@@ -791,7 +796,7 @@ bool fast_ok(const ConvP& p) {
   // uniform-tap chunks + 32-bit element offsets
   const long e0 = (long)p.B * (p.H >> p.up0) * (p.W >> p.up0) * p.ld0;
   const long e1 = (long)p.B * p.H * p.W * p.ld1;
-  return vec_ok(p) && (p.Ctot % 32 == 0) && (p.C1 == 0 || p.C0 % 32 == 0) && p.in_div == 1 && e0 < (1L << 31) &&
+  return vec_ok(p) && (p.Ctot % 32 == 0) && (p.C1 == 0 || p.C0 % 32 == 0) && p.in_div <= 2 && e0 < (1L << 31) &&
          e1 < (1L << 31);
 }
 bool bk64_ok(const ConvP& p) { return fast_ok(p) && (p.Ctot % 64 == 0) && (p.C1 == 0 || p.C0 % 64 == 0); }
@@ -833,6 +838,17 @@ extern "C" int segsde_conv2d_forward(const segsde_conv_desc* d, const float* x0,
   if (!x0 || !wpack || !y || (d->C1 && !x1)) return SEGSDE_ERR_NULL;
   const ConvP p = make_params(d, x0, x1, wpack, bias, y, y2);
   hipStream_t s = static_cast<hipStream_t>(stream);
+  // disparity heads (Cout = 1) and their data-gradients (one gradient channel in): HBM-bound stencil kernels
+  const bool plain3x3 = d->KH == 3 && d->KW == 3 && d->stride == 1 && d->dil == 1 && d->pad == 1 && d->C1 == 0 && !d->up0 &&
+                        d->in_div <= 1 && !d->sum2x2 && d->H == d->Ho && d->W == d->Wo;
+  if (plain3x3 && d->Cout == 1 && d->pad_mode != SEGSDE_PAD_REFLECT_ADJOINT && segsde_c1_supported(d->C0, d->ld0) &&
+      aligned16(x0) && aligned16(wpack))
+    return segsde_c1_forward(x0, d->ld0, d->B, d->H, d->W, d->C0, wpack, bias, d->pad_mode == SEGSDE_PAD_REFLECT, d->act, y,
+                             d->ldy, stream);
+  if (plain3x3 && d->C0 == 1 && d->pad_mode != SEGSDE_PAD_REFLECT && !bias && d->act == 0 &&
+      segsde_c1_supported(d->Cout, p.ldy) && p.vecout)
+    return segsde_c1_dgrad(x0, d->ld0, d->B, d->H, d->W, d->Cout, wpack, d->pad_mode == SEGSDE_PAD_REFLECT_ADJOINT, y, p.ldy,
+                           y2, p.ldy2, p.nsplit, stream);
   if (d->sum2x2) {
     if ((d->Ho & 1) || (d->Wo & 1) || d->stride != 1 || d->act != 0 || bias) return SEGSDE_ERR_SHAPE;
     if (!fast_ok(p)) return SEGSDE_ERR_UNSUPPORTED;   // caller falls back to the two-pass path (full-res dgrad + 2x2 sum)
@@ -896,8 +912,16 @@ void wgrad_plan(const segsde_conv_desc* d, int& bkt, int& bn, int& splits, int& 
 }
 }  // namespace
 
+namespace {
+bool c1_wgrad_route(const segsde_conv_desc* d) {
+  return d->Cout == 1 && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->dil == 1 && d->pad == 1 && d->C1 == 0 && !d->up0 &&
+         d->H == d->Ho && d->W == d->Wo && d->pad_mode != SEGSDE_PAD_REFLECT_ADJOINT && segsde_c1_supported(d->C0, d->ld0);
+}
+}  // namespace
+
 extern "C" size_t segsde_conv2d_wgrad_workspace(const segsde_conv_desc* d) {
   if (validate(d)) return 0;
+  if (c1_wgrad_route(d)) return segsde_c1_wgrad_workspace(d->C0);
   int bkt, bn, splits, cps;
   wgrad_plan(d, bkt, bn, splits, cps);
   return (size_t)splits * d->KH * d->KW * (d->C0 + d->C1) * d->Cout * sizeof(float);
@@ -908,6 +932,9 @@ extern "C" int segsde_conv2d_wgrad(const segsde_conv_desc* d, const float* x0, c
   if (int e = validate(d)) return e;
   if (!x0 || !dy || !dw_oihw || !workspace || (d->C1 && !x1)) return SEGSDE_ERR_NULL;
   if (workspace_bytes < segsde_conv2d_wgrad_workspace(d)) return SEGSDE_ERR_WORKSPACE;
+  if (c1_wgrad_route(d) && aligned16(x0))
+    return segsde_c1_wgrad(x0, d->ld0, d->B, d->H, d->W, d->C0, dy, lddy, d->pad_mode == SEGSDE_PAD_REFLECT, dw_oihw, workspace,
+                           stream);
   ConvP p = make_params(d, x0, x1, dy /*unused as w; keeps alignment test meaningful*/, nullptr, workspace, nullptr);
   hipStream_t s = static_cast<hipStream_t>(stream);
   int bkt, bn, splits, cps;

@@ -1,0 +1,11 @@
+// internal: single-output-channel 3x3 convolution kernels (conv_small.hip), dispatched from the public conv entry points
+#pragma once
+#include <stddef.h>
+bool segsde_c1_supported(int C, int ldx);
+size_t segsde_c1_wgrad_workspace(int C);
+int segsde_c1_forward(const float* x, int ldx, int B, int H, int W, int C, const float* wpack, const float* bias, int reflect,
+                      int act, float* y, int ldy, void* stream);
+int segsde_c1_dgrad(const float* dz, int lddz, int B, int H, int W, int C, const float* wdpack, int adjoint, float* dx, int lddx,
+                    float* dx2, int lddx2, int nsplit, void* stream);
+int segsde_c1_wgrad(const float* x, int ldx, int B, int H, int W, int C, const float* dz, int lddz, int reflect, float* dw,
+                    float* workspace, void* stream);

@@ -48,6 +48,10 @@ CONV_CASES = [
     ("fast_1x1", 2, 7, 9, 96, 0, False, 160, 1, 1, 1, 0, False, True, "none"),
     ("fast_1x1_s2", 1, 8, 10, 64, 0, False, 32, 1, 2, 1, 0, False, False, "none"),
     ("fast64_refl_up_cat", 1, 8, 12, 64, 128, True, 64, 3, 1, 1, 1, True, True, "elu"),
+    # disparity heads: single output channel -> dedicated stencil kernels (C = 64 / 128 / 256)
+    ("disp_c64", 2, 9, 11, 64, 0, False, 1, 3, 1, 1, 1, True, True, "sigmoid"),
+    ("disp_c128_tiny", 1, 3, 5, 128, 0, False, 1, 3, 1, 1, 1, True, True, "sigmoid"),
+    ("disp_c256_zero", 1, 4, 6, 256, 0, False, 1, 3, 1, 1, 1, False, False, "none"),
 ]
 
 
