@@ -8,7 +8,7 @@ import os
 from ctypes import c_int, c_long, c_float, c_void_p, c_size_t, c_uint64, c_int64, POINTER
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsegsde_hip.so")
+LIB_PATH = os.environ.get("SEGSDE_LIB") or os.path.join(_HERE, "libsegsde_hip.so")   # override: kernel experiments
 ABI_VERSION = 1
 
 _LIB = None

@@ -177,10 +177,11 @@ __device__ __forceinline__ unsigned off_at(const SrcSel& s, int b, int hi, int w
 // (hi, wi) = output pixel + tap offset.  Straight-line on purpose (selects, no branches): the address is always formed
 // from clamped coordinates and swapped for the zero page when the tap is out of range.
 __device__ __forceinline__ float4 fast_fetch(const ConvP& p, const SrcSel& s, int b, int hi, int wi, bool ok, int cq) {
-  if (p.in_div == 2) {   // data-gradient of a stride-2 conv: only even coordinates carry a value
-    ok = ok && (((hi | wi) & 1) == 0);
-    hi >>= 1; wi >>= 1;
-  }
+  // data-gradient of a stride-2 conv (in_div == 2): only even coordinates carry a value.  Branch-free (mask + shift by
+  // in_div >> 1) so that the K loop stays one basic block the scheduler can interleave with the MFMA stream.
+  const int ds = p.in_div >> 1;
+  ok = ok && (((hi | wi) & ds) == 0);
+  hi >>= ds; wi >>= ds;
   const bool refl = p.pad_mode == SEGSDE_PAD_REFLECT;
   const int hr = hi < 0 ? -hi : (hi >= p.H ? 2 * p.H - 2 - hi : hi);
   const int wr = wi < 0 ? -wi : (wi >= p.W ? 2 * p.W - 2 - wi : wi);
@@ -246,15 +247,6 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
   bool rok[AR];
 #pragma unroll
   for (int i = 0; i < AR; ++i) decode_m(p, m0 + r0 + RP * i, rb[i], rh[i], rw[i], rok[i]);
-  // FAST: weight-row bases (clamped) and validity
-  const float* wrow[BR];
-  int wstep[BR];
-#pragma unroll
-  for (int i = 0; i < BR; ++i) {
-    const int n = n0 + r0 + RP * i;
-    wrow[i] = n < p.ne ? p.w + (long)n * p.Ktot + 4 * kq : p.zero;   // rows past Cout read zeros
-    wstep[i] = n < p.ne ? BK : 0;
-  }
   ChunkState cs; cs.c0 = 0; cs.kh = 0; cs.kw = 0;
 
   f32x16 acc[TM][TN];
@@ -268,26 +260,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
   float4 ra[AR], rbv[BR], rex[AR];
   const int nchunks = (p.Ktot + BK - 1) / BK;
 
-  auto gload = [&](int kc) {
+  auto gload = [&](int kc) {   // generic gather (MODE 0/1)
     // chunks past the end are loaded from clamped (valid) addresses and discarded: the K loop stays branch-free
-    const bool live = kc < nchunks;
-    const int kcl = live ? kc : nchunks - 1;
-    if constexpr (FAST) {
-      const SrcSel s = select_src(p, cs.c0);
-      const int dh = cs.kh * p.dil - p.pad, dw = cs.kw * p.dil - p.pad;
-#pragma unroll
-      for (int i = 0; i < AR; ++i) ra[i] = fast_fetch(p, s, rb[i], rh[i] + dh, rw[i] + dw, rok[i] && live, 4 * kq);
-#pragma unroll
-      for (int i = 0; i < BR; ++i) {
-        const float4 v = *reinterpret_cast<const float4*>(wrow[i] + kcl * wstep[i]);
-        rbv[i] = make_float4(v.x, v.y, v.z, v.w);
-      }
-      if constexpr (ADJ) {
-#pragma unroll
-        for (int i = 0; i < AR; ++i) rex[i] = adjoint_extras(p, s, rb[i], rh[i], rw[i], rok[i] && live, 4 * kq, dh, dw);
-      }
-      if (live) cs.advance(p, BK);
-    } else {
+    const int kcl = kc < nchunks ? kc : nchunks - 1;
+    {
       const int k = kcl * BK + 4 * kq;
 #pragma unroll
       for (int i = 0; i < AR; ++i) ra[i] = fetch_a4<VEC>(p, k, rb[i], rh[i], rw[i], rok[i]);
@@ -351,16 +327,167 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
   //   kc+2 are issued; second half of the MFMAs.  LDS writes and the address arithmetic of the loads sit in the
   //   middle of the MFMA stream of the same wave instead of serialising in front of the barrier.
   constexpr int NG = BK / 8;
-  gload(0);
-  lstore(0);
-  gload(1);
-  __syncthreads();
-  for (int kc = 0; kc < nchunks; ++kc) {
-    mma_groups(kc & 1, 0, NG / 2);
-    lstore((kc + 1) & 1);
-    gload(kc + 2);
-    mma_groups(kc & 1, NG / 2, NG);
+  if constexpr (FAST) {
+    // FAST path.  Two facts measured on gfx950 shape this loop (profiles/ablate_r01_kloop.log,
+    // profiles/probe_r01_mfma_valu_overlap.log): (1) fp32 MFMA and VALU instructions do not overlap -- every VALU
+    // instruction issued on a SIMD costs ~3 cycles of matrix-pipe time, whichever wave it comes from -- so the ~200
+    // VALU instructions of per-chunk address arithmetic cost 15 % of the kernel no matter how they are scheduled;
+    // (2) the tile loads themselves (L2 or L1 hits alike) are free.  Hence: tile loads are raw buffer loads whose
+    // per-lane byte offset voff[] depends only on (row, tap, source) and is recomputed when the tap or source changes
+    // (every Csrc/BK chunks); the per-chunk channel advance is the wave-uniform SGPR offset and padding is the
+    // out-of-range offset SEGSDE_OOB (hardware returns zeros).  The K loop proper has no address VALU work left.
+    // The chunk's MFMAs are issued as BK/2 k-step units (TM*TN MFMAs each) with the LDS stores of chunk kc+1, the
+    // loads of chunk kc+2 and the fragment reads of the next k-group dealt out between them.
+    constexpr int U = BK / 2;
+    constexpr int LSTEP = (U - 4) / AR;
+    int b0, th0, tw0; bool tok0;
+    decode_m(p, m0, b0, th0, tw0, tok0);
+    b0 = __builtin_amdgcn_readfirstlane(b0);
+    const SrcSel s0 = select_src(p, 0);
+    const SrcSel s1 = select_src(p, p.C0 < p.Ctot ? p.C0 : 0);
+    const float* base0 = s0.src + (size_t)b0 * s0.bstride;   // resources rebased to the first image the tile touches
+    const float* base1 = s1.src + (size_t)b0 * s1.bstride;
+    const segsde_rsrc rsw = segsde_make_rsrc(p.w);
+    unsigned voff[AR], voffB[BR];
+    int bord[AR];
+#pragma unroll
+    for (int i = 0; i < BR; ++i) {
+      const int n = n0 + r0 + RP * i;
+      voffB[i] = n < p.ne ? (unsigned)(n * p.Ktot + 4 * kq) * 4u : SEGSDE_OOB;   // rows past Cout read zeros
+    }
+#pragma unroll
+    for (int i = 0; i < AR; ++i) {
+      rb[i] -= b0;
+      bord[i] = (rok[i] && (rh[i] == 1 || rh[i] == p.H - 2 || rw[i] == 1 || rw[i] == p.W - 2)) ? 1 : 0;
+    }
+    auto tap_update = [&]() {
+      const bool in0 = cs.c0 < p.C0;
+      const int dh = cs.kh * p.dil - p.pad, dw = cs.kw * p.dil - p.pad;
+      const int sh = in0 ? s0.shift : 0;
+      const unsigned ld = in0 ? s0.ld : s1.ld, Ws = in0 ? s0.Ws : s1.Ws, bst = in0 ? s0.bstride : s1.bstride;
+      const int ds = p.in_div >> 1;   // data-gradient of a stride-2 conv: only even coordinates carry a value
+      const bool refl = p.pad_mode == SEGSDE_PAD_REFLECT;
+#pragma unroll
+      for (int i = 0; i < AR; ++i) {
+        int hi = rh[i] + dh, wi = rw[i] + dw;
+        bool ok = rok[i] && (((hi | wi) & ds) == 0);
+        hi >>= ds; wi >>= ds;
+        const int hr = hi < 0 ? -hi : (hi >= p.H ? 2 * p.H - 2 - hi : hi);
+        const int wr = wi < 0 ? -wi : (wi >= p.W ? 2 * p.W - 2 - wi : wi);
+        ok = ok && (refl || ((unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W));
+        hi = refl ? hr : hi; wi = refl ? wr : wi;
+        const unsigned e = (unsigned)rb[i] * bst + ((unsigned)(hi >> sh) * Ws + (unsigned)(wi >> sh)) * ld + 4u * kq;
+        voff[i] = ok ? e * 4u : SEGSDE_OOB;
+      }
+    };
+    // state of the chunk whose loads are being issued
+    bool live; int kcl; segsde_rsrc rsa; unsigned soffA;
+    SrcSel sx; int xdh = 0, xdw = 0;
+    auto chunk_begin = [&](int kc) {
+      live = kc < nchunks;
+      kcl = live ? kc : nchunks - 1;
+      const bool in0 = cs.c0 < p.C0;
+      rsa = segsde_make_rsrc(in0 ? base0 : base1);
+      soffA = (unsigned)(in0 ? cs.c0 : cs.c0 - p.C0) * 4u;
+      if constexpr (ADJ) { sx = select_src(p, cs.c0); xdh = cs.kh * p.dil - p.pad; xdw = cs.kw * p.dil - p.pad; }
+    };
+    auto loadA = [&](int i) {
+      ra[i] = segsde_buffer_load4(rsa, voff[i], soffA);
+      if constexpr (ADJ) {
+        rex[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (bord[i]) rex[i] = adjoint_extras(p, sx, rb[i] + b0, rh[i], rw[i], live, 4 * kq, xdh, xdw);
+      }
+    };
+    auto loadB = [&](int i) { rbv[i] = segsde_buffer_load4(rsw, voffB[i], (unsigned)kcl * (BK * 4u)); };
+    auto chunk_end = [&]() {
+      if (live) {
+        cs.advance(p, BK);
+        if (cs.c0 == 0 || cs.c0 == p.C0) tap_update();
+      }
+    };
+    auto storeA = [&](float* As) {
+#pragma unroll
+      for (int i = 0; i < AR; ++i) {
+        float4 v = ra[i];
+        if constexpr (ADJ) { v.x += rex[i].x; v.y += rex[i].y; v.z += rex[i].z; v.w += rex[i].w; }
+        const int row = r0 + RP * i;
+        *reinterpret_cast<float4*>(As + row * LDT + 4 * (kq ^ swz(row))) = v;
+      }
+    };
+    auto storeB = [&](float* Bs) {
+#pragma unroll
+      for (int i = 0; i < BR; ++i) {
+        const int row = r0 + RP * i;
+        *reinterpret_cast<float4*>(Bs + row * LDT + 4 * (kq ^ swz(row))) = rbv[i];
+      }
+    };
+    auto load_chunk = [&](int kc) {
+      chunk_begin(kc);
+#pragma unroll
+      for (int i = 0; i < AR; ++i) loadA(i);
+#pragma unroll
+      for (int i = 0; i < BR; ++i) loadB(i);
+      chunk_end();
+    };
+
+    tap_update();
+    load_chunk(0);
+    storeA(smem); storeB(smem + BM * LDT);
+    load_chunk(1);
     __syncthreads();
+
+    float4 fa[2][TM], fb[2][TN];
+    const int arow = wm * TM * 32 + (lane & 31), brow = wn * TN * 32 + (lane & 31), h = lane >> 5;
+    const int sa = swz(arow), sb = swz(brow);
+    auto fread = [&](int buf, int g, int slot) {
+      const float* Ap = smem + buf * STAGE + arow * LDT;
+      const float* Bp = smem + buf * STAGE + BM * LDT + brow * LDT;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) fa[slot][i] = *reinterpret_cast<const float4*>(Ap + i * 32 * LDT + 4 * ((2 * g + h) ^ sa));
+#pragma unroll
+      for (int j = 0; j < TN; ++j) fb[slot][j] = *reinterpret_cast<const float4*>(Bp + j * 32 * LDT + 4 * ((2 * g + h) ^ sb));
+    };
+    auto comp = [](const float4& v, int c) { return c == 0 ? v.x : (c == 1 ? v.y : (c == 2 ? v.z : v.w)); };
+    for (int kc = 0; kc < nchunks; ++kc) {
+      const int buf = kc & 1;
+      fread(buf, 0, 0);
+      chunk_begin(kc + 2);
+      float* Asn = smem + (buf ^ 1) * STAGE;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int g = u / 4, st = u % 4;
+        if (st == 2 && g + 1 < NG) fread(buf, g + 1, (g + 1) & 1);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(comp(fa[g & 1][i], st), comp(fb[g & 1][j], st), acc[i][j], 0, 0, 0);
+        if (u == 0) storeA(Asn);
+        if (u == 1) storeB(Asn + BM * LDT);
+#pragma unroll
+        for (int i = 0; i < AR; ++i)
+          if (u == 2 + LSTEP * i) loadA(i);
+        if (u == U - 2) {
+#pragma unroll
+          for (int i = 0; i < BR; ++i) loadB(i);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      chunk_end();
+      __syncthreads();
+    }
+  } else {
+    gload(0);
+    lstore(0);
+    gload(1);
+    __syncthreads();
+    for (int kc = 0; kc < nchunks; ++kc) {
+      mma_groups(kc & 1, 0, NG / 2);
+      lstore((kc + 1) & 1);
+      gload(kc + 2);
+      mma_groups(kc & 1, NG / 2, NG);
+      __syncthreads();
+    }
   }
 
   // epilogue, staged variant: the accumulator tile goes through LDS (free after the K loop) so that every output row
@@ -799,7 +926,13 @@ bool fast_ok(const ConvP& p) {
   return vec_ok(p) && (p.Ctot % 32 == 0) && (p.C1 == 0 || p.C0 % 32 == 0) && p.in_div <= 2 && e0 < (1L << 31) &&
          e1 < (1L << 31);
 }
-bool bk64_ok(const ConvP& p) { return fast_ok(p) && (p.Ctot % 64 == 0) && (p.C1 == 0 || p.C0 % 64 == 0); }
+// forward / data-gradient FAST path: 32-bit BYTE offsets inside buffer resources rebased to the tile's first image
+bool igemm_fast_ok(const ConvP& p) {
+  const long i0 = (long)(p.H >> p.up0) * (p.W >> p.up0) * p.ld0 * 4, i1 = (long)p.H * p.W * p.ld1 * 4;
+  const long span = 128 / ((long)p.Ho * p.Wo) + 2;   // images one 128-row tile can touch
+  return fast_ok(p) && span * (i0 > i1 ? i0 : i1) < (1L << 31) && (long)p.N * p.Ktot * 4 < (1L << 31);
+}
+bool bk64_ok(const ConvP& p) { return igemm_fast_ok(p) && (p.Ctot % 64 == 0) && (p.C1 == 0 || p.C0 % 64 == 0); }
 
 template <int BM, int BN, int WM, int WN, int MODE, int BK>
 int launch_igemm_mode(const ConvP& p, hipStream_t stream) {
@@ -814,9 +947,9 @@ int launch_igemm_mode(const ConvP& p, hipStream_t stream) {
 
 template <int BM, int BN, int WM, int WN>
 int launch_igemm(const ConvP& p, hipStream_t stream) {
-  if (fast_ok(p) && p.pad_mode == SEGSDE_PAD_REFLECT_ADJOINT) return launch_igemm_mode<BM, BN, WM, WN, 3, 32>(p, stream);
+  if (igemm_fast_ok(p) && p.pad_mode == SEGSDE_PAD_REFLECT_ADJOINT) return launch_igemm_mode<BM, BN, WM, WN, 3, 32>(p, stream);
   if (tune().bk64 && bk64_ok(p)) return launch_igemm_mode<BM, BN, WM, WN, 2, 64>(p, stream);
-  if (fast_ok(p)) return launch_igemm_mode<BM, BN, WM, WN, 2, 32>(p, stream);
+  if (igemm_fast_ok(p)) return launch_igemm_mode<BM, BN, WM, WN, 2, 32>(p, stream);
   if (vec_ok(p)) return launch_igemm_mode<BM, BN, WM, WN, 1, 32>(p, stream);
   return launch_igemm_mode<BM, BN, WM, WN, 0, 32>(p, stream);
 }
@@ -851,7 +984,7 @@ extern "C" int segsde_conv2d_forward(const segsde_conv_desc* d, const float* x0,
                            y2, p.ldy2, p.nsplit, stream);
   if (d->sum2x2) {
     if ((d->Ho & 1) || (d->Wo & 1) || d->stride != 1 || d->act != 0 || bias) return SEGSDE_ERR_SHAPE;
-    if (!fast_ok(p)) return SEGSDE_ERR_UNSUPPORTED;   // caller falls back to the two-pass path (full-res dgrad + 2x2 sum)
+    if (!igemm_fast_ok(p)) return SEGSDE_ERR_UNSUPPORTED;   // caller falls back to the two-pass path (full-res dgrad + 2x2 sum)
   }
   int e;
   if (p.N <= 32) e = launch_igemm<128, 32, 4, 1>(p, s);
@@ -864,7 +997,7 @@ extern "C" int segsde_conv2d_forward(const segsde_conv_desc* d, const float* x0,
     if (!e) e = (b.ne - b.nb <= 32) ? launch_igemm<128, 32, 4, 1>(b, s) : launch_igemm<128, 64, 2, 2>(b, s);
   } else e = launch_igemm<128, 128, 2, 2>(p, s);
   if (e) return e;
-  if (d->pad_mode == SEGSDE_PAD_REFLECT_ADJOINT && !fast_ok(p))
+  if (d->pad_mode == SEGSDE_PAD_REFLECT_ADJOINT && !igemm_fast_ok(p))
     // the generic gathers treat the padding as zeros; add the mirrored-padding contributions on the border pixels
     return launch_reflect_fix(x0, p.ld0, wpack, y, p.ldy, y2, p.ldy2, p.nsplit, p.B, p.H, p.W, p.N, p.C0, s);
   return 0;

@@ -12,6 +12,24 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define SEGSDE_SMEM extern __shared__ __attribute__((aligned(16))) unsigned char segsde_smem[]
 #endif
 
+// Raw buffer loads (buffer_load_dwordx4 ... offen): address = resource base + per-lane byte offset (VGPR) + wave-uniform
+// byte offset (SGPR).  A lane whose offset is >= num_records reads zeros -- padding taps / rows past the tile edge set
+// SEGSDE_OOB instead of selecting a pointer, and the per-chunk channel advance rides in the SGPR, so the K loop of the
+// conv kernels issues its tile loads with no vector ALU work at all (on gfx950 fp32 MFMA and VALU share issue cycles:
+// every VALU instruction in the loop is ~3 cycles taken from the matrix pipe, profiles/probe_r01_mfma_valu_overlap.log).
+#ifndef SEGSDE_BUFFER_OPS   // the host interpreter under tests/hipemu supplies its own
+#define SEGSDE_OOB 0x80000000u
+typedef __amdgpu_buffer_rsrc_t segsde_rsrc;
+__device__ __forceinline__ segsde_rsrc segsde_make_rsrc(const void* base) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ float4 segsde_buffer_load4(segsde_rsrc r, unsigned voff, unsigned soff) {
+  typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+  const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+  return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+#endif
+
 #define SEGSDE_CHECK_LAUNCH()                       \
   do {                                              \
     hipError_t e_ = hipGetLastError();              \

@@ -140,6 +140,17 @@ template <class T, class U> inline T shfl_idx(T v, U srcf) {
 
 alignas(16) inline unsigned char emu_lds[160 * 1024];
 #define SEGSDE_SMEM unsigned char* const segsde_smem = ::emu_lds
+// raw buffer loads: range-checked against num_records on the per-lane offset, zeros when out of range
+#define SEGSDE_BUFFER_OPS 1
+#define SEGSDE_OOB 0x80000000u
+struct segsde_rsrc { const char* base; unsigned n; };
+inline segsde_rsrc segsde_make_rsrc(const void* base) { return segsde_rsrc{static_cast<const char*>(base), 0x7fffffffu}; }
+inline float4 segsde_buffer_load4(segsde_rsrc r, unsigned voff, unsigned soff) {
+  if (voff >= r.n) return make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 v;
+  memcpy(&v, r.base + (size_t)voff + soff, sizeof(v));
+  return v;
+}
 
 inline void __syncthreads() { emu::barrier_wait(&emu::S().block_bar); }
 inline float __shfl_xor(float v, int m, int = 64) { return emu::shfl_idx<float>(v, [m](int l) { return l ^ m; }); }
@@ -191,3 +202,5 @@ inline emu_f32x4 emu_mfma_16x16x4(float a, float b, emu_f32x4 c, int, int, int) 
 #define HIP_SYMBOL(x) (&x)
 inline hipError_t hipGetSymbolAddress(void** p, const void* sym) { *p = const_cast<void*>(sym); return 0; }
 inline void __builtin_amdgcn_sched_barrier(int) {}
+inline int __builtin_amdgcn_readfirstlane(int v) { return v; }   // only applied to wave-uniform values
+inline void __builtin_amdgcn_sched_group_barrier(int, int, int) {}

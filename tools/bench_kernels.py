@@ -45,6 +45,9 @@ def main():
         ("dispconv refl 64->1 @512x1024", 512, 1024, 64, 0, False, 1, 3, 1, 1, 1, True),
     ]
     rows = []
+    flt = [f for f in os.environ.get("BENCH_FILTER", "").split(",") if f]
+    if flt:
+        shapes = [sh for sh in shapes if any(f in sh[0] for f in flt)]
     for (name, Hh, W, C0, C1, up0, Cout, k, stride, dil, pad, refl) in shapes:
         g = H.ConvGeom(C0, Cout, k, stride, dil, pad, refl, C1, up0)
         H0, W0 = (Hh // 2, W // 2) if up0 else (Hh, W)
