@@ -609,7 +609,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(ConvP p, const float
   const bool fk_ok = fk < p.Ktot;
   SrcSel fs; int fdh = 0, fdw = 0;
   int fb[AI], fh[AI], fw[AI], fm[AI];
-  if (FAST) {
+  if (FAST && !SIMPLE) {
     const int kk = fk_ok ? fk : 0;
     const int tap = kk / p.Ctot, c = kk - tap * p.Ctot;
     const int kh = tap / p.KW, kw = tap - kh * p.KW;
@@ -622,12 +622,85 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(ConvP p, const float
       decode_m(p, fm[i], fb[i], fh[i], fw[i], ok);   // fh/fw are ho*stride, wo*stride
     }
   }
+  // MODE 2 (Wo % 32 == 0: a chunk is 32 consecutive pixels of ONE image row): the A-side offsets come from four small
+  // LDS tables -- byte offset of padded input row hi / column wi inside one image of source 0 / 1, or TAB_MARK on zero
+  // padding -- so that a chunk's tile loads cost ~10 VALU instructions per thread instead of ~180 (fp32 MFMA and VALU
+  // share issue cycles on gfx950).  voff = Htab[h*stride + kh*dil] + Wtab[(w0 + row)*stride + kw*dil] + channel; the
+  // image base and the dY row base ride in per-chunk buffer resources (scalar work only).
+  constexpr unsigned TAB_MARK = 0x20000000u;     // = num_records of the resources: one image is < 512 MB (host check)
+  unsigned* tabs = reinterpret_cast<unsigned*>(smem + 2 * STAGE);
+  const int He = (p.Ho - 1) * p.stride + (p.KH - 1) * p.dil + 1, We = (p.Wo - 1) * p.stride + (p.KW - 1) * p.dil + 1;
+  unsigned thaddr = 0, twaddr[AI], tcc = 0, voffD[DI];
+  bool tsrc0 = true;
+  int cb = 0, chh = 0, cw = 0;                   // image / output row / first output column of the next chunk to load
+  SrcSel ts0, ts1;
+  if constexpr (SIMPLE) {
+    ts0 = select_src(p, 0);
+    ts1 = select_src(p, p.C0 < p.Ctot ? p.C0 : 0);
+    const bool refl = p.pad_mode == SEGSDE_PAD_REFLECT;
+    for (int j = tid; j < He; j += 256) {
+      const int hi = j - p.pad;
+      const bool ok = refl || (unsigned)hi < (unsigned)p.H;
+      const int hr = hi < 0 ? -hi : (hi >= p.H ? 2 * p.H - 2 - hi : hi);
+      tabs[j] = ok ? (unsigned)(hr >> ts0.shift) * ts0.Ws * ts0.ld * 4u : TAB_MARK;
+      tabs[He + We + j] = ok ? (unsigned)hr * ts1.Ws * ts1.ld * 4u : TAB_MARK;
+    }
+    for (int j = tid; j < We; j += 256) {
+      const int wi = j - p.pad;
+      const bool ok = refl || (unsigned)wi < (unsigned)p.W;
+      const int wr = wi < 0 ? -wi : (wi >= p.W ? 2 * p.W - 2 - wi : wi);
+      tabs[He + j] = ok ? (unsigned)(wr >> ts0.shift) * ts0.ld * 4u : TAB_MARK;
+      tabs[2 * He + We + j] = ok ? (unsigned)wr * ts1.ld * 4u : TAB_MARK;
+    }
+    const int kk = fk_ok ? fk : 0;
+    const int tap = kk / p.Ctot, c = kk - tap * p.Ctot;
+    const int kh = tap / p.KW, kw = tap - kh * p.KW;
+    tsrc0 = c < p.C0;
+    const int tb = tsrc0 ? 0 : He + We;
+    thaddr = (unsigned)(tb + kh * p.dil) * 4u;
+#pragma unroll
+    for (int i = 0; i < AI; ++i) twaddr[i] = (unsigned)(tb + He + kw * p.dil + ((tid + 256 * i) / AQ) * p.stride) * 4u;
+    tcc = fk_ok ? (unsigned)(tsrc0 ? c : c - p.C0) * 4u : 0x80000000u;
+#pragma unroll
+    for (int i = 0; i < DI; ++i) {
+      const int e = tid + 256 * i, row = e / DQ, nq = e - row * DQ;
+      voffD[i] = n0 + 4 * nq < p.N ? (unsigned)(row * lddy + n0 + 4 * nq) * 4u : SEGSDE_OOB;
+    }
+    int b_, h_, w_; bool ok_;
+    decode_m(p, c_begin * BP < p.M ? c_begin * BP : 0, b_, h_, w_, ok_);
+    cb = __builtin_amdgcn_readfirstlane(b_);
+    chh = __builtin_amdgcn_readfirstlane(h_ / p.stride);
+    cw = __builtin_amdgcn_readfirstlane(w_ / p.stride);
+    __syncthreads();
+  }
   const int wstep = BP * p.stride, wlim = p.Wo * p.stride, hlim = p.Ho * p.stride;
   const bool dyvec = SIMPLE || ((p.N % 4 == 0) && (lddy % 4 == 0) && ((reinterpret_cast<uintptr_t>(dy) & 15) == 0));
 
   float4 ra[AI], rd[DI];
   const bool wide = SIMPLE || p.Wo >= BP;   // a 32-pixel step wraps at most one image row: carries, not divisions
   auto gload = [&](int c) {
+    if constexpr (SIMPLE) {
+      const char* tb = reinterpret_cast<const char*>(tabs);
+      const bool live = c < nchunks_total;       // chunks past the last pixel: zero records, every lane reads zeros
+      const unsigned hv = *reinterpret_cast<const unsigned*>(tb + thaddr + (unsigned)(chh * p.stride) * 4u);
+      unsigned wv[AI];
+#pragma unroll
+      for (int i = 0; i < AI; ++i) wv[i] = *reinterpret_cast<const unsigned*>(tb + twaddr[i] + (unsigned)(cw * p.stride) * 4u);
+      const segsde_rsrc r0 = segsde_make_rsrc(ts0.src + (size_t)cb * ts0.bstride, live ? TAB_MARK : 0u);
+      const segsde_rsrc r1 = segsde_make_rsrc(ts1.src + (size_t)cb * ts1.bstride, live ? TAB_MARK : 0u);
+      const segsde_rsrc rd_ = segsde_make_rsrc(dy + (size_t)c * BP * lddy, live ? 0x7fffffffu : 0u);
+#pragma unroll
+      for (int i = 0; i < AI; ++i) {
+        const unsigned vo = hv + wv[i] + tcc;
+        if (tsrc0) ra[i] = segsde_buffer_load4(r0, vo, 0u);
+        else ra[i] = segsde_buffer_load4(r1, vo, 0u);
+      }
+#pragma unroll
+      for (int i = 0; i < DI; ++i) rd[i] = segsde_buffer_load4(rd_, voffD[i], 0u);
+      cw += BP;
+      if (cw == p.Wo) { cw = 0; if (++chh == p.Ho) { chh = 0; ++cb; } }
+      return;
+    }
     if constexpr (FAST) {
 #pragma unroll
       for (int i = 0; i < AI; ++i) {
@@ -1007,7 +1080,9 @@ namespace {
 template <int BKT, int BN, int WM, int WN, int MODE>
 int launch_wgrad_mode(const ConvP& p, const float* dy, int lddy, float* ws, int splits, int cps, hipStream_t stream) {
   const dim3 grid(segsde_cdiv(p.Ktot, BKT), segsde_cdiv(p.N, BN), splits);
-  const size_t smem = 2 * (size_t)BP * (BKT + BN) * sizeof(float);
+  size_t smem = 2 * (size_t)BP * (BKT + BN) * sizeof(float);
+  if (MODE == 2)   // + the four offset tables (padded rows / columns of the two sources)
+    smem += 2 * (size_t)((p.Ho - 1) * p.stride + (p.KH - 1) * p.dil + 1 + (p.Wo - 1) * p.stride + (p.KW - 1) * p.dil + 1) * sizeof(unsigned);
   auto k = conv_wgrad_kernel<BKT, BN, WM, WN, MODE>;
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   hipLaunchKernelGGL(k, grid, dim3(256), smem, stream, p, dy, lddy, ws, cps);
@@ -1020,7 +1095,9 @@ int launch_wgrad(const ConvP& p, const float* dy, int lddy, float* ws, int split
   const bool vec = vec_ok(p) && (p.N % 4 == 0) && (lddy % 4 == 0) && aligned16(dy);
   const long e0 = (long)p.B * (p.H >> p.up0) * (p.W >> p.up0) * p.ld0, e1 = (long)p.B * p.H * p.W * p.ld1;
   const bool fast = vec_ok(p) && e0 < (1L << 31) && e1 < (1L << 31);   // the dY side may be scalar (odd Cout)
-  if (fast && vec && p.Wo >= BP) return launch_wgrad_mode<BKT, BN, WM, WN, 2>(p, dy, lddy, ws, splits, cps, stream);
+  const long i0 = (long)(p.H >> p.up0) * (p.W >> p.up0) * p.ld0 * 4, i1 = (long)p.H * p.W * p.ld1 * 4;
+  const bool table = p.Wo % BP == 0 && i0 < (1L << 29) && i1 < (1L << 29) && (long)BP * lddy * 4 < (1L << 30);
+  if (fast && vec && table) return launch_wgrad_mode<BKT, BN, WM, WN, 2>(p, dy, lddy, ws, splits, cps, stream);
   if (fast) return launch_wgrad_mode<BKT, BN, WM, WN, 3>(p, dy, lddy, ws, splits, cps, stream);
   if (vec) return launch_wgrad_mode<BKT, BN, WM, WN, 1>(p, dy, lddy, ws, splits, cps, stream);
   return launch_wgrad_mode<BKT, BN, WM, WN, 0>(p, dy, lddy, ws, splits, cps, stream);

@@ -20,8 +20,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifndef SEGSDE_BUFFER_OPS   // the host interpreter under tests/hipemu supplies its own
 #define SEGSDE_OOB 0x80000000u
 typedef __amdgpu_buffer_rsrc_t segsde_rsrc;
-__device__ __forceinline__ segsde_rsrc segsde_make_rsrc(const void* base) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000);
+__device__ __forceinline__ segsde_rsrc segsde_make_rsrc(const void* base, unsigned num_records = 0x7fffffffu) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)num_records, 0x00020000);
 }
 __device__ __forceinline__ float4 segsde_buffer_load4(segsde_rsrc r, unsigned voff, unsigned soff) {
   typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));

@@ -144,7 +144,7 @@ alignas(16) inline unsigned char emu_lds[160 * 1024];
 #define SEGSDE_BUFFER_OPS 1
 #define SEGSDE_OOB 0x80000000u
 struct segsde_rsrc { const char* base; unsigned n; };
-inline segsde_rsrc segsde_make_rsrc(const void* base) { return segsde_rsrc{static_cast<const char*>(base), 0x7fffffffu}; }
+inline segsde_rsrc segsde_make_rsrc(const void* base, unsigned n = 0x7fffffffu) { return segsde_rsrc{static_cast<const char*>(base), n}; }
 inline float4 segsde_buffer_load4(segsde_rsrc r, unsigned voff, unsigned soff) {
   if (voff >= r.n) return make_float4(0.f, 0.f, 0.f, 0.f);
   float4 v;

@@ -48,6 +48,12 @@ CONV_CASES = [
     ("fast_1x1", 2, 7, 9, 96, 0, False, 160, 1, 1, 1, 0, False, True, "none"),
     ("fast_1x1_s2", 1, 8, 10, 64, 0, False, 32, 1, 2, 1, 0, False, False, "none"),
     ("fast64_refl_up_cat", 1, 8, 12, 64, 128, True, 64, 3, 1, 1, 1, True, True, "elu"),
+    # output rows that are multiples of 32 pixels wide take the table-driven weight-gradient loader
+    ("w32_refl_up_cat", 2, 4, 32, 8, 12, True, 16, 3, 1, 1, 1, True, True, "elu"),
+    ("w64_s2_zero", 1, 6, 64, 8, 0, False, 16, 3, 2, 1, 1, False, False, "none"),
+    ("w32_dil2", 2, 5, 32, 16, 0, False, 8, 3, 1, 2, 2, False, False, "relu"),
+    ("w32_fast_cat", 1, 3, 32, 32, 32, False, 32, 3, 1, 1, 1, True, True, "none"),
+    ("w32_1x1", 1, 2, 32, 20, 0, False, 36, 1, 1, 1, 0, False, False, "none"),
     # disparity heads: single output channel -> dedicated stencil kernels (C = 64 / 128 / 256)
     ("disp_c64", 2, 9, 11, 64, 0, False, 1, 3, 1, 1, 1, True, True, "sigmoid"),
     ("disp_c128_tiny", 1, 3, 5, 128, 0, False, 1, 3, 1, 1, 1, True, True, "sigmoid"),
