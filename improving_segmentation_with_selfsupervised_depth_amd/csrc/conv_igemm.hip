@@ -632,6 +632,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(ConvP p, const float
   const int He = (p.Ho - 1) * p.stride + (p.KH - 1) * p.dil + 1, We = (p.Wo - 1) * p.stride + (p.KW - 1) * p.dil + 1;
   unsigned thaddr = 0, twaddr[AI], tcc = 0, voffD[DI];
   bool tsrc0 = true;
+  int wave_src = 0;                              // 0 / 1: every column of this wave lies in that source; 2: mixed
   int cb = 0, chh = 0, cw = 0;                   // image / output row / first output column of the next chunk to load
   SrcSel ts0, ts1;
   if constexpr (SIMPLE) {
@@ -661,6 +662,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(ConvP p, const float
 #pragma unroll
     for (int i = 0; i < AI; ++i) twaddr[i] = (unsigned)(tb + He + kw * p.dil + ((tid + 256 * i) / AQ) * p.stride) * 4u;
     tcc = fk_ok ? (unsigned)(tsrc0 ? c : c - p.C0) * 4u : 0x80000000u;
+    wave_src = __all(tsrc0 || !fk_ok) ? 0 : (__all(!tsrc0 || !fk_ok) ? 1 : 2);
 #pragma unroll
     for (int i = 0; i < DI; ++i) {
       const int e = tid + 256 * i, row = e / DQ, nq = e - row * DQ;
@@ -689,11 +691,22 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(ConvP p, const float
       const segsde_rsrc r0 = segsde_make_rsrc(ts0.src + (size_t)cb * ts0.bstride, live ? TAB_MARK : 0u);
       const segsde_rsrc r1 = segsde_make_rsrc(ts1.src + (size_t)cb * ts1.bstride, live ? TAB_MARK : 0u);
       const segsde_rsrc rd_ = segsde_make_rsrc(dy + (size_t)c * BP * lddy, live ? 0x7fffffffu : 0u);
+      // the 128 reduction columns of a tile usually lie in one source: a wave-uniform resource select; a tile that
+      // straddles the concat boundary loads from both with the other source's lanes out of range, and ORs the halves
+      if (wave_src != 2) {
+        const segsde_rsrc rr = segsde_make_rsrc(wave_src == 0 ? ts0.src + (size_t)cb * ts0.bstride : ts1.src + (size_t)cb * ts1.bstride,
+                                                live ? TAB_MARK : 0u);
 #pragma unroll
-      for (int i = 0; i < AI; ++i) {
-        const unsigned vo = hv + wv[i] + tcc;
-        if (tsrc0) ra[i] = segsde_buffer_load4(r0, vo, 0u);
-        else ra[i] = segsde_buffer_load4(r1, vo, 0u);
+        for (int i = 0; i < AI; ++i) ra[i] = segsde_buffer_load4(rr, hv + wv[i] + tcc, 0u);
+      } else {
+#pragma unroll
+        for (int i = 0; i < AI; ++i) {
+          const unsigned vo = hv + wv[i] + tcc;
+          const float4 a = segsde_buffer_load4(r0, tsrc0 ? vo : SEGSDE_OOB, 0u);
+          const float4 b = segsde_buffer_load4(r1, tsrc0 ? SEGSDE_OOB : vo, 0u);
+          ra[i] = make_float4(__uint_as_float(__float_as_uint(a.x) | __float_as_uint(b.x)), __uint_as_float(__float_as_uint(a.y) | __float_as_uint(b.y)),
+                              __uint_as_float(__float_as_uint(a.z) | __float_as_uint(b.z)), __uint_as_float(__float_as_uint(a.w) | __float_as_uint(b.w)));
+        }
       }
 #pragma unroll
       for (int i = 0; i < DI; ++i) rd[i] = segsde_buffer_load4(rd_, voffD[i], 0u);
@@ -779,8 +792,14 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(ConvP p, const float
   auto mma_steps = [&](int buf, int s0, int s1) {
     const float* At = smem + buf * STAGE;
     const float* Dt = At + BP * BKT;
-    const float* Ap = At + (lane >> 5) * BKT + wm * TM * 32 + (lane & 31);
-    const float* Dp = Dt + (lane >> 5) * BN + wn * TN * 32 + (lane & 31);
+    // one base register per 32-column fragment, opaque to the compiler: reads of consecutive k-steps (a multiple of 256 B
+    // apart) then pair into ds_read2st64_b32 with immediate offsets; paired across fragments (128 B apart) every pair
+    // needed its own VALU add for the base -- and VALU cycles are MFMA cycles here
+    const float* Ap[TM]; const float* Dp[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) { int o = (lane >> 5) * BKT + wm * TM * 32 + (lane & 31) + i * 32; SEGSDE_OPAQUE(o); Ap[i] = At + o; }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) { int o = (lane >> 5) * BN + wn * TN * 32 + (lane & 31) + j * 32; SEGSDE_OPAQUE(o); Dp[j] = Dt + o; }
     // fetch the fragments of 4 k-steps at a time ahead of their MFMAs (counted lgkmcnt waits) instead of read-wait-use
     // per step, which exposed the LDS latency every four MFMAs
 #pragma unroll
@@ -789,9 +808,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(ConvP p, const float
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i) a[u][i] = Ap[2 * (sb + u) * BKT + i * 32];
+        for (int i = 0; i < TM; ++i) a[u][i] = Ap[i][2 * (sb + u) * BKT];
 #pragma unroll
-        for (int j = 0; j < TN; ++j) d[u][j] = Dp[2 * (sb + u) * BN + j * 32];
+        for (int j = 0; j < TN; ++j) d[u][j] = Dp[j][2 * (sb + u) * BN];
       }
       __builtin_amdgcn_sched_barrier(0);   // keep the read batch ahead of the MFMAs (the scheduler sinks it otherwise)
 #pragma unroll

@@ -30,6 +30,11 @@ __device__ __forceinline__ float4 segsde_buffer_load4(segsde_rsrc r, unsigned vo
 }
 #endif
 
+// hides a VGPR value's provenance from the optimiser (no instruction is emitted)
+#ifndef SEGSDE_OPAQUE
+#define SEGSDE_OPAQUE(x) asm volatile("" : "+v"(x))
+#endif
+
 #define SEGSDE_CHECK_LAUNCH()                       \
   do {                                              \
     hipError_t e_ = hipGetLastError();              \

@@ -142,6 +142,7 @@ alignas(16) inline unsigned char emu_lds[160 * 1024];
 #define SEGSDE_SMEM unsigned char* const segsde_smem = ::emu_lds
 // raw buffer loads: range-checked against num_records on the per-lane offset, zeros when out of range
 #define SEGSDE_BUFFER_OPS 1
+#define SEGSDE_OPAQUE(x) ((void)(x))
 #define SEGSDE_OOB 0x80000000u
 struct segsde_rsrc { const char* base; unsigned n; };
 inline segsde_rsrc segsde_make_rsrc(const void* base, unsigned n = 0x7fffffffu) { return segsde_rsrc{static_cast<const char*>(base), n}; }
@@ -160,10 +161,20 @@ inline double __shfl_xor(double v, int m, int = 64) { return emu::shfl_idx<doubl
 inline double __shfl_down(double v, int d, int = 64) { return emu::shfl_idx<double>(v, [d](int l) { return l + d; }); }
 inline int __shfl_xor(int v, int m, int = 64) { return (int)emu::shfl_idx<long long>(v, [m](int l) { return l ^ m; }); }
 inline int __shfl_down(int v, int d, int = 64) { return (int)emu::shfl_idx<long long>(v, [d](int l) { return l + d; }); }
+// wave votes: every lane publishes its predicate, then all lanes read the whole wave's
+inline int __all(int pred) {
+  using namespace emu; auto& x = scratch<long long>(); int base = wave() * 64; x[base + lane()] = pred != 0;
+  barrier_wait(wbar()); int n = S().wave_bar[wave()].expected, r = 1;
+  for (int l = 0; l < n; ++l) r &= (int)x[base + l];
+  barrier_wait(wbar()); return r;
+}
+inline int __any(int pred) { return !__all(!pred); }
 inline float atomicAdd(float* p, float v) { float o = *p; *p = o + v; return o; }
 inline double atomicAdd(double* p, double v) { double o = *p; *p = o + v; return o; }
 inline int atomicAdd(int* p, int v) { int o = *p; *p = o + v; return o; }
 inline unsigned atomicAdd(unsigned* p, unsigned v) { unsigned o = *p; *p = o + v; return o; }
+inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
+inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
 inline float __expf(float x) { return expf(x); }
 inline float __frcp_rn(float x) { return 1.0f / x; }
 inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
