@@ -634,24 +634,24 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(ConvP p, const float
   bool tsrc0 = true;
   int wave_src = 0;                              // 0 / 1: every column of this wave lies in that source; 2: mixed
   int cb = 0, chh = 0, cw = 0;                   // image / output row / first output column of the next chunk to load
-  SrcSel ts0, ts1;
+  // per-image geometry of the two sources (plain wave-uniform scalars: they feed SGPR buffer resources)
+  const unsigned tWs0 = (unsigned)(p.W >> p.up0), tld0 = (unsigned)p.ld0, tld1 = (unsigned)p.ld1;
+  const size_t tbs0 = (size_t)(p.H >> p.up0) * tWs0 * tld0, tbs1 = (size_t)p.H * p.W * tld1;
   if constexpr (SIMPLE) {
-    ts0 = select_src(p, 0);
-    ts1 = select_src(p, p.C0 < p.Ctot ? p.C0 : 0);
     const bool refl = p.pad_mode == SEGSDE_PAD_REFLECT;
     for (int j = tid; j < He; j += 256) {
       const int hi = j - p.pad;
       const bool ok = refl || (unsigned)hi < (unsigned)p.H;
       const int hr = hi < 0 ? -hi : (hi >= p.H ? 2 * p.H - 2 - hi : hi);
-      tabs[j] = ok ? (unsigned)(hr >> ts0.shift) * ts0.Ws * ts0.ld * 4u : TAB_MARK;
-      tabs[He + We + j] = ok ? (unsigned)hr * ts1.Ws * ts1.ld * 4u : TAB_MARK;
+      tabs[j] = ok ? (unsigned)(hr >> p.up0) * tWs0 * tld0 * 4u : TAB_MARK;
+      tabs[He + We + j] = ok ? (unsigned)hr * (unsigned)p.W * tld1 * 4u : TAB_MARK;
     }
     for (int j = tid; j < We; j += 256) {
       const int wi = j - p.pad;
       const bool ok = refl || (unsigned)wi < (unsigned)p.W;
       const int wr = wi < 0 ? -wi : (wi >= p.W ? 2 * p.W - 2 - wi : wi);
-      tabs[He + j] = ok ? (unsigned)(wr >> ts0.shift) * ts0.ld * 4u : TAB_MARK;
-      tabs[2 * He + We + j] = ok ? (unsigned)wr * ts1.ld * 4u : TAB_MARK;
+      tabs[He + j] = ok ? (unsigned)(wr >> p.up0) * tld0 * 4u : TAB_MARK;
+      tabs[2 * He + We + j] = ok ? (unsigned)wr * tld1 * 4u : TAB_MARK;
     }
     const int kk = fk_ok ? fk : 0;
     const int tap = kk / p.Ctot, c = kk - tap * p.Ctot;
@@ -662,7 +662,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(ConvP p, const float
 #pragma unroll
     for (int i = 0; i < AI; ++i) twaddr[i] = (unsigned)(tb + He + kw * p.dil + ((tid + 256 * i) / AQ) * p.stride) * 4u;
     tcc = fk_ok ? (unsigned)(tsrc0 ? c : c - p.C0) * 4u : 0x80000000u;
-    wave_src = __all(tsrc0 || !fk_ok) ? 0 : (__all(!tsrc0 || !fk_ok) ? 1 : 2);
+    wave_src = __builtin_amdgcn_readfirstlane(__all(tsrc0 || !fk_ok) ? 0 : (__all(!tsrc0 || !fk_ok) ? 1 : 2));
 #pragma unroll
     for (int i = 0; i < DI; ++i) {
       const int e = tid + 256 * i, row = e / DQ, nq = e - row * DQ;
@@ -680,38 +680,47 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(ConvP p, const float
 
   float4 ra[AI], rd[DI];
   const bool wide = SIMPLE || p.Wo >= BP;   // a 32-pixel step wraps at most one image row: carries, not divisions
+  // MODE 2 pieces of one chunk's tile loads, issued separately so they can be dealt out between the MFMA units
+  unsigned thv = 0, twv[AI];
+  auto tload = [&]() {      // table lookups for the chunk at (cb, chh, cw)
+    const char* tb = reinterpret_cast<const char*>(tabs);
+    thv = *reinterpret_cast<const unsigned*>(tb + thaddr + (unsigned)(chh * p.stride) * 4u);
+#pragma unroll
+    for (int i = 0; i < AI; ++i) twv[i] = *reinterpret_cast<const unsigned*>(tb + twaddr[i] + (unsigned)(cw * p.stride) * 4u);
+  };
+  auto aload = [&](int c) {
+    const bool live = c < nchunks_total;       // chunks past the last pixel: zero records, every lane reads zeros
+    // the 128 reduction columns of a tile usually lie in one source: a wave-uniform resource select; a tile that
+    // straddles the concat boundary loads from both with the other source's lanes out of range, and ORs the halves
+    if (wave_src != 2) {
+      const segsde_rsrc rr = segsde_make_rsrc(wave_src == 0 ? p.x0 + (size_t)cb * tbs0 : p.x1 + (size_t)cb * tbs1, live ? TAB_MARK : 0u);
+#pragma unroll
+      for (int i = 0; i < AI; ++i) ra[i] = segsde_buffer_load4(rr, thv + twv[i] + tcc, 0u);
+    } else {
+      const segsde_rsrc r0 = segsde_make_rsrc(p.x0 + (size_t)cb * tbs0, live ? TAB_MARK : 0u);
+      const segsde_rsrc r1 = segsde_make_rsrc(p.x1 + (size_t)cb * tbs1, live ? TAB_MARK : 0u);
+#pragma unroll
+      for (int i = 0; i < AI; ++i) {
+        const unsigned vo = thv + twv[i] + tcc;
+        const float4 a = segsde_buffer_load4(r0, tsrc0 ? vo : SEGSDE_OOB, 0u);
+        const float4 b = segsde_buffer_load4(r1, tsrc0 ? SEGSDE_OOB : vo, 0u);
+        ra[i] = make_float4(__uint_as_float(__float_as_uint(a.x) | __float_as_uint(b.x)), __uint_as_float(__float_as_uint(a.y) | __float_as_uint(b.y)),
+                            __uint_as_float(__float_as_uint(a.z) | __float_as_uint(b.z)), __uint_as_float(__float_as_uint(a.w) | __float_as_uint(b.w)));
+      }
+    }
+  };
+  auto dload = [&](int c) {
+    const segsde_rsrc rd_ = segsde_make_rsrc(dy + (size_t)c * BP * lddy, c < nchunks_total ? 0x7fffffffu : 0u);
+#pragma unroll
+    for (int i = 0; i < DI; ++i) rd[i] = segsde_buffer_load4(rd_, voffD[i], 0u);
+    cw += BP;
+    if (cw == p.Wo) { cw = 0; if (++chh == p.Ho) { chh = 0; ++cb; } }
+  };
   auto gload = [&](int c) {
     if constexpr (SIMPLE) {
-      const char* tb = reinterpret_cast<const char*>(tabs);
-      const bool live = c < nchunks_total;       // chunks past the last pixel: zero records, every lane reads zeros
-      const unsigned hv = *reinterpret_cast<const unsigned*>(tb + thaddr + (unsigned)(chh * p.stride) * 4u);
-      unsigned wv[AI];
-#pragma unroll
-      for (int i = 0; i < AI; ++i) wv[i] = *reinterpret_cast<const unsigned*>(tb + twaddr[i] + (unsigned)(cw * p.stride) * 4u);
-      const segsde_rsrc r0 = segsde_make_rsrc(ts0.src + (size_t)cb * ts0.bstride, live ? TAB_MARK : 0u);
-      const segsde_rsrc r1 = segsde_make_rsrc(ts1.src + (size_t)cb * ts1.bstride, live ? TAB_MARK : 0u);
-      const segsde_rsrc rd_ = segsde_make_rsrc(dy + (size_t)c * BP * lddy, live ? 0x7fffffffu : 0u);
-      // the 128 reduction columns of a tile usually lie in one source: a wave-uniform resource select; a tile that
-      // straddles the concat boundary loads from both with the other source's lanes out of range, and ORs the halves
-      if (wave_src != 2) {
-        const segsde_rsrc rr = segsde_make_rsrc(wave_src == 0 ? ts0.src + (size_t)cb * ts0.bstride : ts1.src + (size_t)cb * ts1.bstride,
-                                                live ? TAB_MARK : 0u);
-#pragma unroll
-        for (int i = 0; i < AI; ++i) ra[i] = segsde_buffer_load4(rr, hv + wv[i] + tcc, 0u);
-      } else {
-#pragma unroll
-        for (int i = 0; i < AI; ++i) {
-          const unsigned vo = hv + wv[i] + tcc;
-          const float4 a = segsde_buffer_load4(r0, tsrc0 ? vo : SEGSDE_OOB, 0u);
-          const float4 b = segsde_buffer_load4(r1, tsrc0 ? SEGSDE_OOB : vo, 0u);
-          ra[i] = make_float4(__uint_as_float(__float_as_uint(a.x) | __float_as_uint(b.x)), __uint_as_float(__float_as_uint(a.y) | __float_as_uint(b.y)),
-                              __uint_as_float(__float_as_uint(a.z) | __float_as_uint(b.z)), __uint_as_float(__float_as_uint(a.w) | __float_as_uint(b.w)));
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < DI; ++i) rd[i] = segsde_buffer_load4(rd_, voffD[i], 0u);
-      cw += BP;
-      if (cw == p.Wo) { cw = 0; if (++chh == p.Ho) { chh = 0; ++cb; } }
+      tload();
+      aload(c);
+      dload(c);
       return;
     }
     if constexpr (FAST) {
@@ -828,6 +837,46 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(ConvP p, const float
   lstore(0);
   gload(c_begin + 1);
   __syncthreads();
+  if constexpr (SIMPLE) {
+    // dealt-out schedule (see the forward kernel): 16 k-step units per chunk, fragments of 4 k-steps double-buffered
+    // and fetched two units ahead, LDS stores / table lookups / tile loads between the units
+    float fa[2][4][TM], fd[2][4][TN];
+    int ao[TM], dofs[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) { ao[i] = (lane >> 5) * BKT + wm * TM * 32 + (lane & 31) + i * 32; SEGSDE_OPAQUE(ao[i]); }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) { dofs[j] = BP * BKT + (lane >> 5) * BN + wn * TN * 32 + (lane & 31) + j * 32; SEGSDE_OPAQUE(dofs[j]); }
+    auto fread = [&](int buf, int g, int slot) {
+      const float* St = smem + buf * STAGE;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[slot][u][i] = St[ao[i] + 2 * (4 * g + u) * BKT];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fd[slot][u][j] = St[dofs[j] + 2 * (4 * g + u) * BN];
+      }
+    };
+    for (int c = c_begin; c < c_end; ++c) {
+      const int buf = (c - c_begin) & 1;
+      fread(buf, 0, 0);
+      tload();
+#pragma unroll
+      for (int u = 0; u < BP / 2; ++u) {
+        const int g = u / 4, st = u % 4;
+        if (st == 2 && g + 1 < BP / 8) fread(buf, g + 1, (g + 1) & 1);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[g & 1][st][i], fd[g & 1][st][j], acc[i][j], 0, 0, 0);
+        if (u == 0) lstore(buf ^ 1);
+        if (u == 3) aload(c + 2);
+        if (u == 5) dload(c + 2);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      __syncthreads();
+    }
+  } else
   for (int c = c_begin; c < c_end; ++c) {
     const int buf = (c - c_begin) & 1;
     mma_steps(buf, 0, BP / 4);
