@@ -21,6 +21,7 @@
 // (global loads of chunk t+1 are in flight while the MFMAs of chunk t run; one barrier per chunk).
 // MFMA operand order inside a 8-wide k group is permuted (lane half h, step s) -> k = 4h + s so that each
 // lane fetches its 4 A (and 4 B) values with ONE 16-byte LDS read.
+#include <type_traits>
 #include "segsde_common.h"
 #include "conv_small.h"
 #include <cstdlib>
@@ -194,24 +195,6 @@ __device__ __forceinline__ float4 fast_fetch(const ConvP& p, const SrcSel& s, in
   return *reinterpret_cast<const float4*>(ptr);
 }
 
-// SEGSDE_PAD_REFLECT_ADJOINT (data-gradient of a reflection-padded 3x3/s1 conv): a pixel in row 1 (H-2) also collects
-// what flowed into the mirrored padding row -1 (H); that pre-image is reachable only through the tap with dh = +1 (-1);
-// same for columns.  Returns the sum of the (at most three) extra contributions; the common case loads nothing.
-__device__ __forceinline__ float4 adjoint_extras(const ConvP& p, const SrcSel& s, int b, int ho, int wo, bool ok, int cq,
-                                                 int dh, int dw) {
-  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-  const int eh = (ho == 1 && dh == 1) ? 0 : ((ho == p.H - 2 && dh == -1) ? p.H - 1 : -1);
-  const int ew = (wo == 1 && dw == 1) ? 0 : ((wo == p.W - 2 && dw == -1) ? p.W - 1 : -1);
-  if (ok && (eh >= 0 || ew >= 0)) {
-    const int hi = ho + dh, wi = wo + dw;
-    const bool hin = (unsigned)hi < (unsigned)p.H, win = (unsigned)wi < (unsigned)p.W;
-    if (eh >= 0 && win) { const float4 t = *reinterpret_cast<const float4*>(s.src + off_at(s, b, eh, wi, cq)); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
-    if (ew >= 0 && hin) { const float4 t = *reinterpret_cast<const float4*>(s.src + off_at(s, b, hi, ew, cq)); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
-    if (eh >= 0 && ew >= 0) { const float4 t = *reinterpret_cast<const float4*>(s.src + off_at(s, b, eh, ew, cq)); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
-  }
-  return v;
-}
-
 // MODE 0: generic scalar gather, 1: generic float4 gather, 2: FAST (uniform tap per chunk, branch-free loads),
 // 3: FAST + reflection-pad adjoint extras
 template <int BM, int BN, int WM, int WN, int MODE, int BK>
@@ -349,18 +332,29 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
     const float* base1 = s1.src + (size_t)b0 * s1.bstride;
     const segsde_rsrc rsw = segsde_make_rsrc(p.w);
     unsigned voff[AR], voffB[BR];
-    int bord[AR];
+    // reflection-pad adjoint: a pixel in row 1 / H-2 (column 1 / W-2) also collects what flowed into the mirrored
+    // padding row -1 / H (column -1 / W), reachable only through the tap with dh = +1 / -1 (dw likewise).  The extra
+    // pre-image is one more buffer load per tile row (offset voffX, out of range when there is none); only the four
+    // corner-adjacent pixels of an image have up to three extras at once (voffX2/3, loaded when the wave owns one).
+    unsigned voffX[AR], voffX2[AR], voffX3[AR];
 #pragma unroll
     for (int i = 0; i < BR; ++i) {
       const int n = n0 + r0 + RP * i;
       voffB[i] = n < p.ne ? (unsigned)(n * p.Ktot + 4 * kq) * 4u : SEGSDE_OOB;   // rows past Cout read zeros
     }
+    bool wave_bord = false, wave_corner = false;
+    {
+      int anyb = 0, anyc = 0;
 #pragma unroll
-    for (int i = 0; i < AR; ++i) {
-      rb[i] -= b0;
-      bord[i] = (rok[i] && (rh[i] == 1 || rh[i] == p.H - 2 || rw[i] == 1 || rw[i] == p.W - 2)) ? 1 : 0;
+      for (int i = 0; i < AR; ++i) {
+        rb[i] -= b0;
+        const bool br = rok[i] && (rh[i] == 1 || rh[i] == p.H - 2), bc = rok[i] && (rw[i] == 1 || rw[i] == p.W - 2);
+        anyb |= (br || bc) ? 1 : 0; anyc |= (br && bc) ? 1 : 0;
+      }
+      if constexpr (ADJ) { wave_bord = __any(anyb) != 0; wave_corner = __any(anyc) != 0; }
     }
-    auto tap_update = [&]() {
+    auto tap_update = [&](auto wadj_tag) {
+      constexpr bool WADJ = decltype(wadj_tag)::value;
       const bool in0 = cs.c0 < p.C0;
       const int dh = cs.kh * p.dil - p.pad, dw = cs.kw * p.dil - p.pad;
       const int sh = in0 ? s0.shift : 0;
@@ -369,112 +363,137 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
       const bool refl = p.pad_mode == SEGSDE_PAD_REFLECT;
 #pragma unroll
       for (int i = 0; i < AR; ++i) {
+        auto boff = [&](int hh, int ww) {
+          return ((unsigned)rb[i] * bst + ((unsigned)(hh >> sh) * Ws + (unsigned)(ww >> sh)) * ld + 4u * kq) * 4u;
+        };
         int hi = rh[i] + dh, wi = rw[i] + dw;
         bool ok = rok[i] && (((hi | wi) & ds) == 0);
         hi >>= ds; wi >>= ds;
         const int hr = hi < 0 ? -hi : (hi >= p.H ? 2 * p.H - 2 - hi : hi);
         const int wr = wi < 0 ? -wi : (wi >= p.W ? 2 * p.W - 2 - wi : wi);
-        ok = ok && (refl || ((unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W));
-        hi = refl ? hr : hi; wi = refl ? wr : wi;
-        const unsigned e = (unsigned)rb[i] * bst + ((unsigned)(hi >> sh) * Ws + (unsigned)(wi >> sh)) * ld + 4u * kq;
-        voff[i] = ok ? e * 4u : SEGSDE_OOB;
-      }
-    };
-    // state of the chunk whose loads are being issued
-    bool live; int kcl; segsde_rsrc rsa; unsigned soffA;
-    SrcSel sx; int xdh = 0, xdw = 0;
-    auto chunk_begin = [&](int kc) {
-      live = kc < nchunks;
-      kcl = live ? kc : nchunks - 1;
-      const bool in0 = cs.c0 < p.C0;
-      rsa = segsde_make_rsrc(in0 ? base0 : base1);
-      soffA = (unsigned)(in0 ? cs.c0 : cs.c0 - p.C0) * 4u;
-      if constexpr (ADJ) { sx = select_src(p, cs.c0); xdh = cs.kh * p.dil - p.pad; xdw = cs.kw * p.dil - p.pad; }
-    };
-    auto loadA = [&](int i) {
-      ra[i] = segsde_buffer_load4(rsa, voff[i], soffA);
-      if constexpr (ADJ) {
-        rex[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (bord[i]) rex[i] = adjoint_extras(p, sx, rb[i] + b0, rh[i], rw[i], live, 4 * kq, xdh, xdw);
-      }
-    };
-    auto loadB = [&](int i) { rbv[i] = segsde_buffer_load4(rsw, voffB[i], (unsigned)kcl * (BK * 4u)); };
-    auto chunk_end = [&]() {
-      if (live) {
-        cs.advance(p, BK);
-        if (cs.c0 == 0 || cs.c0 == p.C0) tap_update();
-      }
-    };
-    auto storeA = [&](float* As) {
-#pragma unroll
-      for (int i = 0; i < AR; ++i) {
-        float4 v = ra[i];
-        if constexpr (ADJ) { v.x += rex[i].x; v.y += rex[i].y; v.z += rex[i].z; v.w += rex[i].w; }
-        const int row = r0 + RP * i;
-        *reinterpret_cast<float4*>(As + row * LDT + 4 * (kq ^ swz(row))) = v;
-      }
-    };
-    auto storeB = [&](float* Bs) {
-#pragma unroll
-      for (int i = 0; i < BR; ++i) {
-        const int row = r0 + RP * i;
-        *reinterpret_cast<float4*>(Bs + row * LDT + 4 * (kq ^ swz(row))) = rbv[i];
-      }
-    };
-    auto load_chunk = [&](int kc) {
-      chunk_begin(kc);
-#pragma unroll
-      for (int i = 0; i < AR; ++i) loadA(i);
-#pragma unroll
-      for (int i = 0; i < BR; ++i) loadB(i);
-      chunk_end();
-    };
-
-    tap_update();
-    load_chunk(0);
-    storeA(smem); storeB(smem + BM * LDT);
-    load_chunk(1);
-    __syncthreads();
-
-    float4 fa[2][TM], fb[2][TN];
-    const int arow = wm * TM * 32 + (lane & 31), brow = wn * TN * 32 + (lane & 31), h = lane >> 5;
-    const int sa = swz(arow), sb = swz(brow);
-    auto fread = [&](int buf, int g, int slot) {
-      const float* Ap = smem + buf * STAGE + arow * LDT;
-      const float* Bp = smem + buf * STAGE + BM * LDT + brow * LDT;
-#pragma unroll
-      for (int i = 0; i < TM; ++i) fa[slot][i] = *reinterpret_cast<const float4*>(Ap + i * 32 * LDT + 4 * ((2 * g + h) ^ sa));
-#pragma unroll
-      for (int j = 0; j < TN; ++j) fb[slot][j] = *reinterpret_cast<const float4*>(Bp + j * 32 * LDT + 4 * ((2 * g + h) ^ sb));
-    };
-    auto comp = [](const float4& v, int c) { return c == 0 ? v.x : (c == 1 ? v.y : (c == 2 ? v.z : v.w)); };
-    for (int kc = 0; kc < nchunks; ++kc) {
-      const int buf = kc & 1;
-      fread(buf, 0, 0);
-      chunk_begin(kc + 2);
-      float* Asn = smem + (buf ^ 1) * STAGE;
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int g = u / 4, st = u % 4;
-        if (st == 2 && g + 1 < NG) fread(buf, g + 1, (g + 1) & 1);
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(comp(fa[g & 1][i], st), comp(fb[g & 1][j], st), acc[i][j], 0, 0, 0);
-        if (u == 0) storeA(Asn);
-        if (u == 1) storeB(Asn + BM * LDT);
-#pragma unroll
-        for (int i = 0; i < AR; ++i)
-          if (u == 2 + LSTEP * i) loadA(i);
-        if (u == U - 2) {
-#pragma unroll
-          for (int i = 0; i < BR; ++i) loadB(i);
+        const bool hin = (unsigned)hi < (unsigned)p.H, win = (unsigned)wi < (unsigned)p.W;
+        ok = ok && (refl || (hin && win));
+        voff[i] = ok ? boff(refl ? hr : hi, refl ? wr : wi) : SEGSDE_OOB;
+        if constexpr (WADJ) {
+          const int eh = (rh[i] == 1 && dh == 1) ? 0 : ((rh[i] == p.H - 2 && dh == -1) ? p.H - 1 : -1);
+          const int ew = (rw[i] == 1 && dw == 1) ? 0 : ((rw[i] == p.W - 2 && dw == -1) ? p.W - 1 : -1);
+          const bool t1 = rok[i] && eh >= 0 && win, t2 = rok[i] && ew >= 0 && hin, t3 = rok[i] && eh >= 0 && ew >= 0;
+          voffX[i] = t1 ? boff(eh, wi) : (t2 ? boff(hi, ew) : SEGSDE_OOB);
+          if (wave_corner) {
+            voffX2[i] = (t1 && t2) ? boff(hi, ew) : SEGSDE_OOB;
+            voffX3[i] = t3 ? boff(eh, ew) : SEGSDE_OOB;
+          }
         }
-        __builtin_amdgcn_sched_barrier(0);
       }
-      chunk_end();
+    };
+    // The whole K loop exists twice in the adjoint kernel: waves that own no pixel next to the border run the plain
+    // loop, the others the one with the extra loads.  The choice is wave-uniform and both execute the same barriers.
+    auto run = [&](auto wadj_tag) {
+      constexpr bool WADJ = decltype(wadj_tag)::value;
+      // state of the chunk whose loads are being issued
+      bool live; int kcl; segsde_rsrc rsa; unsigned soffA;
+      auto chunk_begin = [&](int kc) {
+        live = kc < nchunks;
+        kcl = live ? kc : nchunks - 1;
+        const bool in0 = cs.c0 < p.C0;
+        rsa = segsde_make_rsrc(in0 ? base0 : base1);
+        soffA = (unsigned)(in0 ? cs.c0 : cs.c0 - p.C0) * 4u;
+      };
+      auto loadA = [&](int i) {
+        ra[i] = segsde_buffer_load4(rsa, voff[i], soffA);
+        if constexpr (WADJ) {
+          rex[i] = segsde_buffer_load4(rsa, voffX[i], soffA);
+          if (wave_corner) {   // rare (four pixels per image): summed on the spot, no registers held across the loop
+            const float4 t2 = segsde_buffer_load4(rsa, voffX2[i], soffA), t3 = segsde_buffer_load4(rsa, voffX3[i], soffA);
+            rex[i].x += t2.x + t3.x; rex[i].y += t2.y + t3.y; rex[i].z += t2.z + t3.z; rex[i].w += t2.w + t3.w;
+          }
+        }
+      };
+      auto loadB = [&](int i) { rbv[i] = segsde_buffer_load4(rsw, voffB[i], (unsigned)kcl * (BK * 4u)); };
+      auto chunk_end = [&]() {
+        if (live) {
+          cs.advance(p, BK);
+          if (cs.c0 == 0 || cs.c0 == p.C0) tap_update(wadj_tag);
+        }
+      };
+      auto storeA = [&](float* As) {
+  #pragma unroll
+        for (int i = 0; i < AR; ++i) {
+          float4 v = ra[i];
+          if constexpr (WADJ) {
+            v.x += rex[i].x; v.y += rex[i].y; v.z += rex[i].z; v.w += rex[i].w;
+          }
+          const int row = r0 + RP * i;
+          *reinterpret_cast<float4*>(As + row * LDT + 4 * (kq ^ swz(row))) = v;
+        }
+      };
+      auto storeB = [&](float* Bs) {
+  #pragma unroll
+        for (int i = 0; i < BR; ++i) {
+          const int row = r0 + RP * i;
+          *reinterpret_cast<float4*>(Bs + row * LDT + 4 * (kq ^ swz(row))) = rbv[i];
+        }
+      };
+      auto load_chunk = [&](int kc) {
+        chunk_begin(kc);
+  #pragma unroll
+        for (int i = 0; i < AR; ++i) loadA(i);
+  #pragma unroll
+        for (int i = 0; i < BR; ++i) loadB(i);
+        chunk_end();
+      };
+
+      tap_update(wadj_tag);
+      load_chunk(0);
+      storeA(smem); storeB(smem + BM * LDT);
+      load_chunk(1);
       __syncthreads();
+
+      float4 fa[2][TM], fb[2][TN];
+      const int arow = wm * TM * 32 + (lane & 31), brow = wn * TN * 32 + (lane & 31), h = lane >> 5;
+      const int sa = swz(arow), sb = swz(brow);
+      auto fread = [&](int buf, int g, int slot) {
+        const float* Ap = smem + buf * STAGE + arow * LDT;
+        const float* Bp = smem + buf * STAGE + BM * LDT + brow * LDT;
+  #pragma unroll
+        for (int i = 0; i < TM; ++i) fa[slot][i] = *reinterpret_cast<const float4*>(Ap + i * 32 * LDT + 4 * ((2 * g + h) ^ sa));
+  #pragma unroll
+        for (int j = 0; j < TN; ++j) fb[slot][j] = *reinterpret_cast<const float4*>(Bp + j * 32 * LDT + 4 * ((2 * g + h) ^ sb));
+      };
+      auto comp = [](const float4& v, int c) { return c == 0 ? v.x : (c == 1 ? v.y : (c == 2 ? v.z : v.w)); };
+      for (int kc = 0; kc < nchunks; ++kc) {
+        const int buf = kc & 1;
+        fread(buf, 0, 0);
+        chunk_begin(kc + 2);
+        float* Asn = smem + (buf ^ 1) * STAGE;
+  #pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int g = u / 4, st = u % 4;
+          if (st == 2 && g + 1 < NG) fread(buf, g + 1, (g + 1) & 1);
+  #pragma unroll
+          for (int i = 0; i < TM; ++i)
+  #pragma unroll
+            for (int j = 0; j < TN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(comp(fa[g & 1][i], st), comp(fb[g & 1][j], st), acc[i][j], 0, 0, 0);
+          if (u == 0) storeA(Asn);
+          if (u == 1) storeB(Asn + BM * LDT);
+  #pragma unroll
+          for (int i = 0; i < AR; ++i)
+            if (u == 2 + LSTEP * i) loadA(i);
+          if (u == U - 2) {
+  #pragma unroll
+            for (int i = 0; i < BR; ++i) loadB(i);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        chunk_end();
+        __syncthreads();
+      }
+    };
+    if constexpr (ADJ) {
+      if (wave_bord) run(std::true_type{}); else run(std::false_type{});
+    } else {
+      run(std::false_type{});
     }
   } else {
     gload(0);
@@ -1000,12 +1019,13 @@ __global__ __launch_bounds__(256) void reflect_dgrad_fix_kernel(const float* dy,
 // experiment knob (environment SEGSDE_TUNE="bk64=1"), read once.  Measured on MI355X (profiles/ab_conv_r01.log):
 // BK=64 (139 KB LDS => 1 workgroup/CU, half the barriers) loses 15-25 % on the large layers against BK=32 with two
 // co-resident workgroups per CU, and start-up staggering of co-resident workgroups changes nothing.
-struct Tune { int bk64 = 0; };
+struct Tune { int bk64 = 0; int adjfix = 0; };
 const Tune& tune() {
   static Tune t = [] {
     Tune r;
     if (const char* e = getenv("SEGSDE_TUNE")) {
       if (const char* q = strstr(e, "bk64=")) r.bk64 = atoi(q + 5);
+      if (const char* q = strstr(e, "adjfix=")) r.adjfix = atoi(q + 7);   // reflection adjoint: plain loop + border fix-up kernel
     }
     return r;
   }();
@@ -1088,7 +1108,7 @@ int launch_igemm_mode(const ConvP& p, hipStream_t stream) {
 
 template <int BM, int BN, int WM, int WN>
 int launch_igemm(const ConvP& p, hipStream_t stream) {
-  if (igemm_fast_ok(p) && p.pad_mode == SEGSDE_PAD_REFLECT_ADJOINT) return launch_igemm_mode<BM, BN, WM, WN, 3, 32>(p, stream);
+  if (igemm_fast_ok(p) && p.pad_mode == SEGSDE_PAD_REFLECT_ADJOINT && !(tune().adjfix && !p.sum2x2) && tune().adjfix < 2) return launch_igemm_mode<BM, BN, WM, WN, 3, 32>(p, stream);
   if (tune().bk64 && bk64_ok(p)) return launch_igemm_mode<BM, BN, WM, WN, 2, 64>(p, stream);
   if (igemm_fast_ok(p)) return launch_igemm_mode<BM, BN, WM, WN, 2, 32>(p, stream);
   if (vec_ok(p)) return launch_igemm_mode<BM, BN, WM, WN, 1, 32>(p, stream);
@@ -1138,7 +1158,7 @@ extern "C" int segsde_conv2d_forward(const segsde_conv_desc* d, const float* x0,
     if (!e) e = (b.ne - b.nb <= 32) ? launch_igemm<128, 32, 4, 1>(b, s) : launch_igemm<128, 64, 2, 2>(b, s);
   } else e = launch_igemm<128, 128, 2, 2>(p, s);
   if (e) return e;
-  if (d->pad_mode == SEGSDE_PAD_REFLECT_ADJOINT && !igemm_fast_ok(p))
+  if (d->pad_mode == SEGSDE_PAD_REFLECT_ADJOINT && (!igemm_fast_ok(p) || (tune().adjfix && !p.sum2x2)))
     // the generic gathers treat the padding as zeros; add the mirrored-padding contributions on the border pixels
     return launch_reflect_fix(x0, p.ld0, wpack, y, p.ldy, y2, p.ldy2, p.nsplit, p.B, p.H, p.W, p.N, p.C0, s);
   return 0;
