@@ -152,12 +152,221 @@ __global__ __launch_bounds__(256) void c1_wgrad_reduce_kernel(const float* part,
   dw[c * 9 + tap] = s;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Strip versions (W % 8 == 0, every real layer): a group of LP lanes owns S = 8 consecutive pixels of one row.  The
+// 3 x (S+2) input window is loaded once and slid across the S outputs (3.75 instead of 9 pixel loads per output: the
+// per-pixel kernels are bound by L1 re-reads, not HBM) and the (b, h, w) decode is one 32-bit division per strip
+// instead of two 64-bit divisions per pixel.
+// ---------------------------------------------------------------------------------------------------
+constexpr int CS = 8;
+
+__device__ __forceinline__ float dot4(const float4& a, const float4& b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
+
+struct Strip { int b, h, w0; bool live; };
+__device__ __forceinline__ Strip strip_decode(int sid, int nstrips, int nsr, int H) {
+  Strip t;
+  t.live = sid < nstrips;
+  const int s = t.live ? sid : 0;
+  const int row = s / nsr;
+  t.w0 = (s - row * nsr) * CS;
+  t.b = row / H;
+  t.h = row - t.b * H;
+  return t;
+}
+
+template <int LP>
+__global__ __launch_bounds__(256) void c1s_fwd_kernel(const float* x, int ldx, int B, int H, int W, const float* wp /*[9][C]*/,
+                                                      const float* bias, int reflect, int act, float* y, int ldy) {
+  constexpr int G = 256 / LP;
+  const int lane_c = threadIdx.x % LP, slot = threadIdx.x / LP;
+  float4 w[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) w[t] = *reinterpret_cast<const float4*>(wp + t * (LP * 4) + 4 * lane_c);
+  const float b0 = bias ? bias[0] : 0.f;
+  const int nsr = W / CS, nstrips = B * H * nsr;
+  for (int s0 = blockIdx.x * G; s0 < nstrips; s0 += gridDim.x * G) {
+    const Strip st = strip_decode(s0 + slot, nstrips, nsr, H);
+    float acc[CS];
+#pragma unroll
+    for (int o = 0; o < CS; ++o) acc[o] = 0.f;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      int hi = st.h + r - 1; bool okh = st.live;
+      if (reflect) hi = refl1(hi, H); else okh = okh && (unsigned)hi < (unsigned)H;
+      const float* rp = x + (size_t)(st.b * H + (okh ? hi : 0)) * W * ldx + 4 * lane_c;
+      float4 v[CS + 2];
+#pragma unroll
+      for (int j = 0; j < CS + 2; ++j) {
+        int wi = st.w0 - 1 + j; bool ok = okh;
+        if (reflect) wi = refl1(wi, W); else ok = ok && (unsigned)wi < (unsigned)W;
+        v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok) v[j] = *reinterpret_cast<const float4*>(rp + (size_t)wi * ldx);
+      }
+#pragma unroll
+      for (int j = 0; j < CS + 2; ++j)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const int o = j - kw;
+          if (o >= 0 && o < CS) acc[o] += dot4(v[j], w[r * 3 + kw]);
+        }
+    }
+    float mine = 0.f;
+#pragma unroll
+    for (int o = 0; o < CS; ++o) {
+      float a = acc[o];
+#pragma unroll
+      for (int d = LP / 2; d > 0; d >>= 1) a += __shfl_xor(a, d);
+      mine = lane_c == o ? a : mine;
+    }
+    if (lane_c < CS && st.live) y[((size_t)(st.b * H + st.h) * W + st.w0 + lane_c) * ldy] = segsde_act(mine + b0, act);
+  }
+}
+
+template <int LP>
+__global__ __launch_bounds__(256) void c1s_wgrad_kernel(const float* x, int ldx, int B, int H, int W, const float* dz, int lddz,
+                                                        int reflect, float* part /*[nblk][9][C]*/) {
+  constexpr int G = 256 / LP;
+  SEGSDE_SMEM;
+  float* sh = reinterpret_cast<float*>(segsde_smem);    // [G][9][C]
+  const int lane_c = threadIdx.x % LP, slot = threadIdx.x / LP;
+  float4 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int nsr = W / CS, nstrips = B * H * nsr;
+  for (int s0 = blockIdx.x * G; s0 < nstrips; s0 += gridDim.x * G) {
+    const Strip st = strip_decode(s0 + slot, nstrips, nsr, H);
+    if (!st.live) continue;
+    float g[CS];
+    const float* gp = dz + ((size_t)(st.b * H + st.h) * W + st.w0) * lddz;
+#pragma unroll
+    for (int o = 0; o < CS; ++o) g[o] = gp[(size_t)o * lddz];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      int hi = st.h + r - 1; bool okh = true;
+      if (reflect) hi = refl1(hi, H); else okh = (unsigned)hi < (unsigned)H;
+      const float* rp = x + (size_t)(st.b * H + (okh ? hi : 0)) * W * ldx + 4 * lane_c;
+      float4 v[CS + 2];
+#pragma unroll
+      for (int j = 0; j < CS + 2; ++j) {
+        int wi = st.w0 - 1 + j; bool ok = okh;
+        if (reflect) wi = refl1(wi, W); else ok = ok && (unsigned)wi < (unsigned)W;
+        v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok) v[j] = *reinterpret_cast<const float4*>(rp + (size_t)wi * ldx);
+      }
+#pragma unroll
+      for (int j = 0; j < CS + 2; ++j)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const int o = j - kw;
+          if (o >= 0 && o < CS) {
+            float4& a = acc[r * 3 + kw];
+            a.x += v[j].x * g[o]; a.y += v[j].y * g[o]; a.z += v[j].z * g[o]; a.w += v[j].w * g[o];
+          }
+        }
+    }
+  }
+  constexpr int C = LP * 4;
+#pragma unroll
+  for (int t = 0; t < 9; ++t) *reinterpret_cast<float4*>(sh + (slot * 9 + t) * C + 4 * lane_c) = acc[t];
+  __syncthreads();
+  for (int e = threadIdx.x; e < 9 * C; e += 256) {
+    float s = 0.f;
+    for (int q = 0; q < G; ++q) s += sh[q * 9 * C + e];
+    part[(long)blockIdx.x * 9 * C + e] = s;
+  }
+}
+
+template <int LP>
+__global__ __launch_bounds__(256) void c1s_dgrad_kernel(const float* dz, int lddz, int B, int H, int W, const float* wd /*[C][9]*/,
+                                                        int adjoint, float* dx, int lddx, float* dx2, int lddx2, int nsplit) {
+  constexpr int G = 256 / LP;
+  const int lane_c = threadIdx.x % LP, slot = threadIdx.x / LP;
+  float w[4][9];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int t = 0; t < 9; ++t) w[j][t] = wd[(4 * lane_c + j) * 9 + t];
+  const int c = 4 * lane_c;
+  const int nsr = W / CS, nstrips = B * H * nsr;
+  for (int s0 = blockIdx.x * G; s0 < nstrips; s0 += gridDim.x * G) {
+    const Strip st = strip_decode(s0 + slot, nstrips, nsr, H);
+    if (!st.live) continue;
+    const size_t pix0 = (size_t)(st.b * H + st.h) * W + st.w0;
+    float* dst = c < nsplit ? dx + pix0 * lddx + c : dx2 + pix0 * lddx2 + (c - nsplit);
+    const int ldd = c < nsplit ? lddx : lddx2;
+    const bool border = adjoint && (st.h == 1 || st.h == H - 2 || st.w0 == 0 || st.w0 + CS == W);
+    if (!border) {
+      float g[3][CS + 2];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const int yh = st.h + r - 1;
+        const bool okh = (unsigned)yh < (unsigned)H;
+        const float* gp = dz + (size_t)(st.b * H + (okh ? yh : 0)) * W * lddz;
+#pragma unroll
+        for (int j = 0; j < CS + 2; ++j) {
+          const int yw = st.w0 - 1 + j;
+          const bool ok = okh && (unsigned)yw < (unsigned)W;
+          g[r][j] = 0.f;
+          if (ok) g[r][j] = gp[(size_t)yw * lddz];
+        }
+      }
+#pragma unroll
+      for (int o = 0; o < CS; ++o) {
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw) {
+            const float gv = g[kh][o + kw];
+            const int t = kh * 3 + kw;
+            a0 += gv * w[0][t]; a1 += gv * w[1][t]; a2 += gv * w[2][t]; a3 += gv * w[3][t];
+          }
+        *reinterpret_cast<float4*>(dst + (size_t)o * ldd) = make_float4(a0, a1, a2, a3);
+      }
+    } else {
+      // strips that touch row 1 / H-2 or column 1 / W-2: pixels also collect the mirrored padding cells
+      for (int o = 0; o < CS; ++o) {
+        const int hq = st.h, wq = st.w0 + o;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        int hp[3], wpp[3], nh = 0, nw = 0;
+        hp[nh++] = hq; wpp[nw++] = wq;
+        if (hq == 1) hp[nh++] = -1;
+        if (hq == H - 2) hp[nh++] = H;
+        if (wq == 1) wpp[nw++] = -1;
+        if (wq == W - 2) wpp[nw++] = W;
+        for (int a = 0; a < nh; ++a)
+          for (int bb = 0; bb < nw; ++bb)
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+              const int yh = hp[a] + kh - 1;
+              if ((unsigned)yh >= (unsigned)H) continue;
+#pragma unroll
+              for (int kw = 0; kw < 3; ++kw) {
+                const int yw = wpp[bb] + kw - 1;
+                if ((unsigned)yw >= (unsigned)W) continue;
+                const float gv = dz[((size_t)(st.b * H + yh) * W + yw) * lddz];
+                const int t = kh * 3 + kw;
+                a0 += gv * w[0][t]; a1 += gv * w[1][t]; a2 += gv * w[2][t]; a3 += gv * w[3][t];
+              }
+            }
+        *reinterpret_cast<float4*>(dst + (size_t)o * ldd) = make_float4(a0, a1, a2, a3);
+      }
+    }
+  }
+}
+
 inline int c1_blocks(long npix, int ppb) { long nb = (npix + ppb - 1) / ppb; return (int)(nb < 1 ? 1 : (nb > 2048 ? 2048 : nb)); }
 }  // namespace
 
 bool segsde_c1_supported(int C, int ldx) { return (C == 64 || C == 128 || C == 256) && (ldx % 4 == 0); }
 
 size_t segsde_c1_wgrad_workspace(int C) { return (size_t)1024 * 9 * C * sizeof(float); }
+
+inline int c1s_blocks(int B, int H, int W, int groups) {
+  const long nb = ((long)B * H * (W / CS) + groups - 1) / groups;
+  return (int)(nb < 1 ? 1 : (nb > 4096 ? 4096 : nb));
+}
+inline bool c1_strips(int B, int H, int W) { return W % CS == 0 && (long)B * H * W < (1L << 31); }
 
 #define C1_DISPATCH(KERNEL, grid, smem, ...)                                                       \
   do {                                                                                             \
@@ -168,6 +377,12 @@ size_t segsde_c1_wgrad_workspace(int C) { return (size_t)1024 * 9 * C * sizeof(f
 
 int segsde_c1_forward(const float* x, int ldx, int B, int H, int W, int C, const float* wpack, const float* bias, int reflect,
                       int act, float* y, int ldy, void* stream) {
+  if (c1_strips(B, H, W)) {
+    const dim3 grid(c1s_blocks(B, H, W, 256 / (C / 4)));
+    C1_DISPATCH(c1s_fwd_kernel, grid, 0, x, ldx, B, H, W, wpack, bias, reflect, act, y, ldy);
+    SEGSDE_CHECK_LAUNCH();
+    return 0;
+  }
   const dim3 grid(c1_blocks((long)B * H * W, 256 / (C / 4)));
   C1_DISPATCH(c1_fwd_kernel, grid, 0, x, ldx, B, H, W, wpack, bias, reflect, act, y, ldy);
   SEGSDE_CHECK_LAUNCH();
@@ -177,6 +392,12 @@ int segsde_c1_forward(const float* x, int ldx, int B, int H, int W, int C, const
 int segsde_c1_dgrad(const float* dz, int lddz, int B, int H, int W, int C, const float* wdpack, int adjoint, float* dx, int lddx,
                     float* dx2, int lddx2, int nsplit, void* stream) {
   if (!dx2) { dx2 = dx; lddx2 = lddx; nsplit = C; }
+  if (c1_strips(B, H, W) && H >= 4 && W >= 2 * CS) {
+    const dim3 grid(c1s_blocks(B, H, W, 256 / (C / 4)));
+    C1_DISPATCH(c1s_dgrad_kernel, grid, 0, dz, lddz, B, H, W, wdpack, adjoint, dx, lddx, dx2, lddx2, nsplit);
+    SEGSDE_CHECK_LAUNCH();
+    return 0;
+  }
   const dim3 grid(c1_blocks((long)B * H * W, 256 / (C / 4)));
   C1_DISPATCH(c1_dgrad_kernel, grid, 0, dz, lddz, B, H, W, wdpack, adjoint, dx, lddx, dx2, lddx2, nsplit);
   SEGSDE_CHECK_LAUNCH();
@@ -189,6 +410,16 @@ int segsde_c1_wgrad(const float* x, int ldx, int B, int H, int W, int C, const f
   long nb = ((long)B * H * W + ppb - 1) / ppb;
   const int nblk = (int)(nb < 1 ? 1 : (nb > 1024 ? 1024 : nb));
   const size_t smem = (size_t)ppb * 9 * C * sizeof(float);
+  if (c1_strips(B, H, W)) {
+    long ns = ((long)B * H * (W / CS) + ppb - 1) / ppb;
+    const int nbs = (int)(ns < 1 ? 1 : (ns > 1024 ? 1024 : ns));
+    C1_DISPATCH(c1s_wgrad_kernel, dim3(nbs), smem, x, ldx, B, H, W, dz, lddz, reflect, workspace);
+    SEGSDE_CHECK_LAUNCH();
+    hipLaunchKernelGGL(c1_wgrad_reduce_kernel, dim3((9 * C + 255) / 256), dim3(256), 0, ST(stream), (const float*)workspace, nbs,
+                       C, dw);
+    SEGSDE_CHECK_LAUNCH();
+    return 0;
+  }
   C1_DISPATCH(c1_wgrad_kernel, dim3(nblk), smem, x, ldx, B, H, W, dz, lddz, reflect, workspace);
   SEGSDE_CHECK_LAUNCH();
   hipLaunchKernelGGL(c1_wgrad_reduce_kernel, dim3((9 * C + 255) / 256), dim3(256), 0, ST(stream), (const float*)workspace, nblk,

@@ -58,6 +58,10 @@ CONV_CASES = [
     ("disp_c64", 2, 9, 11, 64, 0, False, 1, 3, 1, 1, 1, True, True, "sigmoid"),
     ("disp_c128_tiny", 1, 3, 5, 128, 0, False, 1, 3, 1, 1, 1, True, True, "sigmoid"),
     ("disp_c256_zero", 1, 4, 6, 256, 0, False, 1, 3, 1, 1, 1, False, False, "none"),
+    # widths that are multiples of 8 take the strip (sliding-window) stencil kernels
+    ("disp_strip_c64", 2, 6, 24, 64, 0, False, 1, 3, 1, 1, 1, True, True, "sigmoid"),
+    ("disp_strip_c128_zero", 1, 5, 16, 128, 0, False, 1, 3, 1, 1, 1, False, True, "none"),
+    ("disp_strip_c256", 1, 4, 16, 256, 0, False, 1, 3, 1, 1, 1, True, False, "sigmoid"),
 ]
 
 
