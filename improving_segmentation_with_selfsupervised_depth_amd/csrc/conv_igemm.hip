@@ -588,6 +588,17 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
 // ---------------------------------------------------------------------------------------------------
 // weight-gradient kernel: partial[z][k][n] = sum over this split's pixels of A(m,k) * dY[m,n]
 // ---------------------------------------------------------------------------------------------------
+// k -> (tap, channel): tap-major (tap, [src0|src1]) by default; source-major (all taps of source 0, then all taps of
+// source 1) when srcC0 > 0 -- the table-driven weight-gradient kernel orders two-source reductions that way so that a
+// 128-column tile does not straddle the concat boundary inside every tap
+__device__ __forceinline__ void wgrad_k_decode(int k, int Ctot, int taps, int srcC0, int& tap, int& c) {
+  if (srcC0 > 0) {
+    const int n0 = taps * srcC0;
+    if (k < n0) { tap = k / srcC0; c = k - tap * srcC0; }
+    else { const int C1 = Ctot - srcC0, kk = k - n0; tap = kk / C1; c = srcC0 + kk - tap * C1; }
+  } else { tap = k / Ctot; c = k - tap * Ctot; }
+}
+
 constexpr int BP = 32;  // pixels per staged chunk
 
 template <int BKT, int BN, int WM, int WN, int MODE>
@@ -673,7 +684,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(ConvP p, const float
       tabs[2 * He + We + j] = ok ? (unsigned)wr * tld1 * 4u : TAB_MARK;
     }
     const int kk = fk_ok ? fk : 0;
-    const int tap = kk / p.Ctot, c = kk - tap * p.Ctot;
+    int tap, c;
+    wgrad_k_decode(kk, p.Ctot, p.KH * p.KW, p.C1 > 0 ? p.C0 : 0, tap, c);   // source-major for two-source inputs
     const int kh = tap / p.KW, kw = tap - kh * p.KW;
     tsrc0 = c < p.C0;
     const int tb = tsrc0 ? 0 : He + We;
@@ -923,7 +935,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(ConvP p, const float
 
 // dW[o][c][kh][kw] (OIHW, the state_dict layout) = sum_z part[z][(kh*KW+kw)*Ctot + c][o], fixed order
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* part, int splits, int Ktot, int N, int Ctot,
-                                                           int taps, float* dw) {
+                                                           int taps, int srcC0, float* dw) {
   // 32 output elements x 8 split-lanes per block; each lane sums every 8th slab (4 independent chains), fixed order
   SEGSDE_SMEM;
   float* sh = reinterpret_cast<float*>(segsde_smem);
@@ -945,7 +957,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* part, in
     float s = 0.f;
     for (int j = 0; j < 8; ++j) s += sh[j * 32 + tx];
     const int k = (int)(e / N), n = (int)(e - (long)k * N);
-    const int tap = k / Ctot, c = k - tap * Ctot;
+    int tap, c;
+    wgrad_k_decode(k, Ctot, taps, srcC0, tap, c);
     dw[((long)n * Ctot + c) * taps + tap] = s;
   }
 }
@@ -1019,12 +1032,14 @@ __global__ __launch_bounds__(256) void reflect_dgrad_fix_kernel(const float* dy,
 // experiment knob (environment SEGSDE_TUNE="bk64=1"), read once.  Measured on MI355X (profiles/ab_conv_r01.log):
 // BK=64 (139 KB LDS => 1 workgroup/CU, half the barriers) loses 15-25 % on the large layers against BK=32 with two
 // co-resident workgroups per CU, and start-up staggering of co-resident workgroups changes nothing.
-struct Tune { int bk64 = 0; int adjfix = 0; };
+struct Tune { int bk64 = 0; int adjfix = 0; int wplan = 0; int wovh = 4; };
 const Tune& tune() {
   static Tune t = [] {
     Tune r;
     if (const char* e = getenv("SEGSDE_TUNE")) {
       if (const char* q = strstr(e, "bk64=")) r.bk64 = atoi(q + 5);
+      if (const char* q = strstr(e, "wplan=")) r.wplan = atoi(q + 6);     // 1: previous fixed-target split plan
+      if (const char* q = strstr(e, "wovh=")) r.wovh = atoi(q + 5);       // per-workgroup fixed cost in chunk units
       if (const char* q = strstr(e, "adjfix=")) r.adjfix = atoi(q + 7);   // reflection adjoint: plain loop + border fix-up kernel
     }
     return r;
@@ -1178,17 +1193,26 @@ int launch_wgrad_mode(const ConvP& p, const float* dy, int lddy, float* ws, int 
   return 0;
 }
 
-template <int BKT, int BN, int WM, int WN>
-int launch_wgrad(const ConvP& p, const float* dy, int lddy, float* ws, int splits, int cps, hipStream_t stream) {
+// 2: table-driven loader (rows a multiple of 32 pixels wide), 3: general fast gather, 1: float4 gather, 0: scalar gather
+int wgrad_mode(const ConvP& p, const float* dy, int lddy) {
   const bool vec = vec_ok(p) && (p.N % 4 == 0) && (lddy % 4 == 0) && aligned16(dy);
   const long e0 = (long)p.B * (p.H >> p.up0) * (p.W >> p.up0) * p.ld0, e1 = (long)p.B * p.H * p.W * p.ld1;
   const bool fast = vec_ok(p) && e0 < (1L << 31) && e1 < (1L << 31);   // the dY side may be scalar (odd Cout)
   const long i0 = (long)(p.H >> p.up0) * (p.W >> p.up0) * p.ld0 * 4, i1 = (long)p.H * p.W * p.ld1 * 4;
   const bool table = p.Wo % BP == 0 && i0 < (1L << 29) && i1 < (1L << 29) && (long)BP * lddy * 4 < (1L << 30);
-  if (fast && vec && table) return launch_wgrad_mode<BKT, BN, WM, WN, 2>(p, dy, lddy, ws, splits, cps, stream);
-  if (fast) return launch_wgrad_mode<BKT, BN, WM, WN, 3>(p, dy, lddy, ws, splits, cps, stream);
-  if (vec) return launch_wgrad_mode<BKT, BN, WM, WN, 1>(p, dy, lddy, ws, splits, cps, stream);
-  return launch_wgrad_mode<BKT, BN, WM, WN, 0>(p, dy, lddy, ws, splits, cps, stream);
+  if (fast && vec && table) return 2;
+  if (fast) return 3;
+  return vec ? 1 : 0;
+}
+
+template <int BKT, int BN, int WM, int WN>
+int launch_wgrad(const ConvP& p, const float* dy, int lddy, float* ws, int splits, int cps, hipStream_t stream) {
+  switch (wgrad_mode(p, dy, lddy)) {
+    case 2: return launch_wgrad_mode<BKT, BN, WM, WN, 2>(p, dy, lddy, ws, splits, cps, stream);
+    case 3: return launch_wgrad_mode<BKT, BN, WM, WN, 3>(p, dy, lddy, ws, splits, cps, stream);
+    case 1: return launch_wgrad_mode<BKT, BN, WM, WN, 1>(p, dy, lddy, ws, splits, cps, stream);
+    default: return launch_wgrad_mode<BKT, BN, WM, WN, 0>(p, dy, lddy, ws, splits, cps, stream);
+  }
 }
 
 void wgrad_plan(const segsde_conv_desc* d, int& bkt, int& bn, int& splits, int& cps) {
@@ -1198,13 +1222,29 @@ void wgrad_plan(const segsde_conv_desc* d, int& bkt, int& bn, int& splits, int& 
   bkt = 128;
   const long tiles = (long)segsde_cdiv(Ktot, bkt) * segsde_cdiv(d->Cout, bn);
   const int nchunks = segsde_cdiv(M, BP);
-  long want = (1536 + tiles - 1) / tiles;          // ~6 workgroups per CU overall (2 resident): measured best for long loops
-  if (nchunks / want < 64) {                       // short reductions: fewer, longer splits amortise prologue/epilogue
-    want = (1024 + tiles - 1) / tiles;
-    if (want > nchunks / 8) want = nchunks / 8;
+  long want;
+  if (tune().wplan == 0) {
+    // Equal-sized workgroups run in waves of `slots` (2 per CU for the 128x128 tile, 3 for the narrower ones): a split
+    // count that puts a handful of workgroups into one more wave costs a whole extra pass.  Pick the split count that
+    // minimises waves x (chunks per split + fixed per-workgroup cost), preferring fewer splits on ties.
+    const long slots = 256L * (bn == 128 ? 2 : 3);
+    const long ovh = tune().wovh;
+    long best = -1, best_cost = 0;
+    const long smax = nchunks / 8 > 1 ? (nchunks / 8 < 1024 ? nchunks / 8 : 1024) : 1;
+    for (long sp = 1; sp <= smax; ++sp) {
+      const long c = (nchunks + sp - 1) / sp, se = (nchunks + c - 1) / c;
+      const long waves = (tiles * se + slots - 1) / slots;
+      const long cost = waves * (c + ovh);
+      if (best < 0 || cost < best_cost) { best = se; best_cost = cost; }
+    }
+    want = best;
+  } else {
+    want = (1536 + tiles - 1) / tiles;          // ~6 workgroups per CU overall (2 resident): measured best for long loops
+    if (nchunks / want < 64) {                       // short reductions: fewer, longer splits amortise prologue/epilogue
+      want = (1024 + tiles - 1) / tiles;
+      if (want > nchunks / 8) want = nchunks / 8;
+    }
   }
-  if (want < 1) want = 1;
-  if (want > 1024) want = 1024;
   cps = segsde_cdiv(nchunks, want);
   splits = segsde_cdiv(nchunks, cps);
 }
@@ -1244,7 +1284,7 @@ extern "C" int segsde_conv2d_wgrad(const segsde_conv_desc* d, const float* x0, c
   if (e) return e;
   const long total = (long)p.Ktot * p.N;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(segsde_cdiv(total, 32)), dim3(256), 1024, s, workspace, splits,
-                     p.Ktot, p.N, p.Ctot, d->KH * d->KW, dw_oihw);
+                     p.Ktot, p.N, p.Ctot, d->KH * d->KW, (wgrad_mode(p, dy, lddy) == 2 && p.C1 > 0) ? p.C0 : 0, dw_oihw);
   SEGSDE_CHECK_LAUNCH();
   return 0;
 }
