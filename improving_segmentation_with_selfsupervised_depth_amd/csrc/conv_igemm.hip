@@ -1105,7 +1105,7 @@ bool fast_ok(const ConvP& p) {
 // forward / data-gradient FAST path: 32-bit BYTE offsets inside buffer resources rebased to the tile's first image
 bool igemm_fast_ok(const ConvP& p) {
   const long i0 = (long)(p.H >> p.up0) * (p.W >> p.up0) * p.ld0 * 4, i1 = (long)p.H * p.W * p.ld1 * 4;
-  const long span = 128 / ((long)p.Ho * p.Wo) + 2;   // images one 128-row tile can touch
+  const long span = 256 / ((long)p.Ho * p.Wo) + 2;   // images one (up to 256-row) tile can touch
   return fast_ok(p) && span * (i0 > i1 ? i0 : i1) < (1L << 31) && (long)p.N * p.Ktot * 4 < (1L << 31);
 }
 bool bk64_ok(const ConvP& p) { return igemm_fast_ok(p) && (p.Ctot % 64 == 0) && (p.C1 == 0 || p.C0 % 64 == 0); }
@@ -1164,7 +1164,7 @@ extern "C" int segsde_conv2d_forward(const segsde_conv_desc* d, const float* x0,
   }
   int e;
   if (p.N <= 32) e = launch_igemm<128, 32, 4, 1>(p, s);
-  else if (p.N <= 64) e = launch_igemm<128, 64, 2, 2>(p, s);
+  else if (p.N <= 64) e = launch_igemm<128, 64, 2, 2>(p, s);   // (a 256x64 tile measured 3 % slower)
   else if (p.N % 128 > 0 && p.N % 128 <= 64) {
     // e.g. the 192-channel concat data-gradient: 128-wide tiles for the bulk, 64-wide tiles for the 64-channel tail
     ConvP a = p, b = p;

@@ -33,6 +33,9 @@ BIG_CONV = [
     ("big_7x7", 2, 64, 128, 3, 0, False, 64, 7, 2, 1, 3, False, False, "none"),
     ("big_cout19", 2, 64, 128, 64, 0, False, 19, 1, 1, 1, 0, False, True, "none"),
     ("big_disp", 2, 64, 128, 64, 0, False, 1, 3, 1, 1, 1, True, True, "sigmoid"),
+    # many pixel tiles with Cout = 64 (128x64 tile, three workgroups per CU)
+    ("big_n64", 2, 256, 256, 64, 0, False, 64, 3, 1, 1, 1, False, True, "relu"),
+    ("big_n64_refl_up", 2, 256, 256, 64, 0, True, 64, 3, 1, 1, 1, True, True, "elu"),
 ]
 
 
