@@ -37,7 +37,7 @@ _SIGS = {
     "segsde_bn_eval_stats": (c_int, [P, P, c_int, c_float, P, P, P]),
     "segsde_bn_apply": (c_int, [P, c_int, c_long, c_int, P, P, P, P, P, c_int, P, c_int, c_int, c_float, c_uint64, P]),
     "segsde_bn_backward_workspace": (c_size_t, [c_long, c_int]),
-    "segsde_bn_backward": (c_int, [P, c_int, P, c_int, P, c_int, c_long, c_int, P, P, P, c_int, c_float, c_uint64, c_int,
+    "segsde_bn_backward": (c_int, [P, c_int, P, c_int, P, c_int, c_long, c_int, P, P, P, P, c_int, c_float, c_uint64, c_int,
                                    P, P, P, c_int, P, c_int, P, c_size_t, P]),
     "segsde_colsum_workspace": (c_size_t, [c_long, c_int]),
     "segsde_act_backward": (c_int, [P, c_int, P, c_int, c_long, c_int, c_int, P, c_int, P, P, c_size_t, P]),

@@ -1158,6 +1158,12 @@ extern "C" int segsde_conv2d_forward(const segsde_conv_desc* d, const float* x0,
       segsde_c1_supported(d->Cout, p.ldy) && p.vecout)
     return segsde_c1_dgrad(x0, d->ld0, d->B, d->H, d->W, d->Cout, wpack, d->pad_mode == SEGSDE_PAD_REFLECT_ADJOINT, y, p.ldy,
                            y2, p.ldy2, p.nsplit, stream);
+  // 1x1 with a narrow, non-vectorisable input side (data-gradient of the 19-class head): HBM-bound register kernel
+  const bool plain1x1 = d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && d->C1 == 0 && !d->up0 && d->in_div <= 1 &&
+                        !d->sum2x2 && d->H == d->Ho && d->W == d->Wo;
+  if (plain1x1 && d->C0 % 4 != 0 && d->ld0 == d->C0 && aligned16(x0) && !bias && d->act == 0 && !y2 &&
+      segsde_skinny_supported(d->C0, d->Cout) && p.vecout)
+    return segsde_skinny_nk(x0, d->C0, wpack, (long)d->B * d->H * d->W, d->Cout, y, p.ldy, stream);
   if (d->sum2x2) {
     if ((d->Ho & 1) || (d->Wo & 1) || d->stride != 1 || d->act != 0 || bias) return SEGSDE_ERR_SHAPE;
     if (!igemm_fast_ok(p)) return SEGSDE_ERR_UNSUPPORTED;   // caller falls back to the two-pass path (full-res dgrad + 2x2 sum)

@@ -9,3 +9,7 @@ int segsde_c1_dgrad(const float* dz, int lddz, int B, int H, int W, int C, const
                     float* dx2, int lddx2, int nsplit, void* stream);
 int segsde_c1_wgrad(const float* x, int ldx, int B, int H, int W, int C, const float* dz, int lddz, int reflect, float* dw,
                     float* workspace, void* stream);
+// 1x1 convolution with a narrow (<= 32) dense input side (data-gradient of the segmentation head)
+bool segsde_skinny_supported(int K, int C);
+// the narrow side (a / dz) must be dense: row pitch == K, 16-byte aligned base
+int segsde_skinny_nk(const float* a, int K, const float* w, long M, int C, float* y, int ldy, void* stream);

@@ -355,6 +355,56 @@ __global__ __launch_bounds__(256) void c1s_dgrad_kernel(const float* dz, int ldd
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// "Skinny" 1x1 convolutions: a GEMM side of at most 32 (the 19-class segmentation head, joint_segmentation_depth_decoder.py
+// heads): its data-gradient (19 gradient channels in, 64/128/256 out) is HBM-bound (2*19*4 FLOP per 16 output bytes),
+// but the MFMA tile pads 19 -> 32 on a scalar gather (9 TFLOP/s).  (A register kernel for the weight-gradient measured
+// slower than the MFMA path and was dropped.)  Here C/4 lanes
+// own a pixel (one float4 of the wide side each), the narrow side's values are wave-broadcast scalar loads and the
+// weights live in registers.
+// ---------------------------------------------------------------------------------------------------
+// The narrow side must be dense (row pitch == K): a block stages the K values of 64 consecutive pixels -- one contiguous
+// span of memory -- into LDS with coalesced 16-byte loads, and the pixel groups then read them as LDS broadcasts.  (Per-pixel
+// scalar global loads made the kernels latency-bound: 19 load instructions per pixel per wave.)
+constexpr int SKP = 64;   // pixels staged per block pass
+
+__device__ __forceinline__ void skinny_stage(const float* src, long p0, int n, int K, float* sh) {
+  const float* base = src + p0 * K;            // p0 % 4 == 0  =>  16-byte aligned whenever src is
+  const int total = n * K, t4 = total & ~3;
+  for (int e = threadIdx.x * 4; e < t4; e += 1024) *reinterpret_cast<float4*>(sh + e) = *reinterpret_cast<const float4*>(base + e);
+  for (int e = t4 + threadIdx.x; e < total; e += 256) sh[e] = base[e];
+}
+
+// y[p][c] = sum_k a[p][k] * w[c][k]     (a: [M][K] dense, K <= KB; w: [C][K] row-major)
+template <int LP, int KB>
+__global__ __launch_bounds__(256) void skinny_nk_kernel(const float* a, int K, const float* w, long M, float* y, int ldy) {
+  constexpr int G = 256 / LP;
+  SEGSDE_SMEM;
+  float* sh = reinterpret_cast<float*>(segsde_smem);    // [SKP][K]
+  const int lane_c = threadIdx.x % LP, slot = threadIdx.x / LP;
+  float wr[KB][4];
+#pragma unroll
+  for (int k = 0; k < KB; ++k)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) wr[k][j] = k < K ? w[(long)(4 * lane_c + j) * K + k] : 0.f;
+  for (long p0 = (long)blockIdx.x * SKP; p0 < M; p0 += (long)gridDim.x * SKP) {
+    const int n = (int)(M - p0 < SKP ? M - p0 : SKP);
+    __syncthreads();
+    skinny_stage(a, p0, n, K, sh);
+    __syncthreads();
+    for (int q = slot; q < n; q += G) {
+      const float* gp = sh + q * K;
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+      for (int k = 0; k < KB; ++k) {
+        const float g = k < K ? gp[k] : 0.f;
+        a0 += g * wr[k][0]; a1 += g * wr[k][1]; a2 += g * wr[k][2]; a3 += g * wr[k][3];
+      }
+      *reinterpret_cast<float4*>(y + (p0 + q) * ldy + 4 * lane_c) = make_float4(a0, a1, a2, a3);
+    }
+  }
+}
+
 inline int c1_blocks(long npix, int ppb) { long nb = (npix + ppb - 1) / ppb; return (int)(nb < 1 ? 1 : (nb > 2048 ? 2048 : nb)); }
 }  // namespace
 
@@ -424,6 +474,29 @@ int segsde_c1_wgrad(const float* x, int ldx, int B, int H, int W, int C, const f
   SEGSDE_CHECK_LAUNCH();
   hipLaunchKernelGGL(c1_wgrad_reduce_kernel, dim3((9 * C + 255) / 256), dim3(256), 0, ST(stream), (const float*)workspace, nblk,
                      C, dw);
+  SEGSDE_CHECK_LAUNCH();
+  return 0;
+}
+
+bool segsde_skinny_supported(int K, int C) { return K >= 1 && K <= 32 && (C == 64 || C == 128 || C == 256); }
+
+#define SK_DISPATCH(KERNEL, grid, smem, ...)                                                                    \
+  do {                                                                                                          \
+    if (K <= 20) {                                                                                              \
+      if (C == 64) hipLaunchKernelGGL((KERNEL<16, 20>), grid, dim3(256), smem, ST(stream), __VA_ARGS__);         \
+      else if (C == 128) hipLaunchKernelGGL((KERNEL<32, 20>), grid, dim3(256), smem, ST(stream), __VA_ARGS__);   \
+      else hipLaunchKernelGGL((KERNEL<64, 20>), grid, dim3(256), smem, ST(stream), __VA_ARGS__);                 \
+    } else {                                                                                                    \
+      if (C == 64) hipLaunchKernelGGL((KERNEL<16, 32>), grid, dim3(256), smem, ST(stream), __VA_ARGS__);         \
+      else if (C == 128) hipLaunchKernelGGL((KERNEL<32, 32>), grid, dim3(256), smem, ST(stream), __VA_ARGS__);   \
+      else hipLaunchKernelGGL((KERNEL<64, 32>), grid, dim3(256), smem, ST(stream), __VA_ARGS__);                 \
+    }                                                                                                           \
+  } while (0)
+
+int segsde_skinny_nk(const float* a, int K, const float* w, long M, int C, float* y, int ldy, void* stream) {
+  long nb = (M + SKP - 1) / SKP;
+  const dim3 grid((unsigned)(nb < 1 ? 1 : (nb > 8192 ? 8192 : nb)));
+  SK_DISPATCH(skinny_nk_kernel, grid, (size_t)SKP * 32 * sizeof(float), a, K, w, M, y, ldy);
   SEGSDE_CHECK_LAUNCH();
   return 0;
 }

@@ -176,15 +176,29 @@ __device__ __forceinline__ float bn_dz(float dy, float y, int act, float drop_p,
   return g * segsde_act_grad_from_out(y, act);
 }
 
+// y == nullptr ("remask"): the saved output is not read.  Allowed for act = none (y is not needed at all) and for a ReLU
+// with no residual and no dropout, whose mask is recomputed from x exactly as bn_apply formed its argument
+// ((x - mean) * invstd, then * gamma + beta, same operation order, -ffp-contract=off) -- one of the three tensor reads of
+// each backward pass saved on two of every three BatchNorms of a bottleneck.
+__device__ __forceinline__ float bn_dz_remask(float dy, float xh, float gamma, float beta, bool affine, int act) {
+  if (act != SEGSDE_ACT_RELU) return dy;
+  float t = xh;
+  if (affine) t = t * gamma + beta;
+  return t > 0.f ? dy : 0.f;
+}
+
 struct BnBwdOp {
   const float* dy; int lddy; const float* y; int ldy; const float* x; int ldx; const float* mean; const float* invstd;
-  int act, C; float drop_p; uint64_t seed;
+  int act, C; float drop_p; uint64_t seed; const float* gamma; const float* beta;
   template <int VW> __device__ void row(long m, int c, double* s0, double* s1) const {
-    const VecF<VW> g = ldv<VW>(dy + m * lddy + c), yy = ldv<VW>(y + m * ldy + c), xx = ldv<VW>(x + m * ldx + c);
+    const VecF<VW> g = ldv<VW>(dy + m * lddy + c), xx = ldv<VW>(x + m * ldx + c);
+    VecF<VW> yy;
+    if (y) yy = ldv<VW>(y + m * ldy + c);
 #pragma unroll
     for (int j = 0; j < VW; ++j) {
-      const float dz = bn_dz(g.v[j], yy.v[j], act, drop_p, seed, (uint64_t)(m * C + c + j));
       const float xh = (xx.v[j] - mean[c + j]) * invstd[c + j];
+      const float dz = y ? bn_dz(g.v[j], yy.v[j], act, drop_p, seed, (uint64_t)(m * C + c + j))
+                         : bn_dz_remask(g.v[j], xh, gamma ? gamma[c + j] : 1.f, gamma ? beta[c + j] : 0.f, gamma != nullptr, act);
       s0[j] += (double)dz * (double)xh; s1[j] += (double)dz;
     }
   }
@@ -204,8 +218,8 @@ __global__ __launch_bounds__(256) void pair_finalize_kernel(const double* part, 
 template <int VW>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* dy, int lddy, const float* y, int ldy,
                                                            const float* x, int ldx, long M, int C, const float* mean,
-                                                           const float* invstd, const float* gamma, int act,
-                                                           float drop_p, uint64_t seed, int batch_stats,
+                                                           const float* invstd, const float* gamma, const float* beta,
+                                                           int act, float drop_p, uint64_t seed, int batch_stats,
                                                            const float* dgamma, const float* dbeta, float* dx, int lddx,
                                                            float* dres, int lddres, int cv_shift) {
   const int CV = C / VW;
@@ -214,18 +228,23 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* dy, int 
   for (long e = blockIdx.x * 256L + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
     const long m = cv_shift >= 0 ? (e >> cv_shift) : e / CV;
     const int c = (int)(e - m * CV) * VW;
-    const VecF<VW> g = ldv<VW>(dy + m * lddy + c), yy = ldv<VW>(y + m * ldy + c);
-    VecF<VW> xx;
-    if (dx && batch_stats) xx = ldv<VW>(x + m * ldx + c);
-    VecF<VW> dz, o, ga, mu, is, dg, db;
-    if (dx) {
+    const VecF<VW> g = ldv<VW>(dy + m * lddy + c);
+    VecF<VW> xx, yy;
+    const bool remask = y == nullptr;
+    if (!remask) yy = ldv<VW>(y + m * ldy + c);
+    if ((dx && batch_stats) || remask) xx = ldv<VW>(x + m * ldx + c);
+    VecF<VW> dz, o, ga, be, mu, is, dg, db;
+    if (dx || remask) {
       is = ldv<VW>(invstd + c);
       if (gamma) ga = ldv<VW>(gamma + c);
-      if (batch_stats) { mu = ldv<VW>(mean + c); dg = ldv<VW>(dgamma + c); db = ldv<VW>(dbeta + c); }
+      if (gamma && remask) be = ldv<VW>(beta + c);
+      if (batch_stats || remask) mu = ldv<VW>(mean + c);
+      if (batch_stats && dx) { dg = ldv<VW>(dgamma + c); db = ldv<VW>(dbeta + c); }
     }
 #pragma unroll
     for (int j = 0; j < VW; ++j) {
-      dz.v[j] = bn_dz(g.v[j], yy.v[j], act, drop_p, seed, (uint64_t)(m * C + c + j));
+      if (remask) dz.v[j] = bn_dz_remask(g.v[j], (xx.v[j] - mu.v[j]) * is.v[j], gamma ? ga.v[j] : 1.f, gamma ? be.v[j] : 0.f, gamma != nullptr, act);
+      else dz.v[j] = bn_dz(g.v[j], yy.v[j], act, drop_p, seed, (uint64_t)(m * C + c + j));
       if (dx) {
         const float gm = gamma ? ga.v[j] : 1.f;
         if (batch_stats) {
@@ -522,14 +541,19 @@ extern "C" int segsde_bn_apply(const float* x, int ldx, long M, int C, const flo
 }
 
 extern "C" int segsde_bn_backward(const float* dy, int lddy, const float* y, int ldy, const float* x, int ldx, long M,
-                                  int C, const float* mean, const float* invstd, const float* gamma, int act,
-                                  float drop_p, uint64_t seed, int batch_stats, float* dgamma, float* dbeta, float* dx,
-                                  int lddx, float* dres, int lddres, void* ws, size_t ws_bytes, void* stream) {
-  if (!dy || !y || !x || !mean || !invstd || !dgamma || !dbeta || !ws) return SEGSDE_ERR_NULL;
+                                  int C, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                                  int act, float drop_p, uint64_t seed, int batch_stats, float* dgamma, float* dbeta,
+                                  float* dx, int lddx, float* dres, int lddres, void* ws, size_t ws_bytes, void* stream) {
+  if (!dy || !x || !mean || !invstd || !dgamma || !dbeta || !ws) return SEGSDE_ERR_NULL;
+  if (!y) {   // remask mode: only where the mask is a function of x alone
+    if (!(act == SEGSDE_ACT_NONE || (act == SEGSDE_ACT_RELU && drop_p <= 0.f && !dres && (!gamma || beta)))) return SEGSDE_ERR_NULL;
+  }
   if (M <= 0 || C <= 0) return SEGSDE_ERR_SHAPE;
   if (ws_bytes < part_bytes(M, C)) return SEGSDE_ERR_WORKSPACE;
-  BnBwdOp op{dy, lddy, y, ldy, x, ldx, mean, invstd, act, C, drop_p, seed};
-  const bool vec = (C % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) && (lddy % 4 == 0) && al16p(x) && al16p(y) && al16p(dy);
+  if (!y) ldy = ldx;
+  BnBwdOp op{dy, lddy, y, ldy, x, ldx, mean, invstd, act, C, drop_p, seed, gamma, beta};
+  const bool vec = (C % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) && (lddy % 4 == 0) && al16p(x) && (!y || al16p(y)) && al16p(dy) &&
+                   (!gamma || (al16p(gamma) && (!beta || al16p(beta))));
   if (int e = launch_colreduce(op, M, C, (double*)ws, vec, ST(stream))) return e;
   hipLaunchKernelGGL(pair_finalize_kernel, dim3((C + 15) / 16), dim3(256), 4096, ST(stream), (const double*)ws,
                      red_blocks(M), C, dgamma, dbeta);
@@ -538,11 +562,11 @@ extern "C" int segsde_bn_backward(const float* dy, int lddy, const float* y, int
     const bool v4 = vec && (!dx || ((lddx % 4 == 0) && al16p(dx))) && (!dres || ((lddres % 4 == 0) && al16p(dres)));
     if (v4)
       hipLaunchKernelGGL(bn_bwd_apply_kernel<4>, dim3(ew_blocks(M * C / 4)), dim3(256), 0, ST(stream), dy, lddy, y, ldy, x,
-                         ldx, M, C, mean, invstd, gamma, act, drop_p, seed, batch_stats, (const float*)dgamma,
+                         ldx, M, C, mean, invstd, gamma, beta, act, drop_p, seed, batch_stats, (const float*)dgamma,
                          (const float*)dbeta, dx, lddx, dres, lddres, pow2_shift(C / 4));
     else
       hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, dim3(ew_blocks(M * C)), dim3(256), 0, ST(stream), dy, lddy, y, ldy, x, ldx,
-                         M, C, mean, invstd, gamma, act, drop_p, seed, batch_stats, (const float*)dgamma,
+                         M, C, mean, invstd, gamma, beta, act, drop_p, seed, batch_stats, (const float*)dgamma,
                          (const float*)dbeta, dx, lddx, dres, lddres, pow2_shift(C));
     SEGSDE_CHECK_LAUNCH();
   }

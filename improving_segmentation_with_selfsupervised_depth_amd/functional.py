@@ -115,17 +115,19 @@ class BNActFn(Function):
         else:
             mean, invstd = H.bn_eval_stats(running_mean, running_var, eps)
         y = H.bn_apply(x, mean, invstd, gamma, beta, residual, act, drop_p, seed)
-        ctx.cfg = (act, drop_p, seed, training, residual is not None)
-        ctx.save_for_backward(x, gamma, mean, invstd, y)
+        # the backward pass reads the saved output only where the activation mask is not a function of x alone
+        remask = act in ("none", "relu") and residual is None and not drop_p
+        ctx.cfg = (act, drop_p, seed, training, residual is not None, remask)
+        ctx.save_for_backward(x, gamma, beta if remask else None, mean, invstd, None if remask else y)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, gamma, mean, invstd, y = ctx.saved_tensors
-        act, drop_p, seed, training, has_res = ctx.cfg
+        x, gamma, beta, mean, invstd, y = ctx.saved_tensors
+        act, drop_p, seed, training, has_res, remask = ctx.cfg
         dx, dres, dgamma, dbeta = H.bn_backward(_c(dy), y, x, mean, invstd, gamma, act, drop_p, seed, batch_stats=training,
                                                 need_dx=ctx.needs_input_grad[0],
-                                                need_dres=has_res and ctx.needs_input_grad[3])
+                                                need_dres=has_res and ctx.needs_input_grad[3], beta=beta)
         if gamma is None or not ctx.needs_input_grad[1]:
             dgamma = dbeta = None
         return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None, None

@@ -219,7 +219,8 @@ def bn_apply(x, mean, invstd, gamma, beta, residual=None, act="none", drop_p=0.0
 
 
 def bn_backward(dy, y, x, mean, invstd, gamma, act="none", drop_p=0.0, seed=0, batch_stats=True, need_dx=True,
-                need_dres=False):
+                need_dres=False, beta=None):
+    """y=None selects the remask mode of segsde_bn_backward (act none / plain ReLU: mask recomputed from x, beta needed)."""
     M, C, ldx = _rows(x)
     L = _lib.lib()
     dgamma = torch.empty(C, dtype=torch.float32, device=x.device)
@@ -228,8 +229,8 @@ def bn_backward(dy, y, x, mean, invstd, gamma, act="none", drop_p=0.0, seed=0, b
     dres = torch.empty(x.shape, dtype=torch.float32, device=x.device) if need_dres else None
     nb = L.segsde_bn_backward_workspace(M, C)
     ws = _ws(nb, x)
-    check(L.segsde_bn_backward(_p(_f32(dy)), _rows(dy)[2], _p(y), _rows(y)[2], _p(x), ldx, M, C, _p(mean), _p(invstd),
-                               _p(gamma), ACT[act], float(drop_p), int(seed), int(batch_stats), _p(dgamma), _p(dbeta),
+    check(L.segsde_bn_backward(_p(_f32(dy)), _rows(dy)[2], _p(y), _rows(y)[2] if y is not None else ldx, _p(x), ldx, M, C,
+                               _p(mean), _p(invstd), _p(gamma), _p(beta), ACT[act], float(drop_p), int(seed), int(batch_stats), _p(dgamma), _p(dbeta),
                                _p(dx), C, _p(dres), C, _p(ws), nb, _stream(x)), "bn_backward")
     return dx, dres, dgamma, dbeta
 

@@ -97,10 +97,12 @@ int segsde_bn_apply(const float* x, int ldx, long M, int C, const float* mean, c
  * sums[C..2C) = sum dz) where dz = dy * dropout_mask * act'(y); phase 2 writes dx (and dres = dz if non-null).
  * batch_stats=0 (eval-mode BN): dx = gamma*invstd*dz. */
 size_t segsde_bn_backward_workspace(long M, int C);
+/* y may be NULL ("remask"): for act = none, or act = ReLU with no residual / dropout (then beta is required with gamma),
+ * the activation mask is recomputed from x exactly as the forward kernel formed it and the saved output is not read. */
 int segsde_bn_backward(const float* dy, int lddy, const float* y, int ldy, const float* x, int ldx, long M, int C,
-                       const float* mean, const float* invstd, const float* gamma, int act, float drop_p, uint64_t seed,
-                       int batch_stats, float* dgamma, float* dbeta, float* dx, int lddx, float* dres, int lddres,
-                       void* workspace, size_t workspace_bytes, void* stream);
+                       const float* mean, const float* invstd, const float* gamma, const float* beta, int act,
+                       float drop_p, uint64_t seed, int batch_stats, float* dgamma, float* dbeta, float* dx, int lddx,
+                       float* dres, int lddres, void* workspace, size_t workspace_bytes, void* stream);
 /* dz = dy * act'(y) (ELU / ReLU / sigmoid via the saved output, as the reference's in-place ops do);
  * dbias[c] = sum_rows dz (nullable).  Replaces autograd of nn.ELU / nn.ReLU / torch.sigmoid + conv bias grad. */
 size_t segsde_colsum_workspace(long M, int C);

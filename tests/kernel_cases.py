@@ -58,6 +58,10 @@ CONV_CASES = [
     ("disp_c64", 2, 9, 11, 64, 0, False, 1, 3, 1, 1, 1, True, True, "sigmoid"),
     ("disp_c128_tiny", 1, 3, 5, 128, 0, False, 1, 3, 1, 1, 1, True, True, "sigmoid"),
     ("disp_c256_zero", 1, 4, 6, 256, 0, False, 1, 3, 1, 1, 1, False, False, "none"),
+    # segmentation-head shaped 1x1 convs (narrow class side): register kernels for the data- and weight-gradient
+    ("head_c64_19", 2, 5, 7, 64, 0, False, 19, 1, 1, 1, 0, False, True, "none"),
+    ("head_c128_22", 1, 4, 6, 128, 0, False, 22, 1, 1, 1, 0, False, True, "none"),
+    ("head_c256_3", 1, 3, 5, 256, 0, False, 3, 1, 1, 1, 0, False, False, "none"),
     # widths that are multiples of 8 take the strip (sliding-window) stencil kernels
     ("disp_strip_c64", 2, 6, 24, 64, 0, False, 1, 3, 1, 1, 1, True, True, "sigmoid"),
     ("disp_strip_c128_zero", 1, 5, 16, 128, 0, False, 1, 3, 1, 1, 1, False, True, "none"),
@@ -163,6 +167,11 @@ def run_bn_case(device, C=24, act="relu", residual=True, train=True, drop_p=0.0,
     assert_close(dbeta, br.grad, rtol=2e-3, what="bn dbeta")
     if residual:
         assert_close(nchw(dres), rr.grad, what="bn dres")
+    if act in ("none", "relu") and not residual:
+        # remask mode (saved output not read): the mask recomputed from x must reproduce the same gradients bit for bit
+        dx2, _, dgamma2, dbeta2 = H.bn_backward(d(nhwc(gy)), None, xn, mean, invstd, d(gamma), act, batch_stats=train,
+                                                beta=d(beta))
+        assert torch.equal(dx2, dx) and torch.equal(dgamma2, dgamma) and torch.equal(dbeta2, dbeta), "bn remask"
 
 
 def run_dropout_case(device):

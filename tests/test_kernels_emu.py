@@ -21,7 +21,9 @@ def test_conv(case):
 @pytest.mark.parametrize("cfg", [dict(C=24, act="relu", residual=True, train=True),
                                  dict(C=70, act="none", residual=False, train=True),
                                  dict(C=8, act="elu", residual=False, train=True),
-                                 dict(C=16, act="relu", residual=True, train=False)])
+                                 dict(C=16, act="relu", residual=True, train=False),
+                                 dict(C=32, act="relu", residual=False, train=True),
+                                 dict(C=12, act="relu", residual=False, train=False)])
 def test_batchnorm(cfg):
     KC.run_bn_case("cpu", **cfg)
 
