@@ -39,6 +39,11 @@ struct ConvP {
   int vecout;          // outputs allow 16-byte stores (pitches, split point and bases multiples of 4 floats / 16 B)
   int nb, ne;          // output-channel range [nb, ne) handled by this launch (tile-shape mixing for Cout % 128 == 64)
   const float* zero;   // 256 bytes of zeros: target of out-of-range tile loads
+  // Sub-problem view used by the parity-class decomposition of stride-2 data-gradients (FAST path only):
+  // the loop tap (kh', kw') stands for the real tap (kh0 + khs*kh', kw0 + kws*kw') of a KHf x KWf kernel whose packed
+  // rows are Kfull long, and output pixel (b, i, j) of the Ho x Wo sub-grid is stored at (b, os*i + oph, os*j + opw) of
+  // an OHf x OWf image.  Defaults (0, 1, 0, 1, KW, Ktot, os = 1) describe the plain problem.
+  int kh0, khs, kw0, kws, KWf, Kfull, os, oph, opw, OHf, OWf;
 };
 
 struct KInfo {  // decoded reduction index k -> tap + channel + source
@@ -97,6 +102,14 @@ __device__ __forceinline__ void decode_m(const ConvP& p, int m, int& b, int& hb,
   hb = ho * p.stride;
   wb = (rem - ho * p.Wo) * p.stride;
 }
+
+// row index of output GEMM row m in the destination tensor (identity unless the launch writes a strided sub-grid)
+__device__ __forceinline__ long out_row(const ConvP& p, int m) {
+  if (p.os == 1) return m;
+  const int hw = p.Ho * p.Wo, b = m / hw, rem = m - b * hw, i = rem / p.Wo, j = rem - i * p.Wo;
+  return ((long)b * p.OHf + p.os * i + p.oph) * p.OWf + p.os * j + p.opw;
+}
+
 
 template <bool VEC>
 __device__ __forceinline__ float4 fetch_a4(const ConvP& p, int k, int b, int hb, int wb, bool row_ok) {
@@ -340,7 +353,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
 #pragma unroll
     for (int i = 0; i < BR; ++i) {
       const int n = n0 + r0 + RP * i;
-      voffB[i] = n < p.ne ? (unsigned)(n * p.Ktot + 4 * kq) * 4u : SEGSDE_OOB;   // rows past Cout read zeros
+      voffB[i] = n < p.ne ? (unsigned)(n * p.Kfull + 4 * kq) * 4u : SEGSDE_OOB;   // rows past Cout read zeros
     }
     bool wave_bord = false, wave_corner = false;
     {
@@ -391,10 +404,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
     auto run = [&](auto wadj_tag) {
       constexpr bool WADJ = decltype(wadj_tag)::value;
       // state of the chunk whose loads are being issued
-      bool live; int kcl; segsde_rsrc rsa; unsigned soffA;
+      bool more; segsde_rsrc rsa; unsigned soffA, soffB;
       auto chunk_begin = [&](int kc) {
-        live = kc < nchunks;
-        kcl = live ? kc : nchunks - 1;
+        more = kc + 1 < nchunks;   // chunks past the end reload the last one (cs stops advancing there) and are discarded
+        soffB = (unsigned)(((p.kh0 + p.khs * cs.kh) * p.KWf + p.kw0 + p.kws * cs.kw) * p.Ctot + cs.c0) * 4u;
         const bool in0 = cs.c0 < p.C0;
         rsa = segsde_make_rsrc(in0 ? base0 : base1);
         soffA = (unsigned)(in0 ? cs.c0 : cs.c0 - p.C0) * 4u;
@@ -409,9 +422,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
           }
         }
       };
-      auto loadB = [&](int i) { rbv[i] = segsde_buffer_load4(rsw, voffB[i], (unsigned)kcl * (BK * 4u)); };
+      auto loadB = [&](int i) { rbv[i] = segsde_buffer_load4(rsw, voffB[i], soffB); };
       auto chunk_end = [&]() {
-        if (live) {
+        if (more) {
           cs.advance(p, BK);
           if (cs.c0 == 0 || cs.c0 == p.C0) tap_update(wadj_tag);
         }
@@ -539,7 +552,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
 #pragma unroll 4
       for (int ml = rr; ml < BM; ml += RPP) {
         const int m = m0 + ml;
-        if (m < p.M) *reinterpret_cast<float4*>(dst + (long)m * ld + nn) = *reinterpret_cast<const float4*>(Ct + ml * BN + 4 * cq);
+        if (m < p.M) *reinterpret_cast<float4*>(dst + out_row(p, m) * ld + nn) = *reinterpret_cast<const float4*>(Ct + ml * BN + 4 * cq);
       }
     }
     return;
@@ -578,7 +591,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * rhalf;
-          if (m < p.M) dst[(long)m * ld + nn] = segsde_act(acc[i][j][r] + bias, p.act);
+          if (m < p.M) dst[out_row(p, m) * ld + nn] = segsde_act(acc[i][j][r] + bias, p.act);
         }
       }
     }
@@ -1032,12 +1045,13 @@ __global__ __launch_bounds__(256) void reflect_dgrad_fix_kernel(const float* dy,
 // experiment knob (environment SEGSDE_TUNE="bk64=1"), read once.  Measured on MI355X (profiles/ab_conv_r01.log):
 // BK=64 (139 KB LDS => 1 workgroup/CU, half the barriers) loses 15-25 % on the large layers against BK=32 with two
 // co-resident workgroups per CU, and start-up staggering of co-resident workgroups changes nothing.
-struct Tune { int bk64 = 0; int adjfix = 0; int wplan = 0; int wovh = 4; };
+struct Tune { int bk64 = 0; int adjfix = 0; int wplan = 0; int wovh = 4; int nos2 = 0; };
 const Tune& tune() {
   static Tune t = [] {
     Tune r;
     if (const char* e = getenv("SEGSDE_TUNE")) {
       if (const char* q = strstr(e, "bk64=")) r.bk64 = atoi(q + 5);
+      if (const char* q = strstr(e, "nos2=")) r.nos2 = atoi(q + 5);       // 1: stride-2 data-gradients without the parity split
       if (const char* q = strstr(e, "wplan=")) r.wplan = atoi(q + 6);     // 1: previous fixed-target split plan
       if (const char* q = strstr(e, "wovh=")) r.wovh = atoi(q + 5);       // per-workgroup fixed cost in chunk units
       if (const char* q = strstr(e, "adjfix=")) r.adjfix = atoi(q + 7);   // reflection adjoint: plain loop + border fix-up kernel
@@ -1073,6 +1087,7 @@ ConvP make_params(const segsde_conv_desc* d, const float* x0, const float* x1, c
   p.vecout = (p.N % 4 == 0) && (p.ldy % 4 == 0) && (p.ldy2 % 4 == 0) && (p.nsplit % 4 == 0) && aligned16(p.y) &&
              aligned16(p.y2);
   p.zero = zero_page();
+  p.kh0 = 0; p.khs = 1; p.kw0 = 0; p.kws = 1; p.KWf = p.KW; p.Kfull = p.Ktot; p.os = 1; p.oph = 0; p.opw = 0; p.OHf = p.Ho; p.OWf = p.Wo;
   return p;
 }
 
@@ -1164,6 +1179,50 @@ extern "C" int segsde_conv2d_forward(const segsde_conv_desc* d, const float* x0,
   if (plain1x1 && d->C0 % 4 != 0 && d->ld0 == d->C0 && aligned16(x0) && !bias && d->act == 0 && !y2 &&
       segsde_skinny_supported(d->C0, d->Cout) && p.vecout)
     return segsde_skinny_nk(x0, d->C0, wpack, (long)d->B * d->H * d->W, d->Cout, y, p.ldy, stream);
+  // Data-gradient of a stride-2 convolution (in_div == 2): three quarters of the (pixel, tap) pairs hit the holes between
+  // the strided outputs.  Split the gradient image into its four (row parity, column parity) classes: each class is a
+  // dense stride-1 problem over the taps of matching parity (1 / 2 / 2 / 4 of the 9 taps of a 3x3, 1 / 0 / 0 / 0 of a 1x1)
+  // that reads dY without holes and stores into the strided sub-grid -- a quarter of the matrix work, no wasted MFMAs.
+  if (d->in_div == 2 && d->stride == 1 && (d->dil & 1) && d->pad_mode == SEGSDE_PAD_ZERO && !d->sum2x2 && d->C1 == 0 && !d->up0 &&
+      !bias && d->act == 0 && !y2 && !tune().nos2 && p.vecout) {
+    bool ok = true;
+    ConvP sub[4]; int nsub = 0; bool empty = false;
+    for (int ph = 0; ph < 2 && ok; ++ph)
+      for (int pw = 0; pw < 2 && ok; ++pw) {
+        ConvP q = p;
+        // first tap of matching parity per axis; taps then alternate (dilation is odd)
+        int kh0 = -1, kw0 = -1;
+        for (int k = 0; k < d->KH; ++k) if (((ph + k * d->dil - d->pad) & 1) == 0) { kh0 = k; break; }
+        for (int k = 0; k < d->KW; ++k) if (((pw + k * d->dil - d->pad) & 1) == 0) { kw0 = k; break; }
+        const int nI = (d->Ho - ph + 1) / 2, nJ = (d->Wo - pw + 1) / 2;
+        if (nI <= 0 || nJ <= 0) continue;
+        if (kh0 < 0 || kw0 < 0) { empty = true; continue; }   // no tap reaches this class: its pixels are zero
+        q.kh0 = kh0; q.khs = 2; q.kw0 = kw0; q.kws = 2; q.KWf = d->KW; q.Kfull = p.Ktot;
+        q.KH = (d->KH - kh0 + 1) / 2; q.KW = (d->KW - kw0 + 1) / 2;
+        q.Ktot = q.KH * q.KW * q.Ctot;
+        q.in_div = 1;
+        // source row of loop tap kh' for sub-grid row i:  i + (ph + kh0*dil - pad)/2 + kh'*dil   (exact division)
+        q.pad = -((ph + kh0 * d->dil - d->pad) / 2);
+        q.os = 2; q.oph = ph; q.opw = pw; q.OHf = d->Ho; q.OWf = d->Wo;
+        q.Ho = nI; q.Wo = nJ; q.M = d->B * nI * nJ;
+        if (!igemm_fast_ok(q)) ok = false;
+        sub[nsub++] = q;
+      }
+    if (ok) {
+      if (empty) {   // 1x1: only the (even, even) class receives anything
+        if (hipMemsetAsync(y, 0, (size_t)d->B * d->Ho * d->Wo * p.ldy * sizeof(float), s) != hipSuccess) return SEGSDE_ERR_SHAPE;
+      }
+      for (int i = 0; i < nsub; ++i) {
+        const ConvP& q = sub[i];
+        int e;
+        if (q.N <= 32) e = launch_igemm<128, 32, 4, 1>(q, s);
+        else if (q.N <= 64) e = launch_igemm<128, 64, 2, 2>(q, s);
+        else e = launch_igemm<128, 128, 2, 2>(q, s);
+        if (e) return e;
+      }
+      return 0;
+    }
+  }
   if (d->sum2x2) {
     if ((d->Ho & 1) || (d->Wo & 1) || d->stride != 1 || d->act != 0 || bias) return SEGSDE_ERR_SHAPE;
     if (!igemm_fast_ok(p)) return SEGSDE_ERR_UNSUPPORTED;   // caller falls back to the two-pass path (full-res dgrad + 2x2 sum)

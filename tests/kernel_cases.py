@@ -45,6 +45,7 @@ CONV_CASES = [
     ("fast_refl_cat", 1, 5, 6, 64, 32, False, 64, 3, 1, 1, 1, True, False, "none"),
     ("fast_dil3", 1, 12, 10, 64, 0, False, 32, 3, 1, 3, 3, False, False, "none"),
     ("fast_s2", 2, 11, 14, 32, 0, False, 64, 3, 2, 1, 1, False, False, "none"),
+    ("fast_s2_even", 1, 8, 12, 64, 0, False, 32, 3, 2, 1, 1, False, True, "none"),
     ("fast_1x1", 2, 7, 9, 96, 0, False, 160, 1, 1, 1, 0, False, True, "none"),
     ("fast_1x1_s2", 1, 8, 10, 64, 0, False, 32, 1, 2, 1, 0, False, False, "none"),
     ("fast64_refl_up_cat", 1, 8, 12, 64, 128, True, 64, 3, 1, 1, 1, True, True, "elu"),
