@@ -27,16 +27,16 @@ def _c(t):
 
 class _ToNHWC(Function):
     @staticmethod
-    def forward(ctx, x, mean, std):
-        ctx.std = std
-        return H.nchw_to_nhwc(x, mean, std)
+    def forward(ctx, x, mean, std, pad_to):
+        ctx.std, ctx.C = std, x.shape[1]
+        return H.nchw_to_nhwc(x, mean, std, pad_to)
 
     @staticmethod
     def backward(ctx, g):
-        gx = H.nhwc_to_nchw(_c(g))
+        gx = H.nhwc_to_nchw(_c(g[..., :ctx.C]))
         if ctx.std != 1.0:
             gx = H.axpby(1.0 / ctx.std, gx)
-        return gx, None, None
+        return gx, None, None, None
 
 
 class _ToNCHWDense(Function):
@@ -49,13 +49,14 @@ class _ToNCHWDense(Function):
         return H.nchw_to_nhwc(g.contiguous())
 
 
-def to_nhwc(x, mean=0.0, std=1.0):
-    """NCHW-logical tensor -> NHWC tensor (zero-copy when x is channels-last in memory and no normalisation)."""
-    if mean == 0.0 and std == 1.0:
+def to_nhwc(x, mean=0.0, std=1.0, pad_to=1):
+    """NCHW-logical tensor -> NHWC tensor (zero-copy when x is channels-last in memory and no normalisation);
+    pad_to > 1 appends zero channels up to a multiple of pad_to."""
+    if mean == 0.0 and std == 1.0 and x.shape[1] % pad_to == 0:
         v = x.permute(0, 2, 3, 1)
         if v.is_contiguous():
             return v
-    return _ToNHWC.apply(x, mean, std)
+    return _ToNHWC.apply(x, mean, std, pad_to)
 
 
 def to_nchw(x_nhwc):

@@ -350,11 +350,17 @@ def copy_channels(src, dst):
     return dst
 
 
-def nchw_to_nhwc(x, mean=0.0, std=1.0):
+def nchw_to_nhwc(x, mean=0.0, std=1.0, pad_to=1):
+    """pad_to > 1 rounds the channel count of the result up to a multiple of pad_to; the extra channels are zero
+    (the 3 / 6-channel network input becomes 4 / 8 so that the stem convolution takes the float4 gather)."""
     x = _f32(x).contiguous()
     B, C, H, W = x.shape
-    y = torch.empty((B, H, W, C), dtype=torch.float32, device=x.device)
-    check(_lib.lib().segsde_nchw_to_nhwc(_p(x), B, C, H, W, float(mean), float(std), _p(y), C, _stream(x)), "nchw_to_nhwc")
+    Cp = -(-C // pad_to) * pad_to
+    if Cp == C:
+        y = torch.empty((B, H, W, C), dtype=torch.float32, device=x.device)
+    else:
+        y = torch.zeros((B, H, W, Cp), dtype=torch.float32, device=x.device)
+    check(_lib.lib().segsde_nchw_to_nhwc(_p(x), B, C, H, W, float(mean), float(std), _p(y), Cp, _stream(x)), "nchw_to_nhwc")
     return y
 
 

@@ -27,10 +27,16 @@ class Conv2d(nn.Conv2d):
     def forward(self, x, skip=None, up=False, act="none"):
         c0 = x.shape[3]
         c1 = 0 if skip is None else skip.shape[3]
-        assert c0 + c1 == self.in_channels, (c0, c1, self.in_channels)
+        weight = self.weight
+        if skip is None and c0 > self.in_channels:
+            # input carries zero pad channels (network stem: 3 -> 4, 6 -> 8): matching zero weight planes; their gradient
+            # is dropped by the adjoint of the pad
+            weight = torch.nn.functional.pad(weight, (0, 0, 0, 0, 0, c0 - self.in_channels))
+        else:
+            assert c0 + c1 == self.in_channels, (c0, c1, self.in_channels)
         g = ConvGeom(c0, self.out_channels, self.kernel_size[0], self.stride[0], self.dilation[0], self.padding[0],
                      self.reflect, c1, up)
-        return Fn.ConvFn.apply(x, skip, self.weight, self.bias, g, act)
+        return Fn.ConvFn.apply(x, skip, weight, self.bias, g, act)
 
 
 class BatchNorm2d(nn.BatchNorm2d):

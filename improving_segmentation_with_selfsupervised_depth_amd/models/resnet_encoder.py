@@ -122,7 +122,9 @@ class ResnetEncoder(nn.Module):
 
     def forward_nhwc(self, input_image):
         e = self.encoder
-        x = Fn.to_nhwc(input_image, 0.45, 0.225)            # (x - 0.45) / 0.225 fused with the layout change
+        # (x - 0.45) / 0.225 fused with the layout change; channels padded 3 -> 4 / 6 -> 8 with zeros so that the stem's
+        # tile loads are 16-byte gathers (K = 49*4 instead of 49*3, but 2.5x faster than the scalar gather)
+        x = Fn.to_nhwc(input_image, 0.45, 0.225, pad_to=4)
         f0 = e.bn1(e.conv1(x), act="relu")
         feats = [f0]
         x = Fn.MaxPoolFn.apply(f0)

@@ -42,6 +42,8 @@ def main():
         ("probe: 1x1 32->128 @512x1024 (short K)", 512, 1024, 32, 0, False, 128, 1, 1, 1, 0, False),
         ("layer2 conv2 3x3s2 128->128 @128x256", 128, 256, 128, 0, False, 128, 3, 2, 1, 1, False),
         ("layer2 down 1x1s2 256->512 @128x256", 128, 256, 256, 0, False, 512, 1, 2, 1, 0, False),
+        ("stem4 7x7s2 4->64 @512x1024", 512, 1024, 4, 0, False, 64, 7, 2, 1, 3, False),
+        ("stem8 7x7s2 8->64 @512x1024", 512, 1024, 8, 0, False, 64, 7, 2, 1, 3, False),
         ("stem 7x7s2 3->64 @512x1024", 512, 1024, 3, 0, False, 64, 7, 2, 1, 3, False),
         ("seg head 1x1 64->19 @512x1024", 512, 1024, 64, 0, False, 19, 1, 1, 1, 0, False),
         ("dispconv refl 64->1 @512x1024", 512, 1024, 64, 0, False, 1, 3, 1, 1, 1, True),
