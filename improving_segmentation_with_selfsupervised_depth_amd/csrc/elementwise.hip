@@ -192,13 +192,15 @@ struct BnBwdOp {
   int act, C; float drop_p; uint64_t seed; const float* gamma; const float* beta;
   template <int VW> __device__ void row(long m, int c, double* s0, double* s1) const {
     const VecF<VW> g = ldv<VW>(dy + m * lddy + c), xx = ldv<VW>(x + m * ldx + c);
-    VecF<VW> yy;
+    VecF<VW> yy, ga, be;
     if (y) yy = ldv<VW>(y + m * ldy + c);
+    else if (gamma) { ga = ldv<VW>(gamma + c); be = ldv<VW>(beta + c); }
+    const VecF<VW> mu = ldv<VW>(mean + c), is = ldv<VW>(invstd + c);   // per-channel parameters: one vector load each
 #pragma unroll
     for (int j = 0; j < VW; ++j) {
-      const float xh = (xx.v[j] - mean[c + j]) * invstd[c + j];
+      const float xh = (xx.v[j] - mu.v[j]) * is.v[j];
       const float dz = y ? bn_dz(g.v[j], yy.v[j], act, drop_p, seed, (uint64_t)(m * C + c + j))
-                         : bn_dz_remask(g.v[j], xh, gamma ? gamma[c + j] : 1.f, gamma ? beta[c + j] : 0.f, gamma != nullptr, act);
+                         : bn_dz_remask(g.v[j], xh, gamma ? ga.v[j] : 1.f, gamma ? be.v[j] : 0.f, gamma != nullptr, act);
       s0[j] += (double)dz * (double)xh; s1[j] += (double)dz;
     }
   }
@@ -553,7 +555,7 @@ extern "C" int segsde_bn_backward(const float* dy, int lddy, const float* y, int
   if (!y) ldy = ldx;
   BnBwdOp op{dy, lddy, y, ldy, x, ldx, mean, invstd, act, C, drop_p, seed, gamma, beta};
   const bool vec = (C % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) && (lddy % 4 == 0) && al16p(x) && (!y || al16p(y)) && al16p(dy) &&
-                   (!gamma || (al16p(gamma) && (!beta || al16p(beta))));
+                   (!gamma || (al16p(gamma) && (!beta || al16p(beta)))) && al16p(mean) && al16p(invstd);
   if (int e = launch_colreduce(op, M, C, (double*)ws, vec, ST(stream))) return e;
   hipLaunchKernelGGL(pair_finalize_kernel, dim3((C + 15) / 16), dim3(256), 4096, ST(stream), (const double*)ws,
                      red_blocks(M), C, dgamma, dbeta);
