@@ -28,6 +28,10 @@ P = c_void_p
 _SIGS = {
     "segsde_abi_version": (c_int, []),
     "segsde_conv2d_forward": (c_int, [POINTER(ConvDesc), P, P, P, P, P, P, P]),
+    "segsde_conv2d_stats_rows": (c_long, [POINTER(ConvDesc)]),
+    "segsde_conv2d_forward_stats": (c_int, [POINTER(ConvDesc), P, P, P, P, P, P, P, P]),
+    "segsde_bn_stats_from_partials_workspace": (c_size_t, [c_int]),
+    "segsde_bn_stats_from_partials": (c_int, [P, c_long, c_long, c_int, P, P, P, P, c_float, c_float, P, c_size_t, P]),
     "segsde_conv2d_wgrad_workspace": (c_size_t, [POINTER(ConvDesc)]),
     "segsde_conv2d_wgrad": (c_int, [POINTER(ConvDesc), P, P, P, c_int, P, P, c_size_t, P]),
     "segsde_pack_weight": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),

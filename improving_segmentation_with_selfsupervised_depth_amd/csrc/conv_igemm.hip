@@ -44,6 +44,10 @@ struct ConvP {
   // rows are Kfull long, and output pixel (b, i, j) of the Ho x Wo sub-grid is stored at (b, os*i + oph, os*j + opw) of
   // an OHf x OWf image.  Defaults (0, 1, 0, 1, KW, Ktot, os = 1) describe the plain problem.
   int kh0, khs, kw0, kws, KWf, Kfull, os, oph, opw, OHf, OWf;
+  // BatchNorm statistics fused into the epilogue (nullable): per-tile column sums / sums of squares of the stored tile,
+  // [ntm * (256 / BN)][2][N] doubles (sum, sum of squares per row slice of a tile) -- the next layer's batch statistics
+  // without re-reading the tensor
+  double* stats;
 };
 
 struct KInfo {  // decoded reduction index k -> tap + channel + source
@@ -542,6 +546,31 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
         }
     }
     __syncthreads();
+    if (p.stats) {
+      // each thread: one column x one slice of the tile's rows (conflict-free LDS reads), no cross-thread reduction --
+      // the slices are simply more partial rows for the (double precision) reduction that follows
+      constexpr int R = 256 / BN, RS = BM / R;
+      const int scol = tid % BN, sl = tid / BN, sn = n0 + scol;
+      // Double accumulation, eight independent chains.  var = E[x^2] - mean^2 cancels catastrophically in fp32 when a
+      // channel's mean dominates its spread; and with exact (double) sums the statistics come out bit-identical to the
+      // separate segsde_bn_stats pass, which the golden-vector tests of whole models rely on (tiny feature maps make
+      // the gradients sensitive to the last bit of invstd).  A shifted-fp32 variant was no faster end to end.
+      double s8[8], q8[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { s8[u] = 0.0; q8[u] = 0.0; }
+      for (int ml = sl * RS; ml < (sl + 1) * RS; ml += 8) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const double v = (m0 + ml + u < p.M) ? (double)Ct[(ml + u) * BN + scol] : 0.0;
+          s8[u] += v; q8[u] += v * v;
+        }
+      }
+      if (sn < p.ne) {
+        double* pr = p.stats + ((long)(mt * R + sl) * 2) * p.N + sn;
+        pr[0] = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
+        pr[p.N] = ((q8[0] + q8[1]) + (q8[2] + q8[3])) + ((q8[4] + q8[5]) + (q8[6] + q8[7]));
+      }
+    }
     constexpr int CQ = BN / 4, RPP = 256 / CQ;    // float4 columns per row, rows per pass
     const int cq = tid % CQ, rr = tid / CQ;
     const int n = n0 + 4 * cq;
@@ -1088,6 +1117,7 @@ ConvP make_params(const segsde_conv_desc* d, const float* x0, const float* x1, c
              aligned16(p.y2);
   p.zero = zero_page();
   p.kh0 = 0; p.khs = 1; p.kw0 = 0; p.kws = 1; p.KWf = p.KW; p.Kfull = p.Ktot; p.os = 1; p.oph = 0; p.opw = 0; p.OHf = p.Ho; p.OWf = p.Wo;
+  p.stats = nullptr;
   return p;
 }
 
@@ -1156,11 +1186,38 @@ int launch_reflect_fix(const float* dy, int lddy, const float* wd, float* dx, in
 }
 }  // namespace
 
+namespace {
+// rows of statistics partials a forward launch of this shape writes (0: the shape does not take the staged epilogue
+// with a single tile shape, the statistics then have to come from segsde_bn_stats)
+long stats_rows(const segsde_conv_desc* d, const ConvP& p) {
+  if (!p.vecout || d->sum2x2 || d->in_div > 1 || p.y2 != p.y || p.bias || d->act != 0) return 0;
+  if (d->Cout == 1 || (d->Cout % 128 > 0 && d->Cout % 128 <= 64 && d->Cout > 64)) return 0;
+  const int bn = d->Cout <= 32 ? 32 : (d->Cout <= 64 ? 64 : 128);
+  return (long)segsde_cdiv(p.M, 128) * (256 / bn);
+}
+}  // namespace
+
+extern "C" long segsde_conv2d_stats_rows(const segsde_conv_desc* d) {
+  if (validate(d)) return 0;
+  float dummy[4];
+  const ConvP p = make_params(d, dummy, dummy, dummy, nullptr, reinterpret_cast<float*>(16), nullptr);
+  return stats_rows(d, p);
+}
+
 extern "C" int segsde_conv2d_forward(const segsde_conv_desc* d, const float* x0, const float* x1, const float* wpack,
                                      const float* bias, float* y, float* y2, void* stream) {
+  return segsde_conv2d_forward_stats(d, x0, x1, wpack, bias, y, y2, nullptr, stream);
+}
+
+extern "C" int segsde_conv2d_forward_stats(const segsde_conv_desc* d, const float* x0, const float* x1, const float* wpack,
+                                           const float* bias, float* y, float* y2, double* stats, void* stream) {
   if (int e = validate(d)) return e;
   if (!x0 || !wpack || !y || (d->C1 && !x1)) return SEGSDE_ERR_NULL;
-  const ConvP p = make_params(d, x0, x1, wpack, bias, y, y2);
+  ConvP p = make_params(d, x0, x1, wpack, bias, y, y2);
+  if (stats) {
+    if (stats_rows(d, p) == 0) return SEGSDE_ERR_UNSUPPORTED;
+    p.stats = stats;
+  }
   hipStream_t s = static_cast<hipStream_t>(stream);
   // disparity heads (Cout = 1) and their data-gradients (one gradient channel in): HBM-bound stencil kernels
   const bool plain3x3 = d->KH == 3 && d->KW == 3 && d->stride == 1 && d->dil == 1 && d->pad == 1 && d->C1 == 0 && !d->up0 &&
@@ -1176,7 +1233,7 @@ extern "C" int segsde_conv2d_forward(const segsde_conv_desc* d, const float* x0,
   // 1x1 with a narrow, non-vectorisable input side (data-gradient of the 19-class head): HBM-bound register kernel
   const bool plain1x1 = d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && d->C1 == 0 && !d->up0 && d->in_div <= 1 &&
                         !d->sum2x2 && d->H == d->Ho && d->W == d->Wo;
-  if (plain1x1 && d->C0 % 4 != 0 && d->ld0 == d->C0 && aligned16(x0) && !bias && d->act == 0 && !y2 &&
+  if (plain1x1 && !stats && d->C0 % 4 != 0 && d->ld0 == d->C0 && aligned16(x0) && !bias && d->act == 0 && !y2 &&
       segsde_skinny_supported(d->C0, d->Cout) && p.vecout)
     return segsde_skinny_nk(x0, d->C0, wpack, (long)d->B * d->H * d->W, d->Cout, y, p.ldy, stream);
   // Data-gradient of a stride-2 convolution (in_div == 2): three quarters of the (pixel, tap) pairs hit the holes between

@@ -516,6 +516,45 @@ extern "C" int segsde_bn_stats(const float* x, int ldx, long M, int C, float* me
   return 0;
 }
 
+// conv-epilogue partials [rows][2][C] doubles -> partials [nb][2][C] in the colreduce format: block (b, cg) sums the rows
+// b, b + nb, ... of 64 channels with 4 row-lanes, fixed order
+__global__ __launch_bounds__(256) void bn_partials_reduce_kernel(const double* part, long rows, int C, int nb, double* out) {
+  SEGSDE_SMEM;
+  double* sh = reinterpret_cast<double*>(segsde_smem);   // [2][4][64]
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6, c = blockIdx.y * 64 + cl;
+  double a = 0.0, b = 0.0;
+  if (c < C)
+    for (long r = blockIdx.x + (long)rl * nb; r < rows; r += 4L * nb) {
+      a += part[(r * 2) * C + c]; b += part[(r * 2 + 1) * C + c];
+    }
+  sh[rl * 64 + cl] = a; sh[256 + rl * 64 + cl] = b;
+  __syncthreads();
+  if (rl == 0 && c < C) {
+    out[((long)blockIdx.x * 2) * C + c] = (sh[cl] + sh[64 + cl]) + (sh[128 + cl] + sh[192 + cl]);
+    out[((long)blockIdx.x * 2 + 1) * C + c] = (sh[256 + cl] + sh[320 + cl]) + (sh[384 + cl] + sh[448 + cl]);
+  }
+}
+
+namespace { constexpr int PARTIALS_NB = 64; }
+
+extern "C" size_t segsde_bn_stats_from_partials_workspace(int C) { return (size_t)PARTIALS_NB * 2 * (C > 0 ? C : 1) * sizeof(double); }
+
+extern "C" int segsde_bn_stats_from_partials(const double* partials, long rows, long M, int C, float* mean, float* invstd,
+                                             float* running_mean, float* running_var, float momentum, float eps, void* ws,
+                                             size_t ws_bytes, void* stream) {
+  if (!partials || !mean || !invstd || !ws) return SEGSDE_ERR_NULL;
+  if (rows <= 0 || M <= 0 || C <= 0) return SEGSDE_ERR_SHAPE;
+  if (ws_bytes < segsde_bn_stats_from_partials_workspace(C)) return SEGSDE_ERR_WORKSPACE;
+  const int nb = rows < PARTIALS_NB ? (int)rows : PARTIALS_NB;
+  hipLaunchKernelGGL(bn_partials_reduce_kernel, dim3(nb, (C + 63) / 64), dim3(256), 4096, ST(stream), partials, rows, C, nb,
+                     (double*)ws);
+  SEGSDE_CHECK_LAUNCH();
+  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((C + 15) / 16), dim3(256), 4096, ST(stream), (const double*)ws, nb, M, C,
+                     eps, momentum, mean, invstd, running_mean, running_var);
+  SEGSDE_CHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" int segsde_bn_eval_stats(const float* rm, const float* rv, int C, float eps, float* mean, float* invstd,
                                     void* stream) {
   if (!rm || !rv || !mean || !invstd) return SEGSDE_ERR_NULL;

@@ -72,10 +72,15 @@ class ConvFn(Function):
     """y = act(conv([up2x?(x0) | x1], weight) + bias); geometry in ``g`` (hipops.ConvGeom)."""
 
     @staticmethod
-    def forward(ctx, x0, x1, weight, bias, g, act):
+    def forward(ctx, x0, x1, weight, bias, g, act, stats_out=None):
+        """stats_out: optional list; receives the BatchNorm statistics partials of y (or None) -- see Conv2d.forward"""
         x0 = _c(x0) if x0.stride(-1) != 1 else x0
         wp = H.pack_weight(weight, False)
-        y = H.conv_forward(g, x0, x1, wp, bias, act)
+        if stats_out is not None:
+            y, part = H.conv_forward(g, x0, x1, wp, bias, act, want_stats=True)
+            stats_out.append(part)
+        else:
+            y = H.conv_forward(g, x0, x1, wp, bias, act)
         ctx.g, ctx.act = g, act
         ctx.in_hw = (x0.shape[1] * (2 if g.up0 else 1), x0.shape[2] * (2 if g.up0 else 1))
         ctx.has_bias = bias is not None
@@ -102,16 +107,21 @@ class ConvFn(Function):
                 dx1 = None
         if ctx.needs_input_grad[2]:
             dw = H.conv_wgrad(g, x0, x1, dz)
-        return dx0, dx1, dw, dbias, None, None
+        return dx0, dx1, dw, dbias, None, None, None
 
 
 class BNActFn(Function):
     """y = dropout(act(BN(x) + residual)); training=True uses batch statistics and updates the running buffers."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, residual, running_mean, running_var, training, momentum, eps, act, drop_p, seed):
+    def forward(ctx, x, gamma, beta, residual, running_mean, running_var, training, momentum, eps, act, drop_p, seed,
+                partials=None):
         x = _c(x)
-        if training:
+        if training and partials is not None:
+            # the producing convolution already summed x and x^2 per tile in its epilogue
+            mean, invstd = H.bn_stats_from_partials(partials, x.numel() // x.shape[-1], running_mean, running_var, momentum,
+                                                    eps, update_running=running_mean is not None)
+        elif training:
             mean, invstd = H.bn_stats(x, running_mean, running_var, momentum, eps, update_running=running_mean is not None)
         else:
             mean, invstd = H.bn_eval_stats(running_mean, running_var, eps)
@@ -131,7 +141,7 @@ class BNActFn(Function):
                                                 need_dres=has_res and ctx.needs_input_grad[3], beta=beta)
         if gamma is None or not ctx.needs_input_grad[1]:
             dgamma = dbeta = None
-        return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None, None
+        return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None, None, None
 
 
 class MaxPoolFn(Function):

@@ -99,8 +99,10 @@ def pack_weight(w_oihw, for_dgrad=False):
     return out
 
 
-def conv_forward(g, x0, x1, wpack, bias, act="none"):
-    """y = act(conv(cat[up?(x0), x1]) + bias).  x0: [B,H0,W0,C0] (H0 = H/2 if g.up0), x1: [B,H,W,C1] or None."""
+def conv_forward(g, x0, x1, wpack, bias, act="none", want_stats=False):
+    """y = act(conv(cat[up?(x0), x1]) + bias).  x0: [B,H0,W0,C0] (H0 = H/2 if g.up0), x1: [B,H,W,C1] or None.
+    want_stats: also return the per-tile statistics partials of y for the BatchNorm that follows ([rows,2,Cout] doubles,
+    or None when this shape cannot fuse them) -> (y, partials)."""
     B, H0, W0, C0 = x0.shape
     H, W = (2 * H0, 2 * W0) if g.up0 else (H0, W0)
     assert C0 == g.C0 and (g.C1 == 0) == (x1 is None)
@@ -113,10 +115,15 @@ def conv_forward(g, x0, x1, wpack, bias, act="none"):
                  stride=g.stride, dil=g.dil, pad=g.pad, pad_mode=PAD_REFLECT if g.reflect else PAD_ZERO, in_div=1,
                  act=ACT[act], sum2x2=0)
     flops = 2.0 * B * Ho * Wo * g.Cout * g.Cin * g.k * g.k
-    _timed("conv_fwd", flops, x0, lambda: check(_lib.lib().segsde_conv2d_forward(
-        ctypes.byref(d), _p(_f32(x0)), _p(x1), _p(wpack), _p(bias), _p(y), None, _stream(x0)), "conv2d_forward"),
+    part = None
+    if want_stats and bias is None and act == "none":
+        rows = int(_lib.lib().segsde_conv2d_stats_rows(ctypes.byref(d)))
+        if rows > 0:
+            part = torch.empty((rows, 2, g.Cout), dtype=torch.float64, device=x0.device)
+    _timed("conv_fwd", flops, x0, lambda: check(_lib.lib().segsde_conv2d_forward_stats(
+        ctypes.byref(d), _p(_f32(x0)), _p(x1), _p(wpack), _p(bias), _p(y), None, _p(part), _stream(x0)), "conv2d_forward"),
         _tag(g, H, W))
-    return y
+    return (y, part) if want_stats else y
 
 
 def conv_dgrad(g, dy, wdpack, w_oihw, in_hw, need0=True, need1=True):
@@ -197,6 +204,22 @@ def bn_stats(x, running_mean, running_var, momentum, eps, update_running=True):
     check(L.segsde_bn_stats(_p(_f32(x)), ld, M, C, _p(mean), _p(invstd), _p(running_mean if update_running else None),
                             _p(running_var if update_running else None), float(momentum), float(eps), _p(ws), nb,
                             _stream(x)), "bn_stats")
+    return mean, invstd
+
+
+def bn_stats_from_partials(part, M, running_mean, running_var, momentum, eps, update_running=True):
+    """batch statistics from the partial sums a conv_forward(want_stats=True) launch produced (same outputs / running
+    update as bn_stats, without reading the activation tensor again)"""
+    rows, _, C = part.shape
+    L = _lib.lib()
+    mean = torch.empty(C, dtype=torch.float32, device=part.device)
+    invstd = torch.empty_like(mean)
+    nb = L.segsde_bn_stats_from_partials_workspace(C)
+    ws = _ws(nb, part)
+    check(L.segsde_bn_stats_from_partials(_p(part), rows, M, C, _p(mean), _p(invstd),
+                                          _p(running_mean if update_running else None),
+                                          _p(running_var if update_running else None), float(momentum), float(eps), _p(ws),
+                                          nb, _stream(part)), "bn_stats_from_partials")
     return mean, invstd
 
 

@@ -1,6 +1,8 @@
 """HIP-backed building blocks shared by the model mirror: Conv2d / BatchNorm2d subclasses that keep torch.nn's
 parameter names, shapes and default initialisation (so reference checkpoints load and ``isinstance(m,
 nn.BatchNorm2d)`` checks in the reference's train.py keep working) but run on NHWC tensors through the HIP ops."""
+import os
+
 import torch
 from torch import nn
 
@@ -11,6 +13,9 @@ from ..hipops import ConvGeom
 def _seed():
     # CPU generator: no device sync; the dropout mask itself is generated in-kernel from this counter seed
     return int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+
+
+_NO_FUSED_STATS = bool(int(os.environ.get("SEGSDE_NO_FUSED_STATS", "0")))   # debugging: BatchNorm statistics as a separate pass
 
 
 class Conv2d(nn.Conv2d):
@@ -36,6 +41,13 @@ class Conv2d(nn.Conv2d):
             assert c0 + c1 == self.in_channels, (c0, c1, self.in_channels)
         g = ConvGeom(c0, self.out_channels, self.kernel_size[0], self.stride[0], self.dilation[0], self.padding[0],
                      self.reflect, c1, up)
+        if self.bias is None and act == "none" and self.training and not _NO_FUSED_STATS:
+            # bias-free, activation-free convolutions are the ones followed by a BatchNorm (torchvision ResNet / ASPP
+            # convention): their epilogue also leaves the batch-statistics partials, picked up by BatchNorm2d.forward
+            holder = []
+            y = Fn.ConvFn.apply(x, skip, weight, self.bias, g, act, holder)
+            y._bn_partials = holder[0] if holder else None
+            return y
         return Fn.ConvFn.apply(x, skip, weight, self.bias, g, act)
 
 
@@ -49,5 +61,8 @@ class BatchNorm2d(nn.BatchNorm2d):
             self.num_batches_tracked.add_(1)
         momentum = 0.1 if self.momentum is None else self.momentum
         seed = _seed() if drop_p > 0 else 0
+        partials = getattr(x, "_bn_partials", None) if training else None
+        if partials is not None and partials.shape[-1] != self.num_features:
+            partials = None
         return Fn.BNActFn.apply(x, self.weight, self.bias, residual, self.running_mean, self.running_var, training,
-                                momentum, self.eps, act, drop_p, seed)
+                                momentum, self.eps, act, drop_p, seed, partials)

@@ -62,6 +62,14 @@ typedef struct segsde_conv_desc {
  * pad' = (K-1)*dil - pad, stride 1 and in_div = stride it is the data-gradient of the same convolution. */
 int segsde_conv2d_forward(const segsde_conv_desc* d, const float* x0, const float* x1, const float* wpack,
                           const float* bias, float* y, float* y2, void* stream);
+/* Same, and additionally leaves the batch statistics of the output (no bias, no activation) as per-tile partials in
+ * stats[rows][2][Cout] doubles (rows = segsde_conv2d_stats_rows(d) > 0; sum and sum of squares per row slice of a
+ * 128-pixel tile): the statistics of the BatchNorm that follows (models/resnet_encoder.py conv -> bn pairs) without
+ * another pass over the tensor.  Finish with segsde_bn_stats_from_partials.  Returns SEGSDE_ERR_UNSUPPORTED when the
+ * shape cannot fuse (rows == 0). */
+long segsde_conv2d_stats_rows(const segsde_conv_desc* d);
+int segsde_conv2d_forward_stats(const segsde_conv_desc* d, const float* x0, const float* x1, const float* wpack,
+                                const float* bias, float* y, float* y2, double* stats, void* stream);
 
 /* dW (OIHW, the state_dict layout) of the convolution described by d, given dy [B,Ho,Wo,Cout] (pitch lddy). */
 size_t segsde_conv2d_wgrad_workspace(const segsde_conv_desc* d);
@@ -96,6 +104,12 @@ int segsde_bn_apply(const float* x, int ldx, long M, int C, const float* mean, c
 /* Backward of segsde_bn_apply + batch statistics.  Phase 1 reduces dgamma/dbeta (sums[0..C) = sum dz*xhat,
  * sums[C..2C) = sum dz) where dz = dy * dropout_mask * act'(y); phase 2 writes dx (and dres = dz if non-null).
  * batch_stats=0 (eval-mode BN): dx = gamma*invstd*dz. */
+/* mean / invstd (+ running-statistics update, exactly as segsde_bn_stats) from the partial sums a
+ * segsde_conv2d_forward_stats launch left behind; workspace: segsde_bn_stats_from_partials_workspace(C) bytes. */
+size_t segsde_bn_stats_from_partials_workspace(int C);
+int segsde_bn_stats_from_partials(const double* partials, long rows, long M, int C, float* mean, float* invstd,
+                                  float* running_mean, float* running_var, float momentum, float eps, void* workspace,
+                                  size_t workspace_bytes, void* stream);
 size_t segsde_bn_backward_workspace(long M, int C);
 /* y may be NULL ("remask"): for act = none, or act = ReLU with no residual / dropout (then beta is required with gamma),
  * the activation mask is recomputed from x exactly as the forward kernel formed it and the saved output is not read. */

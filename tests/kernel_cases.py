@@ -106,6 +106,21 @@ def run_conv_case(case, device, seed=0):
     wp = H.pack_weight(d(w), False)
     y = H.conv_forward(g, d(x0), d(x1), wp, d(b), act)
     assert_close(nchw(y), ref, what=name + " fwd")
+    if not bias and act == "none":
+        # BatchNorm statistics fused into the conv epilogue: same y, and (where the shape can fuse) the same mean / invstd /
+        # running statistics as a separate pass over y
+        y_s, part = H.conv_forward(g, d(x0), d(x1), wp, None, "none", want_stats=True)
+        assert torch.equal(y_s, y), name + " fwd with stats"
+        if part is not None:
+            M = y.numel() // Cout
+            rm1, rv1 = torch.zeros(Cout, device=device), torch.ones(Cout, device=device)
+            rm2, rv2 = rm1.clone(), rv1.clone()
+            m1, i1 = H.bn_stats_from_partials(part, M, rm1, rv1, 0.1, 1e-5)
+            m2, i2 = H.bn_stats(y, rm2, rv2, 0.1, 1e-5)
+            assert_close(m1, m2, rtol=1e-5, atol=1e-6, what=name + " fused bn mean")
+            assert_close(i1, i2, rtol=1e-4, what=name + " fused bn invstd")
+            assert_close(rm1, rm2, rtol=1e-5, atol=1e-6, what=name + " fused running_mean")
+            assert_close(rv1, rv2, rtol=1e-4, what=name + " fused running_var")
     # backward: pre-activation gradient as the autograd Functions will feed it
     dy_nhwc = nhwc(gy).to(device)
     if act != "none":
