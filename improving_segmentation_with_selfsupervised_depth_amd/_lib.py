@@ -35,6 +35,7 @@ _SIGS = {
     "segsde_conv2d_wgrad_workspace": (c_size_t, [POINTER(ConvDesc)]),
     "segsde_conv2d_wgrad": (c_int, [POINTER(ConvDesc), P, P, P, c_int, P, P, c_size_t, P]),
     "segsde_pack_weight": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    "segsde_pack_weight_both": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P]),
     "segsde_reflect_dgrad_fix": (c_int, [P, c_int, P, P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "segsde_bn_stats_workspace": (c_size_t, [c_long, c_int]),
     "segsde_bn_stats": (c_int, [P, c_int, c_long, c_int, P, P, P, P, c_float, c_float, P, c_size_t, P]),

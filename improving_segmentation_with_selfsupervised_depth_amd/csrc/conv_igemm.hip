@@ -1025,6 +1025,21 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float* w, float*
   }
 }
 
+// both packs in one launch (one thread per OIHW element): the forward pass of a training step needs the forward pack now and
+// the data-gradient pack in its backward pass -- half the (launch-latency bound) pack launches of a step
+__global__ __launch_bounds__(256) void pack_weight_both_kernel(const float* w, float* outf, float* outd, int O, int I, int KH,
+                                                               int KW) {
+  const int total = O * I * KH * KW;
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+    const int kw = e % KW; int t = e / KW;
+    const int kh = t % KH; t /= KH;
+    const int i = t % I, o = t / I;
+    const float v = w[e];
+    outf[((o * KH + kh) * KW + kw) * I + i] = v;
+    outd[((i * KH + (KH - 1 - kh)) * KW + (KW - 1 - kw)) * O + o] = v;
+  }
+}
+
 // Border correction for the data-gradient of a reflection-padded 3x3 convolution (monodepth_layers.py:127-142).
 // The main dgrad GEMM treats the padding as zeros; pixels whose row is 1 or H-2 (col 1 or W-2) additionally
 // receive the gradient that flowed into the mirrored padding cells.  dx[b,h,w,c] += sum over extra padded
@@ -1418,6 +1433,17 @@ extern "C" int segsde_pack_weight(const float* w_oihw, float* out, int O, int I,
   const long total = (long)O * I * KH * KW;
   hipLaunchKernelGGL(pack_weight_kernel, dim3(min(2048, segsde_cdiv(total, 256))), dim3(256), 0,
                      static_cast<hipStream_t>(stream), w_oihw, out, O, I, KH, KW, for_dgrad);
+  SEGSDE_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int segsde_pack_weight_both(const float* w_oihw, float* out_fwd, float* out_dgrad, int O, int I, int KH, int KW,
+                                       void* stream) {
+  if (!w_oihw || !out_fwd || !out_dgrad) return SEGSDE_ERR_NULL;
+  if (O <= 0 || I <= 0 || KH <= 0 || KW <= 0 || (long)O * I * KH * KW >= (1L << 31)) return SEGSDE_ERR_SHAPE;
+  const long total = (long)O * I * KH * KW;
+  hipLaunchKernelGGL(pack_weight_both_kernel, dim3(min(2048, segsde_cdiv(total, 256))), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), w_oihw, out_fwd, out_dgrad, O, I, KH, KW);
   SEGSDE_CHECK_LAUNCH();
   return 0;
 }

@@ -172,17 +172,31 @@ __global__ __launch_bounds__(256) void warp_bwd_kernel(const float* gcolor, cons
 }
 
 // gT[b] += K[b]^T (rows 0..2) * gP[b]
-__global__ __launch_bounds__(64) void warp_bwd_finalize_kernel(const double* gP_part, int nblk, const float* K, int B,
-                                                               float* gT) {
+// 12 sums over the block partials per batch item: 12 elements x 16 lanes in parallel, fixed order (a single thread per
+// element took 214 us per call)
+__global__ __launch_bounds__(256) void warp_bwd_finalize_kernel(const double* gP_part, int nblk, const float* K, int B,
+                                                                float* gT) {
+  SEGSDE_SMEM;
+  double* sh = reinterpret_cast<double*>(segsde_smem);   // [12][16] lane sums, then [12] totals at sh + 192
+  double* gp = sh + 192;
   const int b = blockIdx.x, t = threadIdx.x;
+  if (t < 192) {
+    const int e = t >> 4, l = t & 15;
+    double a = 0.0;
+    for (int i = l; i < nblk; i += 16) a += gP_part[((long)b * nblk + i) * 12 + e];
+    sh[e * 16 + l] = a;
+  }
+  __syncthreads();
+  if (t < 12) {
+    double a = 0.0;
+    for (int l = 0; l < 16; ++l) a += sh[t * 16 + l];
+    gp[t] = a;
+  }
+  __syncthreads();
   if (t >= 16) return;
   const int k = t >> 2, j = t & 3;
   double s = 0.0;
-  for (int r = 0; r < 3; ++r) {
-    double gp = 0.0;
-    for (int i = 0; i < nblk; ++i) gp += gP_part[((long)b * nblk + i) * 12 + r * 4 + j];
-    s += (double)K[b * 16 + r * 4 + k] * gp;
-  }
+  for (int r = 0; r < 3; ++r) s += (double)K[b * 16 + r * 4 + k] * gp[r * 4 + j];
   gT[b * 16 + t] += (float)s;
 }
 
@@ -402,12 +416,22 @@ __global__ __launch_bounds__(256) void smooth_fwd_kernel(const float* disp, cons
     part[((long)b * gridDim.x + blockIdx.x) * 2 + 1] = ry;
   }
 }
-__global__ __launch_bounds__(64) void smooth_finalize_kernel(const double* part, int n, double inv_nx, double inv_ny,
-                                                             float* out) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// 256 lanes sum strided subsets of the block partials, then a fixed-order combine (one thread took 383 us per call)
+__global__ __launch_bounds__(256) void smooth_finalize_kernel(const double* part, int n, double inv_nx, double inv_ny,
+                                                              float* out) {
+  SEGSDE_SMEM;
+  double* shx = reinterpret_cast<double*>(segsde_smem);
+  double* shy = shx + 256;
+  const int t = threadIdx.x;
   double sx = 0.0, sy = 0.0;
-  for (int i = 0; i < n; ++i) { sx += part[2 * i]; sy += part[2 * i + 1]; }
-  out[0] = (float)(sx * inv_nx) + (float)(sy * inv_ny);
+  for (int i = t; i < n; i += 256) { sx += part[2 * i]; sy += part[2 * i + 1]; }
+  shx[t] = sx; shy[t] = sy;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (t < o) { shx[t] += shx[t + o]; shy[t] += shy[t + o]; }
+    __syncthreads();
+  }
+  if (t == 0) out[0] = (float)(shx[0] * inv_nx) + (float)(shy[0] * inv_ny);
 }
 
 __device__ __forceinline__ float sgn(float v) { return v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f); }
@@ -478,7 +502,7 @@ extern "C" int segsde_warp_backward(const float* gcolor, const float* disp, int 
   hipLaunchKernelGGL(warp_bwd_kernel, dim3(nblk, B), dim3(256), 512, ST(stream), gcolor, disp, hs, ws, inv_K, K, T, src, H,
                      W, 1.f / max_depth, 1.f / min_depth, g_disp_up, (double*)ws_);
   SEGSDE_CHECK_LAUNCH();
-  hipLaunchKernelGGL(warp_bwd_finalize_kernel, dim3(B), dim3(64), 0, ST(stream), (const double*)ws_, nblk, K, B, gT);
+  hipLaunchKernelGGL(warp_bwd_finalize_kernel, dim3(B), dim3(256), 204 * sizeof(double), ST(stream), (const double*)ws_, nblk, K, B, gT);
   SEGSDE_CHECK_LAUNCH();
   return 0;
 }
@@ -565,7 +589,7 @@ extern "C" int segsde_smoothness_forward(const float* disp, const float* img, in
   SEGSDE_CHECK_LAUNCH();
   hipLaunchKernelGGL(smooth_fwd_kernel, dim3(nb, B), dim3(256), 64, ST(stream), disp, img, (const float*)mean_disp, h, w, part);
   SEGSDE_CHECK_LAUNCH();
-  hipLaunchKernelGGL(smooth_finalize_kernel, dim3(1), dim3(64), 0, ST(stream), (const double*)part, B * nb,
+  hipLaunchKernelGGL(smooth_finalize_kernel, dim3(1), dim3(256), 512 * sizeof(double), ST(stream), (const double*)part, B * nb,
                      1.0 / ((double)B * h * (w - 1)), 1.0 / ((double)B * (h - 1) * w), out);
   SEGSDE_CHECK_LAUNCH();
   return 0;

@@ -75,7 +75,11 @@ class ConvFn(Function):
     def forward(ctx, x0, x1, weight, bias, g, act, stats_out=None):
         """stats_out: optional list; receives the BatchNorm statistics partials of y (or None) -- see Conv2d.forward"""
         x0 = _c(x0) if x0.stride(-1) != 1 else x0
-        wp = H.pack_weight(weight, False)
+        ctx.wd = None
+        if ctx.needs_input_grad[0] or (x1 is not None and ctx.needs_input_grad[1]):
+            wp, ctx.wd = H.pack_weight_both(weight)     # the data-gradient pack is needed by backward: one launch for both
+        else:
+            wp = H.pack_weight(weight, False)
         if stats_out is not None:
             y, part = H.conv_forward(g, x0, x1, wp, bias, act, want_stats=True)
             stats_out.append(part)
@@ -99,7 +103,7 @@ class ConvFn(Function):
             dz, dbias = dy, (H.colsum(dy) if need_b else None)
         dx0 = dx1 = dw = None
         if ctx.needs_input_grad[0] or (x1 is not None and ctx.needs_input_grad[1]):
-            wd = H.pack_weight(weight, True)
+            wd = ctx.wd if ctx.wd is not None else H.pack_weight(weight, True)
             dx0, dx1 = H.conv_dgrad(g, dz, wd, weight.detach(), ctx.in_hw)
             if not ctx.needs_input_grad[0]:
                 dx0 = None

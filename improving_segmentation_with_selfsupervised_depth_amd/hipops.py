@@ -99,6 +99,16 @@ def pack_weight(w_oihw, for_dgrad=False):
     return out
 
 
+def pack_weight_both(w_oihw):
+    """(forward pack, data-gradient pack) of one OIHW weight in a single launch"""
+    w = _f32(w_oihw.detach()).contiguous()
+    O, I, KH, KW = w.shape
+    outf = torch.empty((O, KH, KW, I), dtype=torch.float32, device=w.device)
+    outd = torch.empty((I, KH, KW, O), dtype=torch.float32, device=w.device)
+    check(_lib.lib().segsde_pack_weight_both(_p(w), _p(outf), _p(outd), O, I, KH, KW, _stream(w)), "pack_weight_both")
+    return outf, outd
+
+
 def conv_forward(g, x0, x1, wpack, bias, act="none", want_stats=False):
     """y = act(conv(cat[up?(x0), x1]) + bias).  x0: [B,H0,W0,C0] (H0 = H/2 if g.up0), x1: [B,H,W,C1] or None.
     want_stats: also return the per-tile statistics partials of y for the BatchNorm that follows ([rows,2,Cout] doubles,

@@ -78,6 +78,9 @@ int segsde_conv2d_wgrad(const segsde_conv_desc* d, const float* x0, const float*
 
 /* OIHW -> [O][KH][KW][I] (for_dgrad=0) or [I][KH][KW][O] spatially flipped (for_dgrad=1). */
 int segsde_pack_weight(const float* w_oihw, float* out, int O, int I, int KH, int KW, int for_dgrad, void* stream);
+/* both packs of one weight tensor in a single launch (training forward: the data-gradient pack is kept for backward) */
+int segsde_pack_weight_both(const float* w_oihw, float* out_fwd, float* out_dgrad, int O, int I, int KH, int KW,
+                            void* stream);
 
 /* Adds to dx the gradient that entered the mirrored padding cells of a reflection-padded 3x3 stride-1 conv
  * (autograd of nn.ReflectionPad2d(1), models/monodepth_layers.py:134,140); wdpack = segsde_pack_weight(for_dgrad=1).
