@@ -117,6 +117,71 @@ __global__ __launch_bounds__(256) void class_mask_kernel(const int64_t* pred, lo
     mask[e] = s;
   }
 }
+
+// ---------------------------------------------------------------------------------------------------
+// the callers on either side of the path (train.py)
+// ---------------------------------------------------------------------------------------------------
+// EMA teacher update (train.py:346-358): ema = alpha * ema + (1 - alpha) * p over every parameter tensor, ONE launch
+// for the ~880 tensors instead of a Python loop of three elementwise kernels each.  The table splits tensors into
+// chunks of at most MT_CHUNK elements; block b owns chunk b.  Same fp32 operation order as the reference
+// (two multiplies, one add; alpha and 1-alpha rounded to fp32 on the host exactly as torch does): bit-exact.
+__global__ __launch_bounds__(256) void multi_tensor_lerp_kernel(const segsde_mt_chunk* table, float alpha, float one_minus_alpha) {
+  const segsde_mt_chunk c = table[blockIdx.x];
+  float* dst = c.dst; const float* src = c.src;
+  const int n = (int)c.n;
+  if ((((uintptr_t)dst | (uintptr_t)src) & 15) == 0) {
+    const int n4 = n >> 2;
+    for (int e = threadIdx.x; e < n4; e += 256) {
+      float4 a = reinterpret_cast<float4*>(dst)[e];
+      const float4 b = reinterpret_cast<const float4*>(src)[e];
+      a.x = alpha * a.x + one_minus_alpha * b.x; a.y = alpha * a.y + one_minus_alpha * b.y;
+      a.z = alpha * a.z + one_minus_alpha * b.z; a.w = alpha * a.w + one_minus_alpha * b.w;
+      reinterpret_cast<float4*>(dst)[e] = a;
+    }
+    for (int e = (n4 << 2) + threadIdx.x; e < n; e += 256) dst[e] = alpha * dst[e] + one_minus_alpha * src[e];
+  } else {
+    for (int e = threadIdx.x; e < n; e += 256) dst[e] = alpha * dst[e] + one_minus_alpha * src[e];
+  }
+}
+
+// Pseudo labels from the (mixed) teacher softmax (train.py:644-651): per pixel max / first argmax over the C class planes of
+// an NCHW tensor, label = ignore_index where the max is exactly 0 (pixels the mix left empty), and the number of
+// pixels whose confidence reaches the threshold (the reference's unlabeled_weight numerator) -- one pass over the
+// 19 x H x W tensor instead of max + compare + masked assignment + ge + sum.
+__global__ __launch_bounds__(256) void pseudo_label_kernel(const float* prob, int C, long HW, long total, float thr,
+                                                           int64_t ignore_index, int64_t* label, float* maxp,
+                                                           unsigned long long* count) {
+  unsigned long long mine = 0;
+  for (long e = blockIdx.x * 256L + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const long b = e / HW, p = e - b * HW;
+    const float* src = prob + b * C * HW + p;
+    float best = src[0]; int arg = 0;
+    for (int c = 1; c < C; ++c) {
+      const float v = src[(long)c * HW];
+      if (v > best) { best = v; arg = c; }     // strict: the first maximum wins, as torch.max(dim) does on the CPU
+    }
+    label[e] = best == 0.f ? ignore_index : (int64_t)arg;
+    if (maxp) maxp[e] = best;
+    mine += best >= thr ? 1ull : 0ull;
+  }
+  // block count -> one atomic per block (integer: order-independent, deterministic)
+  SEGSDE_SMEM;
+  unsigned long long* sh = reinterpret_cast<unsigned long long*>(segsde_smem);
+  sh[threadIdx.x] = mine;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0 && sh[0]) atomicAdd(count, sh[0]);
+}
+
+// pixel weights of calc_pseudo_label_loss: every pixel gets count / total (kept on the device: no .item() round trip)
+__global__ __launch_bounds__(256) void fill_fraction_kernel(const unsigned long long* count, long total, float* out) {
+  // the reference divides two Python numbers in double and fills a float32 tensor with the result
+  const float w = (float)((double)count[0] / (double)total);
+  for (long e = blockIdx.x * 256L + threadIdx.x; e < total; e += (long)gridDim.x * 256) out[e] = w;
+}
 }  // namespace
 
 extern "C" size_t segsde_cross_entropy_workspace(long M) { return (size_t)ce_blocks(M) * 2 * sizeof(double); }
@@ -188,5 +253,31 @@ extern "C" int segsde_class_mask(const int64_t* pred, long n, const int64_t* cla
   if (!pred || !classes || !mask) return SEGSDE_ERR_NULL;
   hipLaunchKernelGGL(class_mask_kernel, dim3(flat_blocks(n)), dim3(256), 0, ST(stream), pred, n, classes, n_classes, mask);
   SEGSDE_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int segsde_multi_tensor_lerp(const segsde_mt_chunk* table_dev, int nchunks, float alpha, float one_minus_alpha,
+                                        void* stream) {
+  if (!table_dev) return SEGSDE_ERR_NULL;
+  if (nchunks <= 0) return SEGSDE_ERR_SHAPE;
+  hipLaunchKernelGGL(multi_tensor_lerp_kernel, dim3(nchunks), dim3(256), 0, ST(stream), table_dev, alpha, one_minus_alpha);
+  SEGSDE_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int segsde_pseudo_label(const float* prob_nchw, int B, int C, long HW, float threshold, int64_t ignore_index,
+                                   int64_t* label, float* max_prob, unsigned long long* count, float* pixel_weight,
+                                   void* stream) {
+  if (!prob_nchw || !label || !count) return SEGSDE_ERR_NULL;
+  if (B <= 0 || C <= 0 || HW <= 0) return SEGSDE_ERR_SHAPE;
+  const long total = (long)B * HW;
+  if (hipMemsetAsync(count, 0, sizeof(unsigned long long), ST(stream)) != hipSuccess) return SEGSDE_ERR_SHAPE;
+  hipLaunchKernelGGL(pseudo_label_kernel, dim3(flat_blocks(total)), dim3(256), 256 * sizeof(unsigned long long), ST(stream),
+                     prob_nchw, C, HW, total, threshold, ignore_index, label, max_prob, count);
+  SEGSDE_CHECK_LAUNCH();
+  if (pixel_weight) {
+    hipLaunchKernelGGL(fill_fraction_kernel, dim3(flat_blocks(total)), dim3(256), 0, ST(stream), (const unsigned long long*)count,
+                       total, pixel_weight);
+    SEGSDE_CHECK_LAUNCH();
+  }
   return 0;
 }

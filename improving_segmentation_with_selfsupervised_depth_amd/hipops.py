@@ -593,3 +593,43 @@ def class_mask(pred, classes):
     check(_lib.lib().segsde_class_mask(_p(pred), pred.numel(), _p(classes), classes.numel(), _p(mask), _stream(pred)),
           "class_mask")
     return mask
+
+
+# ----------------------------------------------------------------------------------------------
+# trainer-side callers
+# ----------------------------------------------------------------------------------------------
+MT_CHUNK = 65536
+
+
+def multi_tensor_table(dsts, srcs):
+    """device table of segsde_mt_chunk {dst, src, n} covering every (dst, src) tensor pair in chunks of <= 65536 floats"""
+    rows = []
+    for d, s in zip(dsts, srcs):
+        assert d.dtype == torch.float32 and s.dtype == torch.float32 and d.is_contiguous() and s.is_contiguous()
+        assert d.numel() == s.numel() and d.device == s.device
+        n, dp, sp = d.numel(), d.data_ptr(), s.data_ptr()
+        for o in range(0, n, MT_CHUNK):
+            rows.append((dp + 4 * o, sp + 4 * o, min(MT_CHUNK, n - o)))
+    if not rows:
+        return None
+    return torch.tensor(rows, dtype=torch.int64).to(dsts[0].device)
+
+
+def multi_tensor_lerp(table, alpha, one_minus_alpha, like):
+    """dst = alpha*dst + one_minus_alpha*src for every chunk of the table (one launch)"""
+    check(_lib.lib().segsde_multi_tensor_lerp(_p(table), int(table.shape[0]), float(alpha), float(one_minus_alpha),
+                                              _stream(like)), "multi_tensor_lerp")
+
+
+def pseudo_label(prob, threshold, ignore_index, want_max=False, want_weight=True):
+    """prob: [B,C,H,W] (NCHW, dense) -> (label int64 [B,H,W], count uint64-as-int64 [1], max_prob or None,
+    pixel_weight [B,H,W] or None)"""
+    prob = _f32(prob).contiguous()
+    B, C, H, W = prob.shape
+    label = torch.empty((B, H, W), dtype=torch.int64, device=prob.device)
+    count = torch.empty(1, dtype=torch.int64, device=prob.device)
+    maxp = torch.empty((B, H, W), dtype=torch.float32, device=prob.device) if want_max else None
+    pw = torch.empty((B, H, W), dtype=torch.float32, device=prob.device) if want_weight else None
+    check(_lib.lib().segsde_pseudo_label(_p(prob), B, C, H * W, float(threshold), int(ignore_index), _p(label), _p(maxp),
+                                         _p(count), _p(pw), _stream(prob)), "pseudo_label")
+    return label, count, maxp, pw

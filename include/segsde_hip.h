@@ -230,6 +230,20 @@ int segsde_depth_threshold_mask(const float* depth, long n, float t1, float t2, 
 /* generate_class_mask: N[h,w] = #{k : pred[h,w] == classes[k]} */
 int segsde_class_mask(const int64_t* pred, long n, const int64_t* classes, int n_classes, int64_t* mask, void* stream);
 
+
+/* ---- SURVEY.md 8(f) "next" rows: the trainer-side callers of the path ------------------------------------------------ */
+/* One chunk of a multi-tensor operation: n <= 65536 contiguous floats of one tensor. */
+typedef struct segsde_mt_chunk { float* dst; const float* src; long n; } segsde_mt_chunk;
+/* EMA teacher update, train.py:346-358 (Trainer.update_ema_variables): dst = alpha*dst + one_minus_alpha*src for every
+ * chunk of the DEVICE-resident table, one launch for all parameter tensors.  alpha / one_minus_alpha: the fp32 roundings
+ * of the reference's Python doubles (min(1 - 1/(iteration+1), alpha_teacher) and 1 minus that). */
+int segsde_multi_tensor_lerp(const segsde_mt_chunk* table_dev, int nchunks, float alpha, float one_minus_alpha, void* stream);
+/* Pseudo labels of Trainer.calc_pseudo_label_loss, train.py:644-651: label = argmax_c prob (first maximum), ignore_index
+ * where the maximum is 0; count[0] = #{max >= threshold}; max_prob (nullable) = the maxima; pixel_weight (nullable) =
+ * count/(B*HW) broadcast to every pixel (the reference's unlabeled_weight * ones, without the host round trip). */
+int segsde_pseudo_label(const float* prob_nchw, int B, int C, long HW, float threshold, int64_t ignore_index, int64_t* label,
+                        float* max_prob, unsigned long long* count, float* pixel_weight, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

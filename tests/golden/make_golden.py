@@ -574,7 +574,51 @@ def gen_encoder():
     save("encoder", d)
 
 
+def gen_trainer():
+    """Trainer.update_ema_variables (train.py:346-358) and Trainer.calc_pseudo_label_loss (train.py:644-651), called
+    unbound with a stand-in ``self`` that carries only the attributes the methods read."""
+    import train as ref_train
+    d = {}
+    gen = torch.Generator().manual_seed(31)
+
+    from trainer_fixture import Tiny      # parameters from an integer formula: reproducible without any RNG stream
+
+    names = [n for n, _ in Tiny(0).named_parameters()]
+    d["ema_param_names"] = np.array(names)
+    branches = {"all": dict(save_monodepth_ema=False, segmentation_name="joint_seg_depth_dec", freeze_backbone=False),
+                "pad": dict(save_monodepth_ema=False, segmentation_name="mtl_pad", freeze_backbone=False),
+                "mono": dict(save_monodepth_ema=True, segmentation_name="mtl_pad", freeze_backbone=False),
+                "mono_frozen": dict(save_monodepth_ema=True, segmentation_name=None, freeze_backbone=True)}
+    d["ema_branches_json"] = json.dumps(branches)
+    for tag, br in branches.items():
+        fake = types.SimpleNamespace(cfg={"training": {"save_monodepth_ema": br["save_monodepth_ema"]},
+                                          "model": {"segmentation_name": br["segmentation_name"],
+                                                    "freeze_backbone": br["freeze_backbone"]}})
+        fake.extract_monodepth_ema_params = types.MethodType(ref_train.Trainer.extract_monodepth_ema_params, fake)
+        fake.extract_pad_ema_params = types.MethodType(ref_train.Trainer.extract_pad_ema_params, fake)
+        for it in (0, 3, 5000):
+            model, ema = Tiny(1), Tiny(2)
+            ref_train.Trainer.update_ema_variables(fake, ema, model, 0.99, it)
+            for n, p in ema.named_parameters():
+                d["ema_%s_it%d_%s" % (tag, it, n)] = p.data if p.numel() < 2000 else p.data[::97]
+    # pseudo labels
+    B, C, H, W = 2, 19, 12, 16
+    logits_t = 4.0 * torch.randn(B, C, H, W, generator=gen)
+    logits_t[:, 3, :4] += 12.0                                   # confident region (softmax >= 0.968)
+    soft = torch.softmax(logits_t, dim=1)
+    soft[0, :, 5, 3:9] = 0.0                                     # pixels the mix left empty: max == 0 -> ignore_index
+    soft[1, 2, 7, 7] = soft[1, 5, 7, 7] = soft[1].max()          # an exact tie: the first maximum wins
+    student = torch.randn(B, C, H, W, generator=gen).requires_grad_(True)
+    fake = types.SimpleNamespace(unlabeled_loader=types.SimpleNamespace(ignore_index=250), consistency_weight=1.5,
+                                 device=torch.device("cpu"))
+    L_u, label = ref_train.Trainer.calc_pseudo_label_loss(fake, soft.clone(), student)
+    L_u.backward()
+    d.update(pl_soft=soft, pl_student=student.detach(), pl_loss=L_u.detach(), pl_label=label, pl_grad=student.grad,
+             pl_consistency_weight=np.float32(1.5))
+    save("trainer", d)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["loss", "geom", "ssim_smooth", "segmix", "blocks", "decoders", "encoder", "nets"]
+    which = sys.argv[1:] or ["loss", "geom", "ssim_smooth", "segmix", "blocks", "decoders", "encoder", "nets", "trainer"]
     for w in which:
         globals()["gen_" + w]()

@@ -44,5 +44,9 @@ def test_segmix(golden):
     KC.run_segmix_cases("cpu", golden)
 
 
+def test_trainer_rows(golden):
+    KC.run_trainer_cases("cpu", golden)
+
+
 def test_loss_kernels(golden):
     KC.run_loss_kernel_cases("cpu", golden)

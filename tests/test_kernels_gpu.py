@@ -70,6 +70,10 @@ def test_segmix(golden):
     KC.run_segmix_cases("cuda", golden)
 
 
+def test_trainer_rows(golden):
+    KC.run_trainer_cases("cuda", golden)
+
+
 def test_loss_kernels(golden):
     KC.run_loss_kernel_cases("cuda", golden)
 

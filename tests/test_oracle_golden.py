@@ -1,6 +1,8 @@
 """CPU: the oracle (oracle/) must reproduce the golden vectors that
 tests/golden/make_golden.py captured from the reference's own code."""
 import json
+import os
+import sys
 
 import numpy as np
 import pytest
@@ -361,3 +363,33 @@ def test_full_model_end_to_end(golden, name):
     assert not bad, bad[:10]
     close(sd["models.encoder.encoder.conv1.weight"].grad, g[name + "_grad_conv1"], rtol=2e-3, atol=1e-6)
     close(sd["models.encoder.encoder.bn1.running_mean"], g[name + "_bn1_running_mean_after"], rtol=1e-4, atol=1e-6)
+
+
+def test_trainer_ema_update_vs_reference(golden):
+    """oracle.trainer.update_ema_variables == Trainer.update_ema_variables for every parameter-selection branch"""
+    import json
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    from trainer_fixture import Tiny
+    from oracle import trainer as OT
+    g = golden("trainer")
+    branches = json.loads(str(g["ema_branches_json"]))
+    for tag, br in branches.items():
+        for it in (0, 3, 5000):
+            model, ema = Tiny(1), Tiny(2)
+            mp, ep = OT.select_ema_params(model, ema, br["save_monodepth_ema"], br["segmentation_name"], br["freeze_backbone"])
+            OT.update_ema_variables(list(ep), list(mp), 0.99, it)
+            for n, p in ema.named_parameters():
+                want = g["ema_%s_it%d_%s" % (tag, it, n)]
+                got = p.data if p.numel() < 2000 else p.data[::97]
+                assert torch.equal(got, want), (tag, it, n)
+
+
+def test_trainer_pseudo_label_loss_vs_reference(golden):
+    from oracle import trainer as OT
+    g = golden("trainer")
+    student = g["pl_student"].clone().requires_grad_(True)
+    L_u, label = OT.calc_pseudo_label_loss(g["pl_soft"], student, float(g["pl_consistency_weight"]))
+    assert torch.equal(label, g["pl_label"])
+    assert torch.allclose(L_u, g["pl_loss"], rtol=1e-6, atol=0)
+    L_u.backward()
+    assert torch.allclose(student.grad, g["pl_grad"], rtol=1e-5, atol=1e-9)

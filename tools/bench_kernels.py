@@ -90,6 +90,23 @@ def main():
     t = timeit(lambda: H.bn_backward(x, y, x, mean, invstd, gam, "relu"))
     print("bn_backward %.3f ms  %.0f GB/s (7 passes)" % (t, 7 * nbytes / t / 1e6))
     rows.append(dict(name="bn_backward", ms=t))
+    # trainer-side rows: EMA multi-tensor update over a ResNet-101-sized parameter set, pseudo labels
+    from improving_segmentation_with_selfsupervised_depth_amd import trainer as T
+    sizes = [64 * 3 * 49, 64, 64] + [256 * 64, 64 * 64 * 9, 256 * 64, 256, 256] * 60 + [2048 * 512 * 9] * 8 + [19 * 64, 19]
+    mp = [torch.randn(n, device=dev) for n in sizes]
+    ep = [torch.randn(n, device=dev) for n in sizes]
+    up = T.EmaUpdater(mp, ep)
+    nel = sum(sizes)
+    t = timeit(lambda: up.step(0.99, 1000))
+    print("ema update  %.3f ms  %d tensors %.1f M floats  %.0f GB/s (12 B/elt)" % (t, len(sizes), nel / 1e6, 12 * nel / t / 1e6))
+    def ref_loop():
+        for e_, p_ in zip(ep, mp):
+            e_.data[:] = 0.99 * e_.data + 0.01 * p_.data
+    t2 = timeit(ref_loop)
+    print("ema update, reference-style Python loop of torch ops: %.3f ms" % t2)
+    soft = torch.softmax(torch.randn(B, 19, 512, 1024, device=dev) * 3, 1)
+    t = timeit(lambda: H.pseudo_label(soft, 0.968, 250))
+    print("pseudo_label %.3f ms  %.0f GB/s (76+8+4 B/px)" % (t, 88 * B * 512 * 1024 / t / 1e6))
     out = os.environ.get("BENCH_OUT")
     if out:
         json.dump(rows, open(out, "w"), indent=1)
