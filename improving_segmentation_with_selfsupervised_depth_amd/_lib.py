@@ -84,6 +84,7 @@ _SIGS = {
     "segsde_depthcomp_mask": (c_int, [P, c_int, c_long, c_float, c_float, P, P]),
     "segsde_depth_threshold_mask": (c_int, [P, c_long, c_float, c_float, c_int, P, P]),
     "segsde_class_mask": (c_int, [P, c_long, P, c_int, P, P]),
+    "segsde_confusion_update": (c_int, [P, c_long, c_long, c_long, P, P, c_int, c_long, c_int, P, P]),
     "segsde_multi_tensor_lerp": (c_int, [P, c_int, c_float, c_float, P]),
     "segsde_pseudo_label": (c_int, [P, c_int, c_int, c_long, c_float, c_int64, P, P, P, P, P]),
 }

@@ -182,6 +182,42 @@ __global__ __launch_bounds__(256) void fill_fraction_kernel(const unsigned long 
   const float w = (float)((double)count[0] / (double)total);
   for (long e = blockIdx.x * 256L + threadIdx.x; e < total; e += (long)gridDim.x * 256) out[e] = w;
 }
+
+// Validation: runningScore._fast_hist, evaluation/metrics.py:12-25 -- hist[n*gt + pred] += 1 over the
+// pixels with 0 <= gt < n -- fused with the argmax over the class planes (train.py:848 `semantics.data.max(1)[1]`) when
+// logits are given instead of predictions.  Block-private LDS histogram, one integer atomic per touched bin per block:
+// exact and order-independent.  logits strides let the tensor be NCHW or channels-last.
+__global__ __launch_bounds__(256) void confusion_kernel(const float* logits, long sb, long sc, long sp, const int64_t* pred,
+                                                        const int64_t* gt, long HW, long total, int C,
+                                                        unsigned long long* hist) {
+  SEGSDE_SMEM;
+  unsigned* sh = reinterpret_cast<unsigned*>(segsde_smem);    // [C*C]
+  const int bins = C * C;
+  for (int i = threadIdx.x; i < bins; i += 256) sh[i] = 0u;
+  __syncthreads();
+  for (long e = blockIdx.x * 256L + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const int64_t t = gt[e];
+    if (t < 0 || t >= C) continue;
+    int64_t pr;
+    if (logits) {
+      const long b = e / HW, p = e - b * HW;
+      const float* src = logits + b * sb + p * sp;
+      float best = src[0]; int arg = 0;
+      for (int c = 1; c < C; ++c) {
+        const float v = src[(long)c * sc];
+        if (v > best) { best = v; arg = c; }
+      }
+      pr = arg;
+    } else {
+      pr = pred[e];
+      if (pr < 0 || pr >= C) continue;        // np.bincount would raise / misplace; the reference never produces these
+    }
+    atomicAdd(&sh[(int)t * C + (int)pr], 1u);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < bins; i += 256)
+    if (sh[i]) atomicAdd(&hist[i], (unsigned long long)sh[i]);
+}
 }  // namespace
 
 extern "C" size_t segsde_cross_entropy_workspace(long M) { return (size_t)ce_blocks(M) * 2 * sizeof(double); }
@@ -279,5 +315,18 @@ extern "C" int segsde_pseudo_label(const float* prob_nchw, int B, int C, long HW
                        total, pixel_weight);
     SEGSDE_CHECK_LAUNCH();
   }
+  return 0;
+}
+
+extern "C" int segsde_confusion_update(const float* logits, long sb, long sc, long sp, const int64_t* pred, const int64_t* gt,
+                                       int B, long HW, int C, unsigned long long* hist, void* stream) {
+  if ((!logits && !pred) || !gt || !hist) return SEGSDE_ERR_NULL;
+  if (B <= 0 || HW <= 0 || C <= 0 || C > 64) return SEGSDE_ERR_SHAPE;
+  const long total = (long)B * HW;
+  long nb = (total + 256L * 64 - 1) / (256L * 64);       // >= 64 pixels per thread: the block histogram flush is amortised
+  nb = nb < 1 ? 1 : (nb > 2048 ? 2048 : nb);
+  hipLaunchKernelGGL(confusion_kernel, dim3((unsigned)nb), dim3(256), (size_t)C * C * sizeof(unsigned), ST(stream), logits, sb, sc,
+                     sp, pred, gt, HW, total, C, hist);
+  SEGSDE_CHECK_LAUNCH();
   return 0;
 }

@@ -633,3 +633,26 @@ def pseudo_label(prob, threshold, ignore_index, want_max=False, want_weight=True
     check(_lib.lib().segsde_pseudo_label(_p(prob), B, C, H * W, float(threshold), int(ignore_index), _p(label), _p(maxp),
                                          _p(count), _p(pw), _stream(prob)), "pseudo_label")
     return label, count, maxp, pw
+
+
+def confusion_update(hist, gt, pred=None, logits=None):
+    """hist: int64 [C*C] on the device (accumulated in place); gt: int64 [B,H,W]; pred int64 [B,H,W] or logits [B,C,H,W]
+    (NCHW-logical, any of dense NCHW / channels-last memory)."""
+    gt = gt.contiguous()
+    B = gt.shape[0]
+    HW = gt.numel() // B
+    C = int(round(hist.numel() ** 0.5))
+    if logits is not None:
+        lg = _f32(logits)
+        assert lg.shape[1] == C and lg.shape[0] == B and lg.shape[2] * lg.shape[3] == HW
+        sb, sc, sh, sw = lg.stride()
+        if sh != lg.shape[3] * sw:      # rows must follow each other with the pixel stride
+            lg = lg.contiguous()
+            sb, sc, sh, sw = lg.stride()
+        check(_lib.lib().segsde_confusion_update(_p(lg), sb, sc, sw, None, _p(gt), B, HW, C, _p(hist), _stream(gt)),
+              "confusion_update")
+    else:
+        pred = pred.contiguous().to(torch.int64)
+        check(_lib.lib().segsde_confusion_update(None, 0, 0, 0, _p(pred), _p(gt), B, HW, C, _p(hist), _stream(gt)),
+              "confusion_update")
+    return hist

@@ -243,6 +243,12 @@ int segsde_multi_tensor_lerp(const segsde_mt_chunk* table_dev, int nchunks, floa
  * count/(B*HW) broadcast to every pixel (the reference's unlabeled_weight * ones, without the host round trip). */
 int segsde_pseudo_label(const float* prob_nchw, int B, int C, long HW, float threshold, int64_t ignore_index, int64_t* label,
                         float* max_prob, unsigned long long* count, float* pixel_weight, void* stream);
+/* runningScore.update / _fast_hist (evaluation/metrics.py:12-25): hist[C*gt + pred] += 1 for every pixel with 0 <= gt < C,
+ * accumulated into the DEVICE-resident hist[C*C].  Either pred (int64, as train.py:848 computes it) or logits (then the
+ * argmax over the C class planes is fused; element strides sb / sc / sp for batch, class and pixel let the tensor be NCHW
+ * or channels-last).  Integer atomics: exact. */
+int segsde_confusion_update(const float* logits, long sb, long sc, long sp, const int64_t* pred, const int64_t* gt, int B,
+                            long HW, int C, unsigned long long* hist, void* stream);
 
 #ifdef __cplusplus
 }

@@ -615,6 +615,23 @@ def gen_trainer():
     L_u.backward()
     d.update(pl_soft=soft, pl_student=student.detach(), pl_loss=L_u.detach(), pl_label=label, pl_grad=student.grad,
              pl_consistency_weight=np.float32(1.5))
+    # validation metric: evaluation/metrics.py runningScore on seeded labels / logits (train.py:848-851)
+    from evaluation.metrics import runningScore as RefScore
+    n = 19
+    logits = torch.randn(3, n, 10, 14, generator=gen)
+    logits[:, 18] -= 100.0                                         # a class that is never predicted (nan IoU path)
+    gt = torch.randint(0, n - 1, (3, 10, 14), generator=gen)
+    gt[0, :2] = 250                                                # ignore label
+    gt[1, 3, 3] = -1
+    gt[(torch.rand(3, 10, 14, generator=gen) < 0.6)] = 0           # a dominant class
+    pred = logits.max(1)[1]
+    rs = RefScore(n)
+    rs.update(gt.numpy(), pred.numpy())
+    rs.update(gt[:1].numpy(), pred[:1].numpy())                    # a second batch accumulates
+    sc, cls_iu = rs.get_scores()
+    d.update(cm_logits=logits, cm_gt=gt, cm_pred=pred, cm_matrix=rs.confusion_matrix,
+             cm_scores=np.array([sc["Overall Acc: \t"], sc["Mean Acc : \t"], sc["FreqW Acc : \t"], sc["Mean IoU : \t"]]),
+             cm_cls_iu=np.array([cls_iu[i] for i in range(n)]))
     save("trainer", d)
 
 

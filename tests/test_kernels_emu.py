@@ -48,5 +48,9 @@ def test_trainer_rows(golden):
     KC.run_trainer_cases("cpu", golden)
 
 
+def test_validation_metric(golden):
+    KC.run_metric_cases("cpu", golden)
+
+
 def test_loss_kernels(golden):
     KC.run_loss_kernel_cases("cpu", golden)

@@ -74,6 +74,10 @@ def test_trainer_rows(golden):
     KC.run_trainer_cases("cuda", golden)
 
 
+def test_validation_metric(golden):
+    KC.run_metric_cases("cuda", golden)
+
+
 def test_loss_kernels(golden):
     KC.run_loss_kernel_cases("cuda", golden)
 

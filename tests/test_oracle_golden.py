@@ -393,3 +393,14 @@ def test_trainer_pseudo_label_loss_vs_reference(golden):
     assert torch.allclose(L_u, g["pl_loss"], rtol=1e-6, atol=0)
     L_u.backward()
     assert torch.allclose(student.grad, g["pl_grad"], rtol=1e-5, atol=1e-9)
+
+
+def test_validation_metric_vs_reference(golden):
+    from oracle import metrics as OM
+    g = golden("trainer")
+    gt, pred = g["cm_gt"].numpy(), g["cm_pred"].numpy()
+    cm = OM.confusion_matrix(gt, pred, 19) + OM.confusion_matrix(gt[:1], pred[:1], 19)
+    assert np.array_equal(cm, g["cm_matrix"].numpy())
+    acc, acc_cls, fw, miou, iu = OM.scores(cm)
+    np.testing.assert_allclose([acc, acc_cls, fw, miou], g["cm_scores"].numpy(), rtol=1e-12)
+    np.testing.assert_allclose(iu, g["cm_cls_iu"].numpy(), rtol=1e-12, equal_nan=True)
