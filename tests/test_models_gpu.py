@@ -1,5 +1,6 @@
 """GPU (-m gpu): product modules and whole models vs the reference's golden vectors / the oracle, plus
 size-independent properties at BASELINE.json's full sizes."""
+import numpy as np
 import pytest
 import torch
 
@@ -155,3 +156,82 @@ def test_full_size_loss_properties():
     ones = torch.ones(B, Hh, W, dtype=torch.int64, device=dev)
     assert torch.equal(H.mix(ones, img), img)
     assert torch.equal(H.mix(torch.zeros_like(ones), img), torch.roll(img, -1, 0))
+
+
+def test_depthmix_unlabeled_step_vs_oracle():
+    """Trainer.train_step_segmentation_unlabeled (train.py:653-724) composed from the package's pieces -- teacher forward,
+    depthcomp mask from the teacher's online disparity, DepthMix of image and teacher softmax, student forward, pseudo-label
+    loss, backward, EMA teacher update -- against the same sequence in the CPU oracle on identical weights."""
+    from oracle import nets as N, segmix as S, trainer as OT
+    from improving_segmentation_with_selfsupervised_depth_amd.models import get_model
+    from improving_segmentation_with_selfsupervised_depth_amd.loader import transformsgpu
+    from improving_segmentation_with_selfsupervised_depth_amd import hipops as H, trainer as T
+    import bench
+    cfg = MC.contract_cfgs()["cfgs"]["r18_jsd"]
+    sd_s = N.build_state_dict(cfg, 19, seed=21, randomize_bn=True, zero_attention=False)
+    sd_t = N.build_state_dict(cfg, 19, seed=22, randomize_bn=True, zero_attention=False)
+    B, Hh, W = 2, 64, 128
+    inp = bench.synthetic_inputs(B, Hh, W, "cpu", 5)
+    margin, ft, cw = 0.03, 0.0, 1.0
+
+    # ---- oracle
+    def grads_of(sd):
+        return {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.clone())
+                for k, v in sd.items()}
+    with torch.no_grad():
+        out_t = N.model_forward({k: v.clone() for k, v in sd_t.items()}, cfg, dict(inp), train=True, dropout=False, use_pose_net=False)
+    soft_o = torch.softmax(out_t["semantics"], dim=1)
+    depth_o = 1.0 / out_t[("disp", 0)]                      # online depth of the teacher (train.py:690-699: depth from disp)
+    mask_o = S.depthcomp_mask(depth_o, margin, ft)
+    img_o, _ = S.mix(mask_o.unsqueeze(1).float(), data=inp[("color_aug", 0, 0)])
+    softm_o, _ = S.mix(mask_o.unsqueeze(1).float(), data=soft_o)
+    sdo = grads_of(sd_s)
+    inp2 = dict(inp); inp2[("color_aug", 0, 0)] = img_o
+    out_s = N.model_forward(sdo, cfg, inp2, train=True, dropout=False, use_pose_net=False)
+    L_o, lab_o = OT.calc_pseudo_label_loss(softm_o, out_s["semantics"], cw)
+    L_o.backward()
+
+    # ---- product
+    student, teacher = get_model(cfg, 19), get_model(cfg, 19)
+    student.load_state_dict(sd_s, strict=True); teacher.load_state_dict(sd_t, strict=True)
+    student.cuda().train(); teacher.cuda().train()
+    MC.dropout_eval(student); MC.dropout_eval(teacher)
+    inp_d = {k: v.cuda() for k, v in inp.items()}
+    teacher.use_pose_net = False
+    with torch.no_grad():
+        o_t = teacher(inp_d)
+    soft = torch.softmax(o_t["semantics"].detach(), dim=1)
+    depth = 1.0 / o_t[("disp", 0)]
+    mask = H.depthcomp_mask(depth, margin, ft)
+    assert_close(soft, soft_o, rtol=2e-3, atol=1e-5, what="teacher softmax")
+    agree = float((mask.cpu() == mask_o).float().mean())
+    assert agree > 0.995, agree                              # ties at the margin may flip on a handful of pixels
+    mask = mask_o.cuda()                                     # continue from the oracle's mask: identical composites
+    img, _ = transformsgpu.mix(mask.unsqueeze(1).float(), data=inp_d[("color_aug", 0, 0)])
+    softm, _ = transformsgpu.mix(mask.unsqueeze(1).float(), data=soft)
+    assert torch.equal(img.cpu(), img_o)
+    inp_d2 = dict(inp_d); inp_d2[("color_aug", 0, 0)] = img
+    student.use_pose_net = False
+    o_s = student(inp_d2)
+    L, lab = T.calc_pseudo_label_loss(softm, o_s["semantics"], cw)
+    assert float((lab.cpu() == lab_o).float().mean()) > 0.99
+    assert_close(L, L_o, rtol=2e-3, what="pseudo-label loss")
+    L.backward()
+    bad = []
+    for k, p in student.named_parameters():
+        go = sdo[k].grad
+        if go is None or p.grad is None:
+            if not (go is None and p.grad is None) and not (go is not None and float(go.abs().max()) == 0 and p.grad is None):
+                bad.append((k, "presence"))
+            continue
+        n_o, n_p = float(go.norm()), float(p.grad.norm())
+        if abs(n_o - n_p) > 3e-2 * n_o + 1e-6:
+            bad.append((k, n_o, n_p))
+    assert not bad, bad[:8]
+    # EMA teacher update after the step (train.py:535-537)
+    before = {k: v.detach().clone() for k, v in teacher.named_parameters()}
+    T.update_ema_variables(teacher, student, 0.99, 10)
+    a = np.float32(min(1 - 1 / 11, 0.99)); b = np.float32(1 - min(1 - 1 / 11, 0.99))
+    sp = dict(student.named_parameters())
+    for k, v in teacher.named_parameters():
+        assert torch.equal(v.data, a * before[k] + b * sp[k].data), k
