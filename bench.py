@@ -11,6 +11,7 @@ joint_seg_depth_dec, 512x1024, per-GPU batch 16, SGD (experiments.py:32-48,139-1
 import argparse
 import json
 import os
+import re
 import sys
 import time
 
@@ -249,12 +250,33 @@ def main():
                     for (kind, tag), v in sorted(layers.items(), key=lambda kv: -kv[1][1]):
                         f.write("%-11s %-40s n=%4d  %8.2f ms/step  %6.1f TF  %5.2f%% of step\n" % (
                             kind, tag, v[2], v[1] / args.steps * 1e3, v[0] / v[1] / 1e12, 100 * v[1] / dt))
+            # algorithmic bytes of a conv launch: its input(s), weights and output once each (fp32), from the geometry tag
+            def tag_bytes(tag):
+                m = re.match(r"(\d+)\+(\d+)->(\d+) k(\d+) s(\d+) d(\d+) (\d+)x(\d+)( up)?", tag)
+                if not m:
+                    return 0.0
+                c0, c1, co, k, st, _, hh, ww = (int(x) for x in m.groups()[:8])
+                up = 2 if m.group(9) else 1
+                ho, wo = -(-hh // st), -(-ww // st)
+                return 4.0 * (B * (hh // up) * (ww // up) * c0 + B * hh * ww * c1 + B * ho * wo * co + co * (c0 + c1) * k * k)
+            abytes = sum(tag_bytes(tag) * v[2] for (kind, tag), v in layers.items() if kind in ("conv_fwd", "conv_dgrad"))
             fl = sum(agg[k][0] for k in ("conv_fwd", "conv_dgrad") if k in agg)
             tt = sum(agg[k][1] for k in ("conv_fwd", "conv_dgrad") if k in agg)
             nl = sum(agg[k][2] for k in ("conv_fwd", "conv_dgrad") if k in agg)
             roof.update(achieved=fl / tt / 1e12, frac=fl / tt / 1e12 / PEAK_FP32_MATRIX_TFLOPS, launches=nl,
                         avg_launch_ms=tt / nl * 1e3, avg_launch_gflop=fl / nl / 1e9,
-                        share_of_step=tt / dt)
+                        share_of_step=tt / dt, algorithmic_bytes_per_launch=abytes / nl)
+            # HBM-side traffic per launch: PMC counters cannot be read live, so this is the committed result of the two
+            # rocprofv3 --pmc passes of this very command (profiles/traffic_r01.json; FETCH_SIZE x2 + WRITE_SIZE, gfx950 rule)
+            tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "traffic_r01.json")
+            if args.workload == "cfg3" and os.path.exists(tpath):
+                try:
+                    tj = json.load(open(tpath))
+                    kk = [k for k in tj["kernels"] if k.startswith("conv_igemm_kernel")][0]
+                    roof["traffic"] = tj["kernels"][kk]["bytes_per_launch"]
+                    roof["traffic_source"] = "profiles/traffic_r01.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py)"
+                except Exception:
+                    pass
             res["kernels"] = {k: {"tflops": v[0] / v[1] / 1e12, "seconds": v[1], "launches": v[2],
                                   "share_of_step": v[1] / dt} for k, v in agg.items()}
         else:
