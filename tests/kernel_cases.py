@@ -465,7 +465,7 @@ def run_trainer_cases(device, golden):
     for (n, p), q in zip(ema.named_parameters(), eref.parameters()):
         assert torch.equal(p.data.cpu(), q.data), ("ema two steps", n)
 
-    soft, student = g["pl_soft"].to(device), g["pl_student"].to(device).requires_grad_(True)
+    soft, student = g["pl_soft"].to(device), g["pl_student"].detach().clone().to(device).requires_grad_(True)
     L_u, label = T.calc_pseudo_label_loss(soft, student, float(g["pl_consistency_weight"]))
     assert torch.equal(label.cpu(), g["pl_label"]), "pseudo label"
     assert_close(L_u, g["pl_loss"], rtol=1e-5, what="pseudo-label loss")

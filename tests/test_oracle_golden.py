@@ -387,7 +387,7 @@ def test_trainer_ema_update_vs_reference(golden):
 def test_trainer_pseudo_label_loss_vs_reference(golden):
     from oracle import trainer as OT
     g = golden("trainer")
-    student = g["pl_student"].clone().requires_grad_(True)
+    student = g["pl_student"].detach().clone().requires_grad_(True)
     L_u, label = OT.calc_pseudo_label_loss(g["pl_soft"], student, float(g["pl_consistency_weight"]))
     assert torch.equal(label, g["pl_label"])
     assert torch.allclose(L_u, g["pl_loss"], rtol=1e-6, atol=0)
