@@ -331,6 +331,34 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* dy, const
   }
 }
 
+// four channels per thread, 32-bit index arithmetic (the scalar version spends its time in three 64-bit divisions per element)
+__global__ __launch_bounds__(256) void maxpool_bwd4_kernel(const float* dy, const uint8_t* idx, int B, int H, int W, int C4,
+                                                           int Ho, int Wo, float* dx) {
+  const int total = B * H * W * C4;       // host guarantees < 2^31
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+    const int c4 = e % C4; int t = e / C4;
+    const int w = t % W; t /= W;
+    const int h = t % H; const int b = t / H;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int kh = 0; kh < 3; ++kh) {
+      const int hn = h + 1 - kh;
+      if (hn < 0 || (hn & 1)) continue;
+      const int ho = hn >> 1; if (ho >= Ho) continue;
+      for (int kw = 0; kw < 3; ++kw) {
+        const int wn = w + 1 - kw;
+        if (wn < 0 || (wn & 1)) continue;
+        const int wo = wn >> 1; if (wo >= Wo) continue;
+        const long o = ((long)(b * Ho + ho) * Wo + wo) * C4 + c4;     // in units of 4 channels
+        const uchar4 k = reinterpret_cast<const uchar4*>(idx)[o];
+        const float4 g = reinterpret_cast<const float4*>(dy)[o];
+        const unsigned char tap = (unsigned char)(kh * 3 + kw);
+        s.x += k.x == tap ? g.x : 0.f; s.y += k.y == tap ? g.y : 0.f; s.z += k.z == tap ? g.z : 0.f; s.w += k.w == tap ? g.w : 0.f;
+      }
+    }
+    reinterpret_cast<float4*>(dx)[e] = s;
+  }
+}
+
 // ------------------------------------------------------------------ nearest x2 upsample adjoint
 __global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const float* dy, int lddy, int B, int h, int w, int C,
                                                              float* dx, int lddx) {
@@ -420,17 +448,29 @@ __global__ __launch_bounds__(256) void resize_bwd_kernel(const float* dy, int ld
 }
 
 // ------------------------------------------------------------------ global average pool
-__global__ __launch_bounds__(256) void gap_fwd_kernel(const float* x, int ldx, long HW, int C, float* y) {
-  // one block per (b, 64-channel slab); 4 row lanes
+__global__ __launch_bounds__(256) void gap_fwd_kernel(const float* x, int ldx, long HW, int C, double scale, float* y, int ldy) {
+  // y[b][c] = scale * sum over the image's HW pixels; one block per (b, 64-channel slab), 4 row lanes, eight independent
+  // accumulators per lane (a single chain of HW/4 dependent loads was pure latency: 216 us for 2048 pixels)
   SEGSDE_SMEM;
   double* sh = reinterpret_cast<double*>(segsde_smem);
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const int c = blockIdx.y * SLAB + tx, b = blockIdx.x;
-  double s = 0.0;
-  if (c < C) for (long m = ty; m < HW; m += RLANES) s += (double)x[((long)b * HW + m) * ldx + c];
-  sh[ty * SLAB + tx] = s;
+  double s8[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) s8[u] = 0.0;
+  if (c < C) {
+    const float* xb = x + (long)b * HW * ldx + c;
+    for (long m = ty; m < HW; m += RLANES * 8) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const long mm = m + (long)u * RLANES;
+        if (mm < HW) s8[u] += (double)xb[mm * ldx];
+      }
+    }
+  }
+  sh[ty * SLAB + tx] = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
   __syncthreads();
-  if (ty == 0 && c < C) y[(long)b * C + c] = (float)((sh[tx] + sh[SLAB + tx] + sh[2 * SLAB + tx] + sh[3 * SLAB + tx]) / (double)HW);
+  if (ty == 0 && c < C) y[(long)b * ldy + c] = (float)((sh[tx] + sh[SLAB + tx] + sh[2 * SLAB + tx] + sh[3 * SLAB + tx]) * scale);
 }
 __global__ __launch_bounds__(256) void gap_bwd_kernel(const float* dy, int B, long HW, int C, float* dx, int lddx) {
   const long total = (long)B * HW * C;
@@ -656,6 +696,12 @@ extern "C" int segsde_maxpool3x3s2_backward(const float* dy, const uint8_t* idx,
                                             void* stream) {
   if (!dy || !idx || !dx) return SEGSDE_ERR_NULL;
   const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  if (C % 4 == 0 && (long)B * H * W * (C / 4) < (1L << 31) && al16p(dy) && al16p(dx) && (reinterpret_cast<uintptr_t>(idx) & 3) == 0) {
+    hipLaunchKernelGGL(maxpool_bwd4_kernel, dim3(ew_blocks((long)B * H * W * (C / 4))), dim3(256), 0, ST(stream), dy, idx, B, H, W,
+                       C / 4, Ho, Wo, dx);
+    SEGSDE_CHECK_LAUNCH();
+    return 0;
+  }
   hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(ew_blocks((long)B * H * W * C)), dim3(256), 0, ST(stream), dy, idx, B, H, W,
                      C, Ho, Wo, dx);
   SEGSDE_CHECK_LAUNCH();
@@ -680,6 +726,13 @@ extern "C" int segsde_resize_bilinear_forward(const float* x, int ldx, int B, in
 extern "C" int segsde_resize_bilinear_backward(const float* dy, int lddy, int B, int Hi, int Wi, int C, float* dx, int lddx,
                                                int Ho, int Wo, int ac, void* stream) {
   if (!dy || !dx) return SEGSDE_ERR_NULL;
+  if (Hi == 1 && Wi == 1) {
+    // a 1x1 source is broadcast by the forward pass (ASPP image-pooling branch): its gradient is the plain per-image sum
+    hipLaunchKernelGGL(gap_fwd_kernel, dim3(B, (C + SLAB - 1) / SLAB), dim3(256), RLANES * SLAB * sizeof(double), ST(stream),
+                       dy, lddy, (long)Ho * Wo, C, 1.0, dx, lddx);
+    SEGSDE_CHECK_LAUNCH();
+    return 0;
+  }
   hipLaunchKernelGGL(resize_bwd_kernel, dim3(ew_blocks((long)B * Hi * Wi * C)), dim3(256), 0, ST(stream), dy, lddy, B, Hi,
                      Wi, C, dx, lddx, Ho, Wo, ac);
   SEGSDE_CHECK_LAUNCH();
@@ -688,7 +741,7 @@ extern "C" int segsde_resize_bilinear_backward(const float* dy, int lddy, int B,
 extern "C" int segsde_global_avgpool_forward(const float* x, int ldx, int B, long HW, int C, float* y, void* stream) {
   if (!x || !y) return SEGSDE_ERR_NULL;
   hipLaunchKernelGGL(gap_fwd_kernel, dim3(B, (C + SLAB - 1) / SLAB), dim3(256), RLANES * SLAB * sizeof(double), ST(stream),
-                     x, ldx, HW, C, y);
+                     x, ldx, HW, C, 1.0 / (double)HW, y, C);
   SEGSDE_CHECK_LAUNCH();
   return 0;
 }

@@ -58,6 +58,84 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* logits, int ld
   }
 }
 
+// Dense logits (row pitch == C, the 19-class head): a block stages 256 consecutive pixels -- one contiguous span -- through
+// LDS with 16-byte accesses; one thread per pixel then works on its row in LDS (row stride C = 19 floats: odd, no bank
+// conflicts).  The per-thread global version above moves 4 bytes per lane at a 76-byte stride (7x off the HBM roofline).
+constexpr int CE_PIX = 256;
+__device__ __forceinline__ void ce_stage_in(const float* src, int n, float* sh) {
+  const int n4 = n >> 2;
+  for (int e = threadIdx.x; e < n4; e += 256) reinterpret_cast<float4*>(sh)[e] = reinterpret_cast<const float4*>(src)[e];
+  for (int e = (n4 << 2) + threadIdx.x; e < n; e += 256) sh[e] = src[e];
+}
+
+__global__ __launch_bounds__(256) void ce_fwd_dense_kernel(const float* logits, long M, int C, const int64_t* target,
+                                                           int64_t ignore, const float* cw, const float* pw, double* part) {
+  SEGSDE_SMEM;
+  float* sx = reinterpret_cast<float*>(segsde_smem);                    // [CE_PIX][C]
+  double* sh = reinterpret_cast<double*>(sx + CE_PIX * C + (CE_PIX * C & 1));   // 8-byte aligned scratch for the block sums
+  double num = 0.0, den = 0.0;
+  for (long m0 = (long)blockIdx.x * CE_PIX; m0 < M; m0 += (long)gridDim.x * CE_PIX) {
+    const int np = (int)(M - m0 < CE_PIX ? M - m0 : CE_PIX);
+    __syncthreads();
+    ce_stage_in(logits + m0 * C, np * C, sx);
+    __syncthreads();
+    const long m = m0 + threadIdx.x;
+    if ((int)threadIdx.x >= np) continue;
+    const int64_t t = target[m];
+    if (t == ignore) continue;
+    const float* x = sx + threadIdx.x * C;
+    float mx = x[0];
+    for (int c = 1; c < C; ++c) mx = fmaxf(mx, x[c]);
+    float se = 0.f;
+    for (int c = 0; c < C; ++c) se += expf(x[c] - mx);
+    const float nll = (mx + logf(se)) - x[t];
+    float w = cw ? cw[t] : 1.f;
+    den += (double)w;
+    if (pw) w *= pw[m];
+    num += (double)(w * nll);
+  }
+  __syncthreads();
+  const double a = segsde_block_sum(num, sh);
+  const double b = segsde_block_sum(den, sh);
+  if (threadIdx.x == 0) { part[2 * blockIdx.x] = a; part[2 * blockIdx.x + 1] = b; }
+}
+
+__global__ __launch_bounds__(256) void ce_bwd_dense_kernel(const float* logits, long M, int C, const int64_t* target,
+                                                           int64_t ignore, const float* cw, const float* pw,
+                                                           const float* scale, float* dl) {
+  SEGSDE_SMEM;
+  float* sx = reinterpret_cast<float*>(segsde_smem);     // [CE_PIX][C], overwritten in place with the gradients
+  const float sc = scale[0];
+  for (long m0 = (long)blockIdx.x * CE_PIX; m0 < M; m0 += (long)gridDim.x * CE_PIX) {
+    const int np = (int)(M - m0 < CE_PIX ? M - m0 : CE_PIX);
+    __syncthreads();
+    ce_stage_in(logits + m0 * C, np * C, sx);
+    __syncthreads();
+    if ((int)threadIdx.x < np) {
+      const long m = m0 + threadIdx.x;
+      const int64_t t = target[m];
+      float* x = sx + threadIdx.x * C;
+      if (t == ignore) {
+        for (int c = 0; c < C; ++c) x[c] = 0.f;
+      } else {
+        float mx = x[0];
+        for (int c = 1; c < C; ++c) mx = fmaxf(mx, x[c]);
+        float se = 0.f;
+        for (int c = 0; c < C; ++c) se += expf(x[c] - mx);
+        float w = (cw ? cw[t] : 1.f) * sc;
+        if (pw) w *= pw[m];
+        const float inv = 1.f / se;
+        for (int c = 0; c < C; ++c) x[c] = w * (expf(x[c] - mx) * inv - (c == t ? 1.f : 0.f));
+      }
+    }
+    __syncthreads();
+    float* dst = dl + m0 * C;
+    const int n = np * C, n4 = n >> 2;
+    for (int e = threadIdx.x; e < n4; e += 256) reinterpret_cast<float4*>(dst)[e] = reinterpret_cast<const float4*>(sx)[e];
+    for (int e = (n4 << 2) + threadIdx.x; e < n; e += 256) dst[e] = sx[e];
+  }
+}
+
 template <class MT>
 __global__ __launch_bounds__(256) void mix_kernel(const MT* mask, int Bm, const float* x, int B, int C, int H, int W,
                                                   long sb, long sc, long sh, long sw, float* out) {
@@ -229,8 +307,13 @@ extern "C" int segsde_cross_entropy_forward(const float* logits, int ld, long M,
   if (M <= 0 || C <= 0 || ld < C) return SEGSDE_ERR_SHAPE;
   if (ws_bytes < segsde_cross_entropy_workspace(M)) return SEGSDE_ERR_WORKSPACE;
   const int nb = ce_blocks(M);
-  hipLaunchKernelGGL(ce_fwd_kernel, dim3(nb), dim3(256), 64, ST(stream), logits, ld, M, C, target, ignore_index, class_weight,
-                     pixel_weights, (double*)ws);
+  const bool dense = ld == C && C <= 64 && (reinterpret_cast<uintptr_t>(logits) & 15) == 0;
+  if (dense)
+    hipLaunchKernelGGL(ce_fwd_dense_kernel, dim3(nb), dim3(256), (size_t)(CE_PIX * C + 2) * sizeof(float) + 64, ST(stream), logits,
+                       M, C, target, ignore_index, class_weight, pixel_weights, (double*)ws);
+  else
+    hipLaunchKernelGGL(ce_fwd_kernel, dim3(nb), dim3(256), 64, ST(stream), logits, ld, M, C, target, ignore_index, class_weight,
+                       pixel_weights, (double*)ws);
   SEGSDE_CHECK_LAUNCH();
   hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(64), 0, ST(stream), (const double*)ws, nb, out);
   SEGSDE_CHECK_LAUNCH();
@@ -241,8 +324,13 @@ extern "C" int segsde_cross_entropy_backward(const float* logits, int ld, long M
                                              const float* scale, float* dlogits, int lddl, void* stream) {
   if (!logits || !target || !scale || !dlogits) return SEGSDE_ERR_NULL;
   if (M <= 0 || C <= 0 || ld < C || lddl < C) return SEGSDE_ERR_SHAPE;
-  hipLaunchKernelGGL(ce_bwd_kernel, dim3(ce_blocks(M)), dim3(256), 0, ST(stream), logits, ld, M, C, target, ignore_index,
-                     class_weight, pixel_weights, scale, dlogits, lddl);
+  const bool dense = ld == C && lddl == C && C <= 64 && ((reinterpret_cast<uintptr_t>(logits) | reinterpret_cast<uintptr_t>(dlogits)) & 15) == 0;
+  if (dense)
+    hipLaunchKernelGGL(ce_bwd_dense_kernel, dim3(ce_blocks(M)), dim3(256), (size_t)CE_PIX * C * sizeof(float), ST(stream), logits, M, C,
+                       target, ignore_index, class_weight, pixel_weights, scale, dlogits);
+  else
+    hipLaunchKernelGGL(ce_bwd_kernel, dim3(ce_blocks(M)), dim3(256), 0, ST(stream), logits, ld, M, C, target, ignore_index,
+                       class_weight, pixel_weights, scale, dlogits, lddl);
   SEGSDE_CHECK_LAUNCH();
   return 0;
 }
