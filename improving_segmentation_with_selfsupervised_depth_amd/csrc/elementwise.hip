@@ -34,13 +34,16 @@ __host__ __device__ inline int red_blocks(long M) {
 // generic column reduction: Op::row(m, c, s0, s1) accumulates two sums for channel c over this block's rows.
 // VW = 4: each thread owns 4 consecutive channels (16-byte loads; 16 channel-quads x 16 row lanes per block),
 // VW = 1: one channel per thread (64 channels x 4 row lanes) for odd channel counts / unaligned pitches.
-template <class Op, int VW>
+// TX channel lanes x TY = 256 / TX row lanes.  Wide tensors: TX = 64 / VW lanes of VW channels each.  Narrow ones (C < 64:
+// the 1-channel disparity heads, the 19-class logits) shrink TX to the next power of two >= C so that all 256 threads
+// stay busy -- with 64 channel lanes a 1-channel reduction ran on 4 threads per block.
+template <class Op, int VW, int TX>
 __global__ __launch_bounds__(256) void colreduce_kernel(Op op, long M, int C, double* part) {
-  constexpr int TX = SLAB / VW, TY = 256 / TX;
+  constexpr int TY = 256 / TX, CW = TX * VW;          // channels per block
   SEGSDE_SMEM;
-  double* sh = reinterpret_cast<double*>(segsde_smem);  // [2][TY][SLAB]
+  double* sh = reinterpret_cast<double*>(segsde_smem);  // [2][TY][CW]
   const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
-  const int c = blockIdx.y * SLAB + tx * VW;
+  const int c = blockIdx.y * CW + tx * VW;
   const int nb = gridDim.x;
   const long rows_per = (M + nb - 1) / nb;
   const long r_begin = blockIdx.x * rows_per;
@@ -52,24 +55,37 @@ __global__ __launch_bounds__(256) void colreduce_kernel(Op op, long M, int C, do
     for (long m = r_begin + ty; m < r_end; m += TY) op.template row<VW>(m, c, s0, s1);
 #pragma unroll
   for (int j = 0; j < VW; ++j) {
-    sh[ty * SLAB + tx * VW + j] = s0[j];
-    sh[(TY + ty) * SLAB + tx * VW + j] = s1[j];
+    sh[ty * CW + tx * VW + j] = s0[j];
+    sh[(TY + ty) * CW + tx * VW + j] = s1[j];
   }
   __syncthreads();
-  const int cc = threadIdx.x;   // first 64 threads finish one channel each
-  if (cc < SLAB && blockIdx.y * SLAB + cc < C) {
+  const int cc = threadIdx.x;   // the first CW threads finish one channel each
+  if (cc < CW && blockIdx.y * CW + cc < C) {
     double a = 0.0, b2 = 0.0;
-    for (int j = 0; j < TY; ++j) { a += sh[j * SLAB + cc]; b2 += sh[(TY + j) * SLAB + cc]; }
-    part[((long)blockIdx.x * 2 + 0) * C + blockIdx.y * SLAB + cc] = a;
-    part[((long)blockIdx.x * 2 + 1) * C + blockIdx.y * SLAB + cc] = b2;
+    for (int j = 0; j < TY; ++j) { a += sh[j * CW + cc]; b2 += sh[(TY + j) * CW + cc]; }
+    part[((long)blockIdx.x * 2 + 0) * C + blockIdx.y * CW + cc] = a;
+    part[((long)blockIdx.x * 2 + 1) * C + blockIdx.y * CW + cc] = b2;
   }
+}
+
+template <class Op, int TX>
+void launch_colreduce_scalar(Op op, long M, int C, double* part, hipStream_t s) {
+  const dim3 grid(red_blocks(M), (C + TX - 1) / TX);
+  hipLaunchKernelGGL((colreduce_kernel<Op, 1, TX>), grid, dim3(256), 2 * 256 * sizeof(double), s, op, M, C, part);
 }
 
 template <class Op>
 int launch_colreduce(Op op, long M, int C, double* part, bool vec, hipStream_t s) {
-  const dim3 grid(red_blocks(M), (C + SLAB - 1) / SLAB);
-  if (vec) hipLaunchKernelGGL((colreduce_kernel<Op, 4>), grid, dim3(256), 2 * 16 * SLAB * sizeof(double), s, op, M, C, part);
-  else hipLaunchKernelGGL((colreduce_kernel<Op, 1>), grid, dim3(256), 2 * 4 * SLAB * sizeof(double), s, op, M, C, part);
+  if (vec) {
+    const dim3 grid(red_blocks(M), (C + SLAB - 1) / SLAB);
+    hipLaunchKernelGGL((colreduce_kernel<Op, 4, SLAB / 4>), grid, dim3(256), 2 * 16 * SLAB * sizeof(double), s, op, M, C, part);
+  } else if (C <= 1) launch_colreduce_scalar<Op, 1>(op, M, C, part, s);
+  else if (C <= 2) launch_colreduce_scalar<Op, 2>(op, M, C, part, s);
+  else if (C <= 4) launch_colreduce_scalar<Op, 4>(op, M, C, part, s);
+  else if (C <= 8) launch_colreduce_scalar<Op, 8>(op, M, C, part, s);
+  else if (C <= 16) launch_colreduce_scalar<Op, 16>(op, M, C, part, s);
+  else if (C <= 32) launch_colreduce_scalar<Op, 32>(op, M, C, part, s);
+  else launch_colreduce_scalar<Op, 64>(op, M, C, part, s);
   SEGSDE_CHECK_LAUNCH();
   return 0;
 }
