@@ -48,6 +48,7 @@ struct ConvP {
   // [ntm * (256 / BN)][2][N] doubles (sum, sum of squares per row slice of a tile) -- the next layer's batch statistics
   // without re-reading the tensor
   double* stats;
+  int accum;           // 1: the staged epilogue adds the tile to what the destination already holds
 };
 
 struct KInfo {  // decoded reduction index k -> tap + channel + source
@@ -581,7 +582,12 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
 #pragma unroll 4
       for (int ml = rr; ml < BM; ml += RPP) {
         const int m = m0 + ml;
-        if (m < p.M) *reinterpret_cast<float4*>(dst + out_row(p, m) * ld + nn) = *reinterpret_cast<const float4*>(Ct + ml * BN + 4 * cq);
+        if (m < p.M) {
+          float4* q = reinterpret_cast<float4*>(dst + out_row(p, m) * ld + nn);
+          float4 v = *reinterpret_cast<const float4*>(Ct + ml * BN + 4 * cq);
+          if (p.accum) { const float4 o = *q; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+          *q = v;
+        }
       }
     }
     return;
@@ -1140,6 +1146,7 @@ ConvP make_params(const segsde_conv_desc* d, const float* x0, const float* x1, c
   p.zero = zero_page();
   p.kh0 = 0; p.khs = 1; p.kw0 = 0; p.kws = 1; p.KWf = p.KW; p.Kfull = p.Ktot; p.os = 1; p.oph = 0; p.opw = 0; p.OHf = p.Ho; p.OWf = p.Wo;
   p.stats = nullptr;
+  p.accum = d->accumulate ? 1 : 0;
   return p;
 }
 
@@ -1239,6 +1246,12 @@ extern "C" int segsde_conv2d_forward_stats(const segsde_conv_desc* d, const floa
   if (stats) {
     if (stats_rows(d, p) == 0) return SEGSDE_ERR_UNSUPPORTED;
     p.stats = stats;
+  }
+  if (d->accumulate) {
+    // only the plain staged-epilogue launches add in place: one destination, no activation / bias, no special route
+    if (y2 || bias || d->act != 0 || d->sum2x2 || d->in_div > 1 || !p.vecout || d->Cout == 1 || d->C0 % 4 != 0 ||
+        d->C0 == 1 || (d->pad_mode == SEGSDE_PAD_REFLECT_ADJOINT && !igemm_fast_ok(p)))
+      return SEGSDE_ERR_UNSUPPORTED;
   }
   hipStream_t s = static_cast<hipStream_t>(stream);
   // disparity heads (Cout = 1) and their data-gradients (one gradient channel in): HBM-bound stencil kernels

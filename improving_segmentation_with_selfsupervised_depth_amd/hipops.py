@@ -136,9 +136,12 @@ def conv_forward(g, x0, x1, wpack, bias, act="none", want_stats=False):
     return (y, part) if want_stats else y
 
 
-def conv_dgrad(g, dy, wdpack, w_oihw, in_hw, need0=True, need1=True):
+def conv_dgrad(g, dy, wdpack, w_oihw, in_hw, need0=True, need1=True, accumulate_into=None):
     """Data gradient(s) of conv_forward w.r.t. (x0, x1).  dy: [B,Ho,Wo,Cout]; in_hw = (H, W) of the virtual input.
-    Returns (dx0, dx1); dx0 is at the *stored* resolution of x0 (2x2-summed when g.up0)."""
+    Returns (dx0, dx1); dx0 is at the *stored* resolution of x0 (2x2-summed when g.up0).
+    accumulate_into: a dense [B,H,W,C0] tensor that already holds another gradient of x0 (single-source, non-upsampled
+    convs): the result is ADDED to it in the kernel epilogue and that tensor is returned as dx0 (None is returned instead
+    when this shape cannot accumulate in place -- the caller then adds)."""
     B, Ho, Wo, Cout = dy.shape
     H, W = in_hw
     assert Cout == g.Cout
@@ -146,10 +149,22 @@ def conv_dgrad(g, dy, wdpack, w_oihw, in_hw, need0=True, need1=True):
     L = _lib.lib()
     flops = 2.0 * B * Ho * Wo * Cout * g.Cin * g.k * g.k
 
-    def desc(sum2x2):
+    def desc(sum2x2, accumulate=0):
         return ConvDesc(B=B, H=Ho, W=Wo, C0=Cout, C1=0, ld0=nhwc_ld(dy), ld1=0, up0=0, Ho=H, Wo=W, Cout=g.Cin, ldy=g.C0,
                         ldy2=g.C1, nsplit=g.C0, KH=g.k, KW=g.k, stride=1, dil=g.dil, pad=(g.k - 1) * g.dil - g.pad,
-                        pad_mode=PAD_REFLECT_ADJOINT if g.reflect else PAD_ZERO, in_div=g.stride, act=0, sum2x2=sum2x2)
+                        pad_mode=PAD_REFLECT_ADJOINT if g.reflect else PAD_ZERO, in_div=g.stride, act=0, sum2x2=sum2x2,
+                        accumulate=accumulate)
+    if accumulate_into is not None:
+        acc = accumulate_into
+        if g.up0 or g.C1 or tuple(acc.shape) != (B, H, W, g.C0) or not acc.is_contiguous():
+            return None, None
+        d = desc(0, 1)
+        rc = _timed("conv_dgrad", flops, dy, lambda: L.segsde_conv2d_forward(
+            ctypes.byref(d), _p(_f32(dy)), None, _p(wdpack), None, _p(acc), None, _stream(dy)), _tag(g, H, W))
+        if rc == -4:
+            return None, None
+        check(rc, "conv2d dgrad (accumulate)")
+        return acc, None
     if g.up0:
         # fused: the 2x2 sum of the upsample adjoint happens in the GEMM epilogue (no full-resolution gradient tensor)
         dx0 = torch.empty((B, H // 2, W // 2, g.C0), dtype=torch.float32, device=dy.device)

@@ -29,7 +29,7 @@ class Conv2d(nn.Conv2d):
         k = self.kernel_size[0]
         assert self.kernel_size[0] == self.kernel_size[1] and self.stride[0] == self.stride[1]
 
-    def forward(self, x, skip=None, up=False, act="none"):
+    def forward(self, x, skip=None, up=False, act="none", grad_box=None):
         c0 = x.shape[3]
         c1 = 0 if skip is None else skip.shape[3]
         weight = self.weight
@@ -45,17 +45,17 @@ class Conv2d(nn.Conv2d):
             # bias-free, activation-free convolutions are the ones followed by a BatchNorm (torchvision ResNet / ASPP
             # convention): their epilogue also leaves the batch-statistics partials, picked up by BatchNorm2d.forward
             holder = []
-            y = Fn.ConvFn.apply(x, skip, weight, self.bias, g, act, holder)
+            y = Fn.ConvFn.apply(x, skip, weight, self.bias, g, act, holder, grad_box)
             y._bn_partials = holder[0] if holder else None
             return y
-        return Fn.ConvFn.apply(x, skip, weight, self.bias, g, act)
+        return Fn.ConvFn.apply(x, skip, weight, self.bias, g, act, None, grad_box)
 
 
 class BatchNorm2d(nn.BatchNorm2d):
     """nn.BatchNorm2d state; ``forward(x_nhwc, residual=None, act="none", drop_p=0.0)`` fuses the residual add,
     the activation and (for ASPP.project) the dropout into the normalisation pass."""
 
-    def forward(self, x, residual=None, act="none", drop_p=0.0):
+    def forward(self, x, residual=None, act="none", drop_p=0.0, grad_box=None):
         training = self.training or (self.running_mean is None)
         if self.training and self.track_running_stats and self.num_batches_tracked is not None:
             self.num_batches_tracked.add_(1)
@@ -65,4 +65,4 @@ class BatchNorm2d(nn.BatchNorm2d):
         if partials is not None and partials.shape[-1] != self.num_features:
             partials = None
         return Fn.BNActFn.apply(x, self.weight, self.bias, residual, self.running_mean, self.running_var, training,
-                                momentum, self.eps, act, drop_p, seed, partials)
+                                momentum, self.eps, act, drop_p, seed, partials, grad_box)

@@ -24,6 +24,12 @@ class BasicBlock(nn.Module):
         self.downsample = downsample
 
     def forward(self, x):
+        if self.downsample is None and x.requires_grad:
+            # identity skip: conv1's data-gradient lands on the skip-path gradient inside its kernel (Fn.SplitFn)
+            box = {}
+            xm, xs = Fn.SplitFn.apply(x, box)
+            o = self.bn1(self.conv1(xm, grad_box=box), act="relu")
+            return self.bn2(self.conv2(o), residual=xs, act="relu", grad_box=box)
         idt = x if self.downsample is None else self.downsample[1](self.downsample[0](x))
         o = self.bn1(self.conv1(x), act="relu")
         return self.bn2(self.conv2(o), residual=idt, act="relu")
@@ -44,6 +50,12 @@ class Bottleneck(nn.Module):
         self.downsample = downsample
 
     def forward(self, x):
+        if self.downsample is None and x.requires_grad:
+            box = {}
+            xm, xs = Fn.SplitFn.apply(x, box)
+            o = self.bn1(self.conv1(xm, grad_box=box), act="relu")
+            o = self.bn2(self.conv2(o), act="relu")
+            return self.bn3(self.conv3(o), residual=xs, act="relu", grad_box=box)
         idt = x if self.downsample is None else self.downsample[1](self.downsample[0](x))
         o = self.bn1(self.conv1(x), act="relu")
         o = self.bn2(self.conv2(o), act="relu")

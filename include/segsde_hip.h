@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SEGSDE_ABI_VERSION 1
+#define SEGSDE_ABI_VERSION 2
 
 enum { SEGSDE_ERR_NULL = -1, SEGSDE_ERR_SHAPE = -2, SEGSDE_ERR_WORKSPACE = -3, SEGSDE_ERR_UNSUPPORTED = -4 };
 enum { SEGSDE_ACT_NONE = 0, SEGSDE_ACT_RELU = 1, SEGSDE_ACT_ELU = 2, SEGSDE_ACT_SIGMOID = 3 };
@@ -51,6 +51,9 @@ typedef struct segsde_conv_desc {
   int sum2x2;       /* 1 (data-gradient through the x2 upsample): output channels < nsplit are summed over 2x2 pixel
                        blocks in registers and stored to y at (Ho/2, Wo/2); channels >= nsplit go to y2 per pixel.
                        Returns SEGSDE_ERR_UNSUPPORTED when the shape cannot take the fused path.                         */
+  int accumulate;   /* 1: y += result instead of y = result (the gradient of a tensor with a second consumer -- a residual
+                       block's input -- lands on the gradient that is already there; no separate add pass).  Single
+                       destination, no activation; SEGSDE_ERR_UNSUPPORTED when the shape does not take the staged epilogue. */
 } segsde_conv_desc;
 
 /* y[b,ho,wo,n] = act(bias[n] + sum_{kh,kw,c} x[b, ho*stride-pad+kh*dil, wo*stride-pad+kw*dil, c] * wpack[n][kh][kw][c])

@@ -52,5 +52,9 @@ def test_validation_metric(golden):
     KC.run_metric_cases("cpu", golden)
 
 
+def test_residual_gradient_fusion():
+    KC.run_residual_fusion_case("cpu")
+
+
 def test_loss_kernels(golden):
     KC.run_loss_kernel_cases("cpu", golden)

@@ -78,6 +78,10 @@ def test_validation_metric(golden):
     KC.run_metric_cases("cuda", golden)
 
 
+def test_residual_gradient_fusion():
+    KC.run_residual_fusion_case("cuda")
+
+
 def test_loss_kernels(golden):
     KC.run_loss_kernel_cases("cuda", golden)
 
