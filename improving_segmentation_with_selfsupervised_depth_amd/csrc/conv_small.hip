@@ -143,21 +143,25 @@ __global__ __launch_bounds__(256) void c1_wgrad_kernel(const float* x, int ldx, 
   }
 }
 
+// 16 lanes per output element split the block partials between them (fixed order), then a shuffle tree: with one thread
+// per element the 9*C outputs were 576 threads walking 1024 partials each -- 300 us of pure latency
 __global__ __launch_bounds__(256) void c1_wgrad_reduce_kernel(const float* part, int nblk, int C, float* dw /*[1][C][3][3]*/) {
-  const int e = blockIdx.x * 256 + threadIdx.x;     // e = tap * C + c
-  if (e >= 9 * C) return;
-  // eight independent chains, fixed combination order (one chain of nblk dependent loads took 290 us)
-  float s8[8];
+  const int e = blockIdx.x * 16 + (threadIdx.x >> 4), l = threadIdx.x & 15;     // e = tap * C + c
+  const bool live = e < 9 * C;
+  float s4[4] = {0.f, 0.f, 0.f, 0.f};
+  if (live)
+    for (int z = l; z < nblk; z += 64) {
 #pragma unroll
-  for (int u = 0; u < 8; ++u) s8[u] = 0.f;
-  for (int z = 0; z < nblk; z += 8) {
+      for (int u = 0; u < 4; ++u)
+        if (z + 16 * u < nblk) s4[u] += part[(long)(z + 16 * u) * 9 * C + e];
+    }
+  float s = (s4[0] + s4[1]) + (s4[2] + s4[3]);
 #pragma unroll
-    for (int u = 0; u < 8; ++u)
-      if (z + u < nblk) s8[u] += part[(long)(z + u) * 9 * C + e];
+  for (int d = 8; d > 0; d >>= 1) s += __shfl_xor(s, d);
+  if (live && l == 0) {
+    const int tap = e / C, c = e - tap * C;
+    dw[c * 9 + tap] = s;
   }
-  const float s = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
-  const int tap = e / C, c = e - tap * C;
-  dw[c * 9 + tap] = s;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -473,14 +477,14 @@ int segsde_c1_wgrad(const float* x, int ldx, int B, int H, int W, int C, const f
     const int nbs = (int)(ns < 1 ? 1 : (ns > 1024 ? 1024 : ns));
     C1_DISPATCH(c1s_wgrad_kernel, dim3(nbs), smem, x, ldx, B, H, W, dz, lddz, reflect, workspace);
     SEGSDE_CHECK_LAUNCH();
-    hipLaunchKernelGGL(c1_wgrad_reduce_kernel, dim3((9 * C + 255) / 256), dim3(256), 0, ST(stream), (const float*)workspace, nbs,
+    hipLaunchKernelGGL(c1_wgrad_reduce_kernel, dim3((9 * C + 15) / 16), dim3(256), 0, ST(stream), (const float*)workspace, nbs,
                        C, dw);
     SEGSDE_CHECK_LAUNCH();
     return 0;
   }
   C1_DISPATCH(c1_wgrad_kernel, dim3(nblk), smem, x, ldx, B, H, W, dz, lddz, reflect, workspace);
   SEGSDE_CHECK_LAUNCH();
-  hipLaunchKernelGGL(c1_wgrad_reduce_kernel, dim3((9 * C + 255) / 256), dim3(256), 0, ST(stream), (const float*)workspace, nblk,
+  hipLaunchKernelGGL(c1_wgrad_reduce_kernel, dim3((9 * C + 15) / 16), dim3(256), 0, ST(stream), (const float*)workspace, nblk,
                      C, dw);
   SEGSDE_CHECK_LAUNCH();
   return 0;
