@@ -1,6 +1,6 @@
 """A/B timing of conv kernel variants selected through SEGSDE_TUNE (each variant needs its own process)."""
 import os, subprocess, sys
-variants = ["", "stagger=16", "stagger=32", "bk64=1", "bk64=1,stagger=32"]
+variants = ["", "bk64=1", "wplan=1", "nos2=1", "adjfix=1"]   # knobs parsed by tune() in csrc/conv_igemm.hip
 for v in variants:
     env = dict(os.environ, SEGSDE_TUNE=v, BENCH_B=os.environ.get("BENCH_B", "8"), BENCH_ONLY_CONV="1")
     print("=== SEGSDE_TUNE=%r" % v, flush=True)
