@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void warp_fwd_kernel(const float* disp, int hs
   const float* disp_b = disp + (long)b * hs * ws;
   const float* src_b = src + (long)b * 3 * HW;
   for (long p = blockIdx.x * 256L + threadIdx.x; p < HW; p += (long)gridDim.x * 256) {
-    const int h = (int)(p / W), w = (int)(p - (long)h * W);
+    const int h = (int)((unsigned)p / (unsigned)W), w = (int)p - h * W;   // p < H*W < 2^31: 32-bit division
     const Geo g = geometry(disp_b, hs, ws, H, W, h, w, iK, P, min_disp, max_disp);
     if (depth) depth[b * HW + p] = g.depth;
     if (grid) { grid[(b * HW + p) * 2] = g.gx; grid[(b * HW + p) * 2 + 1] = g.gy; }
@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256) void warp_bwd_kernel(const float* gcolor, cons
 #pragma unroll
   for (int i = 0; i < 12; ++i) acc[i] = 0.0;
   for (long p = blockIdx.x * 256L + threadIdx.x; p < HW; p += (long)gridDim.x * 256) {
-    const int h = (int)(p / W), w = (int)(p - (long)h * W);
+    const int h = (int)((unsigned)p / (unsigned)W), w = (int)p - h * W;   // p < H*W < 2^31: 32-bit division
     const Geo g = geometry(disp_b, hs, ws, H, W, h, w, iK, P, min_disp, max_disp);
     const float fx = floorf(g.ix), fy = floorf(g.iy);
     const int x0 = (int)fx, y0 = (int)fy, x1 = x0 + 1, y1 = y0 + 1;
@@ -227,7 +227,7 @@ __global__ __launch_bounds__(256) void reproj_err_fwd_kernel(const float* pred, 
   const int b = blockIdx.y;
   const long HW = (long)H * W;
   for (long p = blockIdx.x * 256L + threadIdx.x; p < HW; p += (long)gridDim.x * 256) {
-    const int h = (int)(p / W), w = (int)(p - (long)h * W);
+    const int h = (int)((unsigned)p / (unsigned)W), w = (int)p - h * W;   // p < H*W < 2^31: 32-bit division
     float l1 = 0.f, ss = 0.f;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -254,7 +254,7 @@ __global__ __launch_bounds__(256) void ssim_coef_kernel(const float* pred, const
   const int b = blockIdx.y;
   const long HW = (long)H * W;
   for (long p = blockIdx.x * 256L + threadIdx.x; p < HW; p += (long)gridDim.x * 256) {
-    const int h = (int)(p / W), w = (int)(p - (long)h * W);
+    const int h = (int)((unsigned)p / (unsigned)W), w = (int)p - h * W;   // p < H*W < 2^31: 32-bit division
     const float gq = gerr[b * gerr_bs + p] * (0.85f / 3.f) * (-0.5f);
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -282,7 +282,7 @@ __global__ __launch_bounds__(256) void reproj_err_bwd_kernel(const float* pred, 
   const int b = blockIdx.y;
   const long HW = (long)H * W;
   for (long p = blockIdx.x * 256L + threadIdx.x; p < HW; p += (long)gridDim.x * 256) {
-    const int h = (int)(p / W), w = (int)(p - (long)h * W);
+    const int h = (int)((unsigned)p / (unsigned)W), w = (int)p - h * W;   // p < H*W < 2^31: 32-bit division
     int hp[3], wp[3], nh = 0, nw = 0;
     hp[nh++] = h; if (h == 1) hp[nh++] = -1; if (h == H - 2) hp[nh++] = H;
     wp[nw++] = w; if (w == 1) wp[nw++] = -1; if (w == W - 2) wp[nw++] = W;
@@ -291,7 +291,19 @@ __global__ __launch_bounds__(256) void reproj_err_bwd_kernel(const float* pred, 
     for (int c = 0; c < 3; ++c) {
       const float xv = pred[(b * 3 + c) * HW + p], yv = target[(b * 3 + c) * HW + p];
       float g = 0.f;
-      if (!no_ssim) {
+      if (!no_ssim && h >= 2 && h <= H - 3 && w >= 2 && w <= W - 3) {
+        // interior pixel: exactly the nine windows around it, no mirrored pre-images, no range checks -- fully unrolled
+        const float* o = coef + ((long)(b * 3 + c) * 3) * HW + p;
+        float sa = 0.f, sbx = 0.f, sby = 0.f;
+#pragma unroll
+        for (int dh = -1; dh <= 1; ++dh)
+#pragma unroll
+          for (int dw = -1; dw <= 1; ++dw) {
+            const long q = (long)dh * W + dw;
+            sa += o[q]; sbx += o[HW + q]; sby += o[2 * HW + q];
+          }
+        g = sa + sbx * xv + sby * yv;
+      } else if (!no_ssim) {
         const float* o = coef + ((long)(b * 3 + c) * 3) * HW;
         float sa = 0.f, sbx = 0.f, sby = 0.f;
         for (int a = 0; a < nh; ++a)
@@ -404,7 +416,7 @@ __global__ __launch_bounds__(256) void smooth_fwd_kernel(const float* disp, cons
   const float inv = mean_disp[b] + 1e-7f;
   double ax = 0.0, ay = 0.0;
   for (long p = blockIdx.x * 256L + threadIdx.x; p < HW; p += (long)gridDim.x * 256) {
-    const int y = (int)(p / w), x = (int)(p - (long)y * w);
+    const int y = (int)((unsigned)p / (unsigned)w), x = (int)p - y * w;   // p < h*w < 2^31: 32-bit division
     const float dn = d[p] / inv;
     if (x + 1 < w) ax += (double)(fabsf(dn - d[p + 1] / inv) * edge_w(im, HW, p, p + 1));
     if (y + 1 < h) ay += (double)(fabsf(dn - d[p + w] / inv) * edge_w(im, HW, p, p + w));
@@ -448,7 +460,7 @@ __global__ __launch_bounds__(256) void smooth_bwd_a_kernel(const float* disp, co
   const float inv = mean_disp[b] + 1e-7f;
   double acc = 0.0;
   for (long p = blockIdx.x * 256L + threadIdx.x; p < HW; p += (long)gridDim.x * 256) {
-    const int y = (int)(p / w), x = (int)(p - (long)y * w);
+    const int y = (int)((unsigned)p / (unsigned)w), x = (int)p - y * w;   // p < h*w < 2^31: 32-bit division
     const float dn = d[p] / inv;
     float g = 0.f;
     if (x + 1 < w) g += sx * sgn(dn - d[p + 1] / inv) * edge_w(im, HW, p, p + 1);
@@ -482,7 +494,7 @@ extern "C" int segsde_warp_forward(const float* disp, int hs, int ws, const floa
                                    const float* src, int B, int H, int W, float min_depth, float max_depth, float* color,
                                    float* grid, float* depth, void* stream) {
   if (!disp || !inv_K || !K || !T || !src || !color) return SEGSDE_ERR_NULL;
-  if (B <= 0 || H < 2 || W < 2 || hs <= 0 || ws <= 0) return SEGSDE_ERR_SHAPE;
+  if (B <= 0 || H < 2 || W < 2 || hs <= 0 || ws <= 0 || (long)H * W >= (1L << 31)) return SEGSDE_ERR_SHAPE;
   hipLaunchKernelGGL(warp_fwd_kernel, dim3(plane_blocks((long)H * W), B), dim3(256), 512, ST(stream), disp, hs, ws, inv_K, K,
                      T, src, H, W, 1.f / max_depth, 1.f / min_depth, color, grid, depth);
   SEGSDE_CHECK_LAUNCH();
@@ -510,7 +522,7 @@ extern "C" int segsde_warp_backward(const float* gcolor, const float* disp, int 
 extern "C" int segsde_reprojection_error_forward(const float* pred, const float* target, int B, int H, int W, int no_ssim,
                                                  float* err, long err_bstride, void* stream) {
   if (!pred || !target || !err) return SEGSDE_ERR_NULL;
-  if (B <= 0 || H < 2 || W < 2) return SEGSDE_ERR_SHAPE;
+  if (B <= 0 || H < 2 || W < 2 || (long)H * W >= (1L << 31)) return SEGSDE_ERR_SHAPE;
   hipLaunchKernelGGL(reproj_err_fwd_kernel, dim3(plane_blocks((long)H * W), B), dim3(256), 0, ST(stream), pred, target, H,
                      W, no_ssim, err, err_bstride);
   SEGSDE_CHECK_LAUNCH();
@@ -525,7 +537,7 @@ extern "C" int segsde_reprojection_error_backward(const float* pred, const float
                                                   long gerr_bstride, int B, int H, int W, int no_ssim, float* gpred,
                                                   void* ws_, size_t ws_bytes, void* stream) {
   if (!pred || !target || !gerr || !gpred) return SEGSDE_ERR_NULL;
-  if (B <= 0 || H < 2 || W < 2) return SEGSDE_ERR_SHAPE;
+  if (B <= 0 || H < 2 || W < 2 || (long)H * W >= (1L << 31)) return SEGSDE_ERR_SHAPE;
   const dim3 grid(plane_blocks((long)H * W), B);
   if (!no_ssim) {
     if (!ws_) return SEGSDE_ERR_NULL;
