@@ -46,7 +46,7 @@ class Conv2d(nn.Conv2d):
             # convention): their epilogue also leaves the batch-statistics partials, picked up by BatchNorm2d.forward
             holder = []
             y = Fn.ConvFn.apply(x, skip, weight, self.bias, g, act, holder, grad_box)
-            y._bn_partials = holder[0] if holder else None
+            y._bn_partials = (holder[0], y._version) if holder and holder[0] is not None else None
             return y
         return Fn.ConvFn.apply(x, skip, weight, self.bias, g, act, None, grad_box)
 
@@ -62,7 +62,10 @@ class BatchNorm2d(nn.BatchNorm2d):
         momentum = 0.1 if self.momentum is None else self.momentum
         seed = _seed() if drop_p > 0 else 0
         partials = getattr(x, "_bn_partials", None) if training else None
-        if partials is not None and partials.shape[-1] != self.num_features:
-            partials = None
+        if partials is not None:
+            # valid only for the very tensor the convolution produced: same channel count and no in-place edit since
+            partials, version = partials
+            if partials.shape[-1] != self.num_features or x._version != version:
+                partials = None
         return Fn.BNActFn.apply(x, self.weight, self.bias, residual, self.running_mean, self.running_var, training,
                                 momentum, self.eps, act, drop_p, seed, partials, grad_box)
