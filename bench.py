@@ -1,7 +1,11 @@
 #!/usr/bin/env python
 """Training-throughput benchmark of the hot path.
 
-    python bench.py --gpus N --steps K --warmup W            (N>1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W
+
+N>1 runs one rank per GPU over RCCL: either the caller launches the ranks (``python -m torch.distributed.run
+--nproc-per-node N ... bench.py --gpus N``: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* come from the environment), or --
+when WORLD_SIZE is not set -- this script re-executes itself under torch.distributed.run with N ranks on 127.0.0.1.
 
 A "step" re-enacts the reference's Trainer.train_step (train.py:442-549) on synthetic, device-resident inputs:
 model forward -> monodepth loss -> segmentation loss -> backward -> gradient all-reduce (N>1) -> clip_grad_norm ->
@@ -22,7 +26,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 # algorithmic GFLOP per image (conv + matmul, 2*MAC), measured on the reference model
-GFLOP_PER_IMG = {"cfg1": 216.8, "cfg2": 1423.6, "cfg3": 2467.2, "cfg3pad": 2569.4}
+GFLOP_PER_IMG = {"cfg1": 216.8, "cfg2": 1423.6, "cfg3": 2467.2, "cfg3pad": 2569.4,
+                 # cfg5 (per LABELED image of the step): conv work scales with the pixel count (x4 vs 512x1024); the step runs
+                 # the mtl_pad student three times fwd+bwd (labeled, unlabeled unmixed, unlabeled mixed; the mixed pass
+                 # without a monodepth loss still runs the pose nets like the reference) and the teacher once forward
+                 # (no pose nets): 4 * (3 * 2569.4 + (2569.4 / 3 - 83.4)) GFLOP
+                 "cfg5": 4 * (3 * 2569.4 + (2569.4 / 3.0 - 83.4))}
 PEAK_FP32_MATRIX_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, no TF32 on gfx950
 
 
@@ -45,7 +54,7 @@ def model_cfg(workload, H, W):
     if workload == "cfg3":
         return dict(common, backbone_name="resnet101", replace_stride_with_dilation=[False, False, True],
                     segmentation_name="joint_seg_depth_dec", segmentation_args=jsd, depth_args=dec)
-    if workload == "cfg3pad":
+    if workload in ("cfg3pad", "cfg5"):
         return dict(common, backbone_name="resnet101", replace_stride_with_dilation=[False, False, True],
                     segmentation_name="mtl_pad", segmentation_args=pad, depth_args=dec)
     raise KeyError(workload)
@@ -56,6 +65,9 @@ WORKLOADS = {  # name -> (H, W, per-GPU batch, optimiser, description)
     "cfg2": (512, 1024, 8, "adam", "ResNet-50 monodepth dec5, 512x1024, batch 8 (BASELINE configs[1])"),
     "cfg3": (512, 1024, 16, "sgd", "ResNet-101 joint_seg_depth_dec seg+depth, 512x1024, batch 16/GPU (BASELINE configs[2])"),
     "cfg3pad": (512, 1024, 16, "sgd", "ResNet-101 mtl_pad seg+depth, 512x1024, batch 16/GPU"),
+    "cfg5": (1024, 2048, 2, "sgd", "ResNet-101 mtl_pad seg+depth + DepthMix unlabeled step (teacher fwd, online-depth depthcomp "
+                                   "mask, mix, 2 student fwd/bwd, EMA), 1024x2048 crops, batch 2 labeled + 2 unlabeled per GPU "
+                                   "(BASELINE configs[4]; reference asserts batch 2 for depthcomp, train.py:586)"),
 }
 
 
@@ -95,9 +107,21 @@ def param_groups(model, opt):
     return torch.optim.SGD([{"params": enc, "lr": 1e-3}, {"params": rest}], lr=1e-2, momentum=0.9, weight_decay=5e-4)
 
 
+def cpu_model_name():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown CPU"
+
+
 def cpu_baseline(workload, H, W, budget_s):
-    """The oracle (CPU torch restatement of the reference path) timed on this box's host cores on a bounded sample:
-    one full train step (fwd + mono loss + seg loss + bwd) at batch 2."""
+    """The oracle (CPU torch restatement of the reference path, validated against the reference) timed on this box's host
+    cores: one un-timed warm-up step (first-call costs: oneDNN primitive creation, allocator growth), then
+    whole train steps (fwd + mono loss + seg loss + bwd) until >= 3 steps (>= 10 for cfg1) are done or the budget is spent;
+    batch 2 (cfg1: its own batch 2 = the configuration in full)."""
     from oracle import nets as N, photometric as P, segmix as S
     try:
         cores = len(os.sched_getaffinity(0))
@@ -105,25 +129,45 @@ def cpu_baseline(workload, H, W, budget_s):
         cores = os.cpu_count() or 1
     cores = max(1, min(cores, 64))
     torch.set_num_threads(cores)
-    cfg = model_cfg(workload, H, W)
+    if workload == "cfg5":
+        workload_model, H, W = "cfg3pad", 512, 1024     # the labeled part of the step at the cfg3 shape (CPU budget)
+    else:
+        workload_model = workload
+    cfg = model_cfg(workload_model, H, W)
     B = 2
     sd = N.build_state_dict(cfg, 19, seed=0)
     sd = {k: (v.requires_grad_(True) if v.is_floating_point() and "running" not in k else v) for k, v in sd.items()}
     inp = synthetic_inputs(B, H, W, "cpu", 99, with_labels=cfg.get("segmentation_name") is not None)
-    t0 = time.time()
-    out = N.model_forward(sd, cfg, inp, train=True, dropout=True)
     lo = P.MonodepthLossOracle(**loss_cfg(B, H, W)["training"]["monodepth_loss"], batch_size=B)
-    lo.generate_images_pred(inp, out)
-    total = lo.compute_losses(inp, out)["loss"]
-    if "semantics" in out:
-        total = total + S.cross_entropy2d(out["semantics"], inp["lbl"])
-        if "intermediate_semantics" in out:
-            total = total + S.cross_entropy2d(out["intermediate_semantics"], inp["lbl"])
-    total.backward()
-    dt = time.time() - t0
-    return {"value": B / dt, "unit": "img/s", "cores": cores, "kind": "port",
-            "sample": "oracle (CPU PyTorch restatement, validated against the reference): 1 train step fwd+loss+bwd, "
-                      "%s at batch %d, %.1f s, torch %s" % (workload, B, dt, torch.__version__)}
+
+    def step():
+        for v in sd.values():
+            if v.is_floating_point() and v.grad is not None:
+                v.grad = None
+        out = N.model_forward(sd, cfg, inp, train=True, dropout=True)
+        lo.generate_images_pred(inp, out)
+        total = lo.compute_losses(inp, out)["loss"]
+        if "semantics" in out:
+            seg = S.cross_entropy2d(out["semantics"], inp["lbl"])
+            if "intermediate_semantics" in out:
+                seg = (seg + S.cross_entropy2d(out["intermediate_semantics"], inp["lbl"])) / 2
+            total = total + seg
+        total.backward()
+
+    t0 = time.time()
+    step()
+    warm = time.time() - t0
+    want = 10 if workload == "cfg1" else 3
+    times = []
+    while len(times) < want and (len(times) == 0 or time.time() - t0 + 1.2 * max(times) < budget_s):
+        t1 = time.time()
+        step()
+        times.append(time.time() - t1)
+    med = float(np.median(times))
+    return {"value": B / med, "unit": "img/s", "cores": cores, "kind": "port",
+            "sample": "oracle (CPU PyTorch restatement, validated against the reference): %s at batch %d, 1 warm-up step "
+                      "(%.1f s) + %d timed train steps fwd+loss+bwd (median %.2f s, min %.2f s), %d threads on %s, torch %s"
+                      % (workload_model, B, warm, len(times), med, min(times), cores, cpu_model_name(), torch.__version__)}
 
 
 def main():
@@ -136,17 +180,31 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
-    ap.add_argument("--cpu-baseline-timeout", type=float, default=170.0)
+    ap.add_argument("--cpu-baseline-timeout", type=float, default=150.0)
     args = ap.parse_args()
     if args.cpu_baseline_only:
         Hh, W = WORKLOADS[args.workload][:2]
-        print(json.dumps(cpu_baseline(args.workload, Hh, W, 30)))
+        print(json.dumps(cpu_baseline(args.workload, Hh, W, args.cpu_baseline_timeout - 25.0)))
         return
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N`: become the launcher -- N ranks of this very script over RCCL on 127.0.0.1
+        import socket
+        import subprocess
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        sys.exit(subprocess.call(cmd, env=env))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    assert world == args.gpus or (args.gpus == 1 and world == 1), "--gpus must equal WORLD_SIZE"
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch one rank per GPU (or drop WORLD_SIZE and let bench.py spawn them)"
+                         % (args.gpus, world))
     torch.cuda.set_device(local_rank)     # before constructing anything (SURVEY.md 8b device quirk)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
@@ -154,12 +212,13 @@ def main():
     if world > 1 or force_reducer:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import __graft_entry__ as ge
     if not os.path.exists(ge.LIB):
         ge.build()
     from improving_segmentation_with_selfsupervised_depth_amd import hipops as H
+    from improving_segmentation_with_selfsupervised_depth_amd import trainer as T
     from improving_segmentation_with_selfsupervised_depth_amd.models import get_model
     from improving_segmentation_with_selfsupervised_depth_amd.loss import get_monodepth_loss
     from improving_segmentation_with_selfsupervised_depth_amd.loss.loss import cross_entropy2d
@@ -176,6 +235,19 @@ def main():
     reducer = GradAllReducer(model, always=force_reducer) if (world > 1 or force_reducer) else None
     inputs = synthetic_inputs(B, Hh, W, dev, 1234 + rank, with_labels=cfg.get("segmentation_name") is not None)
     clip = 10.0 if opt_name == "sgd" else None
+    unlabeled = args.workload == "cfg5"
+    if unlabeled:
+        # train.py:280-288, 328-344: the EMA teacher is a second full copy of the model with detached parameters
+        ema_model = get_model(cfg, 19).to(dev).train()
+        ema_model.load_state_dict(model.state_dict())
+        for p_ in ema_model.parameters():
+            p_.detach_()
+        unlabeled_inputs = synthetic_inputs(B, Hh, W, dev, 4321 + rank, with_labels=False)
+    it = [0]
+
+    def nosync():
+        import contextlib
+        return reducer.no_sync() if reducer is not None else contextlib.nullcontext()
 
     def step():
         optimizer.zero_grad(set_to_none=True)
@@ -187,12 +259,27 @@ def main():
             if "intermediate_semantics" in out:
                 seg = (seg + cross_entropy2d(out["intermediate_semantics"], inputs["lbl"])) / 2
             total = total + seg
-        total.backward()
+        if unlabeled:
+            # train.py:511-514: labeled backward, then the unlabeled step accumulates onto the same gradients; only the
+            # last backward of the step may start the gradient all-reduce
+            with nosync():
+                total.backward()
+            del out
+            L_u, mono_u = T.train_step_segmentation_unlabeled(
+                model, ema_model, loss_obj, unlabeled_inputs, mix_mask="depthcomp", depthmix_online_depth=True,
+                monodepth_lambda=1.0, consistency_weight=1.0, backward_first_pseudo_label=False, depthcomp_margin=0.03,
+                depthcomp_foreground_threshold=0.0, color_jitter=False, blur=False, reducer=reducer)
+            total = total.detach() + L_u.detach() + mono_u.detach()
+        else:
+            total.backward()
         if reducer is not None:
             reducer.finish()
         if clip is not None:
             torch.nn.utils.clip_grad_norm_(model.parameters(), clip)
         optimizer.step()
+        if unlabeled:
+            T.update_ema_variables(ema_model, model, 0.99, it[0], segmentation_name=cfg["segmentation_name"])
+        it[0] += 1
         return total
 
     def barrier():
@@ -203,6 +290,7 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
+    torch.cuda.reset_peak_memory_stats(dev)
     prof = None if args.no_kernel_timing else []
     H.PROFILE = prof
     t0 = time.perf_counter()
@@ -221,12 +309,19 @@ def main():
         ms = dt / args.steps * 1e3
         value = B * world * args.steps / dt
         res = {"metric": "train images/sec, ResNet-101 joint seg+depth @512x1024" if args.workload.startswith("cfg3")
-               else "train images/sec (%s)" % args.workload,
+               else ("train labeled images/sec, ResNet-101 joint seg+depth + DepthMix @1024x2048" if unlabeled
+                     else "train images/sec (%s)" % args.workload),
                "value": value, "unit": "img/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
                "data": "synthetic", "config": {"workload": desc, "per_gpu_batch": B, "global_batch": B * world,
                                                "height": Hh, "width": W, "optimizer": opt_name,
-                                               "parallelism": "dp%d" % world, "final_loss": loss_val}}
+                                               "parallelism": "dp%d" % world, "final_loss": loss_val,
+                                               "ranks": dist.get_world_size() if dist.is_initialized() else 1,
+                                               "backend": (dist.get_backend() + " (RCCL)") if dist.is_initialized() else None,
+                                               "allreduce_launches": reducer.collectives if reducer is not None else 0,
+                                               "peak_memory_gb": torch.cuda.max_memory_allocated(dev) / 2 ** 30}}
+        if unlabeled:
+            res["config"]["images_per_step"] = {"labeled": B * world, "unlabeled": B * world}
         gflop_img = GFLOP_PER_IMG[args.workload]
         res["step_tflops"] = value * gflop_img / 1e3 / world
         roof = {"bound": "mfma", "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s", "traffic": None,

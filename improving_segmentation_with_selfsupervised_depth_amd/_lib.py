@@ -87,6 +87,9 @@ _SIGS = {
     "segsde_confusion_update": (c_int, [P, c_long, c_long, c_long, P, P, c_int, c_long, c_int, P, P]),
     "segsde_multi_tensor_lerp": (c_int, [P, c_int, c_float, c_float, P]),
     "segsde_pseudo_label": (c_int, [P, c_int, c_int, c_long, c_float, c_int64, P, P, P, P, P]),
+    "segsde_softmax_nhwc_to_nchw": (c_int, [P, c_int, c_int, c_long, c_int, P, P]),
+    "segsde_minmax_normalize_workspace": (c_size_t, [c_int, c_long]),
+    "segsde_minmax_normalize": (c_int, [P, c_int, c_long, P, P, P, c_size_t, P]),
 }
 EXPORTS = sorted(_SIGS)
 

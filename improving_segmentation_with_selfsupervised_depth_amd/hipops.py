@@ -650,6 +650,28 @@ def pseudo_label(prob, threshold, ignore_index, want_max=False, want_weight=True
     return label, count, maxp, pw
 
 
+def softmax_to_nchw(logits_nhwc):
+    """class softmax of NHWC logits [B,H,W,C] -> dense NCHW probabilities [B,C,H,W] (train.py:666)"""
+    B, Hh, W, C = logits_nhwc.shape
+    out = torch.empty((B, C, Hh, W), dtype=torch.float32, device=logits_nhwc.device)
+    check(_lib.lib().segsde_softmax_nhwc_to_nchw(_p(_f32(logits_nhwc)), nhwc_ld(logits_nhwc), B, Hh * W, C, _p(out),
+                                                 _stream(logits_nhwc)), "softmax_nhwc_to_nchw")
+    return out
+
+
+def minmax_normalize(x):
+    """x: [B, ...] -> (x - min_b) / (max_b - min_b) per sample b (train.py:690-697)"""
+    x = _f32(x).contiguous()
+    B = x.shape[0]
+    HW = x[0].numel()
+    out = torch.empty_like(x)
+    L = _lib.lib()
+    nb = L.segsde_minmax_normalize_workspace(B, HW)
+    ws_ = _ws(nb, x)
+    check(L.segsde_minmax_normalize(_p(x), B, HW, _p(out), None, _p(ws_), nb, _stream(x)), "minmax_normalize")
+    return out
+
+
 def confusion_update(hist, gt, pred=None, logits=None):
     """hist: int64 [C*C] on the device (accumulated in place); gt: int64 [B,H,W]; pred int64 [B,H,W] or logits [B,C,H,W]
     (NCHW-logical, any of dense NCHW / channels-last memory)."""

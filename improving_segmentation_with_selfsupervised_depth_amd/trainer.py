@@ -13,7 +13,8 @@ import torch
 from . import hipops as H
 from .loss.loss import cross_entropy2d
 
-__all__ = ["extract_ema_params", "EmaUpdater", "update_ema_variables", "calc_pseudo_label_loss"]
+__all__ = ["extract_ema_params", "EmaUpdater", "update_ema_variables", "calc_pseudo_label_loss", "teacher_softmax",
+           "normalize_online_depth", "generate_mix_mask", "train_step_segmentation_unlabeled"]
 
 
 def extract_ema_params(model, ema_model, model_names):
@@ -81,3 +82,126 @@ def calc_pseudo_label_loss(teacher_softmax, student_logits, consistency_weight, 
     pseudo_label, _, _, pixel_weight = H.pseudo_label(teacher_softmax.detach(), threshold, ignore_index)
     L_u = consistency_weight * cross_entropy2d(input=student_logits, target=pseudo_label, pixel_weights=pixel_weight)
     return L_u, pseudo_label
+
+
+def teacher_softmax(logits):
+    """train.py:666 ``torch.softmax(logits_u_w.detach(), dim=1)``: [B,C,H,W] logits (NCHW-logical; the segmentation head
+    hands them over channels-last) -> dense NCHW probabilities, one HIP pass."""
+    from . import functional as Fn
+    return H.softmax_to_nchw(Fn.to_nhwc(logits.detach()))
+
+
+def normalize_online_depth(disp):
+    """train.py:690-697: the student's ("disp", 0), per sample min-max normalised to [0, 1] (detached)."""
+    return H.minmax_normalize(disp.detach())
+
+
+def generate_mix_mask(mode, argmax_u_w, unlabeled_imgs, depths, depthcomp_margin=0.03, depthcomp_foreground_threshold=0.0):
+    """Trainer.generate_mix_mask (train.py:572-642): "class" / "depthcomp" / "depth" / None on the HIP mask kernels
+    ("depthhist" is CPU numpy histogram code in the reference and is not part of the path)."""
+    from .loader import transformmasks
+    B = unlabeled_imgs.shape[0]
+    dev = unlabeled_imgs.device
+    if mode == "class":
+        masks = []
+        for i in range(B):
+            classes = torch.unique(argmax_u_w[i])
+            classes = classes[classes != 250]
+            n = classes.shape[0]
+            pick = torch.as_tensor(np.random.choice(n, int((n - n % 2) / 2), replace=False), dtype=torch.int64, device=dev)
+            masks.append(transformmasks.generate_class_mask(argmax_u_w[i], classes[pick]).unsqueeze(0))
+        return torch.cat(masks)
+    if mode == "depthcomp":
+        ft = depthcomp_foreground_threshold
+        if isinstance(ft, (tuple, list)):
+            ft_l, ft_u = ft
+            assert ft_u > ft_l
+            ft = float(torch.rand(1)) * (ft_u - ft_l) + ft_l
+        return transformmasks.generate_depthcomp_mask(depths, depthcomp_margin, ft)
+    if mode == "depth":
+        masks = []
+        for i in range(B):
+            thr = torch.rand(1) * (0.4 - 0.1) + 0.1
+            masks.append(transformmasks.generate_depth_mask(depths[i], thr))
+        return torch.cat(masks)
+    if mode is None:
+        return torch.ones((B,) + tuple(unlabeled_imgs.shape[2:]), device=dev)
+    raise NotImplementedError(f"Unknown mix_mask {mode}")
+
+
+def train_step_segmentation_unlabeled(model, ema_model, monodepth_loss_calculator, unlabeled_inputs, mix_mask="depthcomp",
+                                      depthmix_online_depth=True, monodepth_lambda=1.0, consistency_weight=1.0,
+                                      backward_first_pseudo_label=False, depthcomp_margin=0.03,
+                                      depthcomp_foreground_threshold=0.0, color_jitter=False, blur=False, reducer=None,
+                                      last_backward=True):
+    """Trainer.train_step_segmentation_unlabeled (train.py:653-724) with the ``self.*`` values as arguments: teacher
+    forward -> softmax; student forward on the unmixed frames -> monodepth loss backward and the online depth; mix mask;
+    DepthMix of images and teacher softmax; student forward on the mixed frames; pseudo-label loss backward.
+    Returns (L_2 + L_1, mono_loss) like the reference.  ``reducer`` (ddp.GradAllReducer) keeps the gradient all-reduce
+    out of every backward() except the last one of the step (``last_backward``: the L_2 backward is that one)."""
+    import contextlib
+    import random
+    from .loader import transformsgpu
+
+    def nosync():
+        return reducer.no_sync() if reducer is not None else contextlib.nullcontext()
+
+    def strong_transform(parameters, data=None, target=None):
+        data, target = transformsgpu.mix(mask=parameters["Mix"], data=data, target=target)
+        data, target = transformsgpu.color_jitter(jitter=parameters["ColorJitter"], data=data, target=target)
+        data, target = transformsgpu.gaussian_blur(blur=parameters["GaussianBlur"], data=data, target=None)
+        return data, target
+
+    unlabeled_imgs = unlabeled_inputs[("color_aug", 0, 0)]
+    # first step: teacher -> pseudo-label distribution (train.py:663-672)
+    ema_model.use_pose_net = False
+    with torch.no_grad():
+        logits_u_w = ema_model(unlabeled_inputs)["semantics"]
+    softmax_u_w = teacher_softmax(logits_u_w)
+    argmax_u_w = None
+    if isinstance(mix_mask, str) and mix_mask == "class":
+        argmax_u_w = H.pseudo_label(softmax_u_w, 2.0, -1, want_weight=False)[0]
+    # second step: student on the unaugmented frames -> online depth + monodepth loss (train.py:676-702)
+    mono_loss, L_1 = 0, 0
+    if depthmix_online_depth:
+        outputs_1 = model(unlabeled_inputs)
+        if monodepth_lambda > 0:
+            monodepth_loss_calculator.generate_images_pred(unlabeled_inputs, outputs_1)
+            mono_losses = monodepth_loss_calculator.compute_losses(unlabeled_inputs, outputs_1)
+            mono_loss = monodepth_lambda * mono_losses["loss"]
+            with nosync():
+                mono_loss.backward(retain_graph=backward_first_pseudo_label)
+            depths = normalize_online_depth(outputs_1[("disp", 0)])
+        else:
+            depths = unlabeled_inputs["pseudo_depth"]
+        if backward_first_pseudo_label:
+            L_1, _ = calc_pseudo_label_loss(softmax_u_w, outputs_1["semantics"], consistency_weight)
+            with nosync():
+                L_1.backward()
+        del outputs_1
+    elif "pseudo_depth" in unlabeled_inputs:
+        depths = unlabeled_inputs["pseudo_depth"]
+    else:
+        depths = [None] * unlabeled_imgs.shape[0]
+    # third step: mix (train.py:704-724)
+    if torch.is_tensor(mix_mask):
+        MixMask = mix_mask                    # a precomputed mask (tests; pre-generated masks of a data pipeline)
+    else:
+        MixMask = generate_mix_mask(mix_mask, argmax_u_w, unlabeled_imgs, depths, depthcomp_margin,
+                                    depthcomp_foreground_threshold)
+    strong_parameters = {"Mix": MixMask, "ColorJitter": random.uniform(0, 1) if color_jitter else 0,
+                         "GaussianBlur": random.uniform(0, 1) if blur else 0}
+    inputs_u_s, _ = strong_transform(strong_parameters, data=unlabeled_imgs)
+    mixed_inputs = dict(unlabeled_inputs)
+    mixed_inputs[("color_aug", 0, 0)] = inputs_u_s
+    outputs = model(mixed_inputs)
+    softmax_u_w_mixed, _ = strong_transform(strong_parameters, data=softmax_u_w)
+    L_2, pseudo_label = calc_pseudo_label_loss(softmax_u_w_mixed, outputs["semantics"], consistency_weight)
+    if last_backward:
+        L_2.backward()
+    else:
+        with nosync():
+            L_2.backward()
+    train_step_segmentation_unlabeled.last = {"MixMask": MixMask, "depths": depths, "pseudo_label": pseudo_label,
+                                              "softmax_u_w": softmax_u_w, "inputs_u_s": inputs_u_s}   # debug images :726-744
+    return L_2 + L_1, mono_loss

@@ -253,6 +253,15 @@ int segsde_pseudo_label(const float* prob_nchw, int B, int C, long HW, float thr
 int segsde_confusion_update(const float* logits, long sb, long sc, long sp, const int64_t* pred, const int64_t* gt, int B,
                             long HW, int C, unsigned long long* hist, void* stream);
 
+/* Teacher softmax of the unlabeled step, train.py:666 (torch.softmax(logits_u_w, dim=1)): NHWC logits rows (pitch ld)
+ * -> class probabilities in NCHW planar layout, the layout segsde_mix / segsde_pseudo_label read. */
+int segsde_softmax_nhwc_to_nchw(const float* logits, int ld, int B, long HW, int C, float* out_nchw, void* stream);
+/* Online-depth normalisation for the depthcomp mask, train.py:690-697: per sample b, out = (x - min_b) / (max_b - min_b)
+ * (the reference's clamp to [min, max] is the identity); minmax (nullable) receives [B][2] = {min_b, max_b}. */
+size_t segsde_minmax_normalize_workspace(int B, long HW);
+int segsde_minmax_normalize(const float* x, int B, long HW, float* out, float* minmax, void* workspace, size_t workspace_bytes,
+                            void* stream);
+
 #ifdef __cplusplus
 }
 #endif

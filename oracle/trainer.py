@@ -42,3 +42,33 @@ def calc_pseudo_label_loss(teacher_softmax, student_logits, consistency_weight, 
     pixel_weight = unlabeled_weight * torch.ones(max_probs.shape)
     L_u = consistency_weight * cross_entropy2d(student_logits, pseudo_label, pixel_weights=pixel_weight)
     return L_u, pseudo_label
+
+
+def train_step_segmentation_unlabeled(sd_student, sd_teacher, model_cfg, loss_oracle, unlabeled_inputs, margin=0.03,
+                                      foreground_threshold=0.0, consistency_weight=1.0, monodepth_lambda=1.0,
+                                      tiebreak_noise=None, mask_override=None, dropout=False):
+    """/root/reference/train.py:653-724 with exp-212 flags (mix_mask "depthcomp", depthmix_online_depth True,
+    backward_first_pseudo_label False, jitter / blur off): teacher forward -> softmax (:664-666); student forward on the
+    unmixed frames -> monodepth loss backward (:679-689) and min-max normalised online disparity (:690-697); depthcomp
+    mask (:585-604); mix of image and teacher softmax (:717-722); student forward on the mixed frames; pseudo-label loss
+    backward (:723-724).  ``sd_student`` leaves accumulate .grad.  Returns a dict of the intermediate tensors."""
+    from . import nets as N, segmix as S
+    with torch.no_grad():
+        out_t = N.model_forward({k: v.detach() for k, v in sd_teacher.items()}, model_cfg, dict(unlabeled_inputs), train=True,
+                                dropout=dropout, use_pose_net=False)
+    softmax_u_w = torch.softmax(out_t["semantics"].detach(), dim=1)
+    out_1 = N.model_forward(sd_student, model_cfg, dict(unlabeled_inputs), train=True, dropout=dropout)
+    loss_oracle.generate_images_pred(unlabeled_inputs, out_1)
+    mono = monodepth_lambda * loss_oracle.compute_losses(unlabeled_inputs, out_1, tiebreak_noise=tiebreak_noise)["loss"]
+    mono.backward()
+    depths = S.normalize_disparity(out_1[("disp", 0)].detach())
+    mask = S.depthcomp_mask(depths, margin, foreground_threshold) if mask_override is None else mask_override
+    img_mixed, _ = S.mix(mask, data=unlabeled_inputs[("color_aug", 0, 0)])
+    inp2 = dict(unlabeled_inputs)
+    inp2[("color_aug", 0, 0)] = img_mixed
+    out_2 = N.model_forward(sd_student, model_cfg, inp2, train=True, dropout=dropout)
+    soft_mixed, _ = S.mix(mask, data=softmax_u_w)
+    L_2, label = calc_pseudo_label_loss(soft_mixed, out_2["semantics"], consistency_weight)
+    L_2.backward()
+    return {"softmax_u_w": softmax_u_w, "depths": depths, "mask": mask, "img_mixed": img_mixed, "soft_mixed": soft_mixed,
+            "L_2": L_2.detach(), "mono_loss": mono.detach(), "pseudo_label": label, "disp0": out_1[("disp", 0)].detach()}

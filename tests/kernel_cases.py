@@ -478,6 +478,31 @@ def run_trainer_cases(device, golden):
     assert torch.equal(pw.cpu(), torch.full(mx.shape, int((mx >= 0.968).sum()) / mx.numel(), dtype=torch.float32))
 
 
+def run_depthmix_teacher_cases(device):
+    """teacher softmax (train.py:666) and online-depth normalisation (train.py:690-697) kernels vs the torch ops"""
+    from improving_segmentation_with_selfsupervised_depth_amd import trainer as T
+    gen = torch.Generator().manual_seed(5)
+    for (B, C, Hh, W) in ((2, 19, 24, 40), (1, 19, 7, 37), (2, 5, 16, 16)):
+        lg = (torch.randn(B, Hh, W, C, generator=gen) * 4).to(device)
+        want = torch.softmax(lg.cpu().permute(0, 3, 1, 2), dim=1)
+        got = T.teacher_softmax(lg.permute(0, 3, 1, 2))
+        assert got.is_contiguous() and tuple(got.shape) == (B, C, Hh, W)
+        assert_close(got, want, rtol=2e-6, atol=1e-9, what="teacher softmax")
+        wide = (torch.randn(B, Hh, W, C + 13, generator=gen) * 4).to(device)       # a channel slice of a wider buffer
+        got = H.softmax_to_nchw(wide[..., 3:3 + C])
+        assert_close(got, torch.softmax(wide.cpu()[..., 3:3 + C].permute(0, 3, 1, 2), dim=1), rtol=2e-6, atol=1e-9, what="softmax slice")
+        got = T.teacher_softmax(lg.permute(0, 3, 1, 2).contiguous())                 # dense NCHW logits take the layout kernel
+        assert_close(got, want, rtol=2e-6, atol=1e-9, what="teacher softmax (NCHW in)")
+    for shape in ((2, 1, 33, 65), (3, 1, 8, 8), (1, 1, 300, 700)):
+        d = torch.rand(shape, generator=gen).to(device)
+        want = d.cpu().clone()
+        for j in range(shape[0]):
+            lo, hi = want[j].min(), want[j].max()
+            want[j] = (torch.clamp(want[j], lo, hi) - lo) / (hi - lo)
+        got = T.normalize_online_depth(d)
+        assert torch.equal(got.cpu(), want), "min-max normalised disparity must be bit-exact"
+
+
 def run_metric_cases(device, golden):
     """runningScore mirror (device-resident confusion matrix) vs the reference's vectors: exact"""
     import numpy as np

@@ -48,6 +48,10 @@ def test_trainer_rows(golden):
     KC.run_trainer_cases("cpu", golden)
 
 
+def test_depthmix_teacher_kernels():
+    KC.run_depthmix_teacher_cases("cpu")
+
+
 def test_validation_metric(golden):
     KC.run_metric_cases("cpu", golden)
 

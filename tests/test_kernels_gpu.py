@@ -74,6 +74,10 @@ def test_trainer_rows(golden):
     KC.run_trainer_cases("cuda", golden)
 
 
+def test_depthmix_teacher_kernels():
+    KC.run_depthmix_teacher_cases("cuda")
+
+
 def test_validation_metric(golden):
     KC.run_metric_cases("cuda", golden)
 

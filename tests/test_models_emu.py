@@ -41,3 +41,4 @@ def test_encoder_r18(golden):
 
 def test_monodepth_loss_vs_reference(golden):
     MC.run_loss_vs_reference("cpu", golden)
+

@@ -235,3 +235,15 @@ def test_depthmix_unlabeled_step_vs_oracle():
     sp = dict(student.named_parameters())
     for k, v in teacher.named_parameters():
         assert torch.equal(v.data, a * before[k] + b * sp[k].data), k
+
+
+def test_reducer_around_real_model_nccl():
+    """cfg4's exchange step on the GPU: a 1-rank nccl (RCCL) group around the real ResNet-18 joint model -- gradients
+    through the bucketed all-reducer are bit-identical to the un-reduced run, dead disparity heads stay out of the
+    buckets, multi-backward steps reduce once per bucket"""
+    MC.run_reducer_real_model("cuda", "nccl")
+
+
+def test_unlabeled_step_function_vs_oracle():
+    """cfg5's step function (trainer.train_step_segmentation_unlabeled) vs the oracle restatement of train.py:653-724"""
+    MC.run_unlabeled_step("cuda")
