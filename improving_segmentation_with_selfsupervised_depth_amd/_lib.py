@@ -9,7 +9,7 @@ from ctypes import c_int, c_long, c_float, c_void_p, c_size_t, c_uint64, c_int64
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SEGSDE_LIB") or os.path.join(_HERE, "libsegsde_hip.so")   # override: kernel experiments
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _LIB = None
 # Set only by the test-suite when it injects the host-interpreted build of the same kernel sources
@@ -89,7 +89,8 @@ _SIGS = {
     "segsde_pseudo_label": (c_int, [P, c_int, c_int, c_long, c_float, c_int64, P, P, P, P, P]),
     "segsde_softmax_nhwc_to_nchw": (c_int, [P, c_int, c_int, c_long, c_int, P, P]),
     "segsde_minmax_normalize_workspace": (c_size_t, [c_int, c_long]),
-    "segsde_minmax_normalize": (c_int, [P, c_int, c_long, P, P, P, c_size_t, P]),
+    "segsde_minmax_normalize": (c_int, [P, c_int, c_long, P, P, P, P, c_size_t, P]),
+    "segsde_disp_to_depth": (c_int, [P, c_int, c_int, c_int, c_int, c_int, c_float, c_float, P, P]),
 }
 EXPORTS = sorted(_SIGS)
 

@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void minmax_partial_kernel(const float* x, lon
 // every block folds the (<= 512) partials of its sample itself, then out = (x - min) / (max - min): the reference's two
 // fp32 ops (train.py:696; its clamp to [min, max] is the identity)
 __global__ __launch_bounds__(256) void minmax_apply_kernel(const float* x, long HW, const float* part, int nblk, float* out,
-                                                          float* minmax /*[B][2] or null*/) {
+                                                          float* minmax /*[B][2] or null*/, uint8_t* out_u8 /*or null*/) {
   SEGSDE_SMEM;
   float* sh = reinterpret_cast<float*>(segsde_smem);
   const int b = blockIdx.y;
@@ -85,8 +85,12 @@ __global__ __launch_bounds__(256) void minmax_apply_kernel(const float* x, long 
   if (minmax && blockIdx.x == 0 && threadIdx.x == 0) { minmax[2 * b] = mn; minmax[2 * b + 1] = mx; }
   const float range = mx - mn;
   const float* xb = x + (long)b * HW;
-  float* ob = out + (long)b * HW;
-  for (long e = blockIdx.x * 256L + threadIdx.x; e < HW; e += (long)gridDim.x * 256) ob[e] = (xb[e] - mn) / range;
+  for (long e = blockIdx.x * 256L + threadIdx.x; e < HW; e += (long)gridDim.x * 256) {
+    const float v = (xb[e] - mn) / range;
+    if (out) out[(long)b * HW + e] = v;
+    // the stored depth estimate: torchvision ToPILImage on a float tensor = mul(255).byte() (truncation)
+    if (out_u8) out_u8[(long)b * HW + e] = (uint8_t)(v * 255.f);
+  }
 }
 inline int plane_blocks(long HW) { long nb = (HW + 255) / 256; return (int)(nb < 1 ? 1 : (nb > 512 ? 512 : nb)); }
 }  // namespace
@@ -106,15 +110,15 @@ extern "C" size_t segsde_minmax_normalize_workspace(int B, long HW) {
   return (size_t)B * plane_blocks(HW) * 2 * sizeof(float);
 }
 
-extern "C" int segsde_minmax_normalize(const float* x, int B, long HW, float* out, float* minmax, void* ws, size_t ws_bytes,
-                                       void* stream) {
-  if (!x || !out || !ws) return SEGSDE_ERR_NULL;
+extern "C" int segsde_minmax_normalize(const float* x, int B, long HW, float* out, float* minmax, uint8_t* out_u8, void* ws,
+                                       size_t ws_bytes, void* stream) {
+  if (!x || (!out && !out_u8) || !ws) return SEGSDE_ERR_NULL;
   if (B <= 0 || HW <= 0) return SEGSDE_ERR_SHAPE;
   if (ws_bytes < segsde_minmax_normalize_workspace(B, HW)) return SEGSDE_ERR_WORKSPACE;
   const int nb = plane_blocks(HW);
   hipLaunchKernelGGL(minmax_partial_kernel, dim3(nb, B), dim3(256), 64, ST(stream), x, HW, (float*)ws);
   SEGSDE_CHECK_LAUNCH();
-  hipLaunchKernelGGL(minmax_apply_kernel, dim3(nb, B), dim3(256), 64, ST(stream), x, HW, (const float*)ws, nb, out, minmax);
+  hipLaunchKernelGGL(minmax_apply_kernel, dim3(nb, B), dim3(256), 64, ST(stream), x, HW, (const float*)ws, nb, out, minmax, out_u8);
   SEGSDE_CHECK_LAUNCH();
   return 0;
 }

@@ -112,6 +112,21 @@ __global__ __launch_bounds__(256) void warp_fwd_kernel(const float* disp, int hs
   }
 }
 
+// generate_depth_test_pred (loss/monodepth_loss.py:54-62): upsample + disp_to_depth only
+__global__ __launch_bounds__(256) void disp_to_depth_kernel(const float* disp, int hs, int ws, int H, int W, float min_disp,
+                                                            float max_disp, float* depth) {
+  const int b = blockIdx.y;
+  const long HW = (long)H * W;
+  const float* disp_b = disp + (long)b * hs * ws;
+  for (long p = blockIdx.x * 256L + threadIdx.x; p < HW; p += (long)gridDim.x * 256) {
+    const int h = (int)((unsigned)p / (unsigned)W), w = (int)p - h * W;
+    const Lerp lh = lerp_half(h, hs, H), lw = lerp_half(w, ws, W);
+    const float d = lh.l0 * (lw.l0 * disp_b[lh.i0 * ws + lw.i0] + lw.l1 * disp_b[lh.i0 * ws + lw.i1]) +
+                    lh.l1 * (lw.l0 * disp_b[lh.i1 * ws + lw.i0] + lw.l1 * disp_b[lh.i1 * ws + lw.i1]);
+    depth[b * HW + p] = 1.f / (min_disp + (max_disp - min_disp) * d);
+  }
+}
+
 // adjoint: gcolor [B,3,H,W] -> g_disp_up [B,H,W] (+=) and per-block partial sums of dL/dP (3x4) per batch element
 __global__ __launch_bounds__(256) void warp_bwd_kernel(const float* gcolor, const float* disp, int hs, int ws,
                                                        const float* inv_K, const float* K, const float* T,
@@ -497,6 +512,16 @@ extern "C" int segsde_warp_forward(const float* disp, int hs, int ws, const floa
   if (B <= 0 || H < 2 || W < 2 || hs <= 0 || ws <= 0 || (long)H * W >= (1L << 31)) return SEGSDE_ERR_SHAPE;
   hipLaunchKernelGGL(warp_fwd_kernel, dim3(plane_blocks((long)H * W), B), dim3(256), 512, ST(stream), disp, hs, ws, inv_K, K,
                      T, src, H, W, 1.f / max_depth, 1.f / min_depth, color, grid, depth);
+  SEGSDE_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int segsde_disp_to_depth(const float* disp, int hs, int ws, int B, int H, int W, float min_depth, float max_depth,
+                                    float* depth, void* stream) {
+  if (!disp || !depth) return SEGSDE_ERR_NULL;
+  if (B <= 0 || H < 1 || W < 1 || hs <= 0 || ws <= 0 || (long)H * W >= (1L << 31)) return SEGSDE_ERR_SHAPE;
+  hipLaunchKernelGGL(disp_to_depth_kernel, dim3(plane_blocks((long)H * W), B), dim3(256), 0, ST(stream), disp, hs, ws, H, W,
+                     1.f / max_depth, 1.f / min_depth, depth);
   SEGSDE_CHECK_LAUNCH();
   return 0;
 }

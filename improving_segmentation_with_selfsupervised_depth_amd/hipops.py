@@ -659,17 +659,30 @@ def softmax_to_nchw(logits_nhwc):
     return out
 
 
-def minmax_normalize(x):
-    """x: [B, ...] -> (x - min_b) / (max_b - min_b) per sample b (train.py:690-697)"""
+def minmax_normalize(x, as_uint8=False):
+    """x: [B, ...] -> (x - min_b) / (max_b - min_b) per sample b (train.py:690-697); as_uint8: the 8-bit image
+    loader/depth_estimator.py:83-91 stores (mul(255).byte() of the normalised map) instead"""
     x = _f32(x).contiguous()
     B = x.shape[0]
     HW = x[0].numel()
-    out = torch.empty_like(x)
+    out = torch.empty(x.shape, dtype=torch.uint8 if as_uint8 else torch.float32, device=x.device)
     L = _lib.lib()
     nb = L.segsde_minmax_normalize_workspace(B, HW)
     ws_ = _ws(nb, x)
-    check(L.segsde_minmax_normalize(_p(x), B, HW, _p(out), None, _p(ws_), nb, _stream(x)), "minmax_normalize")
+    check(L.segsde_minmax_normalize(_p(x), B, HW, None if as_uint8 else _p(out), None, _p(out) if as_uint8 else None,
+                                    _p(ws_), nb, _stream(x)), "minmax_normalize")
     return out
+
+
+def disp_to_depth_upsampled(disp, out_hw, min_depth, max_depth):
+    """[B,1,hs,ws] disparity -> [B,1,H,W] depth (loss/monodepth_loss.py:54-62)"""
+    disp = _f32(disp).contiguous()
+    B, _, hs, ws = disp.shape
+    Hh, W = out_hw
+    depth = torch.empty((B, 1, Hh, W), dtype=torch.float32, device=disp.device)
+    check(_lib.lib().segsde_disp_to_depth(_p(disp), hs, ws, B, Hh, W, float(min_depth), float(max_depth), _p(depth),
+                                          _stream(disp)), "disp_to_depth")
+    return depth
 
 
 def confusion_update(hist, gt, pred=None, logits=None):

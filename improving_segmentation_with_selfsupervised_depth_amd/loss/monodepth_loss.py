@@ -124,12 +124,8 @@ class MonodepthLoss:
         """reference :54-62 (eval only)"""
         assert tuple(outputs[("disp", 0)].shape[-2:]) == (self.height, self.width), outputs[("disp", 0)].shape[-2:]
         for s in self.scales:
-            d = outputs[("disp", s)].detach().contiguous()
-            B, _, hs, ws = d.shape
-            up = H.resize_bilinear(d.reshape(B, hs, ws, 1), (self.height, self.width), False)
-            up = up.reshape(B, 1, self.height, self.width)
-            lo, hi = 1.0 / self.test_max_depth, 1.0 / self.test_min_depth
-            outputs[("depth", 0, s)] = 1.0 / (lo + (hi - lo) * up)
+            outputs[("depth", 0, s)] = H.disp_to_depth_upsampled(outputs[("disp", s)].detach(), (self.height, self.width),
+                                                                 self.test_min_depth, self.test_max_depth)
 
     def generate_images_pred(self, inputs, outputs):
         """reference :64-102; tensors written to ``outputs`` are detached (the differentiable path is compute_losses)"""

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SEGSDE_ABI_VERSION 2
+#define SEGSDE_ABI_VERSION 3
 
 enum { SEGSDE_ERR_NULL = -1, SEGSDE_ERR_SHAPE = -2, SEGSDE_ERR_WORKSPACE = -3, SEGSDE_ERR_UNSUPPORTED = -4 };
 enum { SEGSDE_ACT_NONE = 0, SEGSDE_ACT_RELU = 1, SEGSDE_ACT_ELU = 2, SEGSDE_ACT_SIGMOID = 3 };
@@ -256,11 +256,17 @@ int segsde_confusion_update(const float* logits, long sb, long sc, long sp, cons
 /* Teacher softmax of the unlabeled step, train.py:666 (torch.softmax(logits_u_w, dim=1)): NHWC logits rows (pitch ld)
  * -> class probabilities in NCHW planar layout, the layout segsde_mix / segsde_pseudo_label read. */
 int segsde_softmax_nhwc_to_nchw(const float* logits, int ld, int B, long HW, int C, float* out_nchw, void* stream);
-/* Online-depth normalisation for the depthcomp mask, train.py:690-697: per sample b, out = (x - min_b) / (max_b - min_b)
- * (the reference's clamp to [min, max] is the identity); minmax (nullable) receives [B][2] = {min_b, max_b}. */
+/* Online-depth normalisation for the depthcomp mask, train.py:690-697, and the stored depth estimates of
+ * DepthEstimator.prepare_depth_estimates, loader/depth_estimator.py:83-91: per sample b, out = (x - min_b) / (max_b - min_b)
+ * (the reference's clamp to [min, max] is the identity); minmax (nullable) receives [B][2] = {min_b, max_b}; out_u8
+ * (nullable) receives the 8-bit image ToPILImage makes of it (mul(255).byte()).  At least one of out / out_u8. */
 size_t segsde_minmax_normalize_workspace(int B, long HW);
-int segsde_minmax_normalize(const float* x, int B, long HW, float* out, float* minmax, void* workspace, size_t workspace_bytes,
-                            void* stream);
+int segsde_minmax_normalize(const float* x, int B, long HW, float* out, float* minmax, uint8_t* out_u8, void* workspace,
+                            size_t workspace_bytes, void* stream);
+/* Test-time depth, MonodepthLoss.generate_depth_test_pred, loss/monodepth_loss.py:54-62: bilinear upsample of disp
+ * [B,1,hs,ws] to H x W (align_corners=False) and disp_to_depth (monodepth_layers.py:18-27) with the test depth range. */
+int segsde_disp_to_depth(const float* disp, int hs, int ws, int B, int H, int W, float min_depth, float max_depth,
+                         float* depth, void* stream);
 
 #ifdef __cplusplus
 }

@@ -492,3 +492,14 @@ def model_forward(sd, model_cfg, inputs, train=True, dropout=False, use_pose_net
             out[("axisangle", 0, f)], out[("translation", 0, f)] = aa, tr
             out[("cam_T_cam", 0, f)] = G.pose_matrix(aa[:, 0], tr[:, 0], invert=(f < 0))
     return out
+
+
+def predict_test_disp(sd, model_cfg, inputs):
+    """joint_segmentation_depth.py:72-75 in eval mode (BatchNorm running statistics, no dropout), as
+    loader/depth_estimator.py:63-81 calls it: depth decoder on the encoder features of ("color", 0, 0)."""
+    c = Ctx(sd, False, False)
+    nl = int(model_cfg["backbone_name"].replace("resnet", ""))
+    feats = resnet_features(c, "models.encoder.encoder.", inputs[("color", 0, 0)], nl,
+                            model_cfg.get("replace_stride_with_dilation"))
+    return decoder_forward(c, "models.depth.", decoder_plan(num_ch_enc(nl), range(model_cfg["num_scales"]),
+                                                            **_depth_args(model_cfg)), feats)

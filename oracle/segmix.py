@@ -84,3 +84,14 @@ def pseudo_label(teacher_softmax, ignore_index=250, threshold=0.968):
     lab[max_probs == 0] = ignore_index
     weight = (max_probs.ge(threshold).long() == 1).sum().item() / float(lab.numel())
     return lab, weight
+
+
+def depth_estimate_u8(disp0):
+    """/root/reference/loader/depth_estimator.py:83-91: per image clamp, min-max normalise, ToPILImage (float tensor ->
+    mul(255).byte()).  disp0 [B,1,H,W] -> uint8 [B,H,W]."""
+    out = []
+    for depth in disp0:
+        dmin, dmax = torch.min(depth), torch.max(depth)
+        depth = (torch.clamp(depth, dmin, dmax) - dmin) / (dmax - dmin)
+        out.append(depth.squeeze(0).mul(255).byte())
+    return torch.stack(out)

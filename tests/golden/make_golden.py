@@ -635,7 +635,49 @@ def gen_trainer():
     save("trainer", d)
 
 
+def gen_valtail():
+    """Validation tail: MonodepthLoss.generate_depth_test_pred (loss/monodepth_loss.py:54-62),
+    JointSegmentationMonodepth.predict_test_disp in eval mode (models/joint_segmentation_depth.py:72-75, called by
+    loader/depth_estimator.py:80-81) and the min-max-normalised 8-bit disparity DepthEstimator.prepare_depth_estimates
+    stores (loader/depth_estimator.py:83-91: clamp, normalise, ToPILImage = mul(255).byte())."""
+    cfg = model_cfgs()["r18_mono"]
+    torch.manual_seed(0)
+    m = ref_get_model(cfg, 19)
+    sd = onets.build_state_dict(cfg, 19, seed=77, randomize_bn=True)
+    m.load_state_dict(sd, strict=True)
+    m.eval()
+    gen = torch.Generator().manual_seed(6)
+    B, H, W = 2, 64, 128
+    inputs, _, _, _ = make_loss_inputs(B, H, W, gen)
+    loss_obj = RefMonodepthLoss(num_scales=4, frame_ids=[0, -1, 1], height=H, width=W, batch_size=B, min_depth=0.1,
+                                max_depth=100, test_min_depth=1e-3, test_max_depth=80, disparity_smoothness=1e-3,
+                                no_ssim=False, avg_reprojection=False, disable_automasking=False, is_train=False)
+    with torch.no_grad():
+        out = m.predict_test_disp(inputs)
+        loss_obj.generate_depth_test_pred(out)
+    d = {"sd_hash": sd_hash(sd), "in_color_0_0": inputs[("color", 0, 0)]}
+    for s_ in range(4):
+        d["disp_%d" % s_] = out[("disp", s_)]
+        d["depth_%d" % s_] = out[("depth", 0, s_)]
+    imgs = []
+    for depth in out[("disp", 0)].cpu():
+        dmin, dmax = torch.min(depth), torch.max(depth)
+        depth = torch.clamp(depth, dmin, dmax)
+        depth = (depth - dmin) / (dmax - dmin)
+        imgs.append(depth.squeeze(0).mul(255).byte())          # torchvision ToPILImage on a float tensor: mul(255).byte()
+    d["export_u8"] = torch.stack(imgs)
+    # generate_depth_test_pred alone on seeded disparities (no network in front)
+    disps = {s_: (0.02 + 0.96 * torch.rand(B, 1, H // 2 ** s_, W // 2 ** s_, generator=gen)) for s_ in range(4)}
+    o2 = {("disp", s_): disps[s_] for s_ in range(4)}
+    loss_obj.generate_depth_test_pred(o2)
+    for s_ in range(4):
+        d["rnd_disp_%d" % s_] = disps[s_]
+        d["rnd_depth_%d" % s_] = o2[("depth", 0, s_)]
+    save("valtail", d)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["loss", "geom", "ssim_smooth", "segmix", "blocks", "decoders", "encoder", "nets", "trainer"]
+    which = sys.argv[1:] or ["loss", "geom", "ssim_smooth", "segmix", "blocks", "decoders", "encoder", "nets", "trainer",
+                             "valtail"]
     for w in which:
         globals()["gen_" + w]()

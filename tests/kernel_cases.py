@@ -503,6 +503,23 @@ def run_depthmix_teacher_cases(device):
         assert torch.equal(got.cpu(), want), "min-max normalised disparity must be bit-exact"
 
 
+def run_valtail_kernel_cases(device, golden):
+    """generate_depth_test_pred and the 8-bit depth export vs the reference's vectors"""
+    from improving_segmentation_with_selfsupervised_depth_amd.loss import get_monodepth_loss
+    g = golden("valtail")
+    B, _, Hh, W = g["rnd_disp_0"].shape
+    cfg = {"training": {"batch_size": B, "monodepth_loss": dict(
+        num_scales=4, frame_ids=[0, -1, 1], height=Hh, width=W, min_depth=0.1, max_depth=100, test_min_depth=1e-3,
+        test_max_depth=80, disparity_smoothness=1e-3, no_ssim=False, avg_reprojection=False, disable_automasking=False)}}
+    lo = get_monodepth_loss(cfg, is_train=False)
+    out = {("disp", s): g["rnd_disp_%d" % s].to(device) for s in range(4)}
+    lo.generate_depth_test_pred(out)
+    for s in range(4):
+        assert_close(out[("depth", 0, s)], g["rnd_depth_%d" % s], rtol=1e-5, atol=0, what="test depth %d" % s)
+    u8 = H.minmax_normalize(g["disp_0"].to(device), as_uint8=True)
+    assert torch.equal(u8[:, 0].cpu(), g["export_u8"]), "8-bit depth estimate must be bit-exact"
+
+
 def run_metric_cases(device, golden):
     """runningScore mirror (device-resident confusion matrix) vs the reference's vectors: exact"""
     import numpy as np

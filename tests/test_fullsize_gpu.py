@@ -1,0 +1,228 @@
+"""GPU (-m gpu): parity spot-checks AT THE BENCHMARK'S OWN SIZE (batch 16, 512x1024; activations of 2.1 GB, i.e. above
+2^31 bytes): every kernel runs on the full tensor, then sampled outputs -- corners and borders of the first and the LAST
+image, reflection borders, the region past 2^31 bytes, random interior -- are recomputed in float64 from the definition
+(tests/spotcheck.py, pinned against torch autograd by tests/test_spotcheck_ref.py) or by the CPU oracle on one image.
+Also: the loss after two optimiser steps of the headline model at 512x1024 equals the oracle's."""
+import numpy as np
+import pytest
+import torch
+
+import spotcheck as SC
+from kernel_cases import assert_close
+from improving_segmentation_with_selfsupervised_depth_amd import hipops as H
+
+pytestmark = pytest.mark.gpu
+B16 = 16
+
+
+def _cmp(got, want, what, rtol=1e-3, arel=1e-4):
+    got, want = got.double().cpu(), want.double().cpu()
+    tol = rtol * want.abs() + arel * float(want.abs().max())
+    err = (got - want).abs()
+    assert bool((err <= tol).all()), "%s: max err %.3e at scale %.3e (worst ratio %.2f)" % (
+        what, float(err.max()), float(want.abs().max()), float((err / tol).max()))
+
+
+# name, C0, C1, up0, Cout, k, dil, pad, reflect, act, (H, W) virtual input size
+GEOMS = [
+    ("64->64 refl up @512x1024", 64, 0, True, 64, 3, 1, 1, True, "elu", (512, 1024)),
+    ("128up+64->128 refl @256x512", 128, 64, True, 128, 3, 1, 1, True, "elu", (256, 512)),
+    ("2048->256 d18 @32x64", 2048, 0, False, 256, 3, 18, 18, False, "none", (32, 64)),
+]
+
+
+@pytest.mark.parametrize("geom", GEOMS, ids=[g[0] for g in GEOMS])
+def test_conv_fullsize_sampled(geom):
+    name, C0, C1, up0, Cout, k, dil, pad, reflect, act, (Hh, W) = geom
+    dev = "cuda"
+    gen = torch.Generator(device=dev).manual_seed(3)
+    h0, w0 = (Hh // 2, W // 2) if up0 else (Hh, W)
+    x0 = torch.randn(B16, h0, w0, C0, device=dev, generator=gen)
+    x1 = torch.randn(B16, Hh, W, C1, device=dev, generator=gen) if C1 else None
+    wt = torch.randn(Cout, C0 + C1, k, k, device=dev, generator=gen) * (1.0 / np.sqrt((C0 + C1) * k * k))
+    bias = torch.randn(Cout, device=dev, generator=gen) * 0.1 if act != "none" else None
+    g = H.ConvGeom(C0, Cout, k, 1, dil, pad, reflect, C1, up0)
+    wp, wd = H.pack_weight_both(wt)
+    # ---- forward (no activation in the comparison: the pre-activation is what the definition gives)
+    y = H.conv_forward(g, x0, x1, wp, bias, "none")
+    assert tuple(y.shape) == (B16, Hh, W, Cout)
+    pos = SC.pick_positions(B16, Hh, W, 64, seed=1, extra=[(B16 - 1, Hh - 1 - dil, W - 1 - dil), (B16 - 1, dil, dil)])
+    want = SC.conv_samples(x0, x1, up0, wt, bias, 1, dil, pad, reflect, pos)
+    got = torch.stack([y[p] for p in pos])
+    _cmp(got, want, name + " forward")
+    if act != "none":
+        ya = H.conv_forward(g, x0, x1, wp, bias, act)
+        _cmp(torch.stack([ya[p] for p in pos]), torch.nn.functional.elu(want), name + " forward+ELU")
+        del ya
+    del y
+    # ---- data gradient
+    dy = torch.randn(B16, Hh, W, Cout, device=dev, generator=gen)
+    dx0, dx1 = H.conv_dgrad(g, dy, wd, wt, (Hh, W))
+    pos0 = SC.pick_positions(B16, h0, w0, 48, seed=2)
+    want = SC.dgrad_samples(dy, wt, (Hh, W), 0, C0, up0, 1, dil, pad, reflect, pos0)
+    _cmp(torch.stack([dx0[p] for p in pos0]), want, name + " dgrad src0")
+    if C1:
+        pos1 = SC.pick_positions(B16, Hh, W, 48, seed=3)
+        want = SC.dgrad_samples(dy, wt, (Hh, W), C0, C0 + C1, False, 1, dil, pad, reflect, pos1)
+        _cmp(torch.stack([dx1[p] for p in pos1]), want, name + " dgrad src1")
+    del dx0, dx1
+    # ---- weight gradient (sampled taps; each one a reduction over all 16 x H x W output pixels)
+    dw = H.conv_wgrad(g, x0, x1, dy)
+    rng = np.random.RandomState(5)
+    taps = [(0, 0, 0, 0), (Cout - 1, C0 + C1 - 1, k - 1, k - 1), (Cout - 1, 0, 0, k - 1), (0, C0 + C1 - 1, k - 1, 0)]
+    if C1:
+        taps += [(1, C0 - 1, 1, 1), (1, C0, 1, 1)]       # both sides of the concat boundary
+    while len(taps) < 20:
+        taps.append((int(rng.randint(Cout)), int(rng.randint(C0 + C1)), int(rng.randint(k)), int(rng.randint(k))))
+    want = torch.tensor(SC.wgrad_samples(x0, x1, up0, dy, k, 1, dil, pad, reflect, taps), dtype=torch.float64)
+    got = torch.stack([dw[t] for t in taps])
+    _cmp(got, want, name + " wgrad", rtol=1e-3, arel=2e-4)
+
+
+def test_loss_kernels_fullsize_last_image_vs_oracle():
+    """warp / SSIM+L1 error at B=16, 512x1024: the LAST image of the batch (planes that start beyond 2^31 bytes for the
+    9-plane backward workspace) against the CPU oracle run on that one image"""
+    from oracle import geometry as G, photometric as P
+    dev = "cuda"
+    Hh, W = 512, 1024
+    gen = torch.Generator().manual_seed(8)
+    low = torch.rand(B16, 3, Hh // 8, W // 8, generator=gen)
+    tgt = (torch.nn.functional.interpolate(low, size=(Hh, W), mode="bilinear", align_corners=False) * 0.8
+           + 0.2 * torch.rand(B16, 3, Hh, W, generator=gen))
+    src = torch.roll(tgt, shifts=(1, -2), dims=(2, 3)) * 0.97 + 0.01
+    disp = 0.02 + 0.9 * torch.rand(B16, 1, Hh // 2, W // 2, generator=gen)
+    K = torch.tensor([[1.1 * W, 0, 0.5 * W, 0], [0, 1.1 * W, 0.5 * Hh, 0], [0, 0, 1, 0], [0, 0, 0, 1.0]]).repeat(B16, 1, 1)
+    K[:, 0, 2] += torch.arange(B16) * 0.5
+    iK = torch.linalg.pinv(K)
+    aa, tr = 0.01 * torch.randn(B16, 1, 3, generator=gen), 0.05 * torch.randn(B16, 1, 3, generator=gen)
+    T = G.pose_matrix(aa, tr, invert=False)
+    col, grid, depth = H.warp_forward(disp.to(dev), iK.to(dev), K.to(dev), T.to(dev), src.to(dev), 0.1, 100.0, True, True)
+    b = B16 - 1
+    d_up = torch.nn.functional.interpolate(disp[b:b + 1], [Hh, W], mode="bilinear", align_corners=False)
+    depth_o = G.disp_to_depth(d_up, 0.1, 100.0)[1]
+    grid_o = G.project(G.backproject(depth_o, iK[b:b + 1]), K[b:b + 1], T[b:b + 1], Hh, W)
+    col_o = G.warp(src[b:b + 1], grid_o)
+    assert_close(depth[b:b + 1], depth_o, rtol=1e-5, atol=0, what="depth (last image)")
+    assert_close(grid[b:b + 1], grid_o, rtol=1e-4, atol=2e-5, what="sampling grid (last image)")
+    assert_close(col[b:b + 1], col_o, rtol=1e-3, atol=3e-3, what="warped frame (last image)")   # sub-pixel position rounding x image gradient
+    err = torch.empty(B16, 1, Hh, W, device=dev)
+    H.reprojection_error(col, tgt.to(dev), False, err[:, 0])
+    err_o = P.reprojection_error(col[b:b + 1].cpu(), tgt[b:b + 1])
+    assert_close(err[b:b + 1], err_o, rtol=1e-3, atol=2e-5, what="SSIM+L1 error (last image)")
+    # backward of the error w.r.t. the warped frame, last image, vs autograd of the oracle
+    gerr = torch.rand(B16, 1, Hh, W, generator=gen)
+    gpred = H.reprojection_error_backward(col, tgt.to(dev), gerr.to(dev)[:, 0], False)
+    cl = col[b:b + 1].cpu().clone().requires_grad_(True)
+    (P.reprojection_error(cl, tgt[b:b + 1]) * gerr[b:b + 1]).sum().backward()
+    assert_close(gpred[b:b + 1], cl.grad, rtol=1e-3, atol=1e-3 * float(cl.grad.abs().max()), what="d err / d warped (last image)")
+
+
+def test_cross_entropy_and_bn_fullsize():
+    """cross_entropy2d on [16,19,512,1024] logits vs torch on the CPU (loss and sampled gradient rows), and BatchNorm
+    statistics / apply on a [16,512,1024,64] activation vs float64"""
+    from improving_segmentation_with_selfsupervised_depth_amd.loss.loss import cross_entropy2d
+    dev = "cuda"
+    Hh, W, C = 512, 1024, 19
+    gen = torch.Generator().manual_seed(2)
+    logits = (torch.randn(B16, Hh, W, C, generator=gen) * 3).to(dev).permute(0, 3, 1, 2).requires_grad_(True)
+    lbl = torch.randint(0, C, (B16, Hh, W), generator=gen)
+    lbl[torch.rand(B16, Hh, W, generator=gen) < 0.05] = 250
+    loss = cross_entropy2d(logits, lbl.to(dev))
+    loss.backward()
+    lc = logits.detach().cpu().double()
+    want = torch.nn.functional.cross_entropy(lc, lbl, ignore_index=250)
+    assert_close(loss, want, rtol=1e-5, what="cross entropy at 16x512x1024")
+    n_valid = int((lbl != 250).sum())
+    for (b, h, w) in SC.pick_positions(B16, Hh, W, 32, seed=4):
+        row = lc[b, :, h, w]
+        gw = torch.zeros(C, dtype=torch.float64)
+        if int(lbl[b, h, w]) != 250:
+            gw = torch.softmax(row, 0)
+            gw[int(lbl[b, h, w])] -= 1.0
+            gw = gw / n_valid
+        assert_close(logits.grad[b, :, h, w], gw, rtol=1e-4, atol=1e-12, what="CE gradient row")
+    del logits, lc
+    x = (torch.randn(B16, Hh, W, 64, generator=torch.Generator(device=dev).manual_seed(1), device=dev) * 2 + 0.5)
+    mean, invstd = H.bn_stats(x, None, None, 0.1, 1e-5, update_running=False)
+    xd = x.double()
+    m64 = xd.mean((0, 1, 2))
+    v64 = xd.var((0, 1, 2), unbiased=False)
+    del xd
+    assert_close(mean, m64, rtol=1e-5, atol=1e-6, what="BN mean (537M samples per channel)")
+    assert_close(invstd, 1.0 / torch.sqrt(v64 + 1e-5), rtol=1e-5, what="BN invstd")
+    gam = torch.rand(64, device=dev) + 0.5
+    bet = torch.randn(64, device=dev)
+    y = H.bn_apply(x, mean, invstd, gam, bet, None, "relu")
+    for p in SC.pick_positions(B16, Hh, W, 32, seed=6):
+        want = torch.relu((x[p].double() - m64) / torch.sqrt(v64 + 1e-5) * gam.double() + bet.double())
+        assert_close(y[p], want, rtol=1e-4, atol=1e-5, what="BN apply")
+
+
+def test_headline_model_two_steps_vs_oracle():
+    """cfg3 (ResNet-101 joint_seg_depth_dec, 512x1024, SGD + clip as bench.py runs it) at batch 2: forward, both losses,
+    backward, clip_grad_norm, SGD step, and the loss of the SECOND step -- which depends on every gradient of the first --
+    against the CPU oracle on identical weights, inputs and tie-break noise"""
+    from oracle import nets as N, photometric as P, segmix as S
+    from improving_segmentation_with_selfsupervised_depth_amd.models import get_model
+    from improving_segmentation_with_selfsupervised_depth_amd.loss import get_monodepth_loss
+    from improving_segmentation_with_selfsupervised_depth_amd.loss.loss import cross_entropy2d
+    import bench
+    import model_cases as MC
+    B, Hh, W = 2, 512, 1024
+    cfg = bench.model_cfg("cfg3", Hh, W)
+    sd = N.build_state_dict(cfg, 19, seed=11, randomize_bn=False)
+    inp = bench.synthetic_inputs(B, Hh, W, "cpu", 1234)
+    gen = torch.Generator().manual_seed(12)
+    noise = {s: torch.randn(B, 2, Hh, W, generator=gen) for s in range(4)}
+
+    def groups(named):
+        enc = [p for k, p in named if k.startswith("models.encoder.")]
+        rest = [p for k, p in named if not k.startswith("models.encoder.")]
+        return torch.optim.SGD([{"params": enc, "lr": 1e-3}, {"params": rest}], lr=1e-2, momentum=0.9, weight_decay=5e-4)
+
+    # ---- oracle (CPU)
+    torch.set_num_threads(max(1, min(64, len(__import__("os").sched_getaffinity(0)))))
+    sdo = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.clone())
+           for k, v in sd.items()}
+    leaves = [(k, v) for k, v in sdo.items() if v.is_floating_point() and v.requires_grad]
+    opt_o = groups(leaves)
+    lo = P.MonodepthLossOracle(**bench.loss_cfg(B, Hh, W)["training"]["monodepth_loss"], batch_size=B)
+    ref = []
+    for step in range(2):
+        opt_o.zero_grad(set_to_none=True)
+        out = N.model_forward(sdo, cfg, inp, train=True, dropout=False)
+        lo.generate_images_pred(inp, out)
+        mono = lo.compute_losses(inp, out, tiebreak_noise=noise)["loss"]
+        seg = S.cross_entropy2d(out["semantics"], inp["lbl"])
+        (mono + seg).backward()
+        used = [v for _, v in leaves if v.grad is not None]
+        gn = torch.nn.utils.clip_grad_norm_(used, 10.0)
+        opt_o.step()
+        ref.append((float(mono), float(seg), float(gn)))
+        del out
+    # ---- product (GPU)
+    model = get_model(cfg, 19)
+    model.load_state_dict(sd, strict=True)
+    model.cuda().train()
+    MC.dropout_eval(model)
+    opt = groups(list(model.named_parameters()))
+    lp = get_monodepth_loss(bench.loss_cfg(B, Hh, W), True)
+    lp.tiebreak_noise = noise
+    inp_d = {k: v.cuda() for k, v in inp.items()}
+    got = []
+    for step in range(2):
+        opt.zero_grad(set_to_none=True)
+        out = model(inp_d)
+        lp.generate_images_pred(inp_d, out)
+        mono = lp.compute_losses(inp_d, out)["loss"]
+        seg = cross_entropy2d(out["semantics"], inp_d["lbl"])
+        (mono + seg).backward()
+        gn = torch.nn.utils.clip_grad_norm_([p for p in model.parameters() if p.grad is not None], 10.0)
+        opt.step()
+        got.append((float(mono), float(seg), float(gn)))
+        del out
+    print("oracle (mono, seg, grad-norm) per step:", ref, "\nproduct:", got)
+    for step in range(2):
+        for i, what in enumerate(("mono loss", "seg loss", "gradient norm")):
+            tol = 1e-3 if i < 2 else 5e-3       # the norm squares ~100 M gradient entries, some of them ill-conditioned
+            assert abs(got[step][i] - ref[step][i]) <= tol * abs(ref[step][i]), (step, what, got[step][i], ref[step][i])

@@ -52,6 +52,10 @@ def test_depthmix_teacher_kernels():
     KC.run_depthmix_teacher_cases("cpu")
 
 
+def test_validation_tail_kernels(golden):
+    KC.run_valtail_kernel_cases("cpu", golden)
+
+
 def test_validation_metric(golden):
     KC.run_metric_cases("cpu", golden)
 

@@ -78,6 +78,10 @@ def test_depthmix_teacher_kernels():
     KC.run_depthmix_teacher_cases("cuda")
 
 
+def test_validation_tail_kernels(golden):
+    KC.run_valtail_kernel_cases("cuda", golden)
+
+
 def test_validation_metric(golden):
     KC.run_metric_cases("cuda", golden)
 

@@ -404,3 +404,29 @@ def test_validation_metric_vs_reference(golden):
     acc, acc_cls, fw, miou, iu = OM.scores(cm)
     np.testing.assert_allclose([acc, acc_cls, fw, miou], g["cm_scores"].numpy(), rtol=1e-12)
     np.testing.assert_allclose(iu, g["cm_cls_iu"].numpy(), rtol=1e-12, equal_nan=True)
+
+
+def test_validation_tail_vs_reference(golden):
+    """generate_depth_test_pred (monodepth_loss.py:54-62), predict_test_disp in eval mode
+    (joint_segmentation_depth.py:72-75) and the stored 8-bit depth estimate (depth_estimator.py:83-91)"""
+    import os
+    from conftest import GOLDEN
+    g = golden("valtail")
+    B, _, H, W = g["rnd_disp_0"].shape
+    obj = P.MonodepthLossOracle(num_scales=4, frame_ids=[0, -1, 1], height=H, width=W, batch_size=B, min_depth=0.1,
+                                max_depth=100, test_min_depth=1e-3, test_max_depth=80, disparity_smoothness=1e-3,
+                                no_ssim=False, avg_reprojection=False, disable_automasking=False, is_train=False)
+    out = {("disp", s): g["rnd_disp_%d" % s] for s in range(4)}
+    obj.generate_depth_test_pred(out)
+    for s in range(4):
+        close(out[("depth", 0, s)], g["rnd_depth_%d" % s], rtol=1e-6, atol=0)
+    cfg = json.load(open(os.path.join(GOLDEN, "state_dict_contract.json")))["cfgs"]["r18_mono"]
+    sd = N.build_state_dict(cfg, 19, seed=77, randomize_bn=True)
+    if _sd_hash(sd) != str(g["sd_hash"]):
+        pytest.skip("torch RNG stream differs from the build container: cannot regenerate seeded weights")
+    with torch.no_grad():
+        o = N.predict_test_disp(sd, cfg, {("color", 0, 0): g["in_color_0_0"]})
+    for s in range(4):
+        close(o[("disp", s)], g["disp_%d" % s], rtol=1e-4, atol=1e-6)
+    u8 = S.depth_estimate_u8(g["disp_0"])
+    assert torch.equal(u8, g["export_u8"])
