@@ -70,6 +70,11 @@ _SIGS = {
     "segsde_reprojection_error_forward": (c_int, [P, P, c_int, c_int, c_int, c_int, P, c_long, P]),
     "segsde_reprojection_error_backward_workspace": (c_size_t, [c_int, c_int, c_int]),
     "segsde_reprojection_error_backward": (c_int, [P, P, P, c_long, c_int, c_int, c_int, c_int, P, P, c_size_t, P]),
+    "segsde_photometric_workspace": (c_size_t, [c_int, c_int, c_int]),
+    "segsde_photometric_identity": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P, P]),
+    "segsde_photometric_forward": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P, P, P, P, c_size_t, P]),
+    "segsde_photometric_backward": (c_int, [P, P, P, P, c_int, P, c_int, c_int, P, P, P, P, P, P, c_int, c_int, c_int,
+                                            c_float, c_float, c_int, c_int, c_float, P, P, P, P, P, c_size_t, P]),
     "segsde_automask_workspace": (c_size_t, [c_int, c_int, c_int]),
     "segsde_automask_min_forward": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P, P, P, P, c_size_t, P]),
     "segsde_automask_min_backward": (c_int, [P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, P, P]),

@@ -500,6 +500,317 @@ __global__ __launch_bounds__(256) void smooth_bwd_b_kernel(const float* tmp, con
     gdisp[b * HW + p] += tmp[b * HW + p] / inv - corr;
 }
 
+// ======================================================================================== fused photometric kernels
+// One forward and one backward launch per scale (both source frames at once) instead of eleven per-stage launches:
+// target / warped frames are staged once per 32x8 pixel tile (+ halo, reflection applied while staging) in LDS, the
+// 3x3 SSIM windows read LDS, SSIM+L1 -> auto-mask minimum stay in registers, and the backward pass recomputes the window
+// statistics in the tile instead of reading a 9-plane coefficient workspace: per-window-centre coefficients live in LDS
+// for the tile + 1 halo, the 3x3 gather with the reflection fold runs on LDS, and the resulting d err / d warped feeds
+// the warp adjoint (source taps, d/d disparity, d/d pose partial sums) in the same thread -- neither the error planes,
+// nor their gradients, nor the coefficient maps ever exist in HBM.
+constexpr int PT_W = 32, PT_H = 8;                 // pixel tile of a 256-thread block
+constexpr int PF_W = PT_W + 2, PF_H = PT_H + 2;    // forward staging: 1-pixel halo
+constexpr int PB_W = PT_W + 4, PB_H = PT_H + 4;    // backward staging: 2-pixel halo (statistics for tile + 1)
+constexpr int PC_W = PT_W + 2, PC_H = PT_H + 2;    // coefficient tile: tile + 1
+
+__device__ __forceinline__ int refl_clamp(int i, int n) {
+  i = i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i);
+  return i < 0 ? 0 : (i > n - 1 ? n - 1 : i);       // only positions outside a partial tile's image part get clamped
+}
+
+// stage the 9 planes [target c0..2 | pred0 c0..2 | pred1 c0..2][rows][cols] of batch element b, top-left image coordinate
+// (h0, w0), into LDS (reflection applied here, so window code never sees a border)
+__device__ __forceinline__ void stage_planes(float* sm, const float* target_b, const float* pred0_b, const float* pred1_b,
+                                             long HW, int rows, int cols, int h0, int w0, int H, int W) {
+  const int per = rows * cols;
+  for (int e = threadIdx.x; e < 9 * per; e += 256) {
+    const int pl = e / per, r = (e - pl * per) / cols, c = e - pl * per - r * cols;
+    const int which = pl / 3, ch = pl - which * 3;
+    const float* base = which == 0 ? target_b : (which == 1 ? pred0_b : pred1_b);
+    sm[e] = base[ch * HW + (long)refl_clamp(h0 + r, H) * W + refl_clamp(w0 + c, W)];
+  }
+}
+
+// SSIM + L1 error of one (pred, target) pair at tile position (r, c) of staged planes with row pitch `cols`
+// (arithmetic identical to reproj_err_fwd_kernel / window_stats: same summation order)
+__device__ __forceinline__ float tile_error(const float* px, const float* py, int cols, int per, int r, int c, int no_ssim) {
+  float l1 = 0.f, ss = 0.f;
+#pragma unroll
+  for (int ch = 0; ch < 3; ++ch) {
+    const float* x = px + ch * per;
+    const float* y = py + ch * per;
+    l1 += fabsf(y[r * cols + c] - x[r * cols + c]);
+    if (!no_ssim) {
+      float sx = 0.f, sy = 0.f, sxx = 0.f, syy = 0.f, sxy = 0.f;
+#pragma unroll
+      for (int dh = -1; dh <= 1; ++dh)
+#pragma unroll
+        for (int dw = -1; dw <= 1; ++dw) {
+          const float a = x[(r + dh) * cols + c + dw], b = y[(r + dh) * cols + c + dw];
+          sx += a; sy += b; sxx += a * a; syy += b * b; sxy += a * b;
+        }
+      const float mx = sx / 9.f, my = sy / 9.f;
+      const float sig_x = sxx / 9.f - mx * mx, sig_y = syy / 9.f - my * my, sig_xy = sxy / 9.f - mx * my;
+      const float n = (2.f * mx * my + C1) * (2.f * sig_xy + C2);
+      const float d = (mx * mx + my * my + C1) * (sig_x + sig_y + C2);
+      ss += fminf(fmaxf((1.f - n / d) / 2.f, 0.f), 1.f);
+    }
+  }
+  l1 = l1 / 3.f;
+  return no_ssim ? l1 : (0.85f * (ss / 3.f) + 0.15f * l1);
+}
+
+// IDENT = true : err planes of (src0, target), (src1, target) -> out_err [B,2,H,W]         (monodepth_loss.py:139-147)
+// IDENT = false: errors of the two warped frames + auto-mask minimum -> sel, identity_selection, block partial sums
+template <bool IDENT>
+__global__ __launch_bounds__(256) void photometric_fwd_kernel(const float* pred0, const float* pred1, const float* target,
+                                                              const float* ident, const float* noise, int H, int W,
+                                                              int no_ssim, int avg, float* out_err, uint8_t* sel,
+                                                              float* isel, double* part) {
+  SEGSDE_SMEM;
+  float* sm = reinterpret_cast<float*>(segsde_smem);           // [9][PF_H][PF_W]: target 0-2, pred0 3-5, pred1 6-8
+  double* sh = reinterpret_cast<double*>(sm + 9 * PF_H * PF_W + ((9 * PF_H * PF_W) & 1));
+  const int b = blockIdx.z, h0 = blockIdx.y * PT_H, w0 = blockIdx.x * PT_W;
+  const long HW = (long)H * W;
+  stage_planes(sm, target + (long)b * 3 * HW, pred0 + (long)b * 3 * HW, pred1 + (long)b * 3 * HW, HW, PF_H, PF_W, h0 - 1, w0 - 1,
+               H, W);
+  __syncthreads();
+  const int r = threadIdx.x / PT_W, c = threadIdx.x - r * PT_W;
+  const int h = h0 + r, w = w0 + c;
+  const int per = PF_H * PF_W;
+  double acc = 0.0;
+  if (h < H && w < W) {
+    const long p = (long)h * W + w;
+    const float e0 = tile_error(sm + 3 * per, sm, PF_W, per, r + 1, c + 1, no_ssim);
+    const float e1 = tile_error(sm + 6 * per, sm, PF_W, per, r + 1, c + 1, no_ssim);
+    if (IDENT) {
+      out_err[((long)b * 2) * HW + p] = e0;
+      out_err[((long)b * 2 + 1) * HW + p] = e1;
+    } else {
+      // combined = cat(identity (+ noise * 1e-5), reprojection); min over dim 1; first minimum wins (monodepth_loss.py:147-177)
+      float v[4]; int n = 0;
+      const int ni = ident ? (avg ? 1 : 2) : 0;
+      if (ident) {
+        const float i0 = ident[((long)b * 2) * HW + p], i1 = ident[((long)b * 2 + 1) * HW + p];
+        if (avg) { v[n] = (i0 + i1) / 2.f; if (noise) v[n] += noise[(long)b * HW + p] * 0.00001f; ++n; }
+        else {
+          v[n] = i0; if (noise) v[n] += noise[((long)b * 2) * HW + p] * 0.00001f; ++n;
+          v[n] = i1; if (noise) v[n] += noise[((long)b * 2 + 1) * HW + p] * 0.00001f; ++n;
+        }
+      }
+      if (avg) v[n++] = (e0 + e1) / 2.f;
+      else { v[n++] = e0; v[n++] = e1; }
+      float best = v[0]; int bi = 0;
+      for (int j = 1; j < n; ++j) if (v[j] < best) { best = v[j]; bi = j; }
+      sel[(long)b * HW + p] = (uint8_t)bi;
+      if (isel) isel[(long)b * HW + p] = bi > ni - 1 ? 1.f : 0.f;
+      acc = (double)best;
+    }
+  }
+  if (!IDENT) {
+    const double t = segsde_block_sum(acc, sh);
+    if (threadIdx.x == 0) part[((long)b * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = t;
+  }
+}
+
+struct PhotoBwdP {
+  const float* pred[2]; const float* target; const uint8_t* sel; const float* disp; const float* inv_K; const float* K;
+  const float* T[2]; const float* src[2];
+  int hs, ws, H, W, no_ssim, avg, ni;      // ni: number of identity entries in front of the reprojection ones (0, 1, 2)
+  float scale, min_disp, max_disp;
+  float* g_disp_up; double* gP_part;       // [B][nblk][2][12]
+};
+
+__global__ __launch_bounds__(256) void photometric_bwd_kernel(PhotoBwdP a) {
+  SEGSDE_SMEM;
+  float* sm = reinterpret_cast<float*>(segsde_smem);      // [9][PB_H][PB_W] pixels, then [2][3][3][PC_H][PC_W] coefficients
+  float* cf = sm + 9 * PB_H * PB_W;
+  float* geo = cf + 18 * PC_H * PC_W;                      // P0[12] pad P1[12] pad iK[16]
+  double* sh = reinterpret_cast<double*>(geo + 48);
+  const int b = blockIdx.z, h0 = blockIdx.y * PT_H, w0 = blockIdx.x * PT_W;
+  const int H = a.H, W = a.W;
+  const long HW = (long)H * W;
+  {
+    const int t = threadIdx.x;
+    if (t < 24) {
+      const int f = t / 12, e = t - f * 12, r = e >> 2, c = e & 3;
+      float s = 0.f;
+      for (int k = 0; k < 4; ++k) s += a.K[b * 16 + r * 4 + k] * a.T[f][b * 16 + k * 4 + c];
+      geo[f * 16 + e] = s;
+    }
+    if (t >= 32 && t < 48) geo[t] = a.inv_K[b * 16 + t - 32];
+  }
+  stage_planes(sm, a.target + (long)b * 3 * HW, a.pred[0] + (long)b * 3 * HW, a.pred[1] + (long)b * 3 * HW, HW, PB_H, PB_W,
+               h0 - 2, w0 - 2, H, W);
+  __syncthreads();
+  const int perp = PB_H * PB_W, perc = PC_H * PC_W;
+  // ---- per-window-centre coefficients for tile + 1: d err_q / d x_cell = a + bx * x_cell + by * y_cell (times upstream)
+  for (int e = threadIdx.x; e < perc; e += 256) {
+    const int qr = e / PC_W, qc = e - qr * PC_W;
+    const int qh = h0 - 1 + qr, qw = w0 - 1 + qc;
+    float up[2] = {0.f, 0.f};
+    if (qh >= 0 && qh < H && qw >= 0 && qw < W) {
+      const int s = a.sel[(long)b * HW + (long)qh * W + qw];
+      if (a.avg) { if (s == a.ni) up[0] = up[1] = 0.5f * a.scale; }
+      else { if (s == a.ni) up[0] = a.scale; else if (s == a.ni + 1) up[1] = a.scale; }
+    }
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+      const float gq = up[f] * (0.85f / 3.f) * (-0.5f);
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) {
+        float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+        if (up[f] != 0.f && !a.no_ssim) {
+          const float* x = sm + (3 + 3 * f + ch) * perp;
+          const float* y = sm + ch * perp;
+          float sx = 0.f, sy = 0.f, sxx = 0.f, syy = 0.f, sxy = 0.f;
+#pragma unroll
+          for (int dh = -1; dh <= 1; ++dh)
+#pragma unroll
+            for (int dw = -1; dw <= 1; ++dw) {
+              const float xv = x[(qr + 1 + dh) * PB_W + qc + 1 + dw], yv = y[(qr + 1 + dh) * PB_W + qc + 1 + dw];
+              sx += xv; sy += yv; sxx += xv * xv; syy += yv * yv; sxy += xv * yv;
+            }
+          const float mx = sx / 9.f, my = sy / 9.f;
+          const float sig_x = sxx / 9.f - mx * mx, sig_y = syy / 9.f - my * my, sig_xy = sxy / 9.f - mx * my;
+          const float A1 = 2.f * mx * my + C1, A2 = 2.f * sig_xy + C2;
+          const float B1 = mx * mx + my * my + C1, B2 = sig_x + sig_y + C2;
+          const float n = A1 * A2, d = B1 * B2, rr = n / d;
+          const float raw = (1.f - rr) / 2.f;
+          const float m = (raw >= 0.f && raw <= 1.f) ? gq / (9.f * d) : 0.f;   // clamp passes gradient on [0,1]
+          c0 = m * (2.f * my * A2 - 2.f * A1 * my - rr * (2.f * mx * B2 - 2.f * B1 * mx));
+          c1 = m * (-rr * 2.f * B1);
+          c2 = m * (2.f * A1);
+        }
+        float* o = cf + ((f * 3 + ch) * 3) * perc + e;
+        o[0] = c0; o[perc] = c1; o[2 * perc] = c2;
+      }
+    }
+  }
+  __syncthreads();
+  // ---- per pixel: gather the 3x3 coefficient windows (reflection fold as multiplicities), L1 term, warp adjoint
+  const int r = threadIdx.x / PT_W, c = threadIdx.x - r * PT_W;
+  const int h = h0 + r, w = w0 + c;
+  double acc[2][12];
+#pragma unroll
+  for (int f = 0; f < 2; ++f)
+#pragma unroll
+    for (int i = 0; i < 12; ++i) acc[f][i] = 0.0;
+  if (h < H && w < W) {
+    const long p = (long)h * W + w;
+    // how often window centre p + d contains a padded cell that maps to p: the mirrored cell -1 (for h == 1) lies in the
+    // window of centre 0 only, the mirrored cell H (for h == H-2) in the window of centre H-1 only
+    float mh[3], mw[3];
+    mh[0] = h - 1 >= 0 ? (h == 1 ? 2.f : 1.f) : 0.f; mh[1] = 1.f; mh[2] = h + 1 <= H - 1 ? (h == H - 2 ? 2.f : 1.f) : 0.f;
+    mw[0] = w - 1 >= 0 ? (w == 1 ? 2.f : 1.f) : 0.f; mw[1] = 1.f; mw[2] = w + 1 <= W - 1 ? (w == W - 2 ? 2.f : 1.f) : 0.f;
+    const int s = a.sel[(long)b * HW + p];
+    float upp[2] = {0.f, 0.f};
+    if (a.avg) { if (s == a.ni) upp[0] = upp[1] = 0.5f * a.scale; }
+    else { if (s == a.ni) upp[0] = a.scale; else if (s == a.ni + 1) upp[1] = a.scale; }
+    float gdisp = 0.f;
+    const float* disp_b = a.disp + (long)b * a.hs * a.ws;
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+      float gp[3];
+      bool any = false;
+      const float gl1 = upp[f] * (a.no_ssim ? (1.f / 3.f) : (0.15f / 3.f));
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) {
+        const float xv = sm[(3 + 3 * f + ch) * perp + (r + 2) * PB_W + c + 2], yv = sm[ch * perp + (r + 2) * PB_W + c + 2];
+        float g = 0.f;
+        if (!a.no_ssim) {
+          const float* o = cf + ((f * 3 + ch) * 3) * perc + (r + 1) * PC_W + c + 1;
+          float sa = 0.f, sbx = 0.f, sby = 0.f;
+#pragma unroll
+          for (int dh = -1; dh <= 1; ++dh)
+#pragma unroll
+            for (int dw = -1; dw <= 1; ++dw) {
+              const float m = mh[dh + 1] * mw[dw + 1];
+              const int q = dh * PC_W + dw;
+              sa += m * o[q]; sbx += m * o[perc + q]; sby += m * o[2 * perc + q];
+            }
+          g = sa + sbx * xv + sby * yv;
+        }
+        const float df = yv - xv;   // d|t - x|/dx = -sign(t - x)
+        g += gl1 * (df > 0.f ? -1.f : (df < 0.f ? 1.f : 0.f));
+        gp[ch] = g;
+        any = any || (g != 0.f);
+      }
+      if (!any) continue;          // masked out here and in every neighbouring window: no contribution from this frame
+      const float* P = geo + f * 16;
+      const float* iK = geo + 32;
+      const Geo g = geometry(disp_b, a.hs, a.ws, H, W, h, w, iK, P, a.min_disp, a.max_disp);
+      const float fx = floorf(g.ix), fy = floorf(g.iy);
+      const int x0 = (int)fx, y0 = (int)fy, x1 = x0 + 1, y1 = y0 + 1;
+      const bool vx1 = x1 <= W - 1, vy1 = y1 <= H - 1;
+      const float* src_b = a.src[f] + (long)b * 3 * HW;
+      float gix = 0.f, giy = 0.f;   // ATen grid_sampler_2d_backward
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) {
+        const float* sp = src_b + ch * HW;
+        const float go = gp[ch];
+        const float vnw = sp[(long)y0 * W + x0];
+        const float vne = vx1 ? sp[(long)y0 * W + x1] : 0.f;
+        const float vsw = vy1 ? sp[(long)y1 * W + x0] : 0.f;
+        const float vse = (vx1 && vy1) ? sp[(long)y1 * W + x1] : 0.f;
+        gix -= vnw * ((float)y1 - g.iy) * go; giy -= vnw * ((float)x1 - g.ix) * go;
+        gix += vne * ((float)y1 - g.iy) * go; giy -= vne * (g.ix - (float)x0) * go;
+        gix -= vsw * (g.iy - (float)y0) * go; giy += vsw * ((float)x1 - g.ix) * go;
+        gix += vse * (g.iy - (float)y0) * go; giy += vse * (g.ix - (float)x0) * go;
+      }
+      const float g_x = g.in_x ? gix : 0.f, g_y = g.in_y ? giy : 0.f;
+      const float den = g.p2 + 1e-7f;
+      const float gp0 = g_x / den, gp1 = g_y / den, gp2 = -(g_x * g.x + g_y * g.y) / den;
+      const float cx = g.depth * g.xn, cy = g.depth * g.yn, cz = g.depth * g.zn;
+      acc[f][0] += gp0 * cx; acc[f][1] += gp0 * cy; acc[f][2] += gp0 * cz; acc[f][3] += gp0;
+      acc[f][4] += gp1 * cx; acc[f][5] += gp1 * cy; acc[f][6] += gp1 * cz; acc[f][7] += gp1;
+      acc[f][8] += gp2 * cx; acc[f][9] += gp2 * cy; acc[f][10] += gp2 * cz; acc[f][11] += gp2;
+      const float gcx = P[0] * gp0 + P[4] * gp1 + P[8] * gp2;
+      const float gcy = P[1] * gp0 + P[5] * gp1 + P[9] * gp2;
+      const float gcz = P[2] * gp0 + P[6] * gp1 + P[10] * gp2;
+      const float gdepth = gcx * g.xn + gcy * g.yn + gcz * g.zn;
+      gdisp += (-gdepth * g.depth * g.depth) * (a.max_disp - a.min_disp);
+    }
+    a.g_disp_up[(long)b * HW + p] = gdisp;
+  }
+  const long blk = ((long)b * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+#pragma unroll
+  for (int f = 0; f < 2; ++f)
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+      const double t = segsde_block_sum(acc[f][i], sh);
+      if (threadIdx.x == 0) a.gP_part[(blk * 2 + f) * 12 + i] = t;
+    }
+}
+
+// gT_f[b] += weight * K[b]^T (rows 0..2) * sum_blocks gP_f[b]      (both frames: grid (B, 2))
+__global__ __launch_bounds__(256) void photometric_bwd_finalize_kernel(const double* gP_part, int nblk, const float* K,
+                                                                       const float* weight, float* gT0, float* gT1) {
+  SEGSDE_SMEM;
+  double* sh = reinterpret_cast<double*>(segsde_smem);   // [12][16] lane sums, then [12] totals at sh + 192
+  double* gp = sh + 192;
+  const int b = blockIdx.x, f = blockIdx.y, t = threadIdx.x;
+  if (t < 192) {
+    const int e = t >> 4, l = t & 15;
+    double s = 0.0;
+    for (int i = l; i < nblk; i += 16) s += gP_part[(((long)b * nblk + i) * 2 + f) * 12 + e];
+    sh[e * 16 + l] = s;
+  }
+  __syncthreads();
+  if (t < 12) {
+    double s = 0.0;
+    for (int l = 0; l < 16; ++l) s += sh[t * 16 + l];
+    gp[t] = s;
+  }
+  __syncthreads();
+  if (t >= 16) return;
+  const int k = t >> 2, j = t & 3;
+  double s = 0.0;
+  for (int r = 0; r < 3; ++r) s += (double)K[b * 16 + r * 4 + k] * gp[r * 4 + j];
+  float* gT = f ? gT1 : gT0;
+  gT[b * 16 + t] += (weight ? weight[0] : 1.f) * (float)s;
+}
+
 inline int plane_blocks(long HW) { long nb = (HW + 255) / 256; return (int)(nb < 1 ? 1 : (nb > 512 ? 512 : nb)); }
 inline int flat_blocks(long n) { long nb = (n + 255) / 256; return (int)(nb < 1 ? 1 : (nb > 2048 ? 2048 : nb)); }
 
@@ -645,6 +956,69 @@ extern "C" int segsde_smoothness_backward(const float* disp, const float* img, c
   SEGSDE_CHECK_LAUNCH();
   hipLaunchKernelGGL(smooth_bwd_b_kernel, dim3(nb, B), dim3(256), 0, ST(stream), (const float*)tmp, mean_disp,
                      (const double*)part, nb, HW, gdisp);
+  SEGSDE_CHECK_LAUNCH();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------ fused photometric entry points
+static inline dim3 photo_grid(int B, int H, int W) { return dim3((W + PT_W - 1) / PT_W, (H + PT_H - 1) / PT_H, B); }
+static inline long photo_blocks(int B, int H, int W) { return (long)B * ((W + PT_W - 1) / PT_W) * ((H + PT_H - 1) / PT_H); }
+
+extern "C" size_t segsde_photometric_workspace(int B, int H, int W) {
+  return (size_t)photo_blocks(B, H, W) * 24 * sizeof(double);
+}
+
+extern "C" int segsde_photometric_identity(const float* src0, const float* src1, const float* target, int B, int H, int W,
+                                           int no_ssim, float* ident, void* stream) {
+  if (!src0 || !src1 || !target || !ident) return SEGSDE_ERR_NULL;
+  if (B <= 0 || H < 2 || W < 2 || (long)H * W >= (1L << 31)) return SEGSDE_ERR_SHAPE;
+  hipLaunchKernelGGL(photometric_fwd_kernel<true>, photo_grid(B, H, W), dim3(256), (9 * PF_H * PF_W + 1) * sizeof(float) + 64,
+                     ST(stream), src0, src1, target, (const float*)nullptr, (const float*)nullptr, H, W, no_ssim, 0, ident,
+                     (uint8_t*)nullptr, (float*)nullptr, (double*)nullptr);
+  SEGSDE_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int segsde_photometric_forward(const float* pred0, const float* pred1, const float* target, const float* ident,
+                                          const float* noise, int B, int H, int W, int no_ssim, int avg, uint8_t* sel,
+                                          float* identity_selection, float* sum_out, void* ws_, size_t ws_bytes,
+                                          void* stream) {
+  if (!pred0 || !pred1 || !target || !sel || !sum_out || !ws_) return SEGSDE_ERR_NULL;
+  if (B <= 0 || H < 2 || W < 2 || (long)H * W >= (1L << 31)) return SEGSDE_ERR_SHAPE;
+  if (ws_bytes < segsde_photometric_workspace(B, H, W)) return SEGSDE_ERR_WORKSPACE;
+  hipLaunchKernelGGL(photometric_fwd_kernel<false>, photo_grid(B, H, W), dim3(256),
+                     (9 * PF_H * PF_W + 1) * sizeof(float) + 64, ST(stream), pred0, pred1, target, ident, noise, H, W, no_ssim,
+                     avg, (float*)nullptr, sel, identity_selection, (double*)ws_);
+  SEGSDE_CHECK_LAUNCH();
+  hipLaunchKernelGGL(sum_finalize_kernel, dim3(1), dim3(256), 64, ST(stream), (const double*)ws_, (int)photo_blocks(B, H, W),
+                     sum_out, 0, 1.0);
+  SEGSDE_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int segsde_photometric_backward(const float* pred0, const float* pred1, const float* target, const uint8_t* sel,
+                                           int n_ident, const float* disp, int hs, int ws, const float* inv_K, const float* K,
+                                           const float* T0, const float* T1, const float* src0, const float* src1, int B, int H,
+                                           int W, float min_depth, float max_depth, int no_ssim, int avg, float scale,
+                                           const float* weight, float* g_disp_up, float* gT0, float* gT1, void* ws_,
+                                           size_t ws_bytes, void* stream) {
+  if (!pred0 || !pred1 || !target || !sel || !disp || !inv_K || !K || !T0 || !T1 || !src0 || !src1 || !g_disp_up || !gT0 ||
+      !gT1 || !ws_) return SEGSDE_ERR_NULL;
+  if (B <= 0 || H < 2 || W < 2 || hs <= 0 || ws <= 0 || (long)H * W >= (1L << 31)) return SEGSDE_ERR_SHAPE;
+  if (ws_bytes < segsde_photometric_workspace(B, H, W)) return SEGSDE_ERR_WORKSPACE;
+  PhotoBwdP a;
+  a.pred[0] = pred0; a.pred[1] = pred1; a.target = target; a.sel = sel; a.disp = disp; a.inv_K = inv_K; a.K = K;
+  a.T[0] = T0; a.T[1] = T1; a.src[0] = src0; a.src[1] = src1;
+  a.hs = hs; a.ws = ws; a.H = H; a.W = W; a.no_ssim = no_ssim; a.avg = avg;
+  a.ni = n_ident ? (avg ? 1 : 2) : 0;
+  a.scale = scale; a.min_disp = 1.f / max_depth; a.max_disp = 1.f / min_depth;
+  a.g_disp_up = g_disp_up; a.gP_part = (double*)ws_;
+  const size_t lds = (9 * PB_H * PB_W + 18 * PC_H * PC_W + 48) * sizeof(float) + 64;
+  hipLaunchKernelGGL(photometric_bwd_kernel, photo_grid(B, H, W), dim3(256), lds, ST(stream), a);
+  SEGSDE_CHECK_LAUNCH();
+  const int nblk = (int)(photo_blocks(B, H, W) / B);
+  hipLaunchKernelGGL(photometric_bwd_finalize_kernel, dim3(B, 2), dim3(256), 204 * sizeof(double), ST(stream),
+                     (const double*)ws_, nblk, K, weight, gT0, gT1);
   SEGSDE_CHECK_LAUNCH();
   return 0;
 }

@@ -491,6 +491,50 @@ def reprojection_error_backward(pred, target, gerr_plane, no_ssim):
     return gpred
 
 
+def photometric_identity(src0, src1, target, no_ssim):
+    """err(src_f, target), f = 0, 1 -> [B,2,H,W] (the auto-mask's identity terms, the same for every scale)"""
+    B, _, Hh, W = target.shape
+    ident = torch.empty((B, 2, Hh, W), dtype=torch.float32, device=target.device)
+    check(_lib.lib().segsde_photometric_identity(_p(_f32(src0.contiguous())), _p(_f32(src1.contiguous())),
+                                                 _p(_f32(target.contiguous())), B, Hh, W, int(no_ssim), _p(ident),
+                                                 _stream(target)), "photometric_identity")
+    return ident
+
+
+def photometric_forward(pred0, pred1, target, ident, noise, no_ssim, avg, want_selection=True):
+    """fused SSIM+L1 errors of both warped frames + auto-mask minimum -> (sum [1], sel uint8 [B,H,W], identity_selection)"""
+    B, _, Hh, W = target.shape
+    L = _lib.lib()
+    sel = torch.empty((B, Hh, W), dtype=torch.uint8, device=target.device)
+    isel = torch.empty((B, Hh, W), dtype=torch.float32, device=target.device) if (want_selection and ident is not None) else None
+    out = torch.empty(1, dtype=torch.float32, device=target.device)
+    nb = L.segsde_photometric_workspace(B, Hh, W)
+    ws_ = _ws(nb, target)
+    check(L.segsde_photometric_forward(_p(_f32(pred0.contiguous())), _p(_f32(pred1.contiguous())), _p(_f32(target.contiguous())),
+                                       _p(ident), _p(noise), B, Hh, W, int(no_ssim), int(avg), _p(sel), _p(isel), _p(out),
+                                       _p(ws_), nb, _stream(target)), "photometric_forward")
+    return out, sel, isel
+
+
+def photometric_backward(pred0, pred1, target, sel, has_ident, disp, inv_K, K, T0, T1, src0, src1, min_depth, max_depth,
+                         no_ssim, avg, scale, weight, gT0, gT1):
+    """-> g_disp_up [B,H,W] (d loss / d upsampled disparity, both frames); gT0 / gT1 [B,4,4] are accumulated into with the
+    device scalar ``weight`` (upstream gradient of this scale's loss)"""
+    B, _, Hh, W = target.shape
+    _, _, hs, ws = disp.shape
+    L = _lib.lib()
+    gup = torch.empty((B, Hh, W), dtype=torch.float32, device=target.device)
+    nb = L.segsde_photometric_workspace(B, Hh, W)
+    ws_ = _ws(nb, target)
+    check(L.segsde_photometric_backward(_p(pred0.contiguous()), _p(pred1.contiguous()), _p(target.contiguous()), _p(sel),
+                                        2 if has_ident else 0, _p(disp.contiguous()), hs, ws, _p(inv_K.contiguous()),
+                                        _p(K.contiguous()), _p(T0.contiguous()), _p(T1.contiguous()), _p(src0.contiguous()),
+                                        _p(src1.contiguous()), B, Hh, W, float(min_depth), float(max_depth), int(no_ssim),
+                                        int(avg), float(scale), _p(weight), _p(gup), _p(gT0), _p(gT1), _p(ws_), nb,
+                                        _stream(target)), "photometric_backward")
+    return gup
+
+
 def automask_min(ident, noise, reproj, avg, want_selection=True):
     B, nr, H, W = reproj.shape
     L = _lib.lib()

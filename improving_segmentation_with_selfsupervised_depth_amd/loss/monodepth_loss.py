@@ -36,26 +36,22 @@ class _MonoLossFn(Function):
         inv_K, K = inputs[("inv_K", 0)].contiguous(), inputs[("K", 0)].contiguous()
         ident = None
         if automask:   # identical for every scale (reference recomputes it 4x, monodepth_loss.py:139-147)
-            ident = torch.empty((B, nf, Hh, W), dtype=torch.float32, device=dev)
-            for j in range(nf):
-                H.reprojection_error(srcs[j], target, obj.no_ssim, ident[:, j])
+            ident = H.photometric_identity(srcs[0], srcs[1], target, obj.no_ssim)
         losses, saved = [], []
         for s in range(S):
-            reproj = torch.empty((B, nf, Hh, W), dtype=torch.float32, device=dev)
             colors = []
             for j, f in enumerate(frames):
                 col = cache.get(("color", f, s)) if cache is not None else None
                 if col is None:
                     col, _, _ = H.warp_forward(disps[s], inv_K, K, Ts[j], srcs[j], obj.min_depth, obj.max_depth)
                 colors.append(col)
-                H.reprojection_error(col, target, obj.no_ssim, reproj[:, j])
             noise = None
             if automask:
                 if obj.tiebreak_noise is not None:
                     noise = obj.tiebreak_noise[s].to(dev).float().contiguous()
                 else:
                     noise = torch.randn((B, 1 if avg else nf, Hh, W), device=dev)
-            ssum, sel, isel = H.automask_min(ident, noise, reproj, avg)
+            ssum, sel, isel = H.photometric_forward(colors[0], colors[1], target, ident, noise, obj.no_ssim, avg)
             if automask:
                 outputs["identity_selection/{}".format(s)] = isel
             color_s = inputs[("color", 0, s)].contiguous()
@@ -79,17 +75,14 @@ class _MonoLossFn(Function):
         target = ctx.target
         B, _, Hh, W = target.shape
         dev = target.device
-        gd_out, gT_acc = [], [None, None]
+        gd_out = []
+        gT_acc = [torch.zeros((B, 4, 4), dtype=torch.float32, device=dev) for _ in range(2)]
         for s in range(S):
             sel, colors, mean_disp, color_s = ctx.saved[s]
             w_s = (g_total / S + g_scales[s]).reshape(1).contiguous()    # upstream weight of loss/s (device scalar)
-            greproj = H.automask_min_backward(sel, ctx.automask, 2, ctx.avg, 1.0 / float(B * Hh * W))
-            gup = torch.zeros((B, Hh, W), dtype=torch.float32, device=dev)
-            for j in range(2):
-                gpred = H.reprojection_error_backward(colors[j], target, greproj[:, j], obj.no_ssim)
-                gT = torch.zeros((B, 4, 4), dtype=torch.float32, device=dev)
-                H.warp_backward(gpred, ctx.disps[s], inv_K, K, ctx.Ts[j], ctx.srcs[j], obj.min_depth, obj.max_depth, gup, gT)
-                gT_acc[j] = H.axpby_dev(w_s, gT) if gT_acc[j] is None else H.axpby_dev(w_s, gT, _one(dev), gT_acc[j])
+            gup = H.photometric_backward(colors[0], colors[1], target, sel, ctx.automask, ctx.disps[s], inv_K, K, ctx.Ts[0],
+                                         ctx.Ts[1], ctx.srcs[0], ctx.srcs[1], obj.min_depth, obj.max_depth, obj.no_ssim,
+                                         ctx.avg, 1.0 / float(B * Hh * W), w_s, gT_acc[0], gT_acc[1])
             hs, ws = ctx.disps[s].shape[-2:]
             gdisp = H.resize_bilinear_backward(gup.reshape(B, Hh, W, 1), (hs, ws), False).reshape(B, 1, hs, ws)
             H.smoothness_backward(ctx.disps[s], color_s, mean_disp, obj.disparity_smoothness / (2 ** s), gdisp)

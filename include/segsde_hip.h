@@ -263,6 +263,28 @@ int segsde_softmax_nhwc_to_nchw(const float* logits, int ld, int B, long HW, int
 size_t segsde_minmax_normalize_workspace(int B, long HW);
 int segsde_minmax_normalize(const float* x, int B, long HW, float* out, float* minmax, uint8_t* out_u8, void* workspace,
                             size_t workspace_bytes, void* stream);
+/* Fused photometric loss of one scale, both source frames per launch (loss/monodepth_loss.py:104-177 with
+ * models/monodepth_layers.py:224-254): the per-stage entry points above chained through LDS tiles and registers.
+ *   identity : err(src_f, target) for f = 0, 1 -> ident [B,2,H,W]  (identical for all scales: computed once, :139-147)
+ *   forward  : err(pred_f, target), min over [ident (+ noise * 1e-5) | err] (avg: channel means first, :149-156), first
+ *              minimum wins -> sel (uint8 index into the concatenation), identity_selection (nullable, :175-177),
+ *              sum_out[0] = sum of the minima.  ident / noise nullable (disable_automasking).
+ *   backward : d(scale * sum of minima) / d pred_f is formed in the tile (SSIM window statistics recomputed, reflection
+ *              fold included) and pushed straight through the warp adjoint: g_disp_up [B,H,W] is WRITTEN (both frames
+ *              summed), gT_f [B,4,4] += weight[0] * dL/dT_f (weight: nullable device scalar = upstream gradient).
+ * pred_f are the warped frames [B,3,H,W] (segsde_warp_forward); T_f / src_f the pose and source frame of frame f. */
+size_t segsde_photometric_workspace(int B, int H, int W);
+int segsde_photometric_identity(const float* src0, const float* src1, const float* target, int B, int H, int W, int no_ssim,
+                                float* ident, void* stream);
+int segsde_photometric_forward(const float* pred0, const float* pred1, const float* target, const float* ident,
+                               const float* noise, int B, int H, int W, int no_ssim, int avg, uint8_t* sel,
+                               float* identity_selection, float* sum_out, void* workspace, size_t workspace_bytes,
+                               void* stream);
+int segsde_photometric_backward(const float* pred0, const float* pred1, const float* target, const uint8_t* sel, int n_ident,
+                                const float* disp, int hs, int ws, const float* inv_K, const float* K, const float* T0,
+                                const float* T1, const float* src0, const float* src1, int B, int H, int W, float min_depth,
+                                float max_depth, int no_ssim, int avg, float scale, const float* weight, float* g_disp_up,
+                                float* gT0, float* gT1, void* workspace, size_t workspace_bytes, void* stream);
 /* Test-time depth, MonodepthLoss.generate_depth_test_pred, loss/monodepth_loss.py:54-62: bilinear upsample of disp
  * [B,1,hs,ws] to H x W (align_corners=False) and disp_to_depth (monodepth_layers.py:18-27) with the test depth range. */
 int segsde_disp_to_depth(const float* disp, int hs, int ws, int B, int H, int W, float min_depth, float max_depth,
