@@ -5,6 +5,7 @@
 // HBM-bound: every kernel is one coalesced pass over pixel planes; cross-pixel reductions are two-level and
 // deterministic (block partials in double -> a finalize kernel), the pose-matrix gradient included.
 #include "segsde_common.h"
+#include <cstdlib>
 
 namespace {
 #define ST(s) static_cast<hipStream_t>(s)
@@ -518,16 +519,34 @@ __device__ __forceinline__ int refl_clamp(int i, int n) {
   return i < 0 ? 0 : (i > n - 1 ? n - 1 : i);       // only positions outside a partial tile's image part get clamped
 }
 
-// stage the 9 planes [target c0..2 | pred0 c0..2 | pred1 c0..2][rows][cols] of batch element b, top-left image coordinate
-// (h0, w0), into LDS (reflection applied here, so window code never sees a border)
-__device__ __forceinline__ void stage_planes(float* sm, const float* target_b, const float* pred0_b, const float* pred1_b,
-                                             long HW, int rows, int cols, int h0, int w0, int H, int W) {
-  const int per = rows * cols;
-  for (int e = threadIdx.x; e < 9 * per; e += 256) {
-    const int pl = e / per, r = (e - pl * per) / cols, c = e - pl * per - r * cols;
-    const int which = pl / 3, ch = pl - which * 3;
-    const float* base = which == 0 ? target_b : (which == 1 ? pred0_b : pred1_b);
-    sm[e] = base[ch * HW + (long)refl_clamp(h0 + r, H) * W + refl_clamp(w0 + c, W)];
+// Staging of the 9 planes [target c0..2 | pred0 c0..2 | pred1 c0..2][rows][cols] of one tile (+ halo) into LDS, reflection
+// applied while staging so the window code never sees a border.  A thread owns the same one or two (row, col) positions
+// of the staged rectangle for every tile of its strip: the row part of the address is computed once per block, the
+// column part once per tile, and the nine plane loads of a position differ by constant offsets.
+struct StagePos { int e[2]; int c[2]; long rowoff[2]; };
+__device__ __forceinline__ StagePos stage_setup(int rows, int cols, int h_top, int H, int W) {
+  StagePos sp;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int e = threadIdx.x + 256 * i;
+    const int r = e / cols;
+    sp.e[i] = e < rows * cols ? e : -1;
+    sp.c[i] = e - r * cols;
+    sp.rowoff[i] = (long)refl_clamp(h_top + r, H) * W;
+  }
+  return sp;
+}
+__device__ __forceinline__ void stage_tile(float* sm, const StagePos& sp, int per, const float* target_b, const float* pred0_b,
+                                           const float* pred1_b, long HW, int w_left, int W) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    if (sp.e[i] < 0) continue;
+    const long off = sp.rowoff[i] + refl_clamp(w_left + sp.c[i], W);
+    float v[9];
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) { v[ch] = target_b[ch * HW + off]; v[3 + ch] = pred0_b[ch * HW + off]; v[6 + ch] = pred1_b[ch * HW + off]; }
+#pragma unroll
+    for (int pl = 0; pl < 9; ++pl) sm[pl * per + sp.e[i]] = v[pl];
   }
 }
 
@@ -565,46 +584,54 @@ __device__ __forceinline__ float tile_error(const float* px, const float* py, in
 template <bool IDENT>
 __global__ __launch_bounds__(256) void photometric_fwd_kernel(const float* pred0, const float* pred1, const float* target,
                                                               const float* ident, const float* noise, int H, int W,
-                                                              int no_ssim, int avg, float* out_err, uint8_t* sel,
-                                                              float* isel, double* part) {
+                                                              int no_ssim, int avg, int tiles_per_block, float* out_err,
+                                                              uint8_t* sel, float* isel, double* part) {
   SEGSDE_SMEM;
   float* sm = reinterpret_cast<float*>(segsde_smem);           // [9][PF_H][PF_W]: target 0-2, pred0 3-5, pred1 6-8
   double* sh = reinterpret_cast<double*>(sm + 9 * PF_H * PF_W + ((9 * PF_H * PF_W) & 1));
-  const int b = blockIdx.z, h0 = blockIdx.y * PT_H, w0 = blockIdx.x * PT_W;
+  const int b = blockIdx.z, h0 = blockIdx.y * PT_H;
   const long HW = (long)H * W;
-  stage_planes(sm, target + (long)b * 3 * HW, pred0 + (long)b * 3 * HW, pred1 + (long)b * 3 * HW, HW, PF_H, PF_W, h0 - 1, w0 - 1,
-               H, W);
-  __syncthreads();
-  const int r = threadIdx.x / PT_W, c = threadIdx.x - r * PT_W;
-  const int h = h0 + r, w = w0 + c;
+  const float* tb = target + (long)b * 3 * HW;
+  const float* p0b = pred0 + (long)b * 3 * HW;
+  const float* p1b = pred1 + (long)b * 3 * HW;
   const int per = PF_H * PF_W;
+  const StagePos sp = stage_setup(PF_H, PF_W, h0 - 1, H, W);
+  const int r = threadIdx.x / PT_W, c = threadIdx.x - r * PT_W;
+  const int h = h0 + r;
+  const int ntx = (W + PT_W - 1) / PT_W;
   double acc = 0.0;
-  if (h < H && w < W) {
-    const long p = (long)h * W + w;
-    const float e0 = tile_error(sm + 3 * per, sm, PF_W, per, r + 1, c + 1, no_ssim);
-    const float e1 = tile_error(sm + 6 * per, sm, PF_W, per, r + 1, c + 1, no_ssim);
-    if (IDENT) {
-      out_err[((long)b * 2) * HW + p] = e0;
-      out_err[((long)b * 2 + 1) * HW + p] = e1;
-    } else {
-      // combined = cat(identity (+ noise * 1e-5), reprojection); min over dim 1; first minimum wins (monodepth_loss.py:147-177)
-      float v[4]; int n = 0;
-      const int ni = ident ? (avg ? 1 : 2) : 0;
-      if (ident) {
-        const float i0 = ident[((long)b * 2) * HW + p], i1 = ident[((long)b * 2 + 1) * HW + p];
-        if (avg) { v[n] = (i0 + i1) / 2.f; if (noise) v[n] += noise[(long)b * HW + p] * 0.00001f; ++n; }
-        else {
-          v[n] = i0; if (noise) v[n] += noise[((long)b * 2) * HW + p] * 0.00001f; ++n;
-          v[n] = i1; if (noise) v[n] += noise[((long)b * 2 + 1) * HW + p] * 0.00001f; ++n;
+  for (int tx = blockIdx.x * tiles_per_block; tx < ntx && tx < (int)(blockIdx.x + 1) * tiles_per_block; ++tx) {
+    const int w0 = tx * PT_W, w = w0 + c;
+    __syncthreads();                                           // the previous tile's window reads are done
+    stage_tile(sm, sp, per, tb, p0b, p1b, HW, w0 - 1, W);
+    __syncthreads();
+    if (h < H && w < W) {
+      const long p = (long)h * W + w;
+      const float e0 = tile_error(sm + 3 * per, sm, PF_W, per, r + 1, c + 1, no_ssim);
+      const float e1 = tile_error(sm + 6 * per, sm, PF_W, per, r + 1, c + 1, no_ssim);
+      if (IDENT) {
+        out_err[((long)b * 2) * HW + p] = e0;
+        out_err[((long)b * 2 + 1) * HW + p] = e1;
+      } else {
+        // combined = cat(identity (+ noise * 1e-5), reprojection); min over dim 1; first minimum wins (monodepth_loss.py:147-177)
+        float v[4]; int n = 0;
+        const int ni = ident ? (avg ? 1 : 2) : 0;
+        if (ident) {
+          const float i0 = ident[((long)b * 2) * HW + p], i1 = ident[((long)b * 2 + 1) * HW + p];
+          if (avg) { v[n] = (i0 + i1) / 2.f; if (noise) v[n] += noise[(long)b * HW + p] * 0.00001f; ++n; }
+          else {
+            v[n] = i0; if (noise) v[n] += noise[((long)b * 2) * HW + p] * 0.00001f; ++n;
+            v[n] = i1; if (noise) v[n] += noise[((long)b * 2 + 1) * HW + p] * 0.00001f; ++n;
+          }
         }
+        if (avg) v[n++] = (e0 + e1) / 2.f;
+        else { v[n++] = e0; v[n++] = e1; }
+        float best = v[0]; int bi = 0;
+        for (int j = 1; j < n; ++j) if (v[j] < best) { best = v[j]; bi = j; }
+        sel[(long)b * HW + p] = (uint8_t)bi;
+        if (isel) isel[(long)b * HW + p] = bi > ni - 1 ? 1.f : 0.f;
+        acc += (double)best;
       }
-      if (avg) v[n++] = (e0 + e1) / 2.f;
-      else { v[n++] = e0; v[n++] = e1; }
-      float best = v[0]; int bi = 0;
-      for (int j = 1; j < n; ++j) if (v[j] < best) { best = v[j]; bi = j; }
-      sel[(long)b * HW + p] = (uint8_t)bi;
-      if (isel) isel[(long)b * HW + p] = bi > ni - 1 ? 1.f : 0.f;
-      acc = (double)best;
     }
   }
   if (!IDENT) {
@@ -617,6 +644,7 @@ struct PhotoBwdP {
   const float* pred[2]; const float* target; const uint8_t* sel; const float* disp; const float* inv_K; const float* K;
   const float* T[2]; const float* src[2];
   int hs, ws, H, W, no_ssim, avg, ni;      // ni: number of identity entries in front of the reprojection ones (0, 1, 2)
+  int tiles_per_block;                     // a block walks this many horizontally adjacent tiles (one reduction at the end)
   float scale, min_disp, max_disp;
   float* g_disp_up; double* gP_part;       // [B][nblk][2][12]
 };
@@ -627,7 +655,7 @@ __global__ __launch_bounds__(256) void photometric_bwd_kernel(PhotoBwdP a) {
   float* cf = sm + 9 * PB_H * PB_W;
   float* geo = cf + 18 * PC_H * PC_W;                      // P0[12] pad P1[12] pad iK[16]
   double* sh = reinterpret_cast<double*>(geo + 48);
-  const int b = blockIdx.z, h0 = blockIdx.y * PT_H, w0 = blockIdx.x * PT_W;
+  const int b = blockIdx.z, h0 = blockIdx.y * PT_H;
   const int H = a.H, W = a.W;
   const long HW = (long)H * W;
   {
@@ -640,10 +668,24 @@ __global__ __launch_bounds__(256) void photometric_bwd_kernel(PhotoBwdP a) {
     }
     if (t >= 32 && t < 48) geo[t] = a.inv_K[b * 16 + t - 32];
   }
-  stage_planes(sm, a.target + (long)b * 3 * HW, a.pred[0] + (long)b * 3 * HW, a.pred[1] + (long)b * 3 * HW, HW, PB_H, PB_W,
-               h0 - 2, w0 - 2, H, W);
-  __syncthreads();
   const int perp = PB_H * PB_W, perc = PC_H * PC_W;
+  const float* tb = a.target + (long)b * 3 * HW;
+  const float* p0b = a.pred[0] + (long)b * 3 * HW;
+  const float* p1b = a.pred[1] + (long)b * 3 * HW;
+  const StagePos sp = stage_setup(PB_H, PB_W, h0 - 2, H, W);
+  const int r = threadIdx.x / PT_W, c = threadIdx.x - r * PT_W;
+  const int h = h0 + r;
+  const int ntx = (W + PT_W - 1) / PT_W;
+  double acc[2][12];
+#pragma unroll
+  for (int f = 0; f < 2; ++f)
+#pragma unroll
+    for (int i = 0; i < 12; ++i) acc[f][i] = 0.0;
+  for (int tx = blockIdx.x * a.tiles_per_block; tx < ntx && tx < (int)(blockIdx.x + 1) * a.tiles_per_block; ++tx) {
+  const int w0 = tx * PT_W, w = w0 + c;
+  __syncthreads();                                             // the previous tile's LDS reads are done (geo is visible)
+  stage_tile(sm, sp, perp, tb, p0b, p1b, HW, w0 - 2, W);
+  __syncthreads();
   // ---- per-window-centre coefficients for tile + 1: d err_q / d x_cell = a + bx * x_cell + by * y_cell (times upstream)
   for (int e = threadIdx.x; e < perc; e += 256) {
     const int qr = e / PC_W, qc = e - qr * PC_W;
@@ -689,13 +731,6 @@ __global__ __launch_bounds__(256) void photometric_bwd_kernel(PhotoBwdP a) {
   }
   __syncthreads();
   // ---- per pixel: gather the 3x3 coefficient windows (reflection fold as multiplicities), L1 term, warp adjoint
-  const int r = threadIdx.x / PT_W, c = threadIdx.x - r * PT_W;
-  const int h = h0 + r, w = w0 + c;
-  double acc[2][12];
-#pragma unroll
-  for (int f = 0; f < 2; ++f)
-#pragma unroll
-    for (int i = 0; i < 12; ++i) acc[f][i] = 0.0;
   if (h < H && w < W) {
     const long p = (long)h * W + w;
     // how often window centre p + d contains a padded cell that maps to p: the mirrored cell -1 (for h == 1) lies in the
@@ -773,6 +808,7 @@ __global__ __launch_bounds__(256) void photometric_bwd_kernel(PhotoBwdP a) {
     }
     a.g_disp_up[(long)b * HW + p] = gdisp;
   }
+  }   // tiles of the strip
   const long blk = ((long)b * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
 #pragma unroll
   for (int f = 0; f < 2; ++f)
@@ -961,8 +997,23 @@ extern "C" int segsde_smoothness_backward(const float* disp, const float* img, c
 }
 
 // ------------------------------------------------------------------------------------------ fused photometric entry points
-static inline dim3 photo_grid(int B, int H, int W) { return dim3((W + PT_W - 1) / PT_W, (H + PT_H - 1) / PT_H, B); }
-static inline long photo_blocks(int B, int H, int W) { return (long)B * ((W + PT_W - 1) / PT_W) * ((H + PT_H - 1) / PT_H); }
+// a block walks `tiles` horizontally adjacent tiles so that its (double precision, 24-value) reduction is paid once per
+// strip; strips shrink while the launch would otherwise fall below ~8 blocks per CU
+static inline int photo_tiles_per_block(int B, int H, int W) {
+  const int ntx = (W + PT_W - 1) / PT_W, nty = (H + PT_H - 1) / PT_H;
+  if (const char* e = getenv("SEGSDE_PHOTO_TILES")) {            // experiment / test knob: fixed strip length
+    const int t = atoi(e);
+    if (t >= 1) return t < ntx ? t : ntx;
+  }
+  int t = ntx < 16 ? ntx : 16;
+  while (t > 1 && (long)B * nty * ((ntx + t - 1) / t) < 2048) t >>= 1;
+  return t < 1 ? 1 : t;
+}
+static inline dim3 photo_grid(int B, int H, int W) {
+  const int t = photo_tiles_per_block(B, H, W), ntx = (W + PT_W - 1) / PT_W;
+  return dim3((ntx + t - 1) / t, (H + PT_H - 1) / PT_H, B);
+}
+static inline long photo_blocks(int B, int H, int W) { const dim3 g = photo_grid(B, H, W); return (long)g.x * g.y * g.z; }
 
 extern "C" size_t segsde_photometric_workspace(int B, int H, int W) {
   return (size_t)photo_blocks(B, H, W) * 24 * sizeof(double);
@@ -973,7 +1024,8 @@ extern "C" int segsde_photometric_identity(const float* src0, const float* src1,
   if (!src0 || !src1 || !target || !ident) return SEGSDE_ERR_NULL;
   if (B <= 0 || H < 2 || W < 2 || (long)H * W >= (1L << 31)) return SEGSDE_ERR_SHAPE;
   hipLaunchKernelGGL(photometric_fwd_kernel<true>, photo_grid(B, H, W), dim3(256), (9 * PF_H * PF_W + 1) * sizeof(float) + 64,
-                     ST(stream), src0, src1, target, (const float*)nullptr, (const float*)nullptr, H, W, no_ssim, 0, ident,
+                     ST(stream), src0, src1, target, (const float*)nullptr, (const float*)nullptr, H, W, no_ssim, 0,
+                     photo_tiles_per_block(B, H, W), ident,
                      (uint8_t*)nullptr, (float*)nullptr, (double*)nullptr);
   SEGSDE_CHECK_LAUNCH();
   return 0;
@@ -988,7 +1040,7 @@ extern "C" int segsde_photometric_forward(const float* pred0, const float* pred1
   if (ws_bytes < segsde_photometric_workspace(B, H, W)) return SEGSDE_ERR_WORKSPACE;
   hipLaunchKernelGGL(photometric_fwd_kernel<false>, photo_grid(B, H, W), dim3(256),
                      (9 * PF_H * PF_W + 1) * sizeof(float) + 64, ST(stream), pred0, pred1, target, ident, noise, H, W, no_ssim,
-                     avg, (float*)nullptr, sel, identity_selection, (double*)ws_);
+                     avg, photo_tiles_per_block(B, H, W), (float*)nullptr, sel, identity_selection, (double*)ws_);
   SEGSDE_CHECK_LAUNCH();
   hipLaunchKernelGGL(sum_finalize_kernel, dim3(1), dim3(256), 64, ST(stream), (const double*)ws_, (int)photo_blocks(B, H, W),
                      sum_out, 0, 1.0);
@@ -1011,6 +1063,7 @@ extern "C" int segsde_photometric_backward(const float* pred0, const float* pred
   a.T[0] = T0; a.T[1] = T1; a.src[0] = src0; a.src[1] = src1;
   a.hs = hs; a.ws = ws; a.H = H; a.W = W; a.no_ssim = no_ssim; a.avg = avg;
   a.ni = n_ident ? (avg ? 1 : 2) : 0;
+  a.tiles_per_block = photo_tiles_per_block(B, H, W);
   a.scale = scale; a.min_disp = 1.f / max_depth; a.max_disp = 1.f / min_depth;
   a.g_disp_up = g_disp_up; a.gP_part = (double*)ws_;
   const size_t lds = (9 * PB_H * PB_W + 18 * PC_H * PC_W + 48) * sizeof(float) + 64;

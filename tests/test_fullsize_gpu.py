@@ -229,3 +229,57 @@ def test_headline_model_two_steps_vs_oracle():
             # first update are amplified -- its norm is only required to agree to 2 %
             tol = 1e-3 if (i < 2 or step == 0) else 2e-2
             assert abs(got[step][i] - ref[step][i]) <= tol * abs(ref[step][i]), (step, what, got[step][i], ref[step][i])
+
+
+def test_fused_photometric_fullsize_vs_stage_kernels():
+    """B=16, 512x1024: the fused per-scale photometric kernels (16-tile strips per block at this size) against the
+    per-stage kernel chain (warp -> SSIM+L1 error -> auto-mask min, and its hand-derived backward), which the test above
+    and the golden-vector tests pin on the oracle: selection bit-exact, sums / gradients to fp32 round-off"""
+    from oracle import geometry as G
+    dev = "cuda"
+    Hh, W = 512, 1024
+    gen = torch.Generator().manual_seed(18)
+    low = torch.rand(B16, 3, Hh // 8, W // 8, generator=gen)
+    tgt = (torch.nn.functional.interpolate(low, size=(Hh, W), mode="bilinear", align_corners=False) * 0.8
+           + 0.2 * torch.rand(B16, 3, Hh, W, generator=gen)).to(dev)
+    srcs = [(torch.roll(tgt, shifts=(1, -2), dims=(2, 3)) * 0.97 + 0.01).contiguous(),
+            (torch.roll(tgt, shifts=(-1, 3), dims=(2, 3)) * 1.02 - 0.01).contiguous()]
+    disp = (0.02 + 0.9 * torch.rand(B16, 1, Hh // 4, W // 4, generator=gen)).to(dev)
+    K = torch.tensor([[1.1 * W, 0, 0.5 * W, 0], [0, 1.1 * W, 0.5 * Hh, 0], [0, 0, 1, 0], [0, 0, 0, 1.0]]).repeat(B16, 1, 1)
+    iK = torch.linalg.pinv(K).to(dev)
+    K = K.to(dev)
+    Ts = [G.pose_matrix(0.01 * torch.randn(B16, 1, 3, generator=gen), 0.05 * torch.randn(B16, 1, 3, generator=gen),
+                        invert=(j == 0)).to(dev) for j in range(2)]
+    noise = torch.randn(B16, 2, Hh, W, generator=gen).to(dev)
+    cols = [H.warp_forward(disp, iK, K, Ts[j], srcs[j], 0.1, 100.0)[0] for j in range(2)]
+    # ---- stage chain
+    ident = torch.empty(B16, 2, Hh, W, device=dev)
+    reproj = torch.empty(B16, 2, Hh, W, device=dev)
+    for j in range(2):
+        H.reprojection_error(srcs[j], tgt, False, ident[:, j])
+        H.reprojection_error(cols[j], tgt, False, reproj[:, j])
+    ssum0, sel0, isel0 = H.automask_min(ident, noise, reproj, False)
+    scale = 1.0 / (B16 * Hh * W)
+    greproj = H.automask_min_backward(sel0, True, 2, False, scale)
+    gup0 = torch.zeros(B16, Hh, W, device=dev)
+    gT0 = []
+    for j in range(2):
+        gpred = H.reprojection_error_backward(cols[j], tgt, greproj[:, j], False)
+        gT = torch.zeros(B16, 4, 4, device=dev)
+        H.warp_backward(gpred, disp, iK, K, Ts[j], srcs[j], 0.1, 100.0, gup0, gT)
+        gT0.append(gT)
+    # ---- fused
+    ident1 = H.photometric_identity(srcs[0], srcs[1], tgt, False)
+    assert torch.equal(ident1, ident)
+    ssum1, sel1, isel1 = H.photometric_forward(cols[0], cols[1], tgt, ident1, noise, False, False)
+    assert torch.equal(sel1, sel0) and torch.equal(isel1, isel0)
+    assert_close(ssum1, ssum0, rtol=1e-6, what="sum of minima")
+    gT1 = [torch.zeros(B16, 4, 4, device=dev) for _ in range(2)]
+    w = torch.full((1,), 1.0, device=dev)
+    gup1 = H.photometric_backward(cols[0], cols[1], tgt, sel1, True, disp, iK, K, Ts[0], Ts[1], srcs[0], srcs[1], 0.1, 100.0,
+                                  False, False, scale, w, gT1[0], gT1[1])
+    sc = float(gup0.abs().max())
+    assert sc > 0
+    assert_close(gup1, gup0, rtol=1e-4, atol=1e-5 * sc, what="d loss / d upsampled disparity")
+    for j in range(2):
+        assert_close(gT1[j], gT0[j], rtol=1e-4, atol=1e-5 * float(gT0[j].abs().max()), what="d loss / d T%d" % j)

@@ -42,3 +42,9 @@ def test_encoder_r18(golden):
 def test_monodepth_loss_vs_reference(golden):
     MC.run_loss_vs_reference("cpu", golden)
 
+
+
+def test_monodepth_loss_multi_tile_strips(golden, monkeypatch):
+    """the fused photometric kernels walk several tiles per block at real sizes; force that on the small golden case"""
+    monkeypatch.setenv("SEGSDE_PHOTO_TILES", "2")
+    MC.run_loss_vs_reference("cpu", golden)

@@ -19,6 +19,11 @@ def test_monodepth_loss_vs_reference(golden):
     MC.run_loss_vs_reference("cuda", golden)
 
 
+def test_monodepth_loss_multi_tile_strips(golden, monkeypatch):
+    monkeypatch.setenv("SEGSDE_PHOTO_TILES", "2")
+    MC.run_loss_vs_reference("cuda", golden)
+
+
 @pytest.mark.parametrize("which", ["dd1", "dd2", "jsd1", "jsd2", "pad1", "pad2"])
 def test_decoders(golden, which):
     MC.run_decoders("cuda", golden, (which,))
