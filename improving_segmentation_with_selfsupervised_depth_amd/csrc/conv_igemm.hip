@@ -214,12 +214,13 @@ __device__ __forceinline__ float4 fast_fetch(const ConvP& p, const SrcSel& s, in
 }
 
 // MODE 0: generic scalar gather, 1: generic float4 gather, 2: FAST (uniform tap per chunk, branch-free loads),
-// 3: FAST + reflection-pad adjoint extras
+// 3: FAST + reflection-pad adjoint extras, 4: FAST with the tiles written to LDS by the load itself (LDS-DMA)
 template <int BM, int BN, int WM, int WN, int MODE, int BK>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
   constexpr bool VEC = MODE >= 1;
   constexpr bool FAST = MODE >= 2;
   constexpr bool ADJ = MODE == 3;
+  constexpr bool DMA = MODE == 4;
   // LDS rows are unpadded (BK floats); the 16-byte column groups of a row are XOR-swizzled with the row index so that
   // the 16 lanes of every ds_read_b128 lane group hit 16 distinct 16-byte slots of the 256-byte bank row (conflict-free)
   // -- no padding means 48 KB instead of 54 KB for the 128x64 tile, i.e. THREE workgroups per CU instead of two.
@@ -350,6 +351,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
     const float* base1 = s1.src + (size_t)b0 * s1.bstride;
     const segsde_rsrc rsw = segsde_make_rsrc(p.w);
     unsigned voff[AR], voffB[BR];
+    // LDS-DMA writes lane l of an instruction to slot l of a 1 KiB block (8 tile rows x 8 sixteen-byte slots for BK = 32):
+    // the thread that owns slot kq of row r0 therefore FETCHES the channel group that the swizzled layout keeps there,
+    // kq ^ swz(r0) (rows 32 apart share the swizzle, so this is one constant per thread) -- fragment reads are unchanged
+    const unsigned kqs = DMA ? (unsigned)(kq ^ swz(r0)) : (unsigned)kq;
     // reflection-pad adjoint: a pixel in row 1 / H-2 (column 1 / W-2) also collects what flowed into the mirrored
     // padding row -1 / H (column -1 / W), reachable only through the tap with dh = +1 / -1 (dw likewise).  The extra
     // pre-image is one more buffer load per tile row (offset voffX, out of range when there is none); only the four
@@ -358,7 +363,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
 #pragma unroll
     for (int i = 0; i < BR; ++i) {
       const int n = n0 + r0 + RP * i;
-      voffB[i] = n < p.ne ? (unsigned)(n * p.Kfull + 4 * kq) * 4u : SEGSDE_OOB;   // rows past Cout read zeros
+      voffB[i] = n < p.ne ? ((unsigned)(n * p.Kfull) + 4u * kqs) * 4u : SEGSDE_OOB;   // rows past Cout read zeros
     }
     bool wave_bord = false, wave_corner = false;
     {
@@ -382,7 +387,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
 #pragma unroll
       for (int i = 0; i < AR; ++i) {
         auto boff = [&](int hh, int ww) {
-          return ((unsigned)rb[i] * bst + ((unsigned)(hh >> sh) * Ws + (unsigned)(ww >> sh)) * ld + 4u * kq) * 4u;
+          return ((unsigned)rb[i] * bst + ((unsigned)(hh >> sh) * Ws + (unsigned)(ww >> sh)) * ld + 4u * kqs) * 4u;
         };
         int hi = rh[i] + dh, wi = rw[i] + dw;
         bool ok = rok[i] && (((hi | wi) & ds) == 0);
@@ -461,13 +466,90 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
         chunk_end();
       };
 
+      float4 fa[2][TM], fb[2][TN];
+      if constexpr (DMA) {
+        // Two LDS stages, no register staging: during the MFMAs of chunk kc the loads of chunk kc+1 write the other
+        // stage directly (free since the barrier that ended iteration kc-1); they are waited for (vmcnt(0)) right before
+        // the barrier that ends iteration kc.  No ds_write, no staging VGPRs, the loop body has no vector memory
+        // instruction that returns to registers.
+        static_assert(KQ == 8, "LDS-DMA tile pieces are 8 rows x 128 bytes");
+        // LDS byte address of this wave's 8 consecutive tile rows in pass 0 of the A tile of stage 0 (scalar from here on)
+        const unsigned lds0 = segsde_lds_addr(smem) + (unsigned)(__builtin_amdgcn_readfirstlane(wave) * 8 * LDT * 4);
+        constexpr unsigned PASS = RP * LDT * 4, BOFF = BM * LDT * 4, STG = STAGE * 4;
+        // weight-row byte offset of the chunk being fetched: consecutive chunks are consecutive 128-byte pieces of the
+        // packed row except across a tap change of a parity-class sub-problem, where it is recomputed from the tap
+        unsigned wbyte = (unsigned)((p.kh0 * p.KWf + p.kw0) * p.Ctot) * 4u;
+        auto dma_begin = [&]() {
+          const bool in0 = cs.c0 < p.C0;
+          rsa = segsde_make_rsrc(in0 ? base0 : base1);
+          soffA = (unsigned)(in0 ? cs.c0 : cs.c0 - p.C0) * 4u;
+          soffB = wbyte;
+        };
+        auto dma_end = [&](bool adv) {
+          if (adv) {
+            cs.advance(p, BK);
+            wbyte += BK * 4u;
+            if (cs.c0 == 0) wbyte = (unsigned)(((p.kh0 + p.khs * cs.kh) * p.KWf + p.kw0 + p.kws * cs.kw) * p.Ctot) * 4u;
+            if (cs.c0 == 0 || cs.c0 == p.C0) tap_update(wadj_tag);
+          }
+        };
+        auto dmaA = [&](unsigned stage, int i) { segsde_buffer_load4_lds(rsa, voff[i], soffA, lds0 + stage + PASS * i); };
+        auto dmaB = [&](unsigned stage, int i) { segsde_buffer_load4_lds(rsw, voffB[i], soffB, lds0 + stage + BOFF + PASS * i); };
+        tap_update(wadj_tag);
+        dma_begin();
+  #pragma unroll
+        for (int i = 0; i < AR; ++i) dmaA(0u, i);
+  #pragma unroll
+        for (int i = 0; i < BR; ++i) dmaB(0u, i);
+        dma_end(nchunks > 1);
+        segsde_wait_vmcnt0();
+        __syncthreads();
+        const int arow = wm * TM * 32 + (lane & 31), brow = wn * TN * 32 + (lane & 31), h = lane >> 5;
+        const int sa = swz(arow), sb = swz(brow);
+        auto fread = [&](int buf, int g, int slot) {
+          const float* Ap = smem + buf * STAGE + arow * LDT;
+          const float* Bp = smem + buf * STAGE + BM * LDT + brow * LDT;
+  #pragma unroll
+          for (int i = 0; i < TM; ++i) fa[slot][i] = *reinterpret_cast<const float4*>(Ap + i * 32 * LDT + 4 * ((2 * g + h) ^ sa));
+  #pragma unroll
+          for (int j = 0; j < TN; ++j) fb[slot][j] = *reinterpret_cast<const float4*>(Bp + j * 32 * LDT + 4 * ((2 * g + h) ^ sb));
+        };
+        auto comp = [](const float4& v, int c) { return c == 0 ? v.x : (c == 1 ? v.y : (c == 2 ? v.z : v.w)); };
+        constexpr int DSTEP = (U - 2) / (AR + BR) > 0 ? (U - 2) / (AR + BR) : 1;
+        for (int kc = 0; kc < nchunks; ++kc) {
+          const int buf = kc & 1;
+          fread(buf, 0, 0);
+          dma_begin();                     // past the last chunk: the last one is fetched again (harmless, waited for)
+          const unsigned stn = (unsigned)(buf ^ 1) * STG;
+  #pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const int g = u / 4, st = u % 4;
+            if (st == 2 && g + 1 < NG) fread(buf, g + 1, (g + 1) & 1);
+  #pragma unroll
+            for (int i = 0; i < TM; ++i)
+  #pragma unroll
+              for (int j = 0; j < TN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(comp(fa[g & 1][i], st), comp(fb[g & 1][j], st), acc[i][j], 0, 0, 0);
+  #pragma unroll
+            for (int i = 0; i < AR; ++i)
+              if (u == DSTEP * i) dmaA(stn, i);
+  #pragma unroll
+            for (int i = 0; i < BR; ++i)
+              if (u == DSTEP * (AR + i)) dmaB(stn, i);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          dma_end(kc + 2 < nchunks);
+          segsde_wait_vmcnt0();
+          __syncthreads();
+        }
+        return;
+      }
       tap_update(wadj_tag);
       load_chunk(0);
       storeA(smem); storeB(smem + BM * LDT);
       load_chunk(1);
       __syncthreads();
 
-      float4 fa[2][TM], fb[2][TN];
       const int arow = wm * TM * 32 + (lane & 31), brow = wn * TN * 32 + (lane & 31), h = lane >> 5;
       const int sa = swz(arow), sb = swz(brow);
       auto fread = [&](int buf, int g, int slot) {
@@ -1102,7 +1184,7 @@ __global__ __launch_bounds__(256) void reflect_dgrad_fix_kernel(const float* dy,
 // experiment knob (environment SEGSDE_TUNE="bk64=1"), read once.  Measured on MI355X (profiles/ab_conv_r01.log):
 // BK=64 (139 KB LDS => 1 workgroup/CU, half the barriers) loses 15-25 % on the large layers against BK=32 with two
 // co-resident workgroups per CU, and start-up staggering of co-resident workgroups changes nothing.
-struct Tune { int bk64 = 0; int adjfix = 0; int wplan = 0; int wovh = 4; int nos2 = 0; };
+struct Tune { int bk64 = 0; int adjfix = 0; int wplan = 0; int wovh = 4; int nos2 = 0; int dma = 1; };
 const Tune& tune() {
   static Tune t = [] {
     Tune r;
@@ -1112,6 +1194,7 @@ const Tune& tune() {
       if (const char* q = strstr(e, "wplan=")) r.wplan = atoi(q + 6);     // 1: previous fixed-target split plan
       if (const char* q = strstr(e, "wovh=")) r.wovh = atoi(q + 5);       // per-workgroup fixed cost in chunk units
       if (const char* q = strstr(e, "adjfix=")) r.adjfix = atoi(q + 7);   // reflection adjoint: plain loop + border fix-up kernel
+      if (const char* q = strstr(e, "dma=")) r.dma = atoi(q + 4);         // 0: register-staged tile loads (round-1 loop)
     }
     return r;
   }();
@@ -1199,6 +1282,7 @@ template <int BM, int BN, int WM, int WN>
 int launch_igemm(const ConvP& p, hipStream_t stream) {
   if (igemm_fast_ok(p) && p.pad_mode == SEGSDE_PAD_REFLECT_ADJOINT && !(tune().adjfix && !p.sum2x2) && tune().adjfix < 2) return launch_igemm_mode<BM, BN, WM, WN, 3, 32>(p, stream);
   if (tune().bk64 && bk64_ok(p)) return launch_igemm_mode<BM, BN, WM, WN, 2, 64>(p, stream);
+  if (igemm_fast_ok(p) && tune().dma) return launch_igemm_mode<BM, BN, WM, WN, 4, 32>(p, stream);
   if (igemm_fast_ok(p)) return launch_igemm_mode<BM, BN, WM, WN, 2, 32>(p, stream);
   if (vec_ok(p)) return launch_igemm_mode<BM, BN, WM, WN, 1, 32>(p, stream);
   return launch_igemm_mode<BM, BN, WM, WN, 0, 32>(p, stream);

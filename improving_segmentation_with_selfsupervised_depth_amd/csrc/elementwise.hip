@@ -120,10 +120,11 @@ __device__ __forceinline__ void combine_partials(const double* part, int nb, int
 
 __global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const double* part, int nb, long M, int C, float eps,
                                                                 float momentum, float* mean, float* invstd,
-                                                                float* running_mean, float* running_var) {
+                                                                float* running_mean, float* running_var, int64_t* nbt) {
   SEGSDE_SMEM;
   double* sh = reinterpret_cast<double*>(segsde_smem);
   const int c = blockIdx.x * 16 + (threadIdx.x & 15), pl = threadIdx.x >> 4;
+  if (nbt && blockIdx.x == 0 && threadIdx.x == 0) nbt[0] += 1;   // nn.BatchNorm2d.num_batches_tracked, without its own launch
   double s, q;
   combine_partials(part, nb, C, c, pl, sh, s, q);
   if (pl != 0 || c >= C) return;
@@ -559,7 +560,8 @@ extern "C" size_t segsde_bn_backward_workspace(long M, int C) { return part_byte
 extern "C" size_t segsde_colsum_workspace(long M, int C) { return part_bytes(M, C); }
 
 extern "C" int segsde_bn_stats(const float* x, int ldx, long M, int C, float* mean, float* invstd, float* running_mean,
-                               float* running_var, float momentum, float eps, void* ws, size_t ws_bytes, void* stream) {
+                               float* running_var, float momentum, float eps, int64_t* num_batches_tracked, void* ws,
+                               size_t ws_bytes, void* stream) {
   if (!x || !mean || !invstd || !ws) return SEGSDE_ERR_NULL;
   if (M <= 0 || C <= 0 || ldx < C) return SEGSDE_ERR_SHAPE;
   if (ws_bytes < part_bytes(M, C)) return SEGSDE_ERR_WORKSPACE;
@@ -567,7 +569,7 @@ extern "C" int segsde_bn_stats(const float* x, int ldx, long M, int C, float* me
   const bool vec = (C % 4 == 0) && (ldx % 4 == 0) && al16p(x);
   if (int e = launch_colreduce(op, M, C, (double*)ws, vec, ST(stream))) return e;
   hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((C + 15) / 16), dim3(256), 4096, ST(stream), (const double*)ws,
-                     red_blocks(M), M, C, eps, momentum, mean, invstd, running_mean, running_var);
+                     red_blocks(M), M, C, eps, momentum, mean, invstd, running_mean, running_var, num_batches_tracked);
   SEGSDE_CHECK_LAUNCH();
   return 0;
 }
@@ -596,8 +598,8 @@ namespace { constexpr int PARTIALS_NB = 64; }
 extern "C" size_t segsde_bn_stats_from_partials_workspace(int C) { return (size_t)PARTIALS_NB * 2 * (C > 0 ? C : 1) * sizeof(double); }
 
 extern "C" int segsde_bn_stats_from_partials(const double* partials, long rows, long M, int C, float* mean, float* invstd,
-                                             float* running_mean, float* running_var, float momentum, float eps, void* ws,
-                                             size_t ws_bytes, void* stream) {
+                                             float* running_mean, float* running_var, float momentum, float eps,
+                                             int64_t* num_batches_tracked, void* ws, size_t ws_bytes, void* stream) {
   if (!partials || !mean || !invstd || !ws) return SEGSDE_ERR_NULL;
   if (rows <= 0 || M <= 0 || C <= 0) return SEGSDE_ERR_SHAPE;
   if (ws_bytes < segsde_bn_stats_from_partials_workspace(C)) return SEGSDE_ERR_WORKSPACE;
@@ -606,7 +608,7 @@ extern "C" int segsde_bn_stats_from_partials(const double* partials, long rows, 
                      (double*)ws);
   SEGSDE_CHECK_LAUNCH();
   hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((C + 15) / 16), dim3(256), 4096, ST(stream), (const double*)ws, nb, M, C,
-                     eps, momentum, mean, invstd, running_mean, running_var);
+                     eps, momentum, mean, invstd, running_mean, running_var, num_batches_tracked);
   SEGSDE_CHECK_LAUNCH();
   return 0;
 }

@@ -28,6 +28,23 @@ __device__ __forceinline__ float4 segsde_buffer_load4(segsde_rsrc r, unsigned vo
   const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
   return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
+// LDS-DMA: the same raw buffer load, but the 16 bytes of lane l land in LDS at lds_wave_base + 16*l without passing
+// through VGPRs (buffer_load_dwordx4 ... offen lds; destination = M0 + 16*lane, so the LDS image of one instruction is
+// 1 KiB lane-linear -- a swizzled layout is obtained by permuting which SOURCE element each lane fetches).  Out-of-range
+// lanes store zeros.  Issued through inline asm on purpose: hipcc would order a builtin LDS-DMA before every later LDS
+// read with s_waitcnt vmcnt(0) (it cannot prove that the other staging buffer is not the one being read).  hipcc does not
+// count these loads: the caller waits with segsde_wait_vmcnt0() before the barrier that publishes the buffer.
+// lds_wave_addr: LDS BYTE address (segsde_lds_addr) of the 1 KiB block, an SGPR value.
+// LDS byte address of a pointer into the workgroup's LDS (wave-uniform; computed once, outside the loops)
+__device__ __forceinline__ unsigned segsde_lds_addr(const void* p) {
+  return __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) const void*)p);
+}
+__device__ __forceinline__ void segsde_buffer_load4_lds(segsde_rsrc r, unsigned voff, unsigned soff, unsigned lds_wave_addr) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(r), "s"(soff), "s"(lds_wave_addr) : "memory");
+}
+__device__ __forceinline__ void segsde_wait_vmcnt0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 #endif
 
 // hides a VGPR value's provenance from the optimiser (no instruction is emitted)

@@ -129,15 +129,16 @@ class BNActFn(Function):
 
     @staticmethod
     def forward(ctx, x, gamma, beta, residual, running_mean, running_var, training, momentum, eps, act, drop_p, seed,
-                partials=None, grad_box=None):
+                partials=None, grad_box=None, nbt=None):
         ctx.grad_box = grad_box
         x = _c(x)
         if training and partials is not None:
             # the producing convolution already summed x and x^2 per tile in its epilogue
             mean, invstd = H.bn_stats_from_partials(partials, x.numel() // x.shape[-1], running_mean, running_var, momentum,
-                                                    eps, update_running=running_mean is not None)
+                                                    eps, update_running=running_mean is not None, num_batches_tracked=nbt)
         elif training:
-            mean, invstd = H.bn_stats(x, running_mean, running_var, momentum, eps, update_running=running_mean is not None)
+            mean, invstd = H.bn_stats(x, running_mean, running_var, momentum, eps, update_running=running_mean is not None,
+                                      num_batches_tracked=nbt)
         else:
             mean, invstd = H.bn_eval_stats(running_mean, running_var, eps)
         y = H.bn_apply(x, mean, invstd, gamma, beta, residual, act, drop_p, seed)
@@ -158,7 +159,7 @@ class BNActFn(Function):
             dgamma = dbeta = None
         if ctx.grad_box is not None and dres is not None:
             ctx.grad_box["g"] = dres         # the block's first conv may add its data-gradient onto this tensor
-        return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None, None, None, None
+        return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None, None, None, None, None
 
 
 class SplitFn(Function):

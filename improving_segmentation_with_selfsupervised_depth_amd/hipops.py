@@ -219,7 +219,7 @@ def _rows(t):
     return B * H * W, C, nhwc_ld(t)
 
 
-def bn_stats(x, running_mean, running_var, momentum, eps, update_running=True):
+def bn_stats(x, running_mean, running_var, momentum, eps, update_running=True, num_batches_tracked=None):
     M, C, ld = _rows(x)
     L = _lib.lib()
     mean = torch.empty(C, dtype=torch.float32, device=x.device)
@@ -227,12 +227,12 @@ def bn_stats(x, running_mean, running_var, momentum, eps, update_running=True):
     nb = L.segsde_bn_stats_workspace(M, C)
     ws = _ws(nb, x)
     check(L.segsde_bn_stats(_p(_f32(x)), ld, M, C, _p(mean), _p(invstd), _p(running_mean if update_running else None),
-                            _p(running_var if update_running else None), float(momentum), float(eps), _p(ws), nb,
-                            _stream(x)), "bn_stats")
+                            _p(running_var if update_running else None), float(momentum), float(eps),
+                            _p(num_batches_tracked), _p(ws), nb, _stream(x)), "bn_stats")
     return mean, invstd
 
 
-def bn_stats_from_partials(part, M, running_mean, running_var, momentum, eps, update_running=True):
+def bn_stats_from_partials(part, M, running_mean, running_var, momentum, eps, update_running=True, num_batches_tracked=None):
     """batch statistics from the partial sums a conv_forward(want_stats=True) launch produced (same outputs / running
     update as bn_stats, without reading the activation tensor again)"""
     rows, _, C = part.shape
@@ -243,8 +243,8 @@ def bn_stats_from_partials(part, M, running_mean, running_var, momentum, eps, up
     ws = _ws(nb, part)
     check(L.segsde_bn_stats_from_partials(_p(part), rows, M, C, _p(mean), _p(invstd),
                                           _p(running_mean if update_running else None),
-                                          _p(running_var if update_running else None), float(momentum), float(eps), _p(ws),
-                                          nb, _stream(part)), "bn_stats_from_partials")
+                                          _p(running_var if update_running else None), float(momentum), float(eps),
+                                          _p(num_batches_tracked), _p(ws), nb, _stream(part)), "bn_stats_from_partials")
     return mean, invstd
 
 
@@ -691,6 +691,8 @@ def pseudo_label(prob, threshold, ignore_index, want_max=False, want_weight=True
     pw = torch.empty((B, H, W), dtype=torch.float32, device=prob.device) if want_weight else None
     check(_lib.lib().segsde_pseudo_label(_p(prob), B, C, H * W, float(threshold), int(ignore_index), _p(label), _p(maxp),
                                          _p(count), _p(pw), _stream(prob)), "pseudo_label")
+    if pw is not None:
+        pw._segsde_finite = True      # count / total: cannot be NaN (cross_entropy2d skips its host-side NaN check)
     return label, count, maxp, pw
 
 

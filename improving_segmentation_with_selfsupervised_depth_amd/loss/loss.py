@@ -37,7 +37,9 @@ def cross_entropy2d(input, target, class_weight=None, pixel_weights=None):
     mean_over_all = False
     if pixel_weights is not None:
         mean_over_all = True          # reduction="none" followed by torch.mean over every pixel (loss.py:28-36)
-        if torch.any(torch.isnan(pixel_weights)):
+        # reference loss.py:29-31 checks the weights for NaN on the host (a device sync per call).  Weights made by
+        # hipops.pseudo_label (count / total, a finite number by construction) carry a marker and skip that check.
+        if not getattr(pixel_weights, "_segsde_finite", False) and torch.any(torch.isnan(pixel_weights)):
             print("WARN cross_entropy2d pixel_weights contains NaN. Skip weighting.")
             pixel_weights = None
         else:

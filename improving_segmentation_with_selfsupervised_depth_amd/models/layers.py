@@ -26,6 +26,8 @@ class Conv2d(nn.Conv2d):
     def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, bias=True, reflect=False):
         super().__init__(int(in_channels), int(out_channels), kernel_size, stride, padding, dilation, bias=bias)
         self.reflect = reflect
+        self._stats_wanted = None     # None: unknown yet, True: a BatchNorm consumed the fused statistics, False: nobody did
+        self._stats_offered = False
         k = self.kernel_size[0]
         assert self.kernel_size[0] == self.kernel_size[1] and self.stride[0] == self.stride[1]
 
@@ -41,12 +43,18 @@ class Conv2d(nn.Conv2d):
             assert c0 + c1 == self.in_channels, (c0, c1, self.in_channels)
         g = ConvGeom(c0, self.out_channels, self.kernel_size[0], self.stride[0], self.dilation[0], self.padding[0],
                      self.reflect, c1, up)
-        if self.bias is None and act == "none" and self.training and not _NO_FUSED_STATS:
-            # bias-free, activation-free convolutions are the ones followed by a BatchNorm (torchvision ResNet / ASPP
-            # convention): their epilogue also leaves the batch-statistics partials, picked up by BatchNorm2d.forward
+        if self.bias is None and act == "none" and self.training and not _NO_FUSED_STATS and self._stats_wanted is not False:
+            # bias-free, activation-free convolutions are the candidates for a following BatchNorm (torchvision ResNet /
+            # ASPP convention): their epilogue also leaves the batch-statistics partials, picked up by
+            # BatchNorm2d.forward.  A convolution whose partials nobody picked up (SelfAttention's convs, the
+            # segmentation projections) stops producing them after its first training forward.
+            if self._stats_wanted is None and self._stats_offered:
+                self._stats_wanted = False
+                return Fn.ConvFn.apply(x, skip, weight, self.bias, g, act, None, grad_box)
+            self._stats_offered = True
             holder = []
             y = Fn.ConvFn.apply(x, skip, weight, self.bias, g, act, holder, grad_box)
-            y._bn_partials = (holder[0], y._version) if holder and holder[0] is not None else None
+            y._bn_partials = (holder[0], y._version, self) if holder and holder[0] is not None else None
             return y
         return Fn.ConvFn.apply(x, skip, weight, self.bias, g, act, None, grad_box)
 
@@ -57,15 +65,23 @@ class BatchNorm2d(nn.BatchNorm2d):
 
     def forward(self, x, residual=None, act="none", drop_p=0.0, grad_box=None):
         training = self.training or (self.running_mean is None)
-        if self.training and self.track_running_stats and self.num_batches_tracked is not None:
-            self.num_batches_tracked.add_(1)
-        momentum = 0.1 if self.momentum is None else self.momentum
+        # num_batches_tracked is incremented by the statistics finalize kernel (no launch of its own)
+        nbt = self.num_batches_tracked if (self.training and self.track_running_stats
+                                           and self.num_batches_tracked is not None) else None
+        if self.momentum is None:
+            # torch.nn.BatchNorm2d: cumulative moving average, factor 1 / num_batches_tracked after this forward's
+            # increment (reads the device counter: a host sync, on a path no reference config takes)
+            momentum = 1.0 / float(int(self.num_batches_tracked) + 1) if nbt is not None else 0.0
+        else:
+            momentum = self.momentum
         seed = _seed() if drop_p > 0 else 0
         partials = getattr(x, "_bn_partials", None) if training else None
         if partials is not None:
             # valid only for the very tensor the convolution produced: same channel count and no in-place edit since
-            partials, version = partials
+            partials, version, producer = partials
             if partials.shape[-1] != self.num_features or x._version != version:
                 partials = None
+            else:
+                producer._stats_wanted = True
         return Fn.BNActFn.apply(x, self.weight, self.bias, residual, self.running_mean, self.running_var, training,
-                                momentum, self.eps, act, drop_p, seed, partials, grad_box)
+                                momentum, self.eps, act, drop_p, seed, partials, grad_box, nbt)

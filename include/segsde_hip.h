@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SEGSDE_ABI_VERSION 3
+#define SEGSDE_ABI_VERSION 4
 
 enum { SEGSDE_ERR_NULL = -1, SEGSDE_ERR_SHAPE = -2, SEGSDE_ERR_WORKSPACE = -3, SEGSDE_ERR_UNSUPPORTED = -4 };
 enum { SEGSDE_ACT_NONE = 0, SEGSDE_ACT_RELU = 1, SEGSDE_ACT_ELU = 2, SEGSDE_ACT_SIGMOID = 3 };
@@ -95,10 +95,12 @@ int segsde_reflect_dgrad_fix(const float* dy, int lddy, const float* wdpack, flo
  * BatchNorm / activations / pooling / resampling (HBM-bound, NHWC)                                 *
  * ------------------------------------------------------------------------------------------------ */
 /* Training-mode batch statistics over M rows (nn.BatchNorm2d.forward in train(), every BN on the path):
- * mean[c], invstd[c] = 1/sqrt(biased var + eps); running stats updated with `momentum` using the unbiased var. */
+ * mean[c], invstd[c] = 1/sqrt(biased var + eps); running stats updated with `momentum` using the unbiased var;
+ * num_batches_tracked (nullable, device int64 scalar) is incremented by one, as nn.BatchNorm2d does per training forward. */
 size_t segsde_bn_stats_workspace(long M, int C);
 int segsde_bn_stats(const float* x, int ldx, long M, int C, float* mean, float* invstd, float* running_mean,
-                    float* running_var, float momentum, float eps, void* workspace, size_t workspace_bytes, void* stream);
+                    float* running_var, float momentum, float eps, int64_t* num_batches_tracked, void* workspace,
+                    size_t workspace_bytes, void* stream);
 /* Eval mode: mean = running_mean, invstd = 1/sqrt(running_var + eps). */
 int segsde_bn_eval_stats(const float* running_mean, const float* running_var, int C, float eps, float* mean,
                          float* invstd, void* stream);
@@ -114,8 +116,8 @@ int segsde_bn_apply(const float* x, int ldx, long M, int C, const float* mean, c
  * segsde_conv2d_forward_stats launch left behind; workspace: segsde_bn_stats_from_partials_workspace(C) bytes. */
 size_t segsde_bn_stats_from_partials_workspace(int C);
 int segsde_bn_stats_from_partials(const double* partials, long rows, long M, int C, float* mean, float* invstd,
-                                  float* running_mean, float* running_var, float momentum, float eps, void* workspace,
-                                  size_t workspace_bytes, void* stream);
+                                  float* running_mean, float* running_var, float momentum, float eps,
+                                  int64_t* num_batches_tracked, void* workspace, size_t workspace_bytes, void* stream);
 size_t segsde_bn_backward_workspace(long M, int C);
 /* y may be NULL ("remask"): for act = none, or act = ReLU with no residual / dropout (then beta is required with gamma),
  * the activation mask is recomputed from x exactly as the forward kernel formed it and the saved output is not read. */

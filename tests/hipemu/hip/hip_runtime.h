@@ -154,6 +154,15 @@ inline float4 segsde_buffer_load4(segsde_rsrc r, unsigned voff, unsigned soff) {
   return v;
 }
 
+// LDS-DMA flavour: lane l's 16 bytes land at lds_wave_base + 16*l (executed synchronously here: the interpreter cannot
+// model a missing wait, only wrong addresses / wrong buffer hand-over order)
+inline unsigned segsde_lds_addr(const void* p) { return (unsigned)(static_cast<const unsigned char*>(p) - ::emu_lds); }
+inline void segsde_buffer_load4_lds(segsde_rsrc r, unsigned voff, unsigned soff, unsigned lds_wave_addr) {
+  const float4 v = segsde_buffer_load4(r, voff, soff);
+  memcpy(::emu_lds + lds_wave_addr + 16 * emu::lane(), &v, sizeof(v));
+}
+inline void segsde_wait_vmcnt0() {}
+
 inline void __syncthreads() { emu::barrier_wait(&emu::S().block_bar); }
 inline float __shfl_xor(float v, int m, int = 64) { return emu::shfl_idx<float>(v, [m](int l) { return l ^ m; }); }
 inline float __shfl_down(float v, int d, int = 64) { return emu::shfl_idx<float>(v, [d](int l) { return l + d; }); }

@@ -51,7 +51,7 @@ def test_argument_validation_without_gpu():
     d = _lib.ConvDesc(B=1, H=4, W=4, C0=4, C1=0, ld0=4, Ho=4, Wo=4, Cout=4, ldy=4, KH=3, KW=3, stride=1, dil=1, pad=1)
     assert cdll.segsde_conv2d_forward(ctypes.byref(d), None, None, None, None, None, None, None) == -1
     assert cdll.segsde_conv2d_wgrad_workspace(ctypes.byref(d)) > 0
-    assert cdll.segsde_bn_stats(None, 4, 10, 4, None, None, None, None, 0.1, 1e-5, None, 0, None) == -1
+    assert cdll.segsde_bn_stats(None, 4, 10, 4, None, None, None, None, 0.1, 1e-5, None, None, 0, None) == -1
 
 
 def test_product_never_imports_oracle_or_falls_back():
