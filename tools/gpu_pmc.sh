@@ -12,9 +12,10 @@ run() {  # name, counters...
   rocprofv3 --kernel-trace --pmc "$@" -d $OUT/pmc_$name -o pmc -- python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing > $OUT/r2_pmc_$name.log 2>&1
   local db=$(ls $OUT/pmc_$name/*.db 2>/dev/null | head -1)
   [ -n "$db" ] && python $ROOT/tools/pmc_table.py $db $OUT/r2_pmc_$name.txt > /dev/null
+  rm -rf $OUT/pmc_$name      # the databases are tens of MB each: only the summaries travel back
 }
 run mfma SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE
 run waits SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS
 run fetch FETCH_SIZE
 run write WRITE_SIZE
-ls $OUT/pmc_* | head -20
+ls $OUT | head -40

@@ -15,15 +15,17 @@ def short(name):
 def main():
     db = sys.argv[1]
     cur = sqlite3.connect(db).cursor()
-    rows = cur.execute("select name, counter_name, dispatch_id, sum(counter_value) from pmc_events "
+    # one row per (dispatch, counter, hardware instance): SQ_* are summed over instances; GRBM_GUI_ACTIVE (the chip's busy
+    # cycle count, one value per XCD) takes the maximum over instances, as rocprofiler's own MfmaUtil expression does
+    rows = cur.execute("select name, counter_name, dispatch_id, sum(counter_value), max(counter_value) from pmc_events "
                        "group by name, counter_name, dispatch_id").fetchall()
     agg, counters = {}, []
-    for name, cn, _, v in rows:
+    for name, cn, _, vsum, vmax in rows:
         if cn not in counters:
             counters.append(cn)
         a = agg.setdefault(short(name), {})
         t = a.setdefault(cn, [0.0, 0])
-        t[0] += v
+        t[0] += vmax if cn.startswith("GRBM") else vsum
         t[1] += 1
     counters.sort()
     key = "GRBM_GUI_ACTIVE" if "GRBM_GUI_ACTIVE" in counters else counters[0]
