@@ -33,6 +33,10 @@ GFLOP_PER_IMG = {"cfg1": 216.8, "cfg2": 1423.6, "cfg3": 2467.2, "cfg3pad": 2569.
                  # (no pose nets): 4 * (3 * 2569.4 + (2569.4 / 3 - 83.4)) GFLOP
                  "cfg5": 4 * (3 * 2569.4 + (2569.4 / 3.0 - 83.4))}
 PEAK_FP32_MATRIX_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, no TF32 on gfx950
+# measured on the GPU box with rocprof-compute's roofline micro-benchmark (/opt/rocm/bin/roofline-ubuntu22_04-rocm7,
+# profiles/roofline_r02_microbench.txt): the empirical roofs SURVEY.md 8d asks to quote next to the nominal ones
+MEASURED_PEAKS = {"mfma_f32_tflops": 155.06, "hbm_gbs": 6362.5, "mall_gbs": 8711.6, "l2_gbs": 34711.8, "lds_gbs": 68629.9,
+                  "source": "profiles/roofline_r02_microbench.txt"}
 
 
 def model_cfg(workload, H, W):
@@ -361,17 +365,39 @@ def main():
             roof.update(achieved=fl / tt / 1e12, frac=fl / tt / 1e12 / PEAK_FP32_MATRIX_TFLOPS, launches=nl,
                         avg_launch_ms=tt / nl * 1e3, avg_launch_gflop=fl / nl / 1e9,
                         share_of_step=tt / dt, algorithmic_bytes_per_launch=abytes / nl)
-            # HBM-side traffic per launch: PMC counters cannot be read live, so this is the committed result of the two
-            # rocprofv3 --pmc passes of this very command (profiles/traffic_r01.json; FETCH_SIZE x2 + WRITE_SIZE, gfx950 rule)
-            tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "traffic_r01.json")
+            # HBM-side traffic per launch: PMC counters cannot be read live, so this is the committed result of the
+            # rocprofv3 --pmc passes of this very command (tools/gpu_pmc.sh -> profiles/traffic_r02.json; FETCH_SIZE x2 +
+            # WRITE_SIZE, the gfx950 rule of MI355X_MICROARCH.md)
+            tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "traffic_r02.json")
+            wg_traffic = None
             if args.workload == "cfg3" and os.path.exists(tpath):
                 try:
                     tj = json.load(open(tpath))
                     kk = [k for k in tj["kernels"] if k.startswith("conv_igemm_kernel")][0]
                     roof["traffic"] = tj["kernels"][kk]["bytes_per_launch"]
-                    roof["traffic_source"] = "profiles/traffic_r01.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py)"
+                    roof["traffic_source"] = "profiles/traffic_r02.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py)"
+                    wg_traffic = tj["kernels"]["conv_wgrad_kernel"]["bytes_per_launch"]
                 except Exception:
                     pass
+            # matrix-pipe busy fraction of the same kernels, from the committed SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE pass
+            mpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_r02_mfma_busy.txt")
+            if args.workload == "cfg3" and os.path.exists(mpath):
+                busy = {}
+                for line in open(mpath):
+                    if line.startswith("conv_"):
+                        f = line.split()
+                        busy[line[:72].strip()] = float(f[-1])
+                roof["mfma_busy"] = busy
+                roof["mfma_busy_source"] = "profiles/pmc_r02_mfma_busy.txt (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE)"
+            roof["measured_peaks"] = MEASURED_PEAKS
+            roof["frac_of_measured_peak"] = roof["achieved"] / MEASURED_PEAKS["mfma_f32_tflops"]
+            if "conv_wgrad" in agg:
+                wb = sum(tag_bytes(tag) * v[2] for (kind, tag), v in layers.items() if kind == "conv_wgrad")
+                res["wgrad"] = {"kernel": "conv_wgrad_kernel (pixel-reduction GEMM, split + deterministic reduce)",
+                                "achieved": agg["conv_wgrad"][0] / agg["conv_wgrad"][1] / 1e12,
+                                "frac": agg["conv_wgrad"][0] / agg["conv_wgrad"][1] / 1e12 / PEAK_FP32_MATRIX_TFLOPS,
+                                "launches": agg["conv_wgrad"][2],
+                                "algorithmic_bytes_per_launch": wb / agg["conv_wgrad"][2], "traffic": wg_traffic}
             res["kernels"] = {k: {"tflops": v[0] / v[1] / 1e12, "seconds": v[1], "launches": v[2],
                                   "share_of_step": v[1] / dt} for k, v in agg.items()}
         else:
