@@ -70,7 +70,7 @@ WORKLOADS = {  # name -> (H, W, per-GPU batch, optimiser, description)
     "cfg3": (512, 1024, 16, "sgd", "ResNet-101 joint_seg_depth_dec seg+depth, 512x1024, batch 16/GPU (BASELINE configs[2])"),
     "cfg3pad": (512, 1024, 16, "sgd", "ResNet-101 mtl_pad seg+depth, 512x1024, batch 16/GPU"),
     "cfg5": (1024, 2048, 2, "sgd", "ResNet-101 mtl_pad seg+depth + DepthMix unlabeled step (teacher fwd, online-depth depthcomp "
-                                   "mask, mix, 2 student fwd/bwd, EMA), 1024x2048 crops, batch 2 labeled + 2 unlabeled per GPU "
+                                   "mask, mix + colour jitter + blur, 2 student fwd/bwd, EMA), 1024x2048 crops, batch 2 labeled + 2 unlabeled per GPU "
                                    "(BASELINE configs[4]; reference asserts batch 2 for depthcomp, train.py:586)"),
 }
 
@@ -272,7 +272,7 @@ def main():
             L_u, mono_u = T.train_step_segmentation_unlabeled(
                 model, ema_model, loss_obj, unlabeled_inputs, mix_mask="depthcomp", depthmix_online_depth=True,
                 monodepth_lambda=1.0, consistency_weight=1.0, backward_first_pseudo_label=False, depthcomp_margin=0.03,
-                depthcomp_foreground_threshold=0.0, color_jitter=False, blur=False, reducer=reducer)
+                depthcomp_foreground_threshold=0.0, color_jitter=True, blur=True, reducer=reducer)
             total = total.detach() + L_u.detach() + mono_u.detach()
         else:
             total.backward()

@@ -58,6 +58,7 @@ _SIGS = {
     "segsde_gate_backward": (c_int, [P, P, P, c_long, P, P, P]),
     "segsde_axpby": (c_int, [c_long, c_float, P, c_float, P, P, P]),
     "segsde_axpby_dev": (c_int, [c_long, P, P, P, P, P, P]),
+    "segsde_scale_channels": (c_int, [P, c_int, c_int, c_long, c_int, P, P, c_int, P]),
     "segsde_copy_channels": (c_int, [P, c_int, P, c_int, c_long, c_int, P]),
     "segsde_nchw_to_nhwc": (c_int, [P, c_int, c_int, c_int, c_int, c_float, c_float, P, c_int, P]),
     "segsde_nhwc_to_nchw": (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, P]),
@@ -92,6 +93,8 @@ _SIGS = {
     "segsde_confusion_update": (c_int, [P, c_long, c_long, c_long, P, P, c_int, c_long, c_int, P, P]),
     "segsde_multi_tensor_lerp": (c_int, [P, c_int, c_float, c_float, P]),
     "segsde_pseudo_label": (c_int, [P, c_int, c_int, c_long, c_float, c_int64, P, P, P, P, P]),
+    "segsde_color_jitter": (c_int, [P, c_int, c_long, P, POINTER(c_int), P, P]),
+    "segsde_gaussian_blur": (c_int, [P, c_int, c_int, c_int, P, c_int, P, c_int, P, P, P]),
     "segsde_softmax_nhwc_to_nchw": (c_int, [P, c_int, c_int, c_long, c_int, P, P]),
     "segsde_minmax_normalize_workspace": (c_size_t, [c_int, c_long]),
     "segsde_minmax_normalize": (c_int, [P, c_int, c_long, P, P, P, P, c_size_t, P]),

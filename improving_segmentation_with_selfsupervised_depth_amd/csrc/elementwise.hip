@@ -532,6 +532,14 @@ __global__ __launch_bounds__(256) void copy_channels_kernel(const float* src, in
     else dst[m * ldd + c] = src[m * lds + c];
   }
 }
+// y[b, p, c] = x[b, p, c] * scale[b, c]   (nn.Dropout2d: whole channel maps dropped / rescaled; its own adjoint)
+__global__ __launch_bounds__(256) void scale_channels_kernel(const float* x, int ldx, const float* scale, long HW, int C, long total,
+                                                             float* y, int ldy) {
+  for (long e = blockIdx.x * 256L + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const int c = (int)(e % C); const long m = e / C; const long b = m / HW;
+    y[m * ldy + c] = x[m * ldx + c] * scale[b * C + c];
+  }
+}
 __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* x, int B, int C, int H, int W, float mean, float sd,
                                                            float* y, int ldy) {
   const long HW = (long)H * W, total = (long)B * HW * C;
@@ -800,6 +808,15 @@ extern "C" int segsde_copy_channels(const float* src, int lds, float* dst, int l
   const bool v4 = (C % 4 == 0) && (lds % 4 == 0) && (ldd % 4 == 0) && al16(src) && al16(dst);
   if (v4) hipLaunchKernelGGL(copy_channels_kernel<4>, dim3(ew_blocks(M * C / 4)), dim3(256), 0, ST(stream), src, lds, dst, ldd, M, C);
   else hipLaunchKernelGGL(copy_channels_kernel<1>, dim3(ew_blocks(M * C)), dim3(256), 0, ST(stream), src, lds, dst, ldd, M, C);
+  SEGSDE_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int segsde_scale_channels(const float* x, int ldx, int B, long HW, int C, const float* scale, float* y, int ldy,
+                                     void* stream) {
+  if (!x || !scale || !y) return SEGSDE_ERR_NULL;
+  if (B <= 0 || HW <= 0 || C <= 0 || ldx < C || ldy < C) return SEGSDE_ERR_SHAPE;
+  const long total = (long)B * HW * C;
+  hipLaunchKernelGGL(scale_channels_kernel, dim3(ew_blocks(total)), dim3(256), 0, ST(stream), x, ldx, scale, HW, C, total, y, ldy);
   SEGSDE_CHECK_LAUNCH();
   return 0;
 }

@@ -283,6 +283,20 @@ class ConcatFn(Function):
         return tuple(outs)
 
 
+class ChannelDropFn(Function):
+    """nn.Dropout2d on an NHWC tensor: y = x * scale[b, c], scale in {0, 1 / (1 - p)} (models/monodepth_layers.py:117-119)"""
+
+    @staticmethod
+    def forward(ctx, x, scale):
+        ctx.save_for_backward(scale)
+        return H.scale_channels(_c(x), scale)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (scale,) = ctx.saved_tensors
+        return H.scale_channels(_c(dy), scale), None
+
+
 class PoseMatrixFn(Function):
     """transformation_from_parameters(axisangle[:, 0], translation[:, 0], invert) on the [B,F,1,3] network outputs"""
 

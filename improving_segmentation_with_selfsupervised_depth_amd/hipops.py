@@ -398,6 +398,15 @@ def copy_channels(src, dst):
     return dst
 
 
+def scale_channels(x, scale):
+    """x: NHWC [B,H,W,C]; scale [B,C] -> x * scale[b, c] (nn.Dropout2d mask application and its adjoint)"""
+    B, Hh, W, C = x.shape
+    y = torch.empty((B, Hh, W, C), dtype=torch.float32, device=x.device)
+    check(_lib.lib().segsde_scale_channels(_p(_f32(x)), nhwc_ld(x), B, Hh * W, C, _p(_f32(scale.contiguous())), _p(y), C,
+                                           _stream(x)), "scale_channels")
+    return y
+
+
 def nchw_to_nhwc(x, mean=0.0, std=1.0, pad_to=1):
     """pad_to > 1 rounds the channel count of the result up to a multiple of pad_to; the extra channels are zero
     (the 3 / 6-channel network input becomes 4 / 8 so that the stem convolution takes the float4 gather)."""
@@ -694,6 +703,28 @@ def pseudo_label(prob, threshold, ignore_index, want_max=False, want_weight=True
     if pw is not None:
         pw._segsde_finite = True      # count / total: cannot be NaN (cross_entropy2d skips its host-side NaN check)
     return label, count, maxp, pw
+
+
+def color_jitter(x, params, order):
+    """x [B,3,H,W] dense NCHW; params [B,4] device tensor of (brightness, contrast, saturation, hue) factors; order: a
+    permutation of (0, 1, 2, 3) -- see segsde_color_jitter"""
+    x = _f32(x).contiguous()
+    B, C, Hh, W = x.shape
+    assert C == 3 and tuple(params.shape) == (B, 4)
+    y = torch.empty_like(x)
+    arr = (ctypes.c_int * 4)(*[int(o) for o in order])
+    check(_lib.lib().segsde_color_jitter(_p(x), B, Hh * W, _p(_f32(params.contiguous())), arr, _p(y), _stream(x)), "color_jitter")
+    return y
+
+
+def gaussian_blur(x, wy, wx):
+    """x [B,C,H,W] dense NCHW; wy / wx: 1-D device tensors of (odd many) normalised taps for the column / row pass"""
+    x = _f32(x).contiguous()
+    B, C, Hh, W = x.shape
+    tmp, y = torch.empty_like(x), torch.empty_like(x)
+    check(_lib.lib().segsde_gaussian_blur(_p(x), B * C, Hh, W, _p(_f32(wy.contiguous())), wy.numel(), _p(_f32(wx.contiguous())),
+                                          wx.numel(), _p(tmp), _p(y), _stream(x)), "gaussian_blur")
+    return y
 
 
 def softmax_to_nchw(logits_nhwc):

@@ -34,7 +34,15 @@ class JointSegmentationMonodepth(nn.Module):
                 outputs[("translation", 0, f_i)] = translation
                 outputs[("cam_T_cam", 0, f_i)] = Fn.PoseMatrixFn.apply(axisangle, translation, f_i < 0)
         else:
-            raise NotImplementedError("pose_model_input != 'pairs' is not used by any reference config")
+            # all frames go through the pose network together and all poses are predicted at once (reference :52-68)
+            pose_inputs = torch.cat([inputs[(key, i, 0)] for i in self.frame_ids if i != "s"], 1)
+            pose_inputs = [self.models["pose_encoder"](pose_inputs)]
+            axisangle, translation = self.models["pose"](pose_inputs)
+            for i, f_i in enumerate(self.frame_ids[1:]):
+                if f_i != "s":
+                    outputs[("axisangle", 0, f_i)] = axisangle
+                    outputs[("translation", 0, f_i)] = translation
+                    outputs[("cam_T_cam", 0, f_i)] = Fn.PoseMatrixFn.apply(axisangle[:, i:i + 1], translation[:, i:i + 1], False)
         return outputs
 
     def predict_test_disp(self, x):

@@ -44,17 +44,25 @@ class ConvBlock(nn.Module):
 
     def __init__(self, in_channels, out_channels, bn=False, dropout=0.0):
         super().__init__()
-        if dropout > 0:
-            raise NotImplementedError("Dropout2d inside ConvBlock (depth_args.dropout > 0) is not on the benchmarked path")
         self.block = nn.Sequential(
             Conv3x3(in_channels, out_channels),
             BatchNorm2d(int(out_channels)) if bn else nn.Identity(),
             nn.ELU(inplace=True),
-            nn.Identity(),
+            # "Pay attention: 2d version of dropout is used" (reference :117-119)
+            nn.Dropout2d(dropout) if dropout > 0 else nn.Identity(),
         )
         self.bn = bn
 
     def forward(self, x, skip=None, up=False):
         if self.bn:
-            return self.block[1](self.block[0](x, skip, up), act="elu")
-        return self.block[0](x, skip, up, act="elu")
+            y = self.block[1](self.block[0](x, skip, up), act="elu")
+        else:
+            y = self.block[0](x, skip, up, act="elu")
+        drop = self.block[3]
+        if isinstance(drop, nn.Dropout2d) and drop.training and self.training and drop.p > 0:
+            # whole channel maps are zeroed with probability p and the survivors scaled by 1 / (1 - p); the Bernoulli draw
+            # is torch's (device RNG plumbing), the application and its adjoint are HIP
+            B, C = y.shape[0], y.shape[3]
+            keep = torch.bernoulli(torch.full((B, C), 1.0 - drop.p, device=y.device))
+            y = Fn.ChannelDropFn.apply(y, keep / (1.0 - drop.p) if drop.p < 1 else keep)
+        return y

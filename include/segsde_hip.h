@@ -156,6 +156,9 @@ int segsde_axpby(long n, float alpha, const float* x, float beta, const float* y
 int segsde_axpby_dev(long n, const float* alpha, const float* x, const float* beta, const float* y, float* out, void* stream);
 /* channel-slice copy dst[m, 0..C) = src[m, 0..C) (torch.cat of the ASPP branches, models/model_parts.py:31) */
 int segsde_copy_channels(const float* src, int lds, float* dst, int ldd, long M, int C, void* stream);
+/* nn.Dropout2d inside ConvBlock (models/monodepth_layers.py:117-119, depth_args.dropout > 0): y[b,p,c] = x[b,p,c] * scale[b,c]
+ * with scale = 0 or 1/(1-p) per (sample, channel); the same call is its adjoint. */
+int segsde_scale_channels(const float* x, int ldx, int B, long HW, int C, const float* scale, float* y, int ldy, void* stream);
 /* NCHW image -> NHWC with the encoder's input normalisation (x - mean) / std (models/resnet_encoder.py:92);
  * mean = 0, std = 1 gives a plain layout change.  nhwc_to_nchw is the inverse layout change. */
 int segsde_nchw_to_nhwc(const float* x, int B, int C, int H, int W, float mean, float std, float* y, int ldy, void* stream);
@@ -291,6 +294,17 @@ int segsde_photometric_backward(const float* pred0, const float* pred1, const fl
  * [B,1,hs,ws] to H x W (align_corners=False) and disp_to_depth (monodepth_layers.py:18-27) with the test depth range. */
 int segsde_disp_to_depth(const float* disp, int hs, int ws, int B, int H, int W, float min_depth, float max_depth,
                          float* depth, void* stream);
+
+/* strongTransform's colour jitter, loader/transformsgpu.py:10-17 (kornia 0.4.0 ColorJitter(s, s, s, s); third party, parity
+ * unpinned): x, y [B,3,HW] planar; params DEVICE [B][4] = {brightness, contrast, saturation, hue} factors; order HOST int[4],
+ * a permutation of {0 brightness, 1 contrast, 2 saturation, 3 hue}: clamp(x + (bf - 1)), clamp(x * cf), HSV s *= sf (clamped),
+ * HSV h = fmod(h + 2 pi hf, 2 pi). */
+int segsde_color_jitter(const float* x, int B, long HW, const float* params, const int* order, float* y, void* stream);
+/* strongTransform's blur, loader/transformsgpu.py:20-30 (kornia 0.4.0 GaussianBlur2d, reflect border; parity unpinned):
+ * separable -- column pass with the ny (odd) taps wy, then row pass with the nx taps wx -- over `planes` H x W planes;
+ * tmp: planes*H*W floats; taps are DEVICE arrays (normalised Gaussian weights, possibly truncated to their non-zero support). */
+int segsde_gaussian_blur(const float* x, int planes, int H, int W, const float* wy, int ny, const float* wx, int nx, float* tmp,
+                         float* y, void* stream);
 
 #ifdef __cplusplus
 }

@@ -448,7 +448,7 @@ def pose_decoder(c, p, feat, num_frames=2):
 
 
 def model_forward(sd, model_cfg, inputs, train=True, dropout=False, use_pose_net=None):
-    """joint_segmentation_depth.py:77-100 (+ predict_poses :20-70, pairs mode)."""
+    """joint_segmentation_depth.py:77-100 (+ predict_poses :20-70, both pose_model_input modes)."""
     c = Ctx(sd, train, dropout)
     nl = int(model_cfg["backbone_name"].replace("resnet", ""))
     rswd = model_cfg.get("replace_stride_with_dilation")
@@ -480,8 +480,18 @@ def model_forward(sd, model_cfg, inputs, train=True, dropout=False, use_pose_net
         and not model_cfg.get("disable_monodepth")
     if use_pose_net is None:
         use_pose_net = has_pose
-    if use_pose_net and has_pose:
-        assert model_cfg["pose_model_input"] == "pairs"
+    if use_pose_net and has_pose and model_cfg["pose_model_input"] != "pairs":
+        # joint_segmentation_depth.py:52-68: every frame through the pose net at once, all poses together (no inversion)
+        key = "color_full_aug" if model_cfg.get("provide_uncropped_for_pose") else "color_aug"
+        x = torch.cat([inputs[(key, f, 0)] for f in frame_ids if f != "s"], 1)
+        pf = resnet_features(c, "models.pose_encoder.encoder.", x, 18, None)[-1]
+        aa, tr = pose_decoder(c, "models.pose.", pf)
+        for i, f in enumerate(frame_ids[1:]):
+            if f == "s":
+                continue
+            out[("axisangle", 0, f)], out[("translation", 0, f)] = aa, tr
+            out[("cam_T_cam", 0, f)] = G.pose_matrix(aa[:, i], tr[:, i])
+    elif use_pose_net and has_pose:
         key = "color_full_aug" if model_cfg.get("provide_uncropped_for_pose") else "color_aug"
         for f in frame_ids[1:]:
             if f == "s":

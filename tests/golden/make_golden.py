@@ -635,6 +635,35 @@ def gen_trainer():
     save("trainer", d)
 
 
+def gen_poseall():
+    """pose_model_input = "all" (models/joint_segmentation_depth.py:52-68): the three frames through ONE 9-channel pose
+    network, both poses predicted together -- reference outputs for the oracle / product to match."""
+    cfg = dict(model_cfgs()["r18_mono"], pose_model_input="all")
+    torch.manual_seed(0)
+    m = ref_get_model(cfg, 19)
+    sd = onets.build_state_dict(cfg, 19, seed=55, randomize_bn=True)
+    m.load_state_dict(sd, strict=True)
+    m.train()
+    gen = torch.Generator().manual_seed(8)
+    B, H, W = 2, 64, 128
+    inputs, _, _, _ = make_loss_inputs(B, H, W, gen)
+    for f in (0, -1, 1):
+        inputs[("color_aug", f, 0)] = inputs[("color", f, 0)]
+    out = m(inputs)
+    loss = sum((out[("cam_T_cam", 0, f)] ** 2).sum() for f in (-1, 1)) + out[("axisangle", 0, 1)].sum()
+    loss.backward()
+    d = {"sd_hash": sd_hash(sd), "cfg_json": json.dumps(cfg)}
+    for f in (0, -1, 1):
+        d["in_color_%d" % f] = inputs[("color", f, 0)]
+    for f, tag in ((-1, "m1"), (1, "p1")):
+        d["T_" + tag] = out[("cam_T_cam", 0, f)]
+    d["axisangle"], d["translation"] = out[("axisangle", 0, 1)], out[("translation", 0, 1)]
+    d["grad_pose_conv1"] = m.models["pose_encoder"].encoder.conv1.weight.grad
+    d["grad_pose_last"] = m.models["pose"].net[3].weight.grad
+    d["pose_state_keys"] = np.array([k for k in m.state_dict() if k.startswith("models.pose")][:4])
+    save("poseall", d)
+
+
 def gen_valtail():
     """Validation tail: MonodepthLoss.generate_depth_test_pred (loss/monodepth_loss.py:54-62),
     JointSegmentationMonodepth.predict_test_disp in eval mode (models/joint_segmentation_depth.py:72-75, called by
@@ -678,6 +707,6 @@ def gen_valtail():
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["loss", "geom", "ssim_smooth", "segmix", "blocks", "decoders", "encoder", "nets", "trainer",
-                             "valtail"]
+                             "valtail", "poseall"]
     for w in which:
         globals()["gen_" + w]()

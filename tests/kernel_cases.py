@@ -520,6 +520,62 @@ def run_valtail_kernel_cases(device, golden):
     assert torch.equal(u8[:, 0].cpu(), g["export_u8"]), "8-bit depth estimate must be bit-exact"
 
 
+def run_augment_cases(device):
+    """strongTransform's colour jitter / blur kernels vs the (parity-unpinned) torch restatement of kornia 0.4.0 in
+    oracle/augment.py, plus properties that hold whatever kornia's exact rounding is"""
+    import math
+    from oracle import augment as A
+    from improving_segmentation_with_selfsupervised_depth_amd.loader import transformsgpu as TG
+    gen = torch.Generator().manual_seed(31)
+    B, Hh, W = 3, 40, 72
+    x = torch.rand(B, 3, Hh, W, generator=gen)
+    x[0, :, :4] = 0.0                     # black pixels (s = 0 / 0), grey pixels (min == max), saturated pixels
+    x[1, :, :4] = 0.37
+    x[2, 0, 5:9] = 1.0
+    xd = x.to(device)
+    # ---- jitter: every order of the four adjustments, factors at and inside the range limits
+    import itertools
+    for n, order in enumerate(itertools.permutations(range(4))):
+        if n % 5 and n not in (1, 23):
+            continue
+        params, _ = TG.sample_color_jitter_params(B, 0.25, generator=gen)
+        got, _ = TG.color_jitter(0.9, data=xd, params=params, order=list(order))
+        want = A.color_jitter(x, params, list(order))
+        assert_close(got, want, rtol=1e-5, atol=2e-6, what="colour jitter order %s" % (order,))
+        assert float(got.min()) >= 0.0 and float(got.max()) <= 1.0
+    # factor 1 / hue 0: the identity up to the HSV round trip
+    ident = torch.tensor([[1.0, 1.0, 1.0, 0.0]]).repeat(B, 1)
+    got, _ = TG.color_jitter(0.9, data=xd, params=ident, order=[0, 1, 2, 3])
+    assert_close(got, x, rtol=1e-5, atol=2e-6, what="jitter with neutral factors")
+    # below the 0.2 switch and for non-RGB data the call is the identity (transformsgpu.py:13-14)
+    assert TG.color_jitter(0.2, data=xd)[0] is xd
+    soft = torch.rand(B, 19, 8, 8).to(device)
+    assert TG.color_jitter(0.9, data=soft)[0] is soft
+    # a hue shift of a full turn-fraction changes the hue only: value (max channel) is preserved
+    hp = torch.tensor([[1.0, 1.0, 1.0, 0.2]]).repeat(B, 1)
+    got, _ = TG.color_jitter(0.9, data=xd, params=hp, order=[3, 0, 1, 2])
+    assert_close(got.max(1)[0], x.max(1)[0], rtol=1e-5, atol=2e-6, what="hue shift keeps the value channel")
+    # sampled parameters lie in kornia's ranges
+    pr, od = TG.sample_color_jitter_params(512, 0.25, generator=gen)
+    assert float(pr[:, :3].min()) >= 0.75 and float(pr[:, :3].max()) <= 1.25 and float(pr[:, 3].abs().max()) <= 0.25
+    assert sorted(od) == [0, 1, 2, 3]
+    # ---- blur
+    for (hh, ww, sigma) in ((40, 72, 0.15), (40, 72, 1.15), (64, 128, 0.7), (33, 50, 1.0)):
+        xi = torch.rand(2, 3, hh, ww, generator=gen)
+        ky, kx = TG.blur_kernel_size(hh), TG.blur_kernel_size(ww)
+        assert ky % 2 == 1 and kx % 2 == 1
+        got, _ = TG.gaussian_blur(0.9, data=xi.to(device), sigma=sigma)
+        want = A.gaussian_blur(xi, (ky, kx), sigma)
+        assert_close(got, want, rtol=1e-5, atol=2e-6, what="gaussian blur %dx%d sigma %.2f" % (hh, ww, sigma))
+        taps = TG.gaussian_taps(kx, sigma)
+        assert abs(float(taps.sum()) - 1.0) < 1e-6 and taps.numel() % 2 == 1
+        const = torch.full((1, 3, hh, ww), 0.625).to(device)
+        got, _ = TG.gaussian_blur(0.9, data=const, sigma=sigma)
+        assert_close(got, const.cpu(), rtol=1e-6, atol=1e-6, what="blur of a constant image")
+    assert TG.gaussian_blur(0.5, data=xd)[0] is xd
+    assert TG.blur_kernel_size(512) == 51 and TG.blur_kernel_size(1024) == 103 and TG.blur_kernel_size(2048) == 205
+
+
 def run_metric_cases(device, golden):
     """runningScore mirror (device-resident confusion matrix) vs the reference's vectors: exact"""
     import numpy as np

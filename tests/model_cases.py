@@ -308,6 +308,37 @@ def run_loss_vs_reference(device, golden):
                 assert_close(out[("color", f, s)], g["color_%s_%d" % (t, s)], rtol=1e-3, atol=1e-4, what="color")
 
 
+def run_convblock_dropout2d(device):
+    """ConvBlock with depth_args.dropout > 0 (nn.Dropout2d after the ELU, monodepth_layers.py:117-119): every (sample,
+    channel) map is either zero or the un-dropped map times 1/(1-p); the gradient follows the same mask; eval is the identity"""
+    torch.manual_seed(3)
+    blk = ConvBlock(8, 16, dropout=0.5).to(device)
+    ref = ConvBlock(8, 16, dropout=0.0).to(device)
+    ref.load_state_dict(blk.state_dict())
+    x = torch.randn(3, 12, 20, 8, device=device)
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    blk.train(); ref.train()
+    y, y0 = blk(xa), ref(xb)
+    dropped = kept = 0
+    scale = torch.zeros(3, 16)
+    for b in range(3):
+        for c in range(16):
+            m, m0 = y[b, :, :, c], y0[b, :, :, c]
+            if float(m.abs().max()) == 0.0:
+                dropped += 1
+            else:
+                kept += 1
+                scale[b, c] = 2.0
+                assert_close(m, 2.0 * m0, rtol=1e-6, atol=1e-7, what="kept channel is scaled by 1/(1-p)")
+    assert dropped > 5 and kept > 5, (dropped, kept)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    y0.backward(gy * scale.to(device)[:, None, None, :])
+    assert_close(xa.grad, xb.grad, rtol=1e-4, atol=1e-6, what="input gradient through Dropout2d")
+    blk.eval()
+    assert_close(blk(x), ref(x), rtol=0, atol=0, what="eval mode is the identity")
+
+
 def _bench_inputs(B, Hh, W, seed, device, with_labels=True):
     import bench
     inp = bench.synthetic_inputs(B, Hh, W, "cpu", seed, with_labels=with_labels)

@@ -56,6 +56,10 @@ def test_validation_tail_kernels(golden):
     KC.run_valtail_kernel_cases("cpu", golden)
 
 
+def test_strong_transform_jitter_blur():
+    KC.run_augment_cases("cpu")
+
+
 def test_validation_metric(golden):
     KC.run_metric_cases("cpu", golden)
 

@@ -82,6 +82,10 @@ def test_validation_tail_kernels(golden):
     KC.run_valtail_kernel_cases("cuda", golden)
 
 
+def test_strong_transform_jitter_blur():
+    KC.run_augment_cases("cuda")
+
+
 def test_validation_metric(golden):
     KC.run_metric_cases("cuda", golden)
 

@@ -48,3 +48,7 @@ def test_monodepth_loss_multi_tile_strips(golden, monkeypatch):
     """the fused photometric kernels walk several tiles per block at real sizes; force that on the small golden case"""
     monkeypatch.setenv("SEGSDE_PHOTO_TILES", "2")
     MC.run_loss_vs_reference("cpu", golden)
+
+
+def test_convblock_dropout2d():
+    MC.run_convblock_dropout2d("cpu")

@@ -430,3 +430,25 @@ def test_validation_tail_vs_reference(golden):
         close(o[("disp", s)], g["disp_%d" % s], rtol=1e-4, atol=1e-6)
     u8 = S.depth_estimate_u8(g["disp_0"])
     assert torch.equal(u8, g["export_u8"])
+
+
+def test_pose_model_input_all_vs_reference(golden):
+    """pose_model_input = "all" (joint_segmentation_depth.py:52-68) against the reference's outputs"""
+    g = golden("poseall")
+    cfg = json.loads(str(g["cfg_json"]))
+    sd = N.build_state_dict(cfg, 19, seed=55, randomize_bn=True)
+    if _sd_hash(sd) != str(g["sd_hash"]):
+        pytest.skip("torch RNG stream differs from the build container: cannot regenerate seeded weights")
+    sd = _leafify(sd)
+    inputs = {}
+    for f in (0, -1, 1):
+        inputs[("color", f, 0)] = inputs[("color_aug", f, 0)] = g["in_color_%d" % f]
+    out = N.model_forward(sd, cfg, inputs, train=True, dropout=False)
+    close(out[("cam_T_cam", 0, -1)], g["T_m1"], rtol=1e-4, atol=1e-6)
+    close(out[("cam_T_cam", 0, 1)], g["T_p1"], rtol=1e-4, atol=1e-6)
+    close(out[("axisangle", 0, 1)], g["axisangle"], rtol=1e-4, atol=1e-7)
+    close(out[("translation", 0, -1)], g["translation"], rtol=1e-4, atol=1e-7)
+    loss = sum((out[("cam_T_cam", 0, f)] ** 2).sum() for f in (-1, 1)) + out[("axisangle", 0, 1)].sum()
+    loss.backward()
+    close(sd["models.pose_encoder.encoder.conv1.weight"].grad, g["grad_pose_conv1"], rtol=2e-3, atol=1e-7)
+    close(sd["models.pose.net.3.weight"].grad, g["grad_pose_last"], rtol=2e-3, atol=1e-7)
