@@ -676,11 +676,12 @@ __global__ __launch_bounds__(256) void photometric_bwd_kernel(PhotoBwdP a) {
   const int r = threadIdx.x / PT_W, c = threadIdx.x - r * PT_W;
   const int h = h0 + r;
   const int ntx = (W + PT_W - 1) / PT_W;
-  double acc[2][12];
+  // a thread adds at most tiles_per_block (<= 16) values per entry in fp32; from the block reduction on the sums are double
+  float acc[2][12];
 #pragma unroll
   for (int f = 0; f < 2; ++f)
 #pragma unroll
-    for (int i = 0; i < 12; ++i) acc[f][i] = 0.0;
+    for (int i = 0; i < 12; ++i) acc[f][i] = 0.f;
   for (int tx = blockIdx.x * a.tiles_per_block; tx < ntx && tx < (int)(blockIdx.x + 1) * a.tiles_per_block; ++tx) {
   const int w0 = tx * PT_W, w = w0 + c;
   __syncthreads();                                             // the previous tile's LDS reads are done (geo is visible)
@@ -713,13 +714,15 @@ __global__ __launch_bounds__(256) void photometric_bwd_kernel(PhotoBwdP a) {
               const float xv = x[(qr + 1 + dh) * PB_W + qc + 1 + dw], yv = y[(qr + 1 + dh) * PB_W + qc + 1 + dw];
               sx += xv; sy += yv; sxx += xv * xv; syy += yv * yv; sxy += xv * yv;
             }
-          const float mx = sx / 9.f, my = sy / 9.f;
-          const float sig_x = sxx / 9.f - mx * mx, sig_y = syy / 9.f - my * my, sig_xy = sxy / 9.f - mx * my;
+          // gradient path (not part of the bit-exact selection): reciprocal multiplies instead of IEEE divisions by 9
+          constexpr float R9 = 1.f / 9.f;
+          const float mx = sx * R9, my = sy * R9;
+          const float sig_x = sxx * R9 - mx * mx, sig_y = syy * R9 - my * my, sig_xy = sxy * R9 - mx * my;
           const float A1 = 2.f * mx * my + C1, A2 = 2.f * sig_xy + C2;
           const float B1 = mx * mx + my * my + C1, B2 = sig_x + sig_y + C2;
-          const float n = A1 * A2, d = B1 * B2, rr = n / d;
-          const float raw = (1.f - rr) / 2.f;
-          const float m = (raw >= 0.f && raw <= 1.f) ? gq / (9.f * d) : 0.f;   // clamp passes gradient on [0,1]
+          const float n = A1 * A2, d = B1 * B2, rd = 1.f / d, rr = n * rd;
+          const float raw = (1.f - rr) * 0.5f;
+          const float m = (raw >= 0.f && raw <= 1.f) ? gq * R9 * rd : 0.f;   // clamp passes gradient on [0,1]
           c0 = m * (2.f * my * A2 - 2.f * A1 * my - rr * (2.f * mx * B2 - 2.f * B1 * mx));
           c1 = m * (-rr * 2.f * B1);
           c2 = m * (2.f * A1);
@@ -814,7 +817,7 @@ __global__ __launch_bounds__(256) void photometric_bwd_kernel(PhotoBwdP a) {
   for (int f = 0; f < 2; ++f)
 #pragma unroll
     for (int i = 0; i < 12; ++i) {
-      const double t = segsde_block_sum(acc[f][i], sh);
+      const double t = segsde_block_sum((double)acc[f][i], sh);
       if (threadIdx.x == 0) a.gP_part[(blk * 2 + f) * 12 + i] = t;
     }
 }

@@ -72,14 +72,16 @@ class ConvFn(Function):
     """y = act(conv([up2x?(x0) | x1], weight) + bias); geometry in ``g`` (hipops.ConvGeom)."""
 
     @staticmethod
-    def forward(ctx, x0, x1, weight, bias, g, act, stats_out=None, grad_box=None):
+    def forward(ctx, x0, x1, weight, bias, g, act, stats_out=None, grad_box=None, packs=None):
         """stats_out: optional list; receives the BatchNorm statistics partials of y (or None) -- see Conv2d.forward.
         grad_box: optional dict shared with the BNActFn that adds this conv's input as a residual (see SplitFn): when its
         backward has already left the residual-path gradient there, this conv's data-gradient is accumulated onto it."""
         ctx.grad_box = grad_box
         x0 = _c(x0) if x0.stride(-1) != 1 else x0
         ctx.wd = None
-        if ctx.needs_input_grad[0] or (x1 is not None and ctx.needs_input_grad[1]):
+        if packs is not None:
+            wp, ctx.wd = packs                          # the owning module's cache (valid for this version of the weight)
+        elif ctx.needs_input_grad[0] or (x1 is not None and ctx.needs_input_grad[1]):
             wp, ctx.wd = H.pack_weight_both(weight)     # the data-gradient pack is needed by backward: one launch for both
         else:
             wp = H.pack_weight(weight, False)
@@ -121,7 +123,7 @@ class ConvFn(Function):
                 dx1 = None
         if ctx.needs_input_grad[2]:
             dw = H.conv_wgrad(g, x0, x1, dz)
-        return dx0, dx1, dw, dbias, None, None, None, None
+        return dx0, dx1, dw, dbias, None, None, None, None, None
 
 
 class BNActFn(Function):

@@ -7,6 +7,7 @@ import torch
 from torch import nn
 
 from .. import functional as Fn
+from .. import hipops as H
 from ..hipops import ConvGeom
 
 
@@ -18,6 +19,28 @@ def _seed():
 _NO_FUSED_STATS = bool(int(os.environ.get("SEGSDE_NO_FUSED_STATS", "0")))   # debugging: BatchNorm statistics as a separate pass
 
 
+_PACK_SCOPE = [0, 0]      # [id of the active weight-pack scope (0: none), last id handed out]
+
+
+class weight_pack_scope:
+    """``with weight_pack_scope():`` -- inside, a convolution packs its weight once and reuses the packs for every further
+    forward of the scope (the DepthMix step runs the student three times between two optimizer steps).  The caller promises
+    that weights are not modified inside the scope by means autograd cannot see: version counters catch optimizer steps and
+    ``load_state_dict``, but not ``param.data[:] = ...`` (how the reference's own EMA update writes, train.py:353-357), which
+    is why nothing is cached outside a scope."""
+
+    def __enter__(self):
+        self._outer = _PACK_SCOPE[0]
+        if not self._outer:                # a nested scope joins the enclosing one
+            _PACK_SCOPE[1] += 1
+            _PACK_SCOPE[0] = _PACK_SCOPE[1]
+        return self
+
+    def __exit__(self, *exc):
+        _PACK_SCOPE[0] = self._outer
+        return False
+
+
 class Conv2d(nn.Conv2d):
     """nn.Conv2d state, HIP implicit-GEMM compute.  ``forward(x_nhwc, skip=None, up=False, act="none")``:
     ``skip`` is an optional second NHWC source concatenated after x along channels, ``up`` nearest-upsamples x by 2
@@ -26,10 +49,22 @@ class Conv2d(nn.Conv2d):
     def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, bias=True, reflect=False):
         super().__init__(int(in_channels), int(out_channels), kernel_size, stride, padding, dilation, bias=bias)
         self.reflect = reflect
+        self._pack_key, self._packs = None, None   # weight packs of the current weight version (see _weight_packs)
         self._stats_wanted = None     # None: unknown yet, True: a BatchNorm consumed the fused statistics, False: nobody did
         self._stats_offered = False
         k = self.kernel_size[0]
         assert self.kernel_size[0] == self.kernel_size[1] and self.stride[0] == self.stride[1]
+
+    def _weight_packs(self, weight):
+        """(forward pack, data-gradient pack) cached for the active weight_pack_scope, None outside one (ConvFn then packs
+        per call, as the weights may have been rewritten behind autograd's back)"""
+        if not _PACK_SCOPE[0]:
+            self._packs = None
+            return None
+        key = (_PACK_SCOPE[0], weight._version, weight.data_ptr(), weight.device)
+        if key != self._pack_key or self._packs is None:
+            self._packs, self._pack_key = H.pack_weight_both(weight), key
+        return self._packs
 
     def forward(self, x, skip=None, up=False, act="none", grad_box=None):
         c0 = x.shape[3]
@@ -39,8 +74,10 @@ class Conv2d(nn.Conv2d):
             # input carries zero pad channels (network stem: 3 -> 4, 6 -> 8): matching zero weight planes; their gradient
             # is dropped by the adjoint of the pad
             weight = torch.nn.functional.pad(weight, (0, 0, 0, 0, 0, c0 - self.in_channels))
+            packs = None                    # a fresh tensor every call: packed inside ConvFn
         else:
             assert c0 + c1 == self.in_channels, (c0, c1, self.in_channels)
+            packs = self._weight_packs(weight)
         g = ConvGeom(c0, self.out_channels, self.kernel_size[0], self.stride[0], self.dilation[0], self.padding[0],
                      self.reflect, c1, up)
         if self.bias is None and act == "none" and self.training and not _NO_FUSED_STATS and self._stats_wanted is not False:
@@ -50,13 +87,13 @@ class Conv2d(nn.Conv2d):
             # segmentation projections) stops producing them after its first training forward.
             if self._stats_wanted is None and self._stats_offered:
                 self._stats_wanted = False
-                return Fn.ConvFn.apply(x, skip, weight, self.bias, g, act, None, grad_box)
+                return Fn.ConvFn.apply(x, skip, weight, self.bias, g, act, None, grad_box, packs)
             self._stats_offered = True
             holder = []
-            y = Fn.ConvFn.apply(x, skip, weight, self.bias, g, act, holder, grad_box)
+            y = Fn.ConvFn.apply(x, skip, weight, self.bias, g, act, holder, grad_box, packs)
             y._bn_partials = (holder[0], y._version, self) if holder and holder[0] is not None else None
             return y
-        return Fn.ConvFn.apply(x, skip, weight, self.bias, g, act, None, grad_box)
+        return Fn.ConvFn.apply(x, skip, weight, self.bias, g, act, None, grad_box, packs)
 
 
 class BatchNorm2d(nn.BatchNorm2d):

@@ -47,6 +47,7 @@ class EmaUpdater:
         assert len(model_params) == len(ema_params), f"len(mp)={len(model_params)}; len(mcp)={len(ema_params)}"
         self._key = tuple((e.data_ptr(), p.data_ptr(), p.numel()) for e, p in zip(ema_params, model_params))
         self._like = ema_params[0] if ema_params else None
+        self._ema = list(ema_params)
         self._table = H.multi_tensor_table([e.data for e in ema_params], [p.data for p in model_params])
 
     def matches(self, model_params, ema_params):
@@ -58,6 +59,11 @@ class EmaUpdater:
         alpha = min(1 - 1 / (iteration + 1), alpha_teacher)
         if self._table is not None:
             H.multi_tensor_lerp(self._table, np.float32(alpha), np.float32(1 - alpha), self._like)
+            # the kernel writes through raw pointers: tell autograd's version counters, which the convolutions' weight-pack
+            # caches (models/layers.py) and any saved-tensor check rely on
+            with torch.no_grad():
+                for e in self._ema:
+                    torch.autograd.graph.increment_version(e)
 
 
 _UPDATERS = {}
@@ -142,6 +148,7 @@ def train_step_segmentation_unlabeled(model, ema_model, monodepth_loss_calculato
     import contextlib
     import random
     from .loader import transformsgpu
+    from .models.layers import weight_pack_scope
 
     def nosync():
         return reducer.no_sync() if reducer is not None else contextlib.nullcontext()
@@ -163,6 +170,8 @@ def train_step_segmentation_unlabeled(model, ema_model, monodepth_loss_calculato
         argmax_u_w = H.pseudo_label(softmax_u_w, 2.0, -1, want_weight=False)[0]
     # second step: student on the unaugmented frames -> online depth + monodepth loss (train.py:676-702)
     mono_loss, L_1 = 0, 0
+    scope = weight_pack_scope()        # both student passes run on the same weights: their convolutions pack once
+    scope.__enter__()
     if depthmix_online_depth:
         outputs_1 = model(unlabeled_inputs)
         if monodepth_lambda > 0:
@@ -195,6 +204,7 @@ def train_step_segmentation_unlabeled(model, ema_model, monodepth_loss_calculato
     mixed_inputs = dict(unlabeled_inputs)
     mixed_inputs[("color_aug", 0, 0)] = inputs_u_s
     outputs = model(mixed_inputs)
+    scope.__exit__(None, None, None)
     softmax_u_w_mixed, _ = strong_transform(strong_parameters, data=softmax_u_w)
     L_2, pseudo_label = calc_pseudo_label_loss(softmax_u_w_mixed, outputs["semantics"], consistency_weight)
     if last_backward:

@@ -37,7 +37,7 @@ def cl(t):
     return t.clone().contiguous(memory_format=torch.channels_last).requires_grad_(True)
 
 
-def check_param_grads(g, tag, module, rtol=2e-3):
+def check_param_grads(g, tag, module, rtol=1e-3):
     named = dict(module.named_parameters())
     keys = [k for k in named if "%s_g_%s" % (tag, k) in g]
     gscale = max([float(g["%s_g_%s" % (tag, k)].abs().max()) for k in keys] + [1e-30])
@@ -69,7 +69,7 @@ def run_blocks(device, golden):
             assert_close(yy, g["%s_y%d" % (tag, i)], rtol=1e-3, atol=1e-5, what=tag + " out")
             tot = tot + (yy * g["%s_w%d" % (tag, i)].to(device)).sum()
         tot.backward()
-        assert_close(x.grad, g[tag + "_gx0"], rtol=2e-3, atol=1e-5, what=tag + " dx")
+        assert_close(x.grad, g[tag + "_gx0"], rtol=1e-3, atol=1e-5, what=tag + " dx")
         check_param_grads(g, tag, module)
         after = sd_from(g, tag + "_sdafter_")
         for k, v in after.items():
@@ -93,7 +93,7 @@ def run_blocks(device, golden):
     ((aa * g["posedec_w0"].to(device)).sum() + (tr * g["posedec_w1"].to(device)).sum()).backward()
     assert_close(aa, g["posedec_y0"], rtol=1e-3, atol=1e-6, what="pose aa")
     assert_close(tr, g["posedec_y1"], rtol=1e-3, atol=1e-6, what="pose tr")
-    assert_close(x.grad, g["posedec_gx0"], rtol=2e-3, atol=1e-5, what="pose dx")
+    assert_close(x.grad, g["posedec_gx0"], rtol=1e-3, atol=1e-5, what="pose dx")
     check_param_grads(g, "posedec", m)
 
 
@@ -105,13 +105,13 @@ def _check_dec(g, tag, module, feats, out, keys, device):
     tot = 0
     for k in keys:
         name = "%s_out_%s" % (tag, "_".join(str(x) for x in k) if isinstance(k, tuple) else k)
-        assert_close(out[k], g[name], rtol=2e-3, atol=2e-5, what=name)
+        assert_close(out[k], g[name], rtol=1e-3, atol=2e-5, what=name)
         tot = tot + (out[k] * g[name + "_w"].to(device)).sum()
     tot.backward()
     for i, f in enumerate(feats):
         got = f.grad if f.grad is not None else torch.zeros_like(f)
-        assert_close(got, g["%s_gf%d" % (tag, i)], rtol=3e-3, atol=3e-5, what="%s dfeat%d" % (tag, i))
-    check_param_grads(g, tag, module, rtol=3e-3)
+        assert_close(got, g["%s_gf%d" % (tag, i)], rtol=1e-3, atol=3e-5, what="%s dfeat%d" % (tag, i))
+    check_param_grads(g, tag, module, rtol=1e-3)
 
 
 def run_decoders(device, golden, which=("dd1", "dd2", "jsd1", "jsd2", "pad1", "pad2")):
@@ -189,7 +189,7 @@ def run_encoder(device, golden, which=("r18", "r50dil", "r18x2")):
         fs = m(g[tag + "_x"].to(device))
         for i, f in enumerate(fs):
             assert list(f.shape) == g["%s_f%d_shape" % (tag, i)].tolist()
-            assert_close(f if f.numel() < 40000 else f[:, :8], g["%s_f%d" % (tag, i)], rtol=2e-3, atol=2e-4,
+            assert_close(f if f.numel() < 40000 else f[:, :8], g["%s_f%d" % (tag, i)], rtol=1e-3, atol=2e-4,
                          what="%s f%d" % (tag, i))
 
 
@@ -220,7 +220,7 @@ def run_full_model(device, golden, name):
         inputs[("color_aug", f, 0)] = inputs[("color", f, 0)]
     out = model(inputs)
     for s in range(4):
-        assert_close(out[("disp", s)], g[name + "_disp_%d" % s], rtol=2e-3, atol=2e-5, what="disp%d" % s)
+        assert_close(out[("disp", s)], g[name + "_disp_%d" % s], rtol=1e-3, atol=2e-5, what="disp%d" % s)
     assert_close(out[("cam_T_cam", 0, -1)], g[name + "_T_m1"], rtol=1e-3, atol=1e-5, what="T-1")
     assert_close(out[("cam_T_cam", 0, 1)], g[name + "_T_p1"], rtol=1e-3, atol=1e-5, what="T+1")
     B, _, Hh, W = inputs[("color", 0, 0)].shape
@@ -234,7 +234,7 @@ def run_full_model(device, golden, name):
     assert_close(losses["loss"], g[name + "_mono_loss"], rtol=1e-3, what="mono loss")
     total = losses["loss"]
     if "semantics" in out:
-        assert_close(out["semantics"], g[name + "_semantics"], rtol=2e-3, atol=2e-4, what="semantics")
+        assert_close(out["semantics"], g[name + "_semantics"], rtol=1e-3, atol=2e-4, what="semantics")
         seg = cross_entropy2d(out["semantics"], g[name + "_lbl"].to(device))
         assert_close(seg, g[name + "_seg_loss"], rtol=1e-3, what="seg loss")
         total = total + seg
@@ -242,22 +242,42 @@ def run_full_model(device, golden, name):
     names = [str(x) for x in g[name + "_grad_names"]]
     norms = g[name + "_grad_norms"].tolist()
     params = dict(model.named_parameters())
-    # per-parameter gradient norms: the auto-mask argmin (ties broken by 1e-5 noise) can flip on a handful of pixels
-    # under fp32 re-association, which moves strongly cancelling sums (biases, pooled branches) by a percent or so:
-    # every norm must agree to 5 %, and all but 3 % of them to 0.5 %.
-    bad, loose = [], 0
+    # Per-parameter gradient norms.  The whole-model gradient is ill-conditioned for a few parameters (BatchNorm over 64
+    # samples; the auto-mask argmin, ties broken by 1e-5 noise, flips on a handful of pixels under any fp32 re-association
+    # and moves strongly cancelling sums by a percent or so), so a fixed relative tolerance against the reference's own
+    # fp32 numbers would measure that conditioning, not the kernels.  Ground truth = the oracle evaluated in float64 on
+    # the same weights / inputs / noise; the product must be as close to it as the REFERENCE's fp32 evaluation (the
+    # recorded norms) is: median error within 3x the reference's (or 1e-3), worst case within 5x (or 5e-2).
+    from oracle import photometric as P, segmix as S
+    cast = lambda v: v.double() if v.is_floating_point() else v
+    sdo = {k: (cast(v.clone()).requires_grad_(True) if v.is_floating_point() and "running" not in k else cast(v.clone()))
+           for k, v in sd.items()}
+    inp64 = {k: cast(v.cpu()) for k, v in inputs.items()}
+    out64 = N.model_forward(sdo, cfg, inp64, train=True, dropout=False)
+    lo = P.MonodepthLossOracle(**tcfg["training"]["monodepth_loss"], batch_size=B)
+    lo.generate_images_pred(inp64, out64)
+    tot64 = lo.compute_losses(inp64, out64, tiebreak_noise={s: g[name + "_noise_%d" % s].double() for s in range(4)})["loss"]
+    if "semantics" in out64:
+        tot64 = tot64 + S.cross_entropy2d(out64["semantics"], g[name + "_lbl"])
+    tot64.backward()
+    bad, e_prod, e_ref = [], [], []
     for k, n in zip(names, norms):
         p = params[k]
         got = float(p.grad.norm()) if p.grad is not None else -1.0
+        t = sdo[k].grad
         if n < 0 or got < 0:
             if not (n < 0 and got < 0):
                 bad.append((k, n, got))
-        elif abs(got - n) > 5e-2 * abs(n) + 1e-5:
-            bad.append((k, n, got))
-        elif abs(got - n) > 5e-3 * abs(n) + 1e-6:
-            loose += 1
+            continue
+        tn = float(t.norm()) + 1e-30
+        e_prod.append(abs(got - tn) / tn)
+        e_ref.append(abs(n - tn) / tn)
     assert not bad, bad[:10]
-    assert loose <= 0.03 * len(names), (loose, len(names))
+    e_prod, e_ref = np.array(e_prod), np.array(e_ref)
+    print("%s: relative error of the gradient norms vs fp64 truth: product median %.2e max %.2e | reference fp32 median %.2e "
+          "max %.2e" % (name, np.median(e_prod), e_prod.max(), np.median(e_ref), e_ref.max()))
+    assert np.median(e_prod) <= max(3 * np.median(e_ref), 1e-3), (np.median(e_prod), np.median(e_ref))
+    assert e_prod.max() <= max(5 * e_ref.max(), 5e-2), (e_prod.max(), e_ref.max())
     assert_close(params["models.encoder.encoder.conv1.weight"].grad, g[name + "_grad_conv1"], rtol=1e-2, atol=1e-3,
                  what="conv1 grad")
     assert_close(model.models["encoder"].encoder.bn1.running_mean, g[name + "_bn1_running_mean_after"], rtol=1e-3,
@@ -337,6 +357,44 @@ def run_convblock_dropout2d(device):
     assert_close(xa.grad, xb.grad, rtol=1e-4, atol=1e-6, what="input gradient through Dropout2d")
     blk.eval()
     assert_close(blk(x), ref(x), rtol=0, atol=0, what="eval mode is the identity")
+
+
+def run_weight_pack_scope(device):
+    """Conv2d packs its weight per call outside a weight_pack_scope and once per weight version inside one"""
+    from improving_segmentation_with_selfsupervised_depth_amd import hipops as Hh_
+    from improving_segmentation_with_selfsupervised_depth_amd.models.layers import Conv2d, weight_pack_scope
+    torch.manual_seed(5)
+    conv = Conv2d(8, 16, 3, padding=1).to(device)
+    x = torch.randn(2, 6, 7, 8, device=device)
+    calls = []
+    real = Hh_.pack_weight_both
+
+    def counting(w):
+        calls.append(1)
+        return real(w)
+    Hh_.pack_weight_both = counting
+    try:
+        xg = x.clone().requires_grad_(True)
+        y0 = conv(xg)
+        y1 = conv(xg)
+        assert len(calls) == 2                       # no scope: packed per call
+        with weight_pack_scope():
+            ya = conv(xg)
+            with weight_pack_scope():                # nested scopes share the packs
+                yb = conv(xg)
+            assert len(calls) == 3
+            assert torch.equal(ya, y0) and torch.equal(yb, y0)
+            with torch.no_grad():
+                conv.weight.mul_(2.0)                # an in-place update autograd sees: new packs
+            yc = conv(xg)
+            assert len(calls) == 4
+            assert_close(yc - conv.bias.reshape(1, 1, 1, -1), 2.0 * (y0 - conv.bias.reshape(1, 1, 1, -1)), rtol=1e-5, atol=1e-6,
+                         what="conv after the in-place weight update")
+            yc.sum().backward()                      # backward uses the packs of ITS forward
+        conv(xg)
+        assert len(calls) == 5                       # outside again: per call
+    finally:
+        Hh_.pack_weight_both = real
 
 
 def _bench_inputs(B, Hh, W, seed, device, with_labels=True):
@@ -455,8 +513,8 @@ def run_unlabeled_step(device, size=(64, 128)):
     # (1) free-running: the product derives its own mask from its own online depth
     L, mono = T.train_step_segmentation_unlabeled(student, teacher, lp, dict(inp_d), mix_mask="depthcomp")
     last = T.train_step_segmentation_unlabeled.last
-    assert_close(last["softmax_u_w"], ref["softmax_u_w"], rtol=2e-3, atol=1e-5, what="teacher softmax")
-    assert_close(last["depths"], ref["depths"], rtol=2e-3, atol=2e-4, what="normalised online disparity")
+    assert_close(last["softmax_u_w"], ref["softmax_u_w"], rtol=1e-3, atol=1e-5, what="teacher softmax")
+    assert_close(last["depths"], ref["depths"], rtol=1e-3, atol=2e-4, what="normalised online disparity")
     agree = float((last["MixMask"].cpu() == ref["mask"]).float().mean())
     assert agree > 0.99, agree                       # comparisons at the margin may flip on a handful of pixels
     assert_close(mono, ref["mono_loss"], rtol=1e-3, what="unlabeled mono loss")
@@ -468,7 +526,7 @@ def run_unlabeled_step(device, size=(64, 128)):
     assert torch.equal(last["inputs_u_s"].cpu(), ref["img_mixed"])
     assert float((last["pseudo_label"].cpu() == ref["pseudo_label"]).float().mean()) > 0.99
     assert_close(mono, ref["mono_loss"], rtol=1e-3, what="unlabeled mono loss")
-    assert_close(L, ref["L_2"], rtol=2e-3, what="pseudo-label loss")
+    assert_close(L, ref["L_2"], rtol=1e-3, what="pseudo-label loss")
     bad = []
     for k, p in student.named_parameters():
         go = sdo[k].grad

@@ -52,3 +52,7 @@ def test_monodepth_loss_multi_tile_strips(golden, monkeypatch):
 
 def test_convblock_dropout2d():
     MC.run_convblock_dropout2d("cpu")
+
+
+def test_weight_pack_scope():
+    MC.run_weight_pack_scope("cpu")

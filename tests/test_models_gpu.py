@@ -93,9 +93,9 @@ def test_big_models_vs_oracle(name):
         tot = tot + cross_entropy2d(out["intermediate_semantics"], inp_d["lbl"])
     tot.backward()
     for s in range(4):
-        assert_close(out[("disp", s)], out_o[("disp", s)], rtol=2e-3, atol=2e-5, what="disp%d" % s)
+        assert_close(out[("disp", s)], out_o[("disp", s)], rtol=1e-3, atol=2e-5, what="disp%d" % s)
     if "semantics" in out:
-        assert_close(out["semantics"], out_o["semantics"], rtol=2e-3, atol=3e-4, what="semantics")
+        assert_close(out["semantics"], out_o["semantics"], rtol=1e-3, atol=3e-4, what="semantics")
     assert_close(tot, tot64, rtol=1e-3, what="total loss")
     import numpy as np
     e_prod, e_ref, presence = [], [], []
@@ -208,7 +208,7 @@ def test_depthmix_unlabeled_step_vs_oracle():
     soft = torch.softmax(o_t["semantics"].detach(), dim=1)
     depth = 1.0 / o_t[("disp", 0)]
     mask = H.depthcomp_mask(depth, margin, ft)
-    assert_close(soft, soft_o, rtol=2e-3, atol=1e-5, what="teacher softmax")
+    assert_close(soft, soft_o, rtol=1e-3, atol=1e-5, what="teacher softmax")
     agree = float((mask.cpu() == mask_o).float().mean())
     assert agree > 0.995, agree                              # ties at the margin may flip on a handful of pixels
     mask = mask_o.cuda()                                     # continue from the oracle's mask: identical composites
@@ -220,7 +220,7 @@ def test_depthmix_unlabeled_step_vs_oracle():
     o_s = student(inp_d2)
     L, lab = T.calc_pseudo_label_loss(softm, o_s["semantics"], cw)
     assert float((lab.cpu() == lab_o).float().mean()) > 0.99
-    assert_close(L, L_o, rtol=2e-3, what="pseudo-label loss")
+    assert_close(L, L_o, rtol=1e-3, what="pseudo-label loss")
     L.backward()
     bad = []
     for k, p in student.named_parameters():
@@ -314,3 +314,7 @@ def test_pose_model_input_all_vs_reference(golden):
 
 def test_convblock_dropout2d():
     MC.run_convblock_dropout2d("cuda")
+
+
+def test_weight_pack_scope():
+    MC.run_weight_pack_scope("cuda")
