@@ -209,6 +209,12 @@ def main():
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch one rank per GPU (or drop WORLD_SIZE and let bench.py spawn them)"
                          % (args.gpus, world))
+    # test knobs (a 1-GPU box cannot run two RCCL ranks): SEGSDE_BENCH_ONE_DEVICE=1 puts every rank on device 0,
+    # SEGSDE_BENCH_BACKEND=gloo swaps the collective backend -- together they exercise the whole N>1 path (self-spawn,
+    # rendezvous, parameter broadcast, hook-driven bucketed all-reduce, max-over-ranks timing) on one GPU
+    if os.environ.get("SEGSDE_BENCH_ONE_DEVICE"):
+        local_rank = 0
+    backend = os.environ.get("SEGSDE_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)     # before constructing anything (SURVEY.md 8b device quirk)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
@@ -216,7 +222,10 @@ def main():
     if world > 1 or force_reducer:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import __graft_entry__ as ge
     if not os.path.exists(ge.LIB):
@@ -327,7 +336,7 @@ def main():
                                                "height": Hh, "width": W, "optimizer": opt_name,
                                                "parallelism": "dp%d" % world, "final_loss": loss_val,
                                                "ranks": dist.get_world_size() if dist.is_initialized() else 1,
-                                               "backend": (dist.get_backend() + " (RCCL)") if dist.is_initialized() else None,
+                                               "backend": (dist.get_backend() + (" (RCCL)" if dist.get_backend() == "nccl" else "")) if dist.is_initialized() else None,
                                                "allreduce_launches": reducer.collectives if reducer is not None else 0,
                                                "peak_memory_gb": torch.cuda.max_memory_allocated(dev) / 2 ** 30}}
         if unlabeled:

@@ -117,6 +117,10 @@ class ConvFn(Function):
                     box["fused"] = True      # dx0 IS the residual-path gradient, now holding the sum
             if dx0 is None:
                 dx0, dx1 = H.conv_dgrad(g, dz, wd, weight.detach(), ctx.in_hw)
+                if box is not None and box.get("publish") and box.get("g") is None and x1 is None and not g.up0 \
+                        and dx0.is_contiguous():
+                    box["g"] = dx0           # FanoutFn: the next consumer's data-gradient is accumulated onto this tensor
+                    box["fused"] = True
             if not ctx.needs_input_grad[0]:
                 dx0 = None
             if x1 is None or not ctx.needs_input_grad[1]:
@@ -191,6 +195,39 @@ class SplitFn(Function):
         if g_skip is None:
             return g_main, None
         return g_main + g_skip, None
+
+
+class FanoutFn(Function):
+    """x -> n views of x for n consumers (ASPP: the four convolution branches and the pooling branch read the same
+    tensor).  The consumers that are convolutions share ``box``: the first data-gradient that is computed becomes the
+    accumulation target, every later one is added onto it inside its kernel epilogue (conv descriptor ``accumulate``);
+    backward sums what is left -- the shared tensor once plus the gradients of the non-convolution consumers -- instead of
+    n-1 elementwise adds over the full tensor."""
+
+    shared_count = 0         # diagnostics / tests: gradients that arrived already summed in the shared tensor
+
+    @staticmethod
+    def forward(ctx, x, box, n):
+        ctx.box = box
+        box["publish"] = True
+        return tuple(x.view_as(x) for _ in range(n))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        box = ctx.box
+        shared = box.get("g") if box.get("fused") else None
+        box.clear()
+        total, used_shared = None, False
+        for gi in grads:
+            if gi is None:
+                continue
+            if shared is not None and gi.data_ptr() == shared.data_ptr():
+                if used_shared:
+                    FanoutFn.shared_count += 1
+                    continue                 # the same accumulated tensor handed back by another consumer
+                used_shared = True
+            total = gi if total is None else H.axpby(1.0, _c(total), 1.0, _c(gi))
+        return total, None, None
 
 
 class MaxPoolFn(Function):

@@ -13,8 +13,8 @@ class ASPPConv(nn.Sequential):
         super().__init__(Conv2d(in_channels, out_channels, 3, padding=dilation, dilation=dilation, bias=False),
                          BatchNorm2d(out_channels), nn.ReLU())
 
-    def forward(self, x):
-        return self[1](self[0](x), act="relu")
+    def forward(self, x, grad_box=None):
+        return self[1](self[0](x, grad_box=grad_box), act="relu")
 
 
 class ASPPPooling(nn.Sequential):
@@ -46,9 +46,16 @@ class ASPP(nn.Module):
             BatchNorm2d(out_channels), nn.ReLU(), nn.Dropout(0.5))
 
     def forward(self, x):
-        res = [self.convs[0][1](self.convs[0][0](x), act="relu")]
-        for conv in list(self.convs)[1:]:
-            res.append(conv(x))
+        branches = list(self.convs)
+        if x.requires_grad:
+            # the branches read the same tensor: their data-gradients are accumulated in the conv epilogues (Fn.FanoutFn)
+            box = {}
+            xs = Fn.FanoutFn.apply(x, box, len(branches))
+        else:
+            box, xs = None, [x] * len(branches)
+        res = [self.convs[0][1](self.convs[0][0](xs[0], grad_box=box), act="relu")]
+        for conv, xi in zip(branches[1:], xs[1:]):
+            res.append(conv(xi, grad_box=box) if isinstance(conv, ASPPConv) else conv(xi))
         cat = Fn.ConcatFn.apply(*res)
         drop = self.project[3]
         p = drop.p if (drop.training and self.training) else 0.0

@@ -56,3 +56,7 @@ def test_convblock_dropout2d():
 
 def test_weight_pack_scope():
     MC.run_weight_pack_scope("cpu")
+
+
+def test_aspp_fanout_gradient_fusion():
+    MC.run_aspp_fanout("cpu")
