@@ -174,6 +174,15 @@ def cpu_baseline(workload, H, W, budget_s):
                       % (workload_model, B, warm, len(times), med, min(times), cores, cpu_model_name(), torch.__version__)}
 
 
+def _flush_c_stdio():
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.flush()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -430,9 +439,17 @@ def main():
             except Exception as ex:
                 res["cpu_baseline"] = {"value": None, "unit": "img/s", "cores": os.cpu_count(), "kind": "port",
                                        "sample": "not measured: %r" % (ex,)}
-        print(json.dumps(res), flush=True)
+    # RCCL prints a version banner through C stdio, which (stdout being a pipe) would surface at process exit, AFTER the
+    # result: tear the process group down and flush C stdio on every rank first, so that rank 0's JSON line is the last
+    # line on stdout
     if world > 1 or force_reducer:
+        dist.barrier()
         dist.destroy_process_group()
+    _flush_c_stdio()
+    if rank == 0:
+        if world > 1:
+            time.sleep(0.5)          # the other ranks' flushes
+        print(json.dumps(res), flush=True)
 
 
 if __name__ == "__main__":

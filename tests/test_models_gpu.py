@@ -79,7 +79,7 @@ def test_big_models_vs_oracle(name):
         tot_o.backward()
         return out_o, tot_o, {k: v.grad for k, v in sdo.items() if v.is_floating_point() and v.requires_grad}
     out_o, tot_o, g32 = oracle(torch.float32)
-    _, tot64, g64 = oracle(torch.float64)
+    out64, tot64, g64 = oracle(torch.float64)
     # product
     inp_d = {k: v.cuda() for k, v in inp.items()}
     out = model(inp_d)
@@ -92,10 +92,18 @@ def test_big_models_vs_oracle(name):
     if "intermediate_semantics" in out:
         tot = tot + cross_entropy2d(out["intermediate_semantics"], inp_d["lbl"])
     tot.backward()
+    # outputs of a 100-layer network with BatchNorm over 64 samples at its deepest stages: judged against the float64
+    # evaluation -- 1e-3 of the output's scale, or three times the error the reference's own fp32 arithmetic makes
+    def close_to_truth(key, what):
+        t = out64[key].detach()
+        e_prod = float((out[key].detach().double().cpu() - t).norm())
+        e_ref = float((out_o[key].detach().double() - t).norm())
+        assert e_prod <= max(3 * e_ref, 1e-3 * float(t.norm())), (what, e_prod, e_ref, float(t.norm()))
+        return e_prod / float(t.norm()), e_ref / float(t.norm())
     for s in range(4):
-        assert_close(out[("disp", s)], out_o[("disp", s)], rtol=1e-3, atol=2e-5, what="disp%d" % s)
+        print("disp%d rel. error vs fp64: product %.2e, fp32 reference arithmetic %.2e" % ((s,) + close_to_truth(("disp", s), "disp%d" % s)))
     if "semantics" in out:
-        assert_close(out["semantics"], out_o["semantics"], rtol=1e-3, atol=3e-4, what="semantics")
+        print("semantics rel. error vs fp64: product %.2e, fp32 reference arithmetic %.2e" % close_to_truth("semantics", "semantics"))
     assert_close(tot, tot64, rtol=1e-3, what="total loss")
     import numpy as np
     e_prod, e_ref, presence = [], [], []
