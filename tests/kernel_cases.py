@@ -520,6 +520,52 @@ def run_valtail_kernel_cases(device, golden):
     assert torch.equal(u8[:, 0].cpu(), g["export_u8"]), "8-bit depth estimate must be bit-exact"
 
 
+def run_fused_photometric_vs_stage(device):
+    """fused per-scale photometric kernels == the per-stage kernel chain (which the golden vectors pin), at sizes that
+    are not multiples of the 32x8 tile, with a lower-resolution disparity, for every flag combination"""
+    from oracle import geometry as G
+    d = lambda t: None if t is None else t.to(device)
+    for (B, Hh, W, hs, ws) in ((1, 13, 37, 7, 19), (2, 9, 70, 9, 70), (1, 17, 33, 5, 9)):
+        for (no_ssim, avg, automask) in ((False, False, True), (True, False, True), (False, True, True), (False, False, False)):
+            gen = torch.Generator().manual_seed(Hh * 100 + W)
+            tgt = d(torch.rand(B, 3, Hh, W, generator=gen))
+            srcs = [d(torch.rand(B, 3, Hh, W, generator=gen)) for _ in range(2)]
+            disp = d(0.05 + 0.9 * torch.rand(B, 1, hs, ws, generator=gen))
+            K = torch.tensor([[1.1 * W, 0, 0.5 * W, 0], [0, 1.1 * W, 0.5 * Hh, 0], [0, 0, 1, 0], [0, 0, 0, 1.0]]).repeat(B, 1, 1)
+            iK, K = d(torch.linalg.pinv(K)), d(K)
+            Ts = [d(G.pose_matrix(0.02 * torch.randn(B, 1, 3, generator=gen), 0.05 * torch.randn(B, 1, 3, generator=gen),
+                                  invert=(j == 0))) for j in range(2)]
+            noise = d(torch.randn(B, 1 if avg else 2, Hh, W, generator=gen)) if automask else None
+            cols = [H.warp_forward(disp, iK, K, Ts[j], srcs[j], 0.1, 100.0)[0] for j in range(2)]
+            ident = torch.empty(B, 2, Hh, W, device=device) if automask else None
+            reproj = torch.empty(B, 2, Hh, W, device=device)
+            for j in range(2):
+                if automask:
+                    H.reprojection_error(srcs[j], tgt, no_ssim, ident[:, j])
+                H.reprojection_error(cols[j], tgt, no_ssim, reproj[:, j])
+            ssum0, sel0, isel0 = H.automask_min(ident, noise, reproj, avg)
+            scale = 1.0 / (B * Hh * W)
+            greproj = H.automask_min_backward(sel0, automask, 2, avg, scale)
+            gup0, gT0 = torch.zeros(B, Hh, W, device=device), []
+            for j in range(2):
+                gpred = H.reprojection_error_backward(cols[j], tgt, greproj[:, j], no_ssim)
+                gT = torch.zeros(B, 4, 4, device=device)
+                H.warp_backward(gpred, disp, iK, K, Ts[j], srcs[j], 0.1, 100.0, gup0, gT)
+                gT0.append(gT)
+            what = "fused photometric %s no_ssim=%s avg=%s automask=%s" % ((B, Hh, W), no_ssim, avg, automask)
+            ident1 = H.photometric_identity(srcs[0], srcs[1], tgt, no_ssim) if automask else None
+            ssum1, sel1, isel1 = H.photometric_forward(cols[0], cols[1], tgt, ident1, noise, no_ssim, avg)
+            assert torch.equal(sel1, sel0), what
+            assert not automask or (torch.equal(isel1, isel0) and torch.equal(ident1, ident)), what
+            assert_close(ssum1, ssum0, rtol=1e-6, what=what + " sum")
+            gT1 = [torch.zeros(B, 4, 4, device=device) for _ in range(2)]
+            gup1 = H.photometric_backward(cols[0], cols[1], tgt, sel1, automask, disp, iK, K, Ts[0], Ts[1], srcs[0], srcs[1], 0.1,
+                                          100.0, no_ssim, avg, scale, None, gT1[0], gT1[1])
+            assert_close(gup1, gup0, rtol=1e-4, atol=1e-5 * float(gup0.abs().max()), what=what + " d disp")
+            for j in range(2):
+                assert_close(gT1[j], gT0[j], rtol=1e-4, atol=1e-5 * float(gT0[j].abs().max()), what=what + " dT%d" % j)
+
+
 def run_augment_cases(device):
     """strongTransform's colour jitter / blur kernels vs the (parity-unpinned) torch restatement of kornia 0.4.0 in
     oracle/augment.py, plus properties that hold whatever kornia's exact rounding is"""

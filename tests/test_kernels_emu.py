@@ -56,6 +56,10 @@ def test_validation_tail_kernels(golden):
     KC.run_valtail_kernel_cases("cpu", golden)
 
 
+def test_fused_photometric_vs_stage_kernels():
+    KC.run_fused_photometric_vs_stage("cpu")
+
+
 def test_strong_transform_jitter_blur():
     KC.run_augment_cases("cpu")
 

@@ -82,6 +82,10 @@ def test_validation_tail_kernels(golden):
     KC.run_valtail_kernel_cases("cuda", golden)
 
 
+def test_fused_photometric_vs_stage_kernels():
+    KC.run_fused_photometric_vs_stage("cuda")
+
+
 def test_strong_transform_jitter_blur():
     KC.run_augment_cases("cuda")
 
