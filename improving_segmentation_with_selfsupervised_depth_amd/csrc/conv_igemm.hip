@@ -215,7 +215,9 @@ __device__ __forceinline__ float4 fast_fetch(const ConvP& p, const SrcSel& s, in
 
 // MODE 0: generic scalar gather, 1: generic float4 gather, 2: FAST (uniform tap per chunk, branch-free loads),
 // 3: FAST + reflection-pad adjoint extras, 4: FAST with the tiles written to LDS by the load itself (LDS-DMA)
-template <int BM, int BN, int WM, int WN, int MODE, int BK>
+// VAR: experiment variants of the LDS-DMA loop (SEGSDE_TUNE="var=N"; 0 = shipped): 1 = all tile loads of a chunk issued
+// up front, 2 = no scheduling fences between the MFMA units, 3 = raised wave priority around the MFMA units
+template <int BM, int BN, int WM, int WN, int MODE, int BK, int VAR = 0>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
   constexpr bool VEC = MODE >= 1;
   constexpr bool FAST = MODE >= 2;
@@ -521,6 +523,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
           fread(buf, 0, 0);
           dma_begin();                     // past the last chunk: the last one is fetched again (harmless, waited for)
           const unsigned stn = (unsigned)(buf ^ 1) * STG;
+          if constexpr (VAR == 1) {
+  #pragma unroll
+            for (int i = 0; i < AR; ++i) dmaA(stn, i);
+  #pragma unroll
+            for (int i = 0; i < BR; ++i) dmaB(stn, i);
+          }
+          if constexpr (VAR == 3) __builtin_amdgcn_s_setprio(1);
   #pragma unroll
           for (int u = 0; u < U; ++u) {
             const int g = u / 4, st = u % 4;
@@ -530,14 +539,17 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
   #pragma unroll
               for (int j = 0; j < TN; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(comp(fa[g & 1][i], st), comp(fb[g & 1][j], st), acc[i][j], 0, 0, 0);
+            if constexpr (VAR != 1) {
   #pragma unroll
-            for (int i = 0; i < AR; ++i)
-              if (u == DSTEP * i) dmaA(stn, i);
+              for (int i = 0; i < AR; ++i)
+                if (u == DSTEP * i) dmaA(stn, i);
   #pragma unroll
-            for (int i = 0; i < BR; ++i)
-              if (u == DSTEP * (AR + i)) dmaB(stn, i);
-            __builtin_amdgcn_sched_barrier(0);
+              for (int i = 0; i < BR; ++i)
+                if (u == DSTEP * (AR + i)) dmaB(stn, i);
+            }
+            if constexpr (VAR != 2) __builtin_amdgcn_sched_barrier(0);
           }
+          if constexpr (VAR == 3) __builtin_amdgcn_s_setprio(0);
           dma_end(kc + 2 < nchunks);
           segsde_wait_vmcnt0();
           __syncthreads();
@@ -661,14 +673,35 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
       float* dst; long ld; int nn;
       if (n < p.nsplit) { dst = p.y; ld = p.ldy; nn = n; }
       else { dst = p.y2; ld = p.ldy2; nn = n - p.nsplit; }
+      if (p.accum) {
+        // y += tile: every read-modify-write of a row segment depends on a global load; issue all of a thread's loads
+        // first (the accumulators are in LDS by now, registers are free) so that their latency is paid once, not
+        // BM / RPP times in a row -- on the 8-chunk 1x1 data-gradients this epilogue was a third of the tile's time
+        constexpr int NR = BM / RPP;
+        float4 o[NR];
+#pragma unroll
+        for (int t = 0; t < NR; ++t) {
+          const int m = m0 + rr + t * RPP;
+          o[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (m < p.M) o[t] = *reinterpret_cast<const float4*>(dst + out_row(p, m) * ld + nn);
+        }
+#pragma unroll
+        for (int t = 0; t < NR; ++t) {
+          const int ml = rr + t * RPP, m = m0 + ml;
+          if (m < p.M) {
+            float4 v = *reinterpret_cast<const float4*>(Ct + ml * BN + 4 * cq);
+            v.x += o[t].x; v.y += o[t].y; v.z += o[t].z; v.w += o[t].w;
+            *reinterpret_cast<float4*>(dst + out_row(p, m) * ld + nn) = v;
+          }
+        }
+      } else {
 #pragma unroll 4
-      for (int ml = rr; ml < BM; ml += RPP) {
-        const int m = m0 + ml;
-        if (m < p.M) {
-          float4* q = reinterpret_cast<float4*>(dst + out_row(p, m) * ld + nn);
-          float4 v = *reinterpret_cast<const float4*>(Ct + ml * BN + 4 * cq);
-          if (p.accum) { const float4 o = *q; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
-          *q = v;
+        for (int ml = rr; ml < BM; ml += RPP) {
+          const int m = m0 + ml;
+          if (m < p.M) {
+            float4* q = reinterpret_cast<float4*>(dst + out_row(p, m) * ld + nn);
+            *q = *reinterpret_cast<const float4*>(Ct + ml * BN + 4 * cq);
+          }
         }
       }
     }
@@ -1184,7 +1217,7 @@ __global__ __launch_bounds__(256) void reflect_dgrad_fix_kernel(const float* dy,
 // experiment knob (environment SEGSDE_TUNE="bk64=1"), read once.  Measured on MI355X (profiles/ab_conv_r01.log):
 // BK=64 (139 KB LDS => 1 workgroup/CU, half the barriers) loses 15-25 % on the large layers against BK=32 with two
 // co-resident workgroups per CU, and start-up staggering of co-resident workgroups changes nothing.
-struct Tune { int bk64 = 0; int adjfix = 0; int wplan = 0; int wovh = 4; int nos2 = 0; int dma = 1; };
+struct Tune { int bk64 = 0; int adjfix = 0; int wplan = 0; int wovh = 4; int nos2 = 0; int dma = 1; int var = 0; };
 const Tune& tune() {
   static Tune t = [] {
     Tune r;
@@ -1195,6 +1228,7 @@ const Tune& tune() {
       if (const char* q = strstr(e, "wovh=")) r.wovh = atoi(q + 5);       // per-workgroup fixed cost in chunk units
       if (const char* q = strstr(e, "adjfix=")) r.adjfix = atoi(q + 7);   // reflection adjoint: plain loop + border fix-up kernel
       if (const char* q = strstr(e, "dma=")) r.dma = atoi(q + 4);         // 0: register-staged tile loads (round-1 loop)
+      if (const char* q = strstr(e, "var=")) r.var = atoi(q + 4);         // experiment variants of the LDS-DMA loop
     }
     return r;
   }();
@@ -1267,11 +1301,11 @@ bool igemm_fast_ok(const ConvP& p) {
 }
 bool bk64_ok(const ConvP& p) { return igemm_fast_ok(p) && (p.Ctot % 64 == 0) && (p.C1 == 0 || p.C0 % 64 == 0); }
 
-template <int BM, int BN, int WM, int WN, int MODE, int BK>
+template <int BM, int BN, int WM, int WN, int MODE, int BK, int VAR = 0>
 int launch_igemm_mode(const ConvP& p, hipStream_t stream) {
   const int nblk = segsde_cdiv(p.M, BM) * segsde_cdiv(p.ne - p.nb, BN);
   const size_t smem = 2 * (size_t)(BM + BN) * BK * sizeof(float);
-  auto k = conv_igemm_kernel<BM, BN, WM, WN, MODE, BK>;
+  auto k = conv_igemm_kernel<BM, BN, WM, WN, MODE, BK, VAR>;
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   hipLaunchKernelGGL(k, dim3(nblk), dim3(256), smem, stream, p);
   SEGSDE_CHECK_LAUNCH();
@@ -1282,7 +1316,12 @@ template <int BM, int BN, int WM, int WN>
 int launch_igemm(const ConvP& p, hipStream_t stream) {
   if (igemm_fast_ok(p) && p.pad_mode == SEGSDE_PAD_REFLECT_ADJOINT && !(tune().adjfix && !p.sum2x2) && tune().adjfix < 2) return launch_igemm_mode<BM, BN, WM, WN, 3, 32>(p, stream);
   if (tune().bk64 && bk64_ok(p)) return launch_igemm_mode<BM, BN, WM, WN, 2, 64>(p, stream);
-  if (igemm_fast_ok(p) && tune().dma) return launch_igemm_mode<BM, BN, WM, WN, 4, 32>(p, stream);
+  if (igemm_fast_ok(p) && tune().dma) {
+    if (tune().var == 1) return launch_igemm_mode<BM, BN, WM, WN, 4, 32, 1>(p, stream);
+    if (tune().var == 2) return launch_igemm_mode<BM, BN, WM, WN, 4, 32, 2>(p, stream);
+    if (tune().var == 3) return launch_igemm_mode<BM, BN, WM, WN, 4, 32, 3>(p, stream);
+    return launch_igemm_mode<BM, BN, WM, WN, 4, 32>(p, stream);
+  }
   if (igemm_fast_ok(p)) return launch_igemm_mode<BM, BN, WM, WN, 2, 32>(p, stream);
   if (vec_ok(p)) return launch_igemm_mode<BM, BN, WM, WN, 1, 32>(p, stream);
   return launch_igemm_mode<BM, BN, WM, WN, 0, 32>(p, stream);
