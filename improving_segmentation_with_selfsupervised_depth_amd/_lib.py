@@ -9,7 +9,7 @@ from ctypes import c_int, c_long, c_float, c_void_p, c_size_t, c_uint64, c_int64
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SEGSDE_LIB") or os.path.join(_HERE, "libsegsde_hip.so")   # override: kernel experiments
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _LIB = None
 # Set only by the test-suite when it injects the host-interpreted build of the same kernel sources
@@ -30,6 +30,7 @@ _SIGS = {
     "segsde_conv2d_forward": (c_int, [POINTER(ConvDesc), P, P, P, P, P, P, P]),
     "segsde_conv2d_stats_rows": (c_long, [POINTER(ConvDesc)]),
     "segsde_conv2d_forward_stats": (c_int, [POINTER(ConvDesc), P, P, P, P, P, P, P, P]),
+    "segsde_conv2d_dgrad_actgrad": (c_int, [POINTER(ConvDesc), P, P, P, P, P, P, P, P, c_int, c_int, P]),
     "segsde_bn_stats_from_partials_workspace": (c_size_t, [c_int]),
     "segsde_bn_stats_from_partials": (c_int, [P, c_long, c_long, c_int, P, P, P, P, c_float, c_float, P, P, c_size_t, P]),
     "segsde_conv2d_wgrad_workspace": (c_size_t, [POINTER(ConvDesc)]),

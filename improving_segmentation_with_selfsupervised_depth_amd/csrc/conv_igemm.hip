@@ -49,6 +49,11 @@ struct ConvP {
   // without re-reading the tensor
   double* stats;
   int accum;           // 1: the staged epilogue adds the tile to what the destination already holds
+  // Activation backward fused into a data-gradient's epilogue (nullable): the tensor this launch differentiates with
+  // respect to (destination y, channels < nsplit) is the saved OUTPUT of an activation of kind agkind; the stored value is
+  // multiplied by act'(agy) -- the gradient with respect to the PRE-activation, which is what the producing conv's own
+  // backward needs (no separate 12-byte-per-element activation-backward pass).  Same row order / channel order as y, pitch agld.
+  const float* agy; int agld, agkind;
 };
 
 struct KInfo {  // decoded reduction index k -> tap + channel + source
@@ -679,6 +684,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
         // BM / RPP times in a row -- on the 8-chunk 1x1 data-gradients this epilogue was a third of the tile's time
         constexpr int NR = BM / RPP;
         float4 o[NR];
+        const float* ag = (p.agy && n < p.nsplit) ? p.agy + nn : nullptr;
 #pragma unroll
         for (int t = 0; t < NR; ++t) {
           const int m = m0 + rr + t * RPP;
@@ -690,8 +696,27 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
           const int ml = rr + t * RPP, m = m0 + ml;
           if (m < p.M) {
             float4 v = *reinterpret_cast<const float4*>(Ct + ml * BN + 4 * cq);
+            if (ag) {
+              const float4 yv = *reinterpret_cast<const float4*>(ag + out_row(p, m) * p.agld);
+              v.x *= segsde_act_grad_from_out(yv.x, p.agkind); v.y *= segsde_act_grad_from_out(yv.y, p.agkind);
+              v.z *= segsde_act_grad_from_out(yv.z, p.agkind); v.w *= segsde_act_grad_from_out(yv.w, p.agkind);
+            }
             v.x += o[t].x; v.y += o[t].y; v.z += o[t].z; v.w += o[t].w;
             *reinterpret_cast<float4*>(dst + out_row(p, m) * ld + nn) = v;
+          }
+        }
+      } else if (p.agy && n < p.nsplit) {
+        const float* ag = p.agy + nn;
+#pragma unroll 4
+        for (int ml = rr; ml < BM; ml += RPP) {
+          const int m = m0 + ml;
+          if (m < p.M) {
+            const long row = out_row(p, m);
+            float4 v = *reinterpret_cast<const float4*>(Ct + ml * BN + 4 * cq);
+            const float4 yv = *reinterpret_cast<const float4*>(ag + row * p.agld);
+            v.x *= segsde_act_grad_from_out(yv.x, p.agkind); v.y *= segsde_act_grad_from_out(yv.y, p.agkind);
+            v.z *= segsde_act_grad_from_out(yv.z, p.agkind); v.w *= segsde_act_grad_from_out(yv.w, p.agkind);
+            *reinterpret_cast<float4*>(dst + row * ld + nn) = v;
           }
         }
       } else {
@@ -728,7 +753,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
           const int m = m0 + (wm * TM + i) * 32 + 8 * g + 4 * rhalf;
           if (m >= p.M) continue;
           if (n < p.nsplit) {
-            dst[(long)(m >> 2) * ld + nn] = (acc[i][j][4 * g] + acc[i][j][4 * g + 1]) + (acc[i][j][4 * g + 2] + acc[i][j][4 * g + 3]);
+            float v = (acc[i][j][4 * g] + acc[i][j][4 * g + 1]) + (acc[i][j][4 * g + 2] + acc[i][j][4 * g + 3]);
+            if (p.agy) v *= segsde_act_grad_from_out(p.agy[(long)(m >> 2) * p.agld + nn], p.agkind);
+            dst[(long)(m >> 2) * ld + nn] = v;
           } else {
             int b, hb, wb; bool ok;
             decode_m(p, m, b, hb, wb, ok);
@@ -741,7 +768,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * rhalf;
-          if (m < p.M) dst[out_row(p, m) * ld + nn] = segsde_act(acc[i][j][r] + bias, p.act);
+          if (m < p.M) {
+            float v = segsde_act(acc[i][j][r] + bias, p.act);
+            if (p.agy && n < p.nsplit) v *= segsde_act_grad_from_out(p.agy[out_row(p, m) * p.agld + nn], p.agkind);
+            dst[out_row(p, m) * ld + nn] = v;
+          }
         }
       }
     }
@@ -1264,6 +1295,7 @@ ConvP make_params(const segsde_conv_desc* d, const float* x0, const float* x1, c
   p.kh0 = 0; p.khs = 1; p.kw0 = 0; p.kws = 1; p.KWf = p.KW; p.Kfull = p.Ktot; p.os = 1; p.oph = 0; p.opw = 0; p.OHf = p.Ho; p.OWf = p.Wo;
   p.stats = nullptr;
   p.accum = d->accumulate ? 1 : 0;
+  p.agy = nullptr; p.agld = 0; p.agkind = 0;
   return p;
 }
 
@@ -1363,9 +1395,22 @@ extern "C" int segsde_conv2d_forward(const segsde_conv_desc* d, const float* x0,
 
 extern "C" int segsde_conv2d_forward_stats(const segsde_conv_desc* d, const float* x0, const float* x1, const float* wpack,
                                            const float* bias, float* y, float* y2, double* stats, void* stream) {
+  return segsde_conv2d_dgrad_actgrad(d, x0, x1, wpack, bias, y, y2, stats, nullptr, 0, 0, stream);
+}
+
+extern "C" int segsde_conv2d_dgrad_actgrad(const segsde_conv_desc* d, const float* x0, const float* x1, const float* wpack,
+                                           const float* bias, float* y, float* y2, double* stats, const float* act_out,
+                                           int act_ld, int act_kind, void* stream) {
   if (int e = validate(d)) return e;
   if (!x0 || !wpack || !y || (d->C1 && !x1)) return SEGSDE_ERR_NULL;
   ConvP p = make_params(d, x0, x1, wpack, bias, y, y2);
+  if (act_out) {
+    // fused activation backward: a data-gradient launch (no bias / activation / statistics of its own), 16-byte rows
+    if (stats || bias || d->act != 0 || act_kind < SEGSDE_ACT_RELU || act_kind > SEGSDE_ACT_SIGMOID || act_ld < p.nsplit ||
+        (act_ld % 4) || !aligned16(act_out) || d->in_div > 1)
+      return SEGSDE_ERR_UNSUPPORTED;
+    p.agy = act_out; p.agld = act_ld; p.agkind = act_kind;
+  }
   if (stats) {
     if (stats_rows(d, p) == 0) return SEGSDE_ERR_UNSUPPORTED;
     p.stats = stats;
@@ -1387,11 +1432,11 @@ extern "C" int segsde_conv2d_forward_stats(const segsde_conv_desc* d, const floa
   if (plain3x3 && d->C0 == 1 && d->pad_mode != SEGSDE_PAD_REFLECT && !bias && d->act == 0 &&
       segsde_c1_supported(d->Cout, p.ldy) && p.vecout)
     return segsde_c1_dgrad(x0, d->ld0, d->B, d->H, d->W, d->Cout, wpack, d->pad_mode == SEGSDE_PAD_REFLECT_ADJOINT, y, p.ldy,
-                           y2, p.ldy2, p.nsplit, stream);
+                           y2, p.ldy2, p.nsplit, p.agy, p.agld, p.agkind, stream);
   // 1x1 with a narrow, non-vectorisable input side (data-gradient of the 19-class head): HBM-bound register kernel
   const bool plain1x1 = d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && d->C1 == 0 && !d->up0 && d->in_div <= 1 &&
                         !d->sum2x2 && d->H == d->Ho && d->W == d->Wo;
-  if (plain1x1 && !stats && d->C0 % 4 != 0 && d->ld0 == d->C0 && aligned16(x0) && !bias && d->act == 0 && !y2 &&
+  if (plain1x1 && !stats && !p.agy && d->C0 % 4 != 0 && d->ld0 == d->C0 && aligned16(x0) && !bias && d->act == 0 && !y2 &&
       segsde_skinny_supported(d->C0, d->Cout) && p.vecout)
     return segsde_skinny_nk(x0, d->C0, wpack, (long)d->B * d->H * d->W, d->Cout, y, p.ldy, stream);
   // Data-gradient of a stride-2 convolution (in_div == 2): three quarters of the (pixel, tap) pairs hit the holes between
@@ -1438,6 +1483,10 @@ extern "C" int segsde_conv2d_forward_stats(const segsde_conv_desc* d, const floa
       return 0;
     }
   }
+  // shapes whose mirrored-padding contributions are added by a second kernel (below) cannot have the activation derivative
+  // applied in the first kernel's epilogue: the caller runs the separate pass
+  if (p.agy && d->pad_mode == SEGSDE_PAD_REFLECT_ADJOINT && (!igemm_fast_ok(p) || (tune().adjfix && !p.sum2x2)))
+    return SEGSDE_ERR_UNSUPPORTED;
   if (d->sum2x2) {
     if ((d->Ho & 1) || (d->Wo & 1) || d->stride != 1 || d->act != 0 || bias) return SEGSDE_ERR_SHAPE;
     if (!igemm_fast_ok(p)) return SEGSDE_ERR_UNSUPPORTED;   // caller falls back to the two-pass path (full-res dgrad + 2x2 sum)

@@ -55,7 +55,8 @@ __global__ __launch_bounds__(256) void c1_fwd_kernel(const float* x, int ldx, in
 template <int LP>
 __global__ __launch_bounds__(256) void c1_dgrad_kernel(const float* dz, int lddz, int B, int H, int W,
                                                        const float* wd /*[C][9]*/, int adjoint, float* dx, int lddx,
-                                                       float* dx2, int lddx2, int nsplit) {
+                                                       float* dx2, int lddx2, int nsplit, const float* agy, int agld,
+                                                       int agkind) {
   constexpr int PPB = 256 / LP;
   const int lane_c = threadIdx.x % LP, slot = threadIdx.x / LP;
   float w[4][9];
@@ -95,6 +96,11 @@ __global__ __launch_bounds__(256) void c1_dgrad_kernel(const float* dz, int lddz
         }
     const int c = 4 * lane_c;
     float* dst = c < nsplit ? dx + p * lddx + c : dx2 + p * lddx2 + (c - nsplit);
+    if (agy && c < nsplit) {   // the input of this conv is the output of an activation: its derivative is applied here
+      const float4 yv = *reinterpret_cast<const float4*>(agy + p * agld + c);
+      a0 *= segsde_act_grad_from_out(yv.x, agkind); a1 *= segsde_act_grad_from_out(yv.y, agkind);
+      a2 *= segsde_act_grad_from_out(yv.z, agkind); a3 *= segsde_act_grad_from_out(yv.w, agkind);
+    }
     *reinterpret_cast<float4*>(dst) = make_float4(a0, a1, a2, a3);
   }
 }
@@ -290,7 +296,8 @@ __global__ __launch_bounds__(256) void c1s_wgrad_kernel(const float* x, int ldx,
 
 template <int LP>
 __global__ __launch_bounds__(256) void c1s_dgrad_kernel(const float* dz, int lddz, int B, int H, int W, const float* wd /*[C][9]*/,
-                                                        int adjoint, float* dx, int lddx, float* dx2, int lddx2, int nsplit) {
+                                                        int adjoint, float* dx, int lddx, float* dx2, int lddx2, int nsplit,
+                                                        const float* agy, int agld, int agkind) {
   constexpr int G = 256 / LP;
   const int lane_c = threadIdx.x % LP, slot = threadIdx.x / LP;
   float w[4][9];
@@ -306,6 +313,15 @@ __global__ __launch_bounds__(256) void c1s_dgrad_kernel(const float* dz, int ldd
     const size_t pix0 = (size_t)(st.b * H + st.h) * W + st.w0;
     float* dst = c < nsplit ? dx + pix0 * lddx + c : dx2 + pix0 * lddx2 + (c - nsplit);
     const int ldd = c < nsplit ? lddx : lddx2;
+    const float* ag = (agy && c < nsplit) ? agy + pix0 * agld + c : nullptr;
+    auto put = [&](int o, float a0, float a1, float a2, float a3) {
+      if (ag) {   // derivative of the activation whose output this conv read, from that saved output
+        const float4 yv = *reinterpret_cast<const float4*>(ag + (size_t)o * agld);
+        a0 *= segsde_act_grad_from_out(yv.x, agkind); a1 *= segsde_act_grad_from_out(yv.y, agkind);
+        a2 *= segsde_act_grad_from_out(yv.z, agkind); a3 *= segsde_act_grad_from_out(yv.w, agkind);
+      }
+      *reinterpret_cast<float4*>(dst + (size_t)o * ldd) = make_float4(a0, a1, a2, a3);
+    };
     const bool border = adjoint && (st.h == 1 || st.h == H - 2 || st.w0 == 0 || st.w0 + CS == W);
     if (!border) {
       float g[3][CS + 2];
@@ -333,7 +349,7 @@ __global__ __launch_bounds__(256) void c1s_dgrad_kernel(const float* dz, int ldd
             const int t = kh * 3 + kw;
             a0 += gv * w[0][t]; a1 += gv * w[1][t]; a2 += gv * w[2][t]; a3 += gv * w[3][t];
           }
-        *reinterpret_cast<float4*>(dst + (size_t)o * ldd) = make_float4(a0, a1, a2, a3);
+        put(o, a0, a1, a2, a3);
       }
     } else {
       // strips that touch row 1 / H-2 or column 1 / W-2: pixels also collect the mirrored padding cells
@@ -361,7 +377,7 @@ __global__ __launch_bounds__(256) void c1s_dgrad_kernel(const float* dz, int ldd
                 a0 += gv * w[0][t]; a1 += gv * w[1][t]; a2 += gv * w[2][t]; a3 += gv * w[3][t];
               }
             }
-        *reinterpret_cast<float4*>(dst + (size_t)o * ldd) = make_float4(a0, a1, a2, a3);
+        put(o, a0, a1, a2, a3);
       }
     }
   }
@@ -452,16 +468,16 @@ int segsde_c1_forward(const float* x, int ldx, int B, int H, int W, int C, const
 }
 
 int segsde_c1_dgrad(const float* dz, int lddz, int B, int H, int W, int C, const float* wdpack, int adjoint, float* dx, int lddx,
-                    float* dx2, int lddx2, int nsplit, void* stream) {
+                    float* dx2, int lddx2, int nsplit, const float* agy, int agld, int agkind, void* stream) {
   if (!dx2) { dx2 = dx; lddx2 = lddx; nsplit = C; }
   if (c1_strips(B, H, W) && H >= 4 && W >= 2 * CS) {
     const dim3 grid(c1s_blocks(B, H, W, 256 / (C / 4)));
-    C1_DISPATCH(c1s_dgrad_kernel, grid, 0, dz, lddz, B, H, W, wdpack, adjoint, dx, lddx, dx2, lddx2, nsplit);
+    C1_DISPATCH(c1s_dgrad_kernel, grid, 0, dz, lddz, B, H, W, wdpack, adjoint, dx, lddx, dx2, lddx2, nsplit, agy, agld, agkind);
     SEGSDE_CHECK_LAUNCH();
     return 0;
   }
   const dim3 grid(c1_blocks((long)B * H * W, 256 / (C / 4)));
-  C1_DISPATCH(c1_dgrad_kernel, grid, 0, dz, lddz, B, H, W, wdpack, adjoint, dx, lddx, dx2, lddx2, nsplit);
+  C1_DISPATCH(c1_dgrad_kernel, grid, 0, dz, lddz, B, H, W, wdpack, adjoint, dx, lddx, dx2, lddx2, nsplit, agy, agld, agkind);
   SEGSDE_CHECK_LAUNCH();
   return 0;
 }

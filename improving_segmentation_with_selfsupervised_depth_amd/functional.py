@@ -72,11 +72,16 @@ class ConvFn(Function):
     """y = act(conv([up2x?(x0) | x1], weight) + bias); geometry in ``g`` (hipops.ConvGeom)."""
 
     @staticmethod
-    def forward(ctx, x0, x1, weight, bias, g, act, stats_out=None, grad_box=None, packs=None):
+    def forward(ctx, x0, x1, weight, bias, g, act, stats_out=None, grad_box=None, packs=None, x0_act=None, act_box=None):
         """stats_out: optional list; receives the BatchNorm statistics partials of y (or None) -- see Conv2d.forward.
         grad_box: optional dict shared with the BNActFn that adds this conv's input as a residual (see SplitFn): when its
-        backward has already left the residual-path gradient there, this conv's data-gradient is accumulated onto it."""
+        backward has already left the residual-path gradient there, this conv's data-gradient is accumulated onto it.
+        x0_act: x0 is the activated output of a producing ConvFn (its raw output tensor, see ActGradFn): the data-gradient
+        w.r.t. x0 is returned already multiplied by that activation's derivative.
+        NOTE for act != "none": the gradient arriving at this Function's output is taken to be w.r.t. the PRE-activation --
+        consumers reach the output either through ActGradFn (which applies the derivative) or as a fused x0_act consumer."""
         ctx.grad_box = grad_box
+        ctx.x0_act, ctx.act_box = x0_act, act_box
         x0 = _c(x0) if x0.stride(-1) != 1 else x0
         ctx.wd = None
         if packs is not None:
@@ -93,30 +98,32 @@ class ConvFn(Function):
         ctx.g, ctx.act = g, act
         ctx.in_hw = (x0.shape[1] * (2 if g.up0 else 1), x0.shape[2] * (2 if g.up0 else 1))
         ctx.has_bias = bias is not None
-        ctx.save_for_backward(x0, x1, weight, y if act != "none" else None)
+        ctx.save_for_backward(x0, x1, weight)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x0, x1, weight, y = ctx.saved_tensors
+        x0, x1, weight = ctx.saved_tensors
         g = ctx.g
-        dy = _c(dy)
+        dz = _c(dy)                      # act != "none": already the pre-activation gradient (ActGradFn / fused consumers)
         need_b = ctx.has_bias and ctx.needs_input_grad[3]
-        if ctx.act != "none":
-            dz, dbias = H.act_backward(dy, y, ctx.act, need_dbias=need_b)
-        else:
-            dz, dbias = dy, (H.colsum(dy) if need_b else None)
+        dbias = None
+        if need_b:
+            stash = ctx.act_box.pop("dbias", None) if ctx.act_box is not None else None
+            # the bias gradient ActGradFn reduced in its pass is valid only if nothing else was added to its dz since
+            dbias = stash[1] if (stash is not None and stash[0] == dz.data_ptr()) else H.colsum(dz)
+        actgrad = (x0, ctx.x0_act) if ctx.x0_act is not None else None
         dx0 = dx1 = dw = None
         if ctx.needs_input_grad[0] or (x1 is not None and ctx.needs_input_grad[1]):
             wd = ctx.wd if ctx.wd is not None else H.pack_weight(weight, True)
             dx0 = None
             box = ctx.grad_box
             if box is not None and box.get("g") is not None and x1 is None:
-                dx0, dx1 = H.conv_dgrad(g, dz, wd, weight.detach(), ctx.in_hw, accumulate_into=box["g"])
+                dx0, dx1 = H.conv_dgrad(g, dz, wd, weight.detach(), ctx.in_hw, accumulate_into=box["g"], actgrad=actgrad)
                 if dx0 is not None:
                     box["fused"] = True      # dx0 IS the residual-path gradient, now holding the sum
             if dx0 is None:
-                dx0, dx1 = H.conv_dgrad(g, dz, wd, weight.detach(), ctx.in_hw)
+                dx0, dx1 = H.conv_dgrad(g, dz, wd, weight.detach(), ctx.in_hw, actgrad=actgrad)
                 if box is not None and box.get("publish") and box.get("g") is None and x1 is None and not g.up0 \
                         and dx0.is_contiguous():
                     box["g"] = dx0           # FanoutFn: the next consumer's data-gradient is accumulated onto this tensor
@@ -127,7 +134,32 @@ class ConvFn(Function):
                 dx1 = None
         if ctx.needs_input_grad[2]:
             dw = H.conv_wgrad(g, x0, x1, dz)
-        return dx0, dx1, dw, dbias, None, None, None, None, None
+        return dx0, dx1, dw, dbias, None, None, None, None, None, None, None
+
+
+class ActGradFn(Function):
+    """The activation of a ConvFn(act=...) seen from autograd: forward hands the already activated tensor on (the
+    activation itself ran in the conv epilogue); backward is the activation backward dz = dy * act'(y) as its own pass
+    (plus, in the same pass, the bias gradient, left in ``box`` for the ConvFn).  Consumers that can apply act'(y) in their
+    own data-gradient epilogue bypass this node: they take the ConvFn's raw output (``y._preact``) and return the
+    pre-activation gradient directly -- autograd adds both kinds of contribution at the ConvFn's output."""
+
+    passes = 0               # diagnostics / tests: how many separate activation-backward passes ran
+
+    @staticmethod
+    def forward(ctx, y, act, box):
+        ctx.act, ctx.box = act, box
+        ctx.save_for_backward(y)
+        return y.view_as(y)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        ActGradFn.passes += 1
+        dz, dbias = H.act_backward(_c(dy), y, ctx.act, need_dbias=bool(ctx.box.get("need_dbias")))
+        if dbias is not None:
+            ctx.box["dbias"] = (dz.data_ptr(), dbias)
+        return dz, None, None
 
 
 class BNActFn(Function):

@@ -136,31 +136,50 @@ def conv_forward(g, x0, x1, wpack, bias, act="none", want_stats=False):
     return (y, part) if want_stats else y
 
 
-def conv_dgrad(g, dy, wdpack, w_oihw, in_hw, need0=True, need1=True, accumulate_into=None):
+def conv_dgrad(g, dy, wdpack, w_oihw, in_hw, need0=True, need1=True, accumulate_into=None, actgrad=None):
     """Data gradient(s) of conv_forward w.r.t. (x0, x1).  dy: [B,Ho,Wo,Cout]; in_hw = (H, W) of the virtual input.
     Returns (dx0, dx1); dx0 is at the *stored* resolution of x0 (2x2-summed when g.up0).
     accumulate_into: a dense [B,H,W,C0] tensor that already holds another gradient of x0 (single-source, non-upsampled
     convs): the result is ADDED to it in the kernel epilogue and that tensor is returned as dx0 (None is returned instead
-    when this shape cannot accumulate in place -- the caller then adds)."""
+    when this shape cannot accumulate in place -- the caller then adds).
+    actgrad = (x0_saved, kind): x0 is the OUTPUT of an activation ("relu" / "elu" / "sigmoid"); dx0 is returned already
+    multiplied by its derivative, i.e. as the gradient w.r.t. the PRE-activation (fused into the kernel epilogue where the
+    shape allows, otherwise by a separate pass)."""
     B, Ho, Wo, Cout = dy.shape
     H, W = in_hw
     assert Cout == g.Cout
     dx1 = torch.empty((B, H, W, g.C1), dtype=torch.float32, device=dy.device) if g.C1 else None
     L = _lib.lib()
     flops = 2.0 * B * Ho * Wo * Cout * g.Cin * g.k * g.k
+    ag_y, ag_ld, ag_kind = None, 0, 0
+    if actgrad is not None:
+        ag_y, ag_kind = actgrad[0], ACT[actgrad[1]]
+        ag_ld = nhwc_ld(ag_y)
 
     def desc(sum2x2, accumulate=0):
         return ConvDesc(B=B, H=Ho, W=Wo, C0=Cout, C1=0, ld0=nhwc_ld(dy), ld1=0, up0=0, Ho=H, Wo=W, Cout=g.Cin, ldy=g.C0,
                         ldy2=g.C1, nsplit=g.C0, KH=g.k, KW=g.k, stride=1, dil=g.dil, pad=(g.k - 1) * g.dil - g.pad,
                         pad_mode=PAD_REFLECT_ADJOINT if g.reflect else PAD_ZERO, in_div=g.stride, act=0, sum2x2=sum2x2,
                         accumulate=accumulate)
+
+    def launch(d, y, y2, fuse):
+        return L.segsde_conv2d_dgrad_actgrad(ctypes.byref(d), _p(_f32(dy)), None, _p(wdpack), None, _p(y), _p(y2), None,
+                                             _p(ag_y) if fuse else None, ag_ld if fuse else 0, ag_kind if fuse else 0,
+                                             _stream(dy))
+
+    def finish_unfused(dx0):
+        """the activation derivative as its own pass (shapes whose epilogue cannot take it)"""
+        if actgrad is None or dx0 is None:
+            return dx0
+        dz, _ = act_backward(dx0, ag_y, actgrad[1])
+        return dz
+
     if accumulate_into is not None:
         acc = accumulate_into
         if g.up0 or g.C1 or tuple(acc.shape) != (B, H, W, g.C0) or not acc.is_contiguous():
             return None, None
         d = desc(0, 1)
-        rc = _timed("conv_dgrad", flops, dy, lambda: L.segsde_conv2d_forward(
-            ctypes.byref(d), _p(_f32(dy)), None, _p(wdpack), None, _p(acc), None, _stream(dy)), _tag(g, H, W))
+        rc = _timed("conv_dgrad", flops, dy, lambda: launch(d, acc, None, actgrad is not None), _tag(g, H, W))
         if rc == -4:
             return None, None
         check(rc, "conv2d dgrad (accumulate)")
@@ -169,24 +188,30 @@ def conv_dgrad(g, dy, wdpack, w_oihw, in_hw, need0=True, need1=True, accumulate_
         # fused: the 2x2 sum of the upsample adjoint happens in the GEMM epilogue (no full-resolution gradient tensor)
         dx0 = torch.empty((B, H // 2, W // 2, g.C0), dtype=torch.float32, device=dy.device)
         d = desc(1)
-        rc = _timed("conv_dgrad", flops, dy, lambda: L.segsde_conv2d_forward(
-            ctypes.byref(d), _p(_f32(dy)), None, _p(wdpack), None, _p(dx0), _p(dx1), _stream(dy)), _tag(g, H, W))
+        rc = _timed("conv_dgrad", flops, dy, lambda: launch(d, dx0, dx1, actgrad is not None), _tag(g, H, W))
         if rc == 0:
             return dx0, dx1
+        if rc == -4 and actgrad is not None:
+            rc = launch(d, dx0, dx1, False)
+            if rc == 0:
+                return finish_unfused(dx0), dx1
         if rc != -4:
             check(rc, "conv2d dgrad (fused upsample adjoint)")
     full0 = torch.empty((B, H, W, g.C0), dtype=torch.float32, device=dy.device)
     d = desc(0)
-    _timed("conv_dgrad", flops, dy, lambda: check(L.segsde_conv2d_forward(
-        ctypes.byref(d), _p(_f32(dy)), None, _p(wdpack), None, _p(full0), _p(dx1), _stream(dy)), "conv2d dgrad"),
-        _tag(g, H, W))
+    fused = actgrad is not None and not g.up0
+    rc = _timed("conv_dgrad", flops, dy, lambda: launch(d, full0, dx1, fused), _tag(g, H, W))
+    if rc == -4 and fused:
+        fused = False
+        rc = launch(d, full0, dx1, False)
+    check(rc, "conv2d dgrad")
     if g.up0:
         dx0 = torch.empty((B, H // 2, W // 2, g.C0), dtype=torch.float32, device=dy.device)
         check(L.segsde_upsample2x_backward(_p(full0), g.C0, B, H // 2, W // 2, g.C0, _p(dx0), g.C0, _stream(dy)),
               "upsample2x_backward")
     else:
         dx0 = full0
-    return dx0, dx1
+    return (dx0 if fused else finish_unfused(dx0)), dx1
 
 
 def conv_wgrad(g, x0, x1, dy):

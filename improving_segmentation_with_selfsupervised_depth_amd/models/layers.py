@@ -80,6 +80,13 @@ class Conv2d(nn.Conv2d):
             packs = self._weight_packs(weight)
         g = ConvGeom(c0, self.out_channels, self.kernel_size[0], self.stride[0], self.dilation[0], self.padding[0],
                      self.reflect, c1, up)
+        # x may be the activated output of another convolution of this package (ConvBlock -> ELU): then this conv's
+        # data-gradient applies the activation's derivative itself (conv epilogue) and hands the pre-activation gradient
+        # straight to the producer -- see Fn.ActGradFn
+        x0_act = None
+        pre = getattr(x, "_preact", None)
+        if pre is not None and pre[2] == x._version and torch.is_grad_enabled() and pre[0].requires_grad:
+            x, x0_act = pre[0], pre[1]
         if self.bias is None and act == "none" and self.training and not _NO_FUSED_STATS and self._stats_wanted is not False:
             # bias-free, activation-free convolutions are the candidates for a following BatchNorm (torchvision ResNet /
             # ASPP convention): their epilogue also leaves the batch-statistics partials, picked up by
@@ -87,13 +94,21 @@ class Conv2d(nn.Conv2d):
             # segmentation projections) stops producing them after its first training forward.
             if self._stats_wanted is None and self._stats_offered:
                 self._stats_wanted = False
-                return Fn.ConvFn.apply(x, skip, weight, self.bias, g, act, None, grad_box, packs)
+                return Fn.ConvFn.apply(x, skip, weight, self.bias, g, act, None, grad_box, packs, x0_act)
             self._stats_offered = True
             holder = []
-            y = Fn.ConvFn.apply(x, skip, weight, self.bias, g, act, holder, grad_box, packs)
+            y = Fn.ConvFn.apply(x, skip, weight, self.bias, g, act, holder, grad_box, packs, x0_act)
             y._bn_partials = (holder[0], y._version, self) if holder and holder[0] is not None else None
             return y
-        return Fn.ConvFn.apply(x, skip, weight, self.bias, g, act, None, grad_box, packs)
+        if act == "none":
+            return Fn.ConvFn.apply(x, skip, weight, self.bias, g, act, None, grad_box, packs, x0_act)
+        box = {"need_dbias": self.bias is not None and self.bias.requires_grad}
+        yz = Fn.ConvFn.apply(x, skip, weight, self.bias, g, act, None, grad_box, packs, x0_act, box)
+        if not (torch.is_grad_enabled() and yz.requires_grad):
+            return yz
+        y = Fn.ActGradFn.apply(yz, act, box)
+        y._preact = (yz, act, y._version)
+        return y
 
 
 class BatchNorm2d(nn.BatchNorm2d):

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SEGSDE_ABI_VERSION 4
+#define SEGSDE_ABI_VERSION 5
 
 enum { SEGSDE_ERR_NULL = -1, SEGSDE_ERR_SHAPE = -2, SEGSDE_ERR_WORKSPACE = -3, SEGSDE_ERR_UNSUPPORTED = -4 };
 enum { SEGSDE_ACT_NONE = 0, SEGSDE_ACT_RELU = 1, SEGSDE_ACT_ELU = 2, SEGSDE_ACT_SIGMOID = 3 };
@@ -73,6 +73,15 @@ int segsde_conv2d_forward(const segsde_conv_desc* d, const float* x0, const floa
 long segsde_conv2d_stats_rows(const segsde_conv_desc* d);
 int segsde_conv2d_forward_stats(const segsde_conv_desc* d, const float* x0, const float* x1, const float* wpack,
                                 const float* bias, float* y, float* y2, double* stats, void* stream);
+/* Data-gradient launch that also applies the backward of the activation which produced the tensor it differentiates with
+ * respect to (models/monodepth_layers.py:108-124: ConvBlock = conv -> ELU; the next layer's data-gradient lands on the ELU
+ * output): channels < nsplit of y are multiplied by act'(act_out) (act_out = that saved activation output, same row /
+ * channel order as y, pitch act_ld, kind SEGSDE_ACT_RELU / ELU / SIGMOID) in the epilogue -- the separate activation-backward
+ * pass over the tensor (segsde_act_backward) is not needed.  act_out = NULL: identical to segsde_conv2d_forward_stats.
+ * SEGSDE_ERR_UNSUPPORTED when this shape cannot fuse it (the caller then runs segsde_act_backward itself). */
+int segsde_conv2d_dgrad_actgrad(const segsde_conv_desc* d, const float* x0, const float* x1, const float* wpack,
+                                const float* bias, float* y, float* y2, double* stats, const float* act_out, int act_ld,
+                                int act_kind, void* stream);
 
 /* dW (OIHW, the state_dict layout) of the convolution described by d, given dy [B,Ho,Wo,Cout] (pitch lddy). */
 size_t segsde_conv2d_wgrad_workspace(const segsde_conv_desc* d);

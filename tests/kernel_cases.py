@@ -520,6 +520,42 @@ def run_valtail_kernel_cases(device, golden):
     assert torch.equal(u8[:, 0].cpu(), g["export_u8"]), "8-bit depth estimate must be bit-exact"
 
 
+def run_conv_actgrad_cases(device):
+    """data-gradient with the activation backward of its input fused into the epilogue == plain data-gradient times
+    act'(saved output), on every route: staged epilogue (LDS-DMA / reflection-adjoint loops), fused 2x2 upsample sum,
+    two-source split, generic scalar epilogue, stencil kernels (strip and per-pixel), shapes that fall back to a second pass"""
+    gen = torch.Generator().manual_seed(11)
+    cases = [  # C0, C1, up0, Cout, k, dil, pad, reflect, (H, W) of the virtual input
+        (32, 0, False, 64, 3, 1, 1, True, (10, 12)), (32, 0, True, 32, 3, 1, 1, True, (12, 16)),
+        (32, 32, True, 64, 3, 1, 1, True, (8, 16)), (64, 0, False, 64, 1, 1, 0, False, (9, 7)),
+        (12, 0, False, 20, 3, 1, 1, False, (7, 9)), (8, 8, True, 16, 3, 1, 1, True, (8, 8)),
+        (16, 0, False, 1, 3, 1, 1, True, (6, 10)), (64, 0, False, 1, 3, 1, 1, True, (8, 32)), (64, 0, False, 1, 3, 1, 1, False, (8, 32)),
+    ]
+    for (C0, C1, up0, Cout, k, dil, pad, reflect, (Hh, W)) in cases:
+        g = H.ConvGeom(C0, Cout, k, 1, dil, pad, reflect, C1, up0)
+        wt = (torch.randn(Cout, C0 + C1, k, k, generator=gen) * 0.1).to(device)
+        wd = H.pack_weight(wt, True)
+        dy = torch.randn(2, Hh, W, Cout, generator=gen).to(device)
+        h0, w0 = (Hh // 2, W // 2) if up0 else (Hh, W)
+        for kind in ("elu", "relu", "sigmoid"):
+            y = torch.randn(2, h0, w0, C0, generator=gen)
+            y = {"elu": torch.nn.functional.elu(y), "relu": torch.relu(y), "sigmoid": torch.sigmoid(y)}[kind].to(device)
+            d0, d1 = H.conv_dgrad(g, dy, wd, wt, (Hh, W))
+            f0, f1 = H.conv_dgrad(g, dy, wd, wt, (Hh, W), actgrad=(y, kind))
+            der = {"elu": torch.where(y > 0, torch.ones_like(y), y + 1), "relu": (y > 0).float(), "sigmoid": y * (1 - y)}[kind]
+            what = "actgrad %s C0=%d C1=%d up=%s Cout=%d k=%d refl=%s" % (kind, C0, C1, up0, Cout, k, reflect)
+            assert_close(f0, d0 * der, rtol=1e-6, atol=1e-6, what=what)
+            if C1:
+                assert torch.equal(f1, d1), what + " (second source untouched)"
+        if not up0 and not C1:
+            # accumulate epilogue: y_acc += act'(y) * dgrad
+            base = torch.randn(2, Hh, W, C0, generator=gen).to(device)
+            acc = base.clone()
+            r0, _ = H.conv_dgrad(g, dy, wd, wt, (Hh, W), accumulate_into=acc, actgrad=(y, kind))
+            if r0 is not None:
+                assert_close(r0, base + d0 * der, rtol=1e-6, atol=1e-6, what=what + " accumulate")
+
+
 def run_fused_photometric_vs_stage(device):
     """fused per-scale photometric kernels == the per-stage kernel chain (which the golden vectors pin), at sizes that
     are not multiples of the 32x8 tile, with a lower-resolution disparity, for every flag combination"""

@@ -359,6 +359,21 @@ def run_convblock_dropout2d(device):
     assert_close(blk(x), ref(x), rtol=0, atol=0, what="eval mode is the identity")
 
 
+def run_decoder_activation_fusion(device):
+    """DepthDecoder: the ELU of every ConvBlock whose output feeds convolutions only is differentiated inside those
+    convolutions' data-gradient epilogues -- separate activation-backward passes remain only for tensors that leave the
+    convolution chain (the sigmoid disparities)"""
+    torch.manual_seed(1)
+    dec = DepthDecoder(ENC, range(4), [32, 64], num_ch_dec=[8, 8, 16, 16, 32]).to(device).train()
+    feats = [torch.randn(2, 32 >> i, 64 >> i, c, device=device, requires_grad=True) for i, c in enumerate(ENC)]
+    before = Fn.ActGradFn.passes
+    out = dec.forward_nhwc(feats)
+    sum(out[("disp", s)].sum() for s in range(4)).backward()
+    # 4 sigmoid heads go through ActGradFn; none of the 10 ELU ConvBlocks does
+    assert Fn.ActGradFn.passes - before == 4, Fn.ActGradFn.passes - before
+    assert all(f.grad is not None and torch.isfinite(f.grad).all() for f in feats)
+
+
 def run_aspp_fanout(device):
     """ASPP's branches read one tensor: three of the four convolution data-gradients are accumulated in the conv epilogue
     onto the first one (Fn.FanoutFn) -- and the result is the plain sum"""

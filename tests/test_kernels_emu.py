@@ -56,6 +56,10 @@ def test_validation_tail_kernels(golden):
     KC.run_valtail_kernel_cases("cpu", golden)
 
 
+def test_conv_dgrad_fused_activation_backward():
+    KC.run_conv_actgrad_cases("cpu")
+
+
 def test_fused_photometric_vs_stage_kernels():
     KC.run_fused_photometric_vs_stage("cpu")
 

@@ -82,6 +82,10 @@ def test_validation_tail_kernels(golden):
     KC.run_valtail_kernel_cases("cuda", golden)
 
 
+def test_conv_dgrad_fused_activation_backward():
+    KC.run_conv_actgrad_cases("cuda")
+
+
 def test_fused_photometric_vs_stage_kernels():
     KC.run_fused_photometric_vs_stage("cuda")
 

@@ -60,3 +60,7 @@ def test_weight_pack_scope():
 
 def test_aspp_fanout_gradient_fusion():
     MC.run_aspp_fanout("cpu")
+
+
+def test_decoder_activation_backward_is_fused():
+    MC.run_decoder_activation_fusion("cpu")

@@ -337,3 +337,7 @@ def test_weight_pack_scope():
 
 def test_aspp_fanout_gradient_fusion():
     MC.run_aspp_fanout("cuda")
+
+
+def test_decoder_activation_backward_is_fused():
+    MC.run_decoder_activation_fusion("cuda")
