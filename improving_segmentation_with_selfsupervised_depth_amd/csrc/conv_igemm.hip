@@ -221,7 +221,8 @@ __device__ __forceinline__ float4 fast_fetch(const ConvP& p, const SrcSel& s, in
 // MODE 0: generic scalar gather, 1: generic float4 gather, 2: FAST (uniform tap per chunk, branch-free loads),
 // 3: FAST + reflection-pad adjoint extras, 4: FAST with the tiles written to LDS by the load itself (LDS-DMA)
 // VAR: experiment variants of the LDS-DMA loop (SEGSDE_TUNE="var=N"; 0 = shipped): 1 = all tile loads of a chunk issued
-// up front, 2 = no scheduling fences between the MFMA units, 3 = raised wave priority around the MFMA units
+// up front, 2 = no scheduling fences between the MFMA units, 3 = raised wave priority around the MFMA units, 4 = (with BK = 16)
+// four LDS stages: the loads of chunk k+3 are issued during chunk k, two chunks of loads stay in flight across barriers
 template <int BM, int BN, int WM, int WN, int MODE, int BK, int VAR = 0>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
   constexpr bool VEC = MODE >= 1;
@@ -479,9 +480,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
         // stage directly (free since the barrier that ended iteration kc-1); they are waited for (vmcnt(0)) right before
         // the barrier that ends iteration kc.  No ds_write, no staging VGPRs, the loop body has no vector memory
         // instruction that returns to registers.
-        static_assert(KQ == 8, "LDS-DMA tile pieces are 8 rows x 128 bytes");
-        // LDS byte address of this wave's 8 consecutive tile rows in pass 0 of the A tile of stage 0 (scalar from here on)
-        const unsigned lds0 = segsde_lds_addr(smem) + (unsigned)(__builtin_amdgcn_readfirstlane(wave) * 8 * LDT * 4);
+        static_assert(KQ == 8 || KQ == 4, "an LDS-DMA piece is 1 KiB: 8 rows x 128 bytes or 16 rows x 64 bytes");
+        constexpr int NST = VAR == 4 ? 4 : 2;                  // LDS stages; loads run NST-1 chunks ahead of the MFMAs
+        constexpr int INFLIGHT = (NST - 2) * (AR + BR);        // loads allowed to stay outstanding at a chunk's barrier
+        // LDS byte address of this wave's 1 KiB piece in pass 0 of the A tile of stage 0 (scalar from here on)
+        const unsigned lds0 = segsde_lds_addr(smem) + (unsigned)(__builtin_amdgcn_readfirstlane(wave) * 1024);
         constexpr unsigned PASS = RP * LDT * 4, BOFF = BM * LDT * 4, STG = STAGE * 4;
         // weight-row byte offset of the chunk being fetched: consecutive chunks are consecutive 128-byte pieces of the
         // packed row except across a tap change of a parity-class sub-problem, where it is recomputed from the tap
@@ -503,13 +506,16 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
         auto dmaA = [&](unsigned stage, int i) { segsde_buffer_load4_lds(rsa, voff[i], soffA, lds0 + stage + PASS * i); };
         auto dmaB = [&](unsigned stage, int i) { segsde_buffer_load4_lds(rsw, voffB[i], soffB, lds0 + stage + BOFF + PASS * i); };
         tap_update(wadj_tag);
-        dma_begin();
   #pragma unroll
-        for (int i = 0; i < AR; ++i) dmaA(0u, i);
+        for (int j = 0; j < NST - 1; ++j) {                    // chunks 0 .. NST-2
+          dma_begin();
   #pragma unroll
-        for (int i = 0; i < BR; ++i) dmaB(0u, i);
-        dma_end(nchunks > 1);
-        segsde_wait_vmcnt0();
+          for (int i = 0; i < AR; ++i) dmaA((unsigned)j * STG, i);
+  #pragma unroll
+          for (int i = 0; i < BR; ++i) dmaB((unsigned)j * STG, i);
+          dma_end(j + 1 < nchunks);
+        }
+        segsde_wait_vmcnt<INFLIGHT>();                         // chunk 0 has landed
         __syncthreads();
         const int arow = wm * TM * 32 + (lane & 31), brow = wn * TN * 32 + (lane & 31), h = lane >> 5;
         const int sa = swz(arow), sb = swz(brow);
@@ -524,10 +530,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
         auto comp = [](const float4& v, int c) { return c == 0 ? v.x : (c == 1 ? v.y : (c == 2 ? v.z : v.w)); };
         constexpr int DSTEP = (U - 2) / (AR + BR) > 0 ? (U - 2) / (AR + BR) : 1;
         for (int kc = 0; kc < nchunks; ++kc) {
-          const int buf = kc & 1;
+          const int buf = kc & (NST - 1);
           fread(buf, 0, 0);
           dma_begin();                     // past the last chunk: the last one is fetched again (harmless, waited for)
-          const unsigned stn = (unsigned)(buf ^ 1) * STG;
+          const unsigned stn = (unsigned)((kc + NST - 1) & (NST - 1)) * STG;
           if constexpr (VAR == 1) {
   #pragma unroll
             for (int i = 0; i < AR; ++i) dmaA(stn, i);
@@ -555,7 +561,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
             if constexpr (VAR != 2) __builtin_amdgcn_sched_barrier(0);
           }
           if constexpr (VAR == 3) __builtin_amdgcn_s_setprio(0);
-          dma_end(kc + 2 < nchunks);
+          dma_end(kc + NST < nchunks);
+          segsde_wait_vmcnt<INFLIGHT>();   // chunk kc+1 has landed (later chunks may still be in flight)
+          __syncthreads();
+        }
+        if constexpr (INFLIGHT > 0) {      // the epilogue reuses the stages: nothing may still be landing
           segsde_wait_vmcnt0();
           __syncthreads();
         }
@@ -1336,7 +1346,7 @@ bool bk64_ok(const ConvP& p) { return igemm_fast_ok(p) && (p.Ctot % 64 == 0) && 
 template <int BM, int BN, int WM, int WN, int MODE, int BK, int VAR = 0>
 int launch_igemm_mode(const ConvP& p, hipStream_t stream) {
   const int nblk = segsde_cdiv(p.M, BM) * segsde_cdiv(p.ne - p.nb, BN);
-  const size_t smem = 2 * (size_t)(BM + BN) * BK * sizeof(float);
+  const size_t smem = (VAR == 4 ? 4 : 2) * (size_t)(BM + BN) * BK * sizeof(float);
   auto k = conv_igemm_kernel<BM, BN, WM, WN, MODE, BK, VAR>;
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   hipLaunchKernelGGL(k, dim3(nblk), dim3(256), smem, stream, p);
@@ -1352,6 +1362,9 @@ int launch_igemm(const ConvP& p, hipStream_t stream) {
     if (tune().var == 1) return launch_igemm_mode<BM, BN, WM, WN, 4, 32, 1>(p, stream);
     if (tune().var == 2) return launch_igemm_mode<BM, BN, WM, WN, 4, 32, 2>(p, stream);
     if (tune().var == 3) return launch_igemm_mode<BM, BN, WM, WN, 4, 32, 3>(p, stream);
+    if constexpr (BN >= 64) {
+      if (tune().var == 4) return launch_igemm_mode<BM, BN, WM, WN, 4, 16, 4>(p, stream);
+    }
     return launch_igemm_mode<BM, BN, WM, WN, 4, 32>(p, stream);
   }
   if (igemm_fast_ok(p)) return launch_igemm_mode<BM, BN, WM, WN, 2, 32>(p, stream);

@@ -45,6 +45,8 @@ __device__ __forceinline__ void segsde_buffer_load4_lds(segsde_rsrc r, unsigned 
                : "=&s"(keep) : "v"(voff), "s"(r), "s"(soff), "s"(lds_wave_addr) : "memory");
 }
 __device__ __forceinline__ void segsde_wait_vmcnt0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// at most N of this wave's vector-memory operations still outstanding (N tile loads of later chunks may stay in flight)
+template <int N> __device__ __forceinline__ void segsde_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 #endif
 
 // hides a VGPR value's provenance from the optimiser (no instruction is emitted)

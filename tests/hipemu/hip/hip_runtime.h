@@ -162,6 +162,7 @@ inline void segsde_buffer_load4_lds(segsde_rsrc r, unsigned voff, unsigned soff,
   memcpy(::emu_lds + lds_wave_addr + 16 * emu::lane(), &v, sizeof(v));
 }
 inline void segsde_wait_vmcnt0() {}
+template <int N> inline void segsde_wait_vmcnt() {}
 
 inline void __syncthreads() { emu::barrier_wait(&emu::S().block_bar); }
 inline float __shfl_xor(float v, int m, int = 64) { return emu::shfl_idx<float>(v, [m](int l) { return l ^ m; }); }
