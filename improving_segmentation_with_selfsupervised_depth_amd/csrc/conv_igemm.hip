@@ -809,10 +809,12 @@ template <int BKT, int BN, int WM, int WN, int MODE>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(ConvP p, const float* dy, int lddy, float* part,
                                                          int chunks_per_split) {
   // MODE 0: scalar gather, 1: float4 gather, 2: FAST A side + vector dY + rows at least 32 pixels wide (straight-line
-  // loop), 3: FAST A side with the general row walk / scalar dY (odd Cout, tiny feature maps)
+  // loop), 3: FAST A side with the general row walk / scalar dY (odd Cout, tiny feature maps), 4: MODE 2 with the tile
+  // loads writing LDS themselves (LDS-DMA, see the forward kernel)
   constexpr bool VEC = MODE >= 1;
   constexpr bool FAST = MODE >= 2;
-  constexpr bool SIMPLE = MODE == 2;
+  constexpr bool SIMPLE = MODE == 2 || MODE == 4;
+  constexpr bool DMA = MODE == 4;
   constexpr int TM = BKT / (WM * 32), TN = BN / (WN * 32);
   constexpr int AQ = BKT / 4, DQ = BN / 4;             // float4 columns per tile row
   constexpr int AI = (BP * AQ) / 256, DI = (BP * DQ) / 256;
@@ -1075,6 +1077,77 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(ConvP p, const float
   };
   // same software pipeline as the forward kernel: LDS stores + the loads of chunk c+2 sit between the two halves of
   // chunk c's MFMAs; rows past M load the zero page, so running one or two chunks past c_end is harmless
+  if constexpr (DMA) {
+    // Two LDS stages filled by the loads themselves.  The plain row-major [pixel][channel] image is lane-linear as it is:
+    // thread e = tid + 256 i owns float4 column e % Q of tile row e / Q, so the 64 lanes of a wave cover 64 / Q consecutive
+    // rows = 1 KiB (Q = 32: two 512-byte rows; Q = 16: four 256-byte rows).  A wave whose 128 reduction columns straddle
+    // the concat boundary (wave_src == 2) has to OR two loads and keeps the register path for its A pieces.
+    const unsigned lds0 = segsde_lds_addr(smem);
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    constexpr unsigned STG = STAGE * 4;
+    auto issue = [&](int c, unsigned stage) {     // all tile loads of chunk c into stage (byte offset)
+      const bool live = c < nchunks_total;
+      if (wave_src != 2) {
+        const segsde_rsrc rr = segsde_make_rsrc(wave_src == 0 ? p.x0 + (size_t)cb * tbs0 : p.x1 + (size_t)cb * tbs1, live ? TAB_MARK : 0u);
+#pragma unroll
+        for (int i = 0; i < AI; ++i)
+          segsde_buffer_load4_lds(rr, thv + twv[i] + tcc, 0u, lds0 + stage + (unsigned)(((256 / AQ) * i + (64 / AQ) * wv) * BKT * 4));
+      } else {
+        aload(c);
+        float* At = smem + (stage / 4);
+#pragma unroll
+        for (int i = 0; i < AI; ++i) {
+          const int e = tid + 256 * i, row = e / AQ, kq = e - row * AQ;
+          *reinterpret_cast<float4*>(At + row * BKT + 4 * kq) = ra[i];
+        }
+      }
+      const segsde_rsrc rd_ = segsde_make_rsrc(dy + (size_t)c * BP * lddy, live ? 0x7fffffffu : 0u);
+#pragma unroll
+      for (int i = 0; i < DI; ++i)
+        segsde_buffer_load4_lds(rd_, voffD[i], 0u, lds0 + stage + (unsigned)((BP * BKT + ((256 / DQ) * i + (64 / DQ) * wv) * BN) * 4));
+      cw += BP;
+      if (cw == p.Wo) { cw = 0; if (++chh == p.Ho) { chh = 0; ++cb; } }
+    };
+    tload();
+    issue(c_begin, 0u);
+    segsde_wait_vmcnt0();
+    __syncthreads();
+    float fa[2][4][TM], fd[2][4][TN];
+    int ao[TM], dofs[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) { ao[i] = (lane >> 5) * BKT + wm * TM * 32 + (lane & 31) + i * 32; SEGSDE_OPAQUE(ao[i]); }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) { dofs[j] = BP * BKT + (lane >> 5) * BN + wn * TN * 32 + (lane & 31) + j * 32; SEGSDE_OPAQUE(dofs[j]); }
+    auto fread = [&](int buf, int g, int slot) {
+      const float* St = smem + buf * STAGE;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[slot][u][i] = St[ao[i] + 2 * (4 * g + u) * BKT];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fd[slot][u][j] = St[dofs[j] + 2 * (4 * g + u) * BN];
+      }
+    };
+    for (int c = c_begin; c < c_end; ++c) {
+      const int buf = (c - c_begin) & 1;
+      fread(buf, 0, 0);
+      tload();
+#pragma unroll
+      for (int u = 0; u < BP / 2; ++u) {
+        const int g = u / 4, st = u % 4;
+        if (st == 2 && g + 1 < BP / 8) fread(buf, g + 1, (g + 1) & 1);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[g & 1][st][i], fd[g & 1][st][j], acc[i][j], 0, 0, 0);
+        if (u == 1) issue(c + 1, (unsigned)(buf ^ 1) * STG);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      segsde_wait_vmcnt0();
+      __syncthreads();
+    }
+  } else {
   gload(c_begin);
   lstore(0);
   gload(c_begin + 1);
@@ -1126,6 +1199,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(ConvP p, const float
     gload(c + 2);
     mma_steps(buf, BP / 4, BP / 2);
     __syncthreads();
+  }
   }
 
   float* out = part + (long)zt * p.Ktot * p.N;
@@ -1258,7 +1332,7 @@ __global__ __launch_bounds__(256) void reflect_dgrad_fix_kernel(const float* dy,
 // experiment knob (environment SEGSDE_TUNE="bk64=1"), read once.  Measured on MI355X (profiles/ab_conv_r01.log):
 // BK=64 (139 KB LDS => 1 workgroup/CU, half the barriers) loses 15-25 % on the large layers against BK=32 with two
 // co-resident workgroups per CU, and start-up staggering of co-resident workgroups changes nothing.
-struct Tune { int bk64 = 0; int adjfix = 0; int wplan = 0; int wovh = 4; int nos2 = 0; int dma = 1; int var = 0; };
+struct Tune { int bk64 = 0; int adjfix = 0; int wplan = 0; int wovh = 4; int nos2 = 0; int dma = 1; int var = 0; int wdma = 1; };
 const Tune& tune() {
   static Tune t = [] {
     Tune r;
@@ -1270,6 +1344,7 @@ const Tune& tune() {
       if (const char* q = strstr(e, "adjfix=")) r.adjfix = atoi(q + 7);   // reflection adjoint: plain loop + border fix-up kernel
       if (const char* q = strstr(e, "dma=")) r.dma = atoi(q + 4);         // 0: register-staged tile loads (round-1 loop)
       if (const char* q = strstr(e, "var=")) r.var = atoi(q + 4);         // experiment variants of the LDS-DMA loop
+      if (const char* q = strstr(e, "wlds=")) r.wdma = atoi(q + 5);       // 0: register-staged weight-gradient tile loads
     }
     return r;
   }();
@@ -1526,7 +1601,7 @@ template <int BKT, int BN, int WM, int WN, int MODE>
 int launch_wgrad_mode(const ConvP& p, const float* dy, int lddy, float* ws, int splits, int cps, hipStream_t stream) {
   const dim3 grid(segsde_cdiv(p.Ktot, BKT) * segsde_cdiv(p.N, BN) * splits);
   size_t smem = 2 * (size_t)BP * (BKT + BN) * sizeof(float);
-  if (MODE == 2)   // + the four offset tables (padded rows / columns of the two sources)
+  if (MODE == 2 || MODE == 4)   // + the four offset tables (padded rows / columns of the two sources)
     smem += 2 * (size_t)((p.Ho - 1) * p.stride + (p.KH - 1) * p.dil + 1 + (p.Wo - 1) * p.stride + (p.KW - 1) * p.dil + 1) * sizeof(unsigned);
   auto k = conv_wgrad_kernel<BKT, BN, WM, WN, MODE>;
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -1550,7 +1625,9 @@ int wgrad_mode(const ConvP& p, const float* dy, int lddy) {
 template <int BKT, int BN, int WM, int WN>
 int launch_wgrad(const ConvP& p, const float* dy, int lddy, float* ws, int splits, int cps, hipStream_t stream) {
   switch (wgrad_mode(p, dy, lddy)) {
-    case 2: return launch_wgrad_mode<BKT, BN, WM, WN, 2>(p, dy, lddy, ws, splits, cps, stream);
+    case 2:
+      if (tune().wdma) return launch_wgrad_mode<BKT, BN, WM, WN, 4>(p, dy, lddy, ws, splits, cps, stream);
+      return launch_wgrad_mode<BKT, BN, WM, WN, 2>(p, dy, lddy, ws, splits, cps, stream);
     case 3: return launch_wgrad_mode<BKT, BN, WM, WN, 3>(p, dy, lddy, ws, splits, cps, stream);
     case 1: return launch_wgrad_mode<BKT, BN, WM, WN, 1>(p, dy, lddy, ws, splits, cps, stream);
     default: return launch_wgrad_mode<BKT, BN, WM, WN, 0>(p, dy, lddy, ws, splits, cps, stream);
