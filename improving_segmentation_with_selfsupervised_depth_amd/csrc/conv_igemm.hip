@@ -54,6 +54,9 @@ struct ConvP {
   // multiplied by act'(agy) -- the gradient with respect to the PRE-activation, which is what the producing conv's own
   // backward needs (no separate 12-byte-per-element activation-backward pass).  Same row order / channel order as y, pitch agld.
   const float* agy; int agld, agkind;
+  // division of a GEMM row index (< 2^31) by the image size / row length without the ~30-instruction runtime division:
+  // q = umulhi(n, magic) >> shift (set_divs).  d1 = Ho*Wo, d2 = Wo; for sum2x2 launches the 2x2-block counts.
+  unsigned mg1, mg2; int sf1, sf2, d1, d2;
 };
 
 struct KInfo {  // decoded reduction index k -> tap + channel + source
@@ -92,31 +95,35 @@ __device__ __forceinline__ long a_offset(const ConvP& p, const KInfo& t, int b, 
   return ((long)(b * t.Hs + hi) * t.Ws + wi) * t.ld + t.cc;
 }
 
+// n / d for 0 <= n < 2^31 with the (magic, shift) pair of set_divs; d == 1 is flagged by magic == 0
+__device__ __forceinline__ int fast_div(int n, unsigned magic, int shift) {
+  return magic ? (int)(__umulhi((unsigned)n, magic) >> shift) : n;
+}
+
 __device__ __forceinline__ void decode_m(const ConvP& p, int m, int& b, int& hb, int& wb, bool& ok) {
   ok = m < p.M;
   const int mm = ok ? m : 0;
   if (p.sum2x2) {
     // output pixels enumerated patch-major: m = ((b*Ho/2 + h/2)*Wo/2 + w/2)*4 + (h&1)*2 + (w&1), so the four members of
     // a 2x2 block are four consecutive GEMM rows = the four registers (r&3) of one lane in the MFMA accumulator
-    const int q = mm >> 2, sub = mm & 3, w2 = p.Wo >> 1, hw2 = (p.Ho >> 1) * w2;
-    b = q / hw2;
-    const int rem = q - b * hw2, h2 = rem / w2;
+    const int q = mm >> 2, sub = mm & 3;
+    b = fast_div(q, p.mg1, p.sf1);
+    const int rem = q - b * p.d1, h2 = fast_div(rem, p.mg2, p.sf2);
     hb = 2 * h2 + (sub >> 1);
-    wb = 2 * (rem - h2 * w2) + (sub & 1);
+    wb = 2 * (rem - h2 * p.d2) + (sub & 1);
     return;
   }
-  const int hw = p.Ho * p.Wo;
-  b = mm / hw;
-  const int rem = mm - b * hw;
-  const int ho = rem / p.Wo;
+  b = fast_div(mm, p.mg1, p.sf1);
+  const int rem = mm - b * p.d1;
+  const int ho = fast_div(rem, p.mg2, p.sf2);
   hb = ho * p.stride;
-  wb = (rem - ho * p.Wo) * p.stride;
+  wb = (rem - ho * p.d2) * p.stride;
 }
 
 // row index of output GEMM row m in the destination tensor (identity unless the launch writes a strided sub-grid)
 __device__ __forceinline__ long out_row(const ConvP& p, int m) {
   if (p.os == 1) return m;
-  const int hw = p.Ho * p.Wo, b = m / hw, rem = m - b * hw, i = rem / p.Wo, j = rem - i * p.Wo;
+  const int b = fast_div(m, p.mg1, p.sf1), rem = m - b * p.d1, i = fast_div(rem, p.mg2, p.sf2), j = rem - i * p.d2;
   return ((long)b * p.OHf + p.os * i + p.oph) * p.OWf + p.os * j + p.opw;
 }
 
@@ -224,11 +231,11 @@ __device__ __forceinline__ float4 fast_fetch(const ConvP& p, const SrcSel& s, in
 // up front, 2 = no scheduling fences between the MFMA units, 3 = raised wave priority around the MFMA units, 4 = (with BK = 16)
 // four LDS stages: the loads of chunk k+3 are issued during chunk k, two chunks of loads stay in flight across barriers
 template <int BM, int BN, int WM, int WN, int MODE, int BK, int VAR = 0>
-__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
+__global__ __launch_bounds__(256, VAR == 6 ? 3 : 2) void conv_igemm_kernel(ConvP p) {
   constexpr bool VEC = MODE >= 1;
   constexpr bool FAST = MODE >= 2;
   constexpr bool ADJ = MODE == 3;
-  constexpr bool DMA = MODE == 4;
+  constexpr bool DMA = MODE == 4 || (MODE == 3 && VAR != 5);   // MODE 3: the waves that own no border pixel run the LDS-DMA loop too
   // LDS rows are unpadded (BK floats); the 16-byte column groups of a row are XOR-swizzled with the row index so that
   // the 16 lanes of every ds_read_b128 lane group hit 16 distinct 16-byte slots of the 256-byte bank row (conflict-free)
   // -- no padding means 48 KB instead of 54 KB for the 128x64 tile, i.e. THREE workgroups per CU instead of two.
@@ -239,6 +246,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
   constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
   constexpr int AR = BM / RP, BR = BN / RP;
   constexpr int STAGE = (BM + BN) * LDT;
+  constexpr int NSTAGES = VAR == 4 ? 4 : 2;
+  // floats of LDS in front of the FAST path's tap table: the stages or the staged epilogue's tile, whichever is larger
+  constexpr int TAB0 = NSTAGES * STAGE > BM * BN ? NSTAGES * STAGE : BM * BN;
   static_assert(WM * WN == 4, "4 waves per workgroup");
   SEGSDE_SMEM;
   float* smem = reinterpret_cast<float*>(segsde_smem);
@@ -359,20 +369,6 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
     const float* base1 = s1.src + (size_t)b0 * s1.bstride;
     const segsde_rsrc rsw = segsde_make_rsrc(p.w);
     unsigned voff[AR], voffB[BR];
-    // LDS-DMA writes lane l of an instruction to slot l of a 1 KiB block (8 tile rows x 8 sixteen-byte slots for BK = 32):
-    // the thread that owns slot kq of row r0 therefore FETCHES the channel group that the swizzled layout keeps there,
-    // kq ^ swz(r0) (rows 32 apart share the swizzle, so this is one constant per thread) -- fragment reads are unchanged
-    const unsigned kqs = DMA ? (unsigned)(kq ^ swz(r0)) : (unsigned)kq;
-    // reflection-pad adjoint: a pixel in row 1 / H-2 (column 1 / W-2) also collects what flowed into the mirrored
-    // padding row -1 / H (column -1 / W), reachable only through the tap with dh = +1 / -1 (dw likewise).  The extra
-    // pre-image is one more buffer load per tile row (offset voffX, out of range when there is none); only the four
-    // corner-adjacent pixels of an image have up to three extras at once (voffX2/3, loaded when the wave owns one).
-    unsigned voffX[AR], voffX2[AR], voffX3[AR];
-#pragma unroll
-    for (int i = 0; i < BR; ++i) {
-      const int n = n0 + r0 + RP * i;
-      voffB[i] = n < p.ne ? ((unsigned)(n * p.Kfull) + 4u * kqs) * 4u : SEGSDE_OOB;   // rows past Cout read zeros
-    }
     bool wave_bord = false, wave_corner = false;
     {
       int anyb = 0, anyc = 0;
@@ -384,10 +380,27 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
       }
       if constexpr (ADJ) { wave_bord = __any(anyb) != 0; wave_corner = __any(anyc) != 0; }
     }
-    auto tap_update = [&](auto wadj_tag) {
+    // LDS-DMA writes lane l of an instruction to slot l of a 1 KiB block (8 tile rows x 8 sixteen-byte slots for BK = 32):
+    // the thread that owns slot kq of row r0 therefore FETCHES the channel group that the swizzled layout keeps there,
+    // kq ^ swz(r0) (rows 32 apart share the swizzle, so this is one constant per thread) -- fragment reads are unchanged.
+    // A wave that owns a border pixel of a reflection adjoint adds extra pre-images to its rows before they reach LDS and
+    // keeps the register-staged path (logical slot, swizzle at the LDS store) -- a wave-uniform choice.
+    const unsigned kqs = (DMA && !wave_bord) ? (unsigned)(kq ^ swz(r0)) : (unsigned)kq;
+    // reflection-pad adjoint: a pixel in row 1 / H-2 (column 1 / W-2) also collects what flowed into the mirrored
+    // padding row -1 / H (column -1 / W), reachable only through the tap with dh = +1 / -1 (dw likewise).  The extra
+    // pre-image is one more buffer load per tile row (offset voffX, out of range when there is none); only the four
+    // corner-adjacent pixels of an image have up to three extras at once (voffX2/3, loaded when the wave owns one).
+    unsigned voffX[AR], voffX2[AR], voffX3[AR];
+#pragma unroll
+    for (int i = 0; i < BR; ++i) {
+      const int n = n0 + r0 + RP * i;
+      voffB[i] = n < p.ne ? ((unsigned)(n * p.Kfull) + 4u * kqs) * 4u : SEGSDE_OOB;   // rows past Cout read zeros
+    }
+    // byte offsets of the tile rows' source pixels for tap (kh, kw) of one source (col = the thread's own column part, in
+    // floats); with WADJ also the extra pre-images of the reflection adjoint (those need col = 4 * kqs)
+    auto compute_voff = [&](bool in0, int kh, int kw, unsigned* out, unsigned col, auto wadj_tag) {
       constexpr bool WADJ = decltype(wadj_tag)::value;
-      const bool in0 = cs.c0 < p.C0;
-      const int dh = cs.kh * p.dil - p.pad, dw = cs.kw * p.dil - p.pad;
+      const int dh = kh * p.dil - p.pad, dw = kw * p.dil - p.pad;
       const int sh = in0 ? s0.shift : 0;
       const unsigned ld = in0 ? s0.ld : s1.ld, Ws = in0 ? s0.Ws : s1.Ws, bst = in0 ? s0.bstride : s1.bstride;
       const int ds = p.in_div >> 1;   // data-gradient of a stride-2 conv: only even coordinates carry a value
@@ -395,7 +408,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
 #pragma unroll
       for (int i = 0; i < AR; ++i) {
         auto boff = [&](int hh, int ww) {
-          return ((unsigned)rb[i] * bst + ((unsigned)(hh >> sh) * Ws + (unsigned)(ww >> sh)) * ld + 4u * kqs) * 4u;
+          return ((unsigned)rb[i] * bst + ((unsigned)(hh >> sh) * Ws + (unsigned)(ww >> sh)) * ld + col) * 4u;
         };
         int hi = rh[i] + dh, wi = rw[i] + dw;
         bool ok = rok[i] && (((hi | wi) & ds) == 0);
@@ -404,7 +417,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
         const int wr = wi < 0 ? -wi : (wi >= p.W ? 2 * p.W - 2 - wi : wi);
         const bool hin = (unsigned)hi < (unsigned)p.H, win = (unsigned)wi < (unsigned)p.W;
         ok = ok && (refl || (hin && win));
-        voff[i] = ok ? boff(refl ? hr : hi, refl ? wr : wi) : SEGSDE_OOB;
+        out[i] = ok ? boff(refl ? hr : hi, refl ? wr : wi) : SEGSDE_OOB;
         if constexpr (WADJ) {
           const int eh = (rh[i] == 1 && dh == 1) ? 0 : ((rh[i] == p.H - 2 && dh == -1) ? p.H - 1 : -1);
           const int ew = (rw[i] == 1 && dw == 1) ? 0 : ((rw[i] == p.W - 2 && dw == -1) ? p.W - 1 : -1);
@@ -415,6 +428,37 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
             voffX3[i] = t3 ? boff(eh, ew) : SEGSDE_OOB;
           }
         }
+      }
+    };
+    // Tap table.  The ~120 VALU instructions of compute_voff used to run at every tap / source change -- every second
+    // chunk of a 64-channel layer, i.e. 3.4 VALU instructions per MFMA over such a tile, and VALU cycles are matrix-pipe
+    // cycles on this chip.  Instead every (source, tap) offset of every tile row is computed once per tile, into LDS behind
+    // the stages (the eight threads that share a row set split the taps), while the first tile loads are in flight; a tap
+    // change in the K loop is then AR ds_read_b32 + AR adds.  Rows of waves that run the adjoint's register loop are
+    // left out (that loop recomputes, it needs the extra pre-images anyway).
+    unsigned* tab = reinterpret_cast<unsigned*>(smem + TAB0);
+    const int ntaps = p.KH * p.KW;
+    auto tab_build = [&]() {
+      const int T = (p.C0 < p.Ctot ? 2 : 1) * ntaps;
+      for (int t = 1 + kq; t < T; t += KQ) {   // entry 0 is the first tap, computed directly and never revisited
+        const bool in0 = t < ntaps;
+        const int tt = in0 ? t : t - ntaps, kh = tt / p.KW, kw = tt - kh * p.KW;
+        unsigned o[AR];
+        compute_voff(in0, kh, kw, o, 0u, std::false_type{});
+#pragma unroll
+        for (int i = 0; i < AR; ++i) tab[t * BM + r0 + RP * i] = o[i];
+      }
+    };
+    // direct: the table is not visible yet (prologue, before the first barrier)
+    auto tap_update = [&](auto wadj_tag, bool direct) {
+      constexpr bool WADJ = decltype(wadj_tag)::value;
+      const bool in0 = cs.c0 < p.C0;
+      if (WADJ || direct) {
+        compute_voff(in0, cs.kh, cs.kw, voff, 4u * kqs, wadj_tag);
+      } else {
+        const unsigned* tp = tab + ((in0 ? 0 : ntaps) + cs.kh * p.KW + cs.kw) * BM + r0;
+#pragma unroll
+        for (int i = 0; i < AR; ++i) voff[i] = tp[RP * i] + 16u * kqs;
       }
     };
     // The whole K loop exists twice in the adjoint kernel: waves that own no pixel next to the border run the plain
@@ -441,10 +485,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
         }
       };
       auto loadB = [&](int i) { rbv[i] = segsde_buffer_load4(rsw, voffB[i], soffB); };
-      auto chunk_end = [&]() {
+      auto chunk_end = [&](bool direct) {
         if (more) {
           cs.advance(p, BK);
-          if (cs.c0 == 0 || cs.c0 == p.C0) tap_update(wadj_tag);
+          if (cs.c0 == 0 || cs.c0 == p.C0) tap_update(wadj_tag, direct);
         }
       };
       auto storeA = [&](float* As) {
@@ -465,17 +509,17 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
           *reinterpret_cast<float4*>(Bs + row * LDT + 4 * (kq ^ swz(row))) = rbv[i];
         }
       };
-      auto load_chunk = [&](int kc) {
+      auto load_chunk = [&](int kc) {     // prologue only
         chunk_begin(kc);
   #pragma unroll
         for (int i = 0; i < AR; ++i) loadA(i);
   #pragma unroll
         for (int i = 0; i < BR; ++i) loadB(i);
-        chunk_end();
+        chunk_end(true);
       };
 
       float4 fa[2][TM], fb[2][TN];
-      if constexpr (DMA) {
+      if constexpr (DMA && !WADJ) {
         // Two LDS stages, no register staging: during the MFMAs of chunk kc the loads of chunk kc+1 write the other
         // stage directly (free since the barrier that ended iteration kc-1); they are waited for (vmcnt(0)) right before
         // the barrier that ends iteration kc.  No ds_write, no staging VGPRs, the loop body has no vector memory
@@ -495,17 +539,17 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
           soffA = (unsigned)(in0 ? cs.c0 : cs.c0 - p.C0) * 4u;
           soffB = wbyte;
         };
-        auto dma_end = [&](bool adv) {
+        auto dma_end = [&](bool adv, bool direct) {
           if (adv) {
             cs.advance(p, BK);
             wbyte += BK * 4u;
             if (cs.c0 == 0) wbyte = (unsigned)(((p.kh0 + p.khs * cs.kh) * p.KWf + p.kw0 + p.kws * cs.kw) * p.Ctot) * 4u;
-            if (cs.c0 == 0 || cs.c0 == p.C0) tap_update(wadj_tag);
+            if (cs.c0 == 0 || cs.c0 == p.C0) tap_update(wadj_tag, direct);
           }
         };
         auto dmaA = [&](unsigned stage, int i) { segsde_buffer_load4_lds(rsa, voff[i], soffA, lds0 + stage + PASS * i); };
         auto dmaB = [&](unsigned stage, int i) { segsde_buffer_load4_lds(rsw, voffB[i], soffB, lds0 + stage + BOFF + PASS * i); };
-        tap_update(wadj_tag);
+        tap_update(wadj_tag, true);
   #pragma unroll
         for (int j = 0; j < NST - 1; ++j) {                    // chunks 0 .. NST-2
           dma_begin();
@@ -513,8 +557,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
           for (int i = 0; i < AR; ++i) dmaA((unsigned)j * STG, i);
   #pragma unroll
           for (int i = 0; i < BR; ++i) dmaB((unsigned)j * STG, i);
-          dma_end(j + 1 < nchunks);
+          dma_end(j + 1 < nchunks, true);
         }
+        tab_build();                                           // under the latency of the first loads
         segsde_wait_vmcnt<INFLIGHT>();                         // chunk 0 has landed
         __syncthreads();
         const int arow = wm * TM * 32 + (lane & 31), brow = wn * TN * 32 + (lane & 31), h = lane >> 5;
@@ -561,7 +606,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
             if constexpr (VAR != 2) __builtin_amdgcn_sched_barrier(0);
           }
           if constexpr (VAR == 3) __builtin_amdgcn_s_setprio(0);
-          dma_end(kc + NST < nchunks);
+          dma_end(kc + NST < nchunks, false);
           segsde_wait_vmcnt<INFLIGHT>();   // chunk kc+1 has landed (later chunks may still be in flight)
           __syncthreads();
         }
@@ -571,10 +616,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
         }
         return;
       }
-      tap_update(wadj_tag);
+      tap_update(wadj_tag, true);
       load_chunk(0);
       storeA(smem); storeB(smem + BM * LDT);
       load_chunk(1);
+      if constexpr (!WADJ) tab_build();
       __syncthreads();
 
       const int arow = wm * TM * 32 + (lane & 31), brow = wn * TN * 32 + (lane & 31), h = lane >> 5;
@@ -613,7 +659,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
           }
           __builtin_amdgcn_sched_barrier(0);
         }
-        chunk_end();
+        chunk_end(false);
         __syncthreads();
       }
     };
@@ -1332,7 +1378,7 @@ __global__ __launch_bounds__(256) void reflect_dgrad_fix_kernel(const float* dy,
 // experiment knob (environment SEGSDE_TUNE="bk64=1"), read once.  Measured on MI355X (profiles/ab_conv_r01.log):
 // BK=64 (139 KB LDS => 1 workgroup/CU, half the barriers) loses 15-25 % on the large layers against BK=32 with two
 // co-resident workgroups per CU, and start-up staggering of co-resident workgroups changes nothing.
-struct Tune { int bk64 = 0; int adjfix = 0; int wplan = 0; int wovh = 4; int nos2 = 0; int dma = 1; int var = 0; int wdma = 1; };
+struct Tune { int bk64 = 0; int adjfix = 0; int wplan = 0; int wovh = 4; int nos2 = 0; int dma = 1; int var = 0; int wdma = 1; int adjlds = 1; };
 const Tune& tune() {
   static Tune t = [] {
     Tune r;
@@ -1344,6 +1390,7 @@ const Tune& tune() {
       if (const char* q = strstr(e, "adjfix=")) r.adjfix = atoi(q + 7);   // reflection adjoint: plain loop + border fix-up kernel
       if (const char* q = strstr(e, "dma=")) r.dma = atoi(q + 4);         // 0: register-staged tile loads (round-1 loop)
       if (const char* q = strstr(e, "var=")) r.var = atoi(q + 4);         // experiment variants of the LDS-DMA loop
+      if (const char* q = strstr(e, "adjl=")) r.adjlds = atoi(q + 5);     // 0: reflection-adjoint loop register-staged in every wave
       if (const char* q = strstr(e, "wlds=")) r.wdma = atoi(q + 5);       // 0: register-staged weight-gradient tile loads
     }
     return r;
@@ -1362,6 +1409,24 @@ const float* zero_page() {
   return z;
 }
 
+// magic = ceil(2^(31+l) / d), l = ceil(log2 d) >= 1: umulhi(n, magic) >> (l - 1) == n / d for every 0 <= n < 2^31
+// (the rounding error of the product is below n / 2^(31+l) < 2^-l <= 1/d); d == 1 -> magic 0 (identity)
+void magic_for(int d, unsigned& magic, int& shift) {
+  if (d <= 1) { magic = 0; shift = 0; return; }
+  int l = 1;
+  while ((1L << l) < d) ++l;
+  const unsigned long long num = 1ULL << (31 + l);
+  magic = (unsigned)((num + (unsigned long long)d - 1) / (unsigned long long)d);
+  shift = l - 1;
+}
+void set_divs(ConvP& p) {
+  // out_row (strided sub-grid stores) is only used by launches that are not sum2x2
+  p.d1 = p.sum2x2 ? (p.Ho >> 1) * (p.Wo >> 1) : p.Ho * p.Wo;
+  p.d2 = p.sum2x2 ? (p.Wo >> 1) : p.Wo;
+  magic_for(p.d1, p.mg1, p.sf1);
+  magic_for(p.d2, p.mg2, p.sf2);
+}
+
 ConvP make_params(const segsde_conv_desc* d, const float* x0, const float* x1, const float* w, const float* bias,
                   float* y, float* y2) {
   ConvP p;
@@ -1373,6 +1438,7 @@ ConvP make_params(const segsde_conv_desc* d, const float* x0, const float* x1, c
   p.in_div = d->in_div < 1 ? 1 : d->in_div;
   p.Ctot = d->C0 + d->C1; p.Ktot = d->KH * d->KW * p.Ctot; p.M = d->B * d->Ho * d->Wo; p.act = d->act;
   p.sum2x2 = d->sum2x2;
+  set_divs(p);
   p.nb = 0; p.ne = p.N;
   p.vecout = (p.N % 4 == 0) && (p.ldy % 4 == 0) && (p.ldy2 % 4 == 0) && (p.nsplit % 4 == 0) && aligned16(p.y) &&
              aligned16(p.y2);
@@ -1414,14 +1480,17 @@ bool fast_ok(const ConvP& p) {
 bool igemm_fast_ok(const ConvP& p) {
   const long i0 = (long)(p.H >> p.up0) * (p.W >> p.up0) * p.ld0 * 4, i1 = (long)p.H * p.W * p.ld1 * 4;
   const long span = 256 / ((long)p.Ho * p.Wo) + 2;   // images one (up to 256-row) tile can touch
-  return fast_ok(p) && span * (i0 > i1 ? i0 : i1) < (1L << 31) && (long)p.N * p.Ktot * 4 < (1L << 31);
+  return fast_ok(p) && p.KH * p.KW <= 16 /* tap table in LDS */ && span * (i0 > i1 ? i0 : i1) < (1L << 31) &&
+         (long)p.N * p.Ktot * 4 < (1L << 31);
 }
 bool bk64_ok(const ConvP& p) { return igemm_fast_ok(p) && (p.Ctot % 64 == 0) && (p.C1 == 0 || p.C0 % 64 == 0); }
 
 template <int BM, int BN, int WM, int WN, int MODE, int BK, int VAR = 0>
 int launch_igemm_mode(const ConvP& p, hipStream_t stream) {
   const int nblk = segsde_cdiv(p.M, BM) * segsde_cdiv(p.ne - p.nb, BN);
-  const size_t smem = (VAR == 4 ? 4 : 2) * (size_t)(BM + BN) * BK * sizeof(float);
+  size_t smem = (VAR == 4 ? 4 : 2) * (size_t)(BM + BN) * BK * sizeof(float);
+  if (smem < (size_t)BM * BN * sizeof(float)) smem = (size_t)BM * BN * sizeof(float);   // the staged epilogue's tile
+  if (MODE >= 2) smem += (size_t)(p.C0 < p.Ctot ? 2 : 1) * p.KH * p.KW * BM * sizeof(unsigned);   // tap table
   auto k = conv_igemm_kernel<BM, BN, WM, WN, MODE, BK, VAR>;
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   hipLaunchKernelGGL(k, dim3(nblk), dim3(256), smem, stream, p);
@@ -1431,7 +1500,8 @@ int launch_igemm_mode(const ConvP& p, hipStream_t stream) {
 
 template <int BM, int BN, int WM, int WN>
 int launch_igemm(const ConvP& p, hipStream_t stream) {
-  if (igemm_fast_ok(p) && p.pad_mode == SEGSDE_PAD_REFLECT_ADJOINT && !(tune().adjfix && !p.sum2x2) && tune().adjfix < 2) return launch_igemm_mode<BM, BN, WM, WN, 3, 32>(p, stream);
+  if (igemm_fast_ok(p) && p.pad_mode == SEGSDE_PAD_REFLECT_ADJOINT && !(tune().adjfix && !p.sum2x2) && tune().adjfix < 2)
+    return tune().adjlds ? launch_igemm_mode<BM, BN, WM, WN, 3, 32>(p, stream) : launch_igemm_mode<BM, BN, WM, WN, 3, 32, 5>(p, stream);
   if (tune().bk64 && bk64_ok(p)) return launch_igemm_mode<BM, BN, WM, WN, 2, 64>(p, stream);
   if (igemm_fast_ok(p) && tune().dma) {
     if (tune().var == 1) return launch_igemm_mode<BM, BN, WM, WN, 4, 32, 1>(p, stream);
@@ -1439,6 +1509,9 @@ int launch_igemm(const ConvP& p, hipStream_t stream) {
     if (tune().var == 3) return launch_igemm_mode<BM, BN, WM, WN, 4, 32, 3>(p, stream);
     if constexpr (BN >= 64) {
       if (tune().var == 4) return launch_igemm_mode<BM, BN, WM, WN, 4, 16, 4>(p, stream);
+    }
+    if constexpr (BN == 64) {
+      if (tune().var == 6) return launch_igemm_mode<BM, BN, WM, WN, 4, 16, 6>(p, stream);
     }
     return launch_igemm_mode<BM, BN, WM, WN, 4, 32>(p, stream);
   }
@@ -1553,6 +1626,7 @@ extern "C" int segsde_conv2d_dgrad_actgrad(const segsde_conv_desc* d, const floa
         q.pad = -((ph + kh0 * d->dil - d->pad) / 2);
         q.os = 2; q.oph = ph; q.opw = pw; q.OHf = d->Ho; q.OWf = d->Wo;
         q.Ho = nI; q.Wo = nJ; q.M = d->B * nI * nJ;
+        set_divs(q);
         if (!igemm_fast_ok(q)) ok = false;
         sub[nsub++] = q;
       }

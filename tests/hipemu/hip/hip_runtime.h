@@ -226,5 +226,6 @@ inline emu_f32x4 emu_mfma_16x16x4(float a, float b, emu_f32x4 c, int, int, int) 
 inline hipError_t hipGetSymbolAddress(void** p, const void* sym) { *p = const_cast<void*>(sym); return 0; }
 inline void __builtin_amdgcn_sched_barrier(int) {}
 inline void __builtin_amdgcn_s_setprio(int) {}
+inline void __builtin_amdgcn_s_sleep(int) {}
 inline int __builtin_amdgcn_readfirstlane(int v) { return v; }   // only applied to wave-uniform values
 inline void __builtin_amdgcn_sched_group_barrier(int, int, int) {}

@@ -55,6 +55,9 @@ CONV_CASES = [
     ("w32_dil2", 2, 5, 32, 16, 0, False, 8, 3, 1, 2, 2, False, False, "relu"),
     ("w32_fast_cat", 1, 3, 32, 32, 32, False, 32, 3, 1, 1, 1, True, True, "none"),
     ("w32_1x1", 1, 2, 32, 20, 0, False, 36, 1, 1, 1, 0, False, False, "none"),
+    # wide rows: some waves of a reflection-adjoint tile own no border pixel (LDS-DMA loop) while others do (register loop)
+    ("fast_refl_w64", 1, 6, 64, 32, 0, False, 32, 3, 1, 1, 1, True, True, "elu"),
+    ("fast_refl_w64_up_cat", 1, 4, 64, 32, 32, True, 64, 3, 1, 1, 1, True, True, "none"),
     # disparity heads: single output channel -> dedicated stencil kernels (C = 64 / 128 / 256)
     ("disp_c64", 2, 9, 11, 64, 0, False, 1, 3, 1, 1, 1, True, True, "sigmoid"),
     ("disp_c128_tiny", 1, 3, 5, 128, 0, False, 1, 3, 1, 1, 1, True, True, "sigmoid"),

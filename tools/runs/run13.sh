@@ -1,0 +1,4 @@
+mkdir -p gpurun_out
+SEGSDE_TUNE=var=6 timeout 900 python -m pytest tests/test_kernels_gpu.py -q -x -k "conv" 2>&1 | tail -3 > gpurun_out/r13_tests.log
+for v in var=0 var=6; do echo "=== $v"; SEGSDE_TUNE=$v BENCH_B=16 BENCH_ONLY_CONV=1 timeout 600 python tools/bench_kernels.py 2>&1 | grep " TF" ; done > gpurun_out/r13_ab_var6.log 2>&1
+tail -3 gpurun_out/r13_tests.log
