@@ -688,18 +688,35 @@ __global__ __launch_bounds__(256, VAR == 6 ? 3 : 2) void conv_igemm_kernel(ConvP
   if (p.vecout && !p.sum2x2) {
     float* Ct = smem;                      // [BM][BN] floats = 2 stages of (BM+BN)*BK only when BN <= 2*BK... checked on host
     const int col = lane & 31, rhalf = lane >> 5;
+    if (!p.bias && p.act == SEGSDE_ACT_NONE) {
+      // every BatchNorm-followed convolution and every data-gradient: the accumulators go to LDS as they are (one base
+      // address per thread, immediate offsets, no VALU work)
+      float* cw = Ct + (wm * TM * 32 + 4 * rhalf) * BN + wn * TN * 32 + col;
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int nl = (wn * TN + j) * 32 + col;
-      const int n = n0 + nl;
-      const float bias = (p.bias && n < p.ne) ? p.bias[n] : 0.f;
+      for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int ml = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * rhalf;
-          Ct[ml * BN + nl] = segsde_act(acc[i][j][r] + bias, p.act);
+          for (int r = 0; r < 16; ++r) cw[(i * 32 + (r & 3) + 8 * (r >> 2)) * BN + j * 32] = acc[i][j][r];
+    } else {
+      // one copy of the loop per activation kind, branch-free inside: the generic segsde_act(v, p.act) cost ~45 VALU
+      // instructions per accumulator (a libm expf behind a divergent branch, for each of 64 values)
+      auto put = [&](auto f) {
+        float* cw = Ct + (wm * TM * 32 + 4 * rhalf) * BN + wn * TN * 32 + col;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int n = n0 + (wn * TN + j) * 32 + col;
+          const float bias = (p.bias && n < p.ne) ? p.bias[n] : 0.f;
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) cw[(i * 32 + (r & 3) + 8 * (r >> 2)) * BN + j * 32] = f(acc[i][j][r] + bias);
         }
+      };
+      if (p.act == SEGSDE_ACT_ELU) put([](float v) { return v > 0.f ? v : __expf(fminf(v, 0.f)) - 1.f; });
+      else if (p.act == SEGSDE_ACT_RELU) put([](float v) { return fmaxf(v, 0.f); });
+      else if (p.act == SEGSDE_ACT_SIGMOID) put([](float v) { return segsde_act(v, SEGSDE_ACT_SIGMOID); });
+      else put([](float v) { return v; });
     }
     __syncthreads();
     if (p.stats) {
@@ -730,6 +747,48 @@ __global__ __launch_bounds__(256, VAR == 6 ? 3 : 2) void conv_igemm_kernel(ConvP
     constexpr int CQ = BN / 4, RPP = 256 / CQ;    // float4 columns per row, rows per pass
     const int cq = tid % CQ, rr = tid / CQ;
     const int n = n0 + 4 * cq;
+    {
+      // Common case -- a full tile whose rows are consecutive rows of ONE destination tensor: the stores (and the loads of
+      // the accumulate / activation-gradient variants) are raw buffer operations on a resource placed at the tile's first
+      // row, the per-thread byte offset is computed once and the row advance rides in the scalar offset.  The general
+      // code below spends ~45 VALU instructions per row segment on 64-bit addresses, bounds and out_row -- 700 per thread
+      // on a 128x128 tile, more than one per MFMA of an 8-chunk 1x1 layer, and VALU cycles are matrix-pipe cycles here.
+      const int nend = n0 + BN < p.ne ? n0 + BN : p.ne;
+      const bool side1 = n0 >= p.nsplit;
+      if (p.os == 1 && m0 + BM <= p.M && (side1 || nend <= p.nsplit)) {
+        constexpr int NR = BM / RPP;
+        float* dbase = side1 ? p.y2 + ((long)m0 * p.ldy2 + (n0 - p.nsplit)) : p.y + ((long)m0 * p.ldy + n0);
+        const unsigned ld = (unsigned)(side1 ? p.ldy2 : p.ldy);
+        const segsde_rsrc rd = segsde_make_rsrc(dbase);
+        const unsigned vo = n < p.ne ? ((unsigned)rr * ld + 4u * cq) * 4u : SEGSDE_OOB;
+        const unsigned step = (unsigned)RPP * ld * 4u;
+        const bool ag = p.agy && !side1;
+        const segsde_rsrc ra = segsde_make_rsrc(ag ? p.agy + ((long)m0 * p.agld + n0) : p.zero);
+        const unsigned voa = (ag && n < p.ne) ? ((unsigned)rr * (unsigned)p.agld + 4u * cq) * 4u : SEGSDE_OOB;
+        const unsigned stepa = (unsigned)RPP * (unsigned)p.agld * 4u;
+        const float* cp = Ct + rr * BN + 4 * cq;
+        float4 o[NR];
+        if (p.accum) {
+          unsigned so = 0;
+#pragma unroll
+          for (int t = 0; t < NR; ++t) { o[t] = segsde_buffer_load4(rd, vo, so); so += step; }
+        }
+        unsigned so = 0, soa = 0;
+#pragma unroll
+        for (int t = 0; t < NR; ++t) {
+          float4 v = *reinterpret_cast<const float4*>(cp + t * RPP * BN);
+          if (ag) {
+            const float4 yv = segsde_buffer_load4(ra, voa, soa);
+            v.x *= segsde_act_grad_from_out(yv.x, p.agkind); v.y *= segsde_act_grad_from_out(yv.y, p.agkind);
+            v.z *= segsde_act_grad_from_out(yv.z, p.agkind); v.w *= segsde_act_grad_from_out(yv.w, p.agkind);
+          }
+          if (p.accum) { v.x += o[t].x; v.y += o[t].y; v.z += o[t].z; v.w += o[t].w; }
+          segsde_buffer_store4(rd, vo, so, v);
+          so += step; soa += stepa;
+        }
+        return;
+      }
+    }
     if (n < p.ne) {
       float* dst; long ld; int nn;
       if (n < p.nsplit) { dst = p.y; ld = p.ldy; nn = n; }

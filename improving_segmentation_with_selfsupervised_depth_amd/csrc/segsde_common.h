@@ -28,6 +28,12 @@ __device__ __forceinline__ float4 segsde_buffer_load4(segsde_rsrc r, unsigned vo
   const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
   return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
+__device__ __forceinline__ void segsde_buffer_store4(segsde_rsrc r, unsigned voff, unsigned soff, float4 v) {
+  typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+  u32x4_t d;
+  d.x = __float_as_uint(v.x); d.y = __float_as_uint(v.y); d.z = __float_as_uint(v.z); d.w = __float_as_uint(v.w);
+  __builtin_amdgcn_raw_buffer_store_b128(d, r, voff, soff, 0);   // out-of-range voff: the store is dropped
+}
 // LDS-DMA: the same raw buffer load, but the 16 bytes of lane l land in LDS at lds_wave_base + 16*l without passing
 // through VGPRs (buffer_load_dwordx4 ... offen lds; destination = M0 + 16*lane, so the LDS image of one instruction is
 // 1 KiB lane-linear -- a swizzled layout is obtained by permuting which SOURCE element each lane fetches).  Out-of-range

@@ -153,6 +153,10 @@ inline float4 segsde_buffer_load4(segsde_rsrc r, unsigned voff, unsigned soff) {
   memcpy(&v, r.base + (size_t)voff + soff, sizeof(v));
   return v;
 }
+inline void segsde_buffer_store4(segsde_rsrc r, unsigned voff, unsigned soff, float4 v) {
+  if (voff >= r.n) return;
+  memcpy(const_cast<char*>(r.base) + (size_t)voff + soff, &v, sizeof(v));
+}
 
 // LDS-DMA flavour: lane l's 16 bytes land at lds_wave_base + 16*l (executed synchronously here: the interpreter cannot
 // model a missing wait, only wrong addresses / wrong buffer hand-over order)
