@@ -57,6 +57,7 @@ struct ConvP {
   // division of a GEMM row index (< 2^31) by the image size / row length without the ~30-instruction runtime division:
   // q = umulhi(n, magic) >> shift (set_divs).  d1 = Ho*Wo, d2 = Wo; for sum2x2 launches the 2x2-block counts.
   unsigned mg1, mg2; int sf1, sf2, d1, d2;
+  int lin;   // 1x1, stride 1, unpadded, one source at output resolution: GEMM row m IS pixel m of the input (no row decode)
 };
 
 struct KInfo {  // decoded reduction index k -> tap + channel + source
@@ -265,8 +266,14 @@ __global__ __launch_bounds__(256, VAR == 6 ? 3 : 2) void conv_igemm_kernel(ConvP
 
   int rb[AR], rh[AR], rw[AR];
   bool rok[AR];
+  const bool lin = FAST && p.lin;   // the bottleneck 1x1 convolutions and their data-gradients: rows are consecutive pixels
+  if (lin) {
 #pragma unroll
-  for (int i = 0; i < AR; ++i) decode_m(p, m0 + r0 + RP * i, rb[i], rh[i], rw[i], rok[i]);
+    for (int i = 0; i < AR; ++i) { rb[i] = 0; rh[i] = 0; rw[i] = 0; rok[i] = m0 + r0 + RP * i < p.M; }
+  } else {
+#pragma unroll
+    for (int i = 0; i < AR; ++i) decode_m(p, m0 + r0 + RP * i, rb[i], rh[i], rw[i], rok[i]);
+  }
   ChunkState cs; cs.c0 = 0; cs.kh = 0; cs.kw = 0;
 
   f32x16 acc[TM][TN];
@@ -400,6 +407,12 @@ __global__ __launch_bounds__(256, VAR == 6 ? 3 : 2) void conv_igemm_kernel(ConvP
     // floats); with WADJ also the extra pre-images of the reflection adjoint (those need col = 4 * kqs)
     auto compute_voff = [&](bool in0, int kh, int kw, unsigned* out, unsigned col, auto wadj_tag) {
       constexpr bool WADJ = decltype(wadj_tag)::value;
+      if (lin) {   // the tile's first image starts b0 * H * W pixels before the resource's base row
+#pragma unroll
+        for (int i = 0; i < AR; ++i)
+          out[i] = rok[i] ? ((unsigned)(m0 + r0 + RP * i - b0 * p.d1) * s0.ld + col) * 4u : SEGSDE_OOB;
+        return;
+      }
       const int dh = kh * p.dil - p.pad, dw = kw * p.dil - p.pad;
       const int sh = in0 ? s0.shift : 0;
       const unsigned ld = in0 ? s0.ld : s1.ld, Ws = in0 ? s0.Ws : s1.Ws, bst = in0 ? s0.bstride : s1.bstride;
@@ -1506,6 +1519,8 @@ ConvP make_params(const segsde_conv_desc* d, const float* x0, const float* x1, c
   p.stats = nullptr;
   p.accum = d->accumulate ? 1 : 0;
   p.agy = nullptr; p.agld = 0; p.agkind = 0;
+  p.lin = d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && d->in_div <= 1 && !d->up0 && !d->sum2x2 && d->C1 == 0 &&
+          d->H == d->Ho && d->W == d->Wo;
   return p;
 }
 
