@@ -266,7 +266,7 @@ __global__ __launch_bounds__(256, VAR == 6 ? 3 : 2) void conv_igemm_kernel(ConvP
 
   int rb[AR], rh[AR], rw[AR];
   bool rok[AR];
-  const bool lin = FAST && p.lin;   // the bottleneck 1x1 convolutions and their data-gradients: rows are consecutive pixels
+  const bool lin = FAST && MODE != 3 && p.lin;   // the bottleneck 1x1 convolutions and their data-gradients: rows are consecutive pixels
   if (lin) {
 #pragma unroll
     for (int i = 0; i < AR; ++i) { rb[i] = 0; rh[i] = 0; rw[i] = 0; rok[i] = m0 + r0 + RP * i < p.M; }
@@ -695,13 +695,17 @@ __global__ __launch_bounds__(256, VAR == 6 ? 3 : 2) void conv_igemm_kernel(ConvP
     }
   }
 
+  // The epilogue's parameters (destinations, pitches, split point, statistics / activation-gradient pointers ...) are
+  // re-read from the kernel-argument segment HERE: held in SGPRs across the K loop they pushed the adjoint kernel over the
+  // SGPR budget -- 16 v_readlane + 2 scratch accesses per chunk inside its loop (and every VALU cycle is a matrix cycle).
+  const ConvP pe = VAR == 7 ? p : SEGSDE_REFRESH_KERNARG(ConvP, p);   // var=7: A/B knob, no refresh
   // epilogue, staged variant: the accumulator tile goes through LDS (free after the K loop) so that every output row
   // leaves as 16-byte stores covering whole 512-byte (BN*4) row segments, instead of 4-byte stores per lane -- the
   // short-K layers (1x1 bottleneck convs and their gradients) are bound by exactly this store stream.
-  if (p.vecout && !p.sum2x2) {
+  if (pe.vecout && !pe.sum2x2) {
     float* Ct = smem;                      // [BM][BN] floats = 2 stages of (BM+BN)*BK only when BN <= 2*BK... checked on host
     const int col = lane & 31, rhalf = lane >> 5;
-    if (!p.bias && p.act == SEGSDE_ACT_NONE) {
+    if (!pe.bias && pe.act == SEGSDE_ACT_NONE) {
       // every BatchNorm-followed convolution and every data-gradient: the accumulators go to LDS as they are (one base
       // address per thread, immediate offsets, no VALU work)
       float* cw = Ct + (wm * TM * 32 + 4 * rhalf) * BN + wn * TN * 32 + col;
@@ -712,27 +716,27 @@ __global__ __launch_bounds__(256, VAR == 6 ? 3 : 2) void conv_igemm_kernel(ConvP
 #pragma unroll
           for (int r = 0; r < 16; ++r) cw[(i * 32 + (r & 3) + 8 * (r >> 2)) * BN + j * 32] = acc[i][j][r];
     } else {
-      // one copy of the loop per activation kind, branch-free inside: the generic segsde_act(v, p.act) cost ~45 VALU
+      // one copy of the loop per activation kind, branch-free inside: the generic segsde_act(v, pe.act) cost ~45 VALU
       // instructions per accumulator (a libm expf behind a divergent branch, for each of 64 values)
       auto put = [&](auto f) {
         float* cw = Ct + (wm * TM * 32 + 4 * rhalf) * BN + wn * TN * 32 + col;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
           const int n = n0 + (wn * TN + j) * 32 + col;
-          const float bias = (p.bias && n < p.ne) ? p.bias[n] : 0.f;
+          const float bias = (pe.bias && n < pe.ne) ? pe.bias[n] : 0.f;
 #pragma unroll
           for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) cw[(i * 32 + (r & 3) + 8 * (r >> 2)) * BN + j * 32] = f(acc[i][j][r] + bias);
         }
       };
-      if (p.act == SEGSDE_ACT_ELU) put([](float v) { return v > 0.f ? v : __expf(fminf(v, 0.f)) - 1.f; });
-      else if (p.act == SEGSDE_ACT_RELU) put([](float v) { return fmaxf(v, 0.f); });
-      else if (p.act == SEGSDE_ACT_SIGMOID) put([](float v) { return segsde_act(v, SEGSDE_ACT_SIGMOID); });
+      if (pe.act == SEGSDE_ACT_ELU) put([](float v) { return v > 0.f ? v : __expf(fminf(v, 0.f)) - 1.f; });
+      else if (pe.act == SEGSDE_ACT_RELU) put([](float v) { return fmaxf(v, 0.f); });
+      else if (pe.act == SEGSDE_ACT_SIGMOID) put([](float v) { return segsde_act(v, SEGSDE_ACT_SIGMOID); });
       else put([](float v) { return v; });
     }
     __syncthreads();
-    if (p.stats) {
+    if (pe.stats) {
       // each thread: one column x one slice of the tile's rows (conflict-free LDS reads), no cross-thread reduction --
       // the slices are simply more partial rows for the (double precision) reduction that follows
       constexpr int R = 256 / BN, RS = BM / R;
@@ -747,14 +751,14 @@ __global__ __launch_bounds__(256, VAR == 6 ? 3 : 2) void conv_igemm_kernel(ConvP
       for (int ml = sl * RS; ml < (sl + 1) * RS; ml += 8) {
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-          const double v = (m0 + ml + u < p.M) ? (double)Ct[(ml + u) * BN + scol] : 0.0;
+          const double v = (m0 + ml + u < pe.M) ? (double)Ct[(ml + u) * BN + scol] : 0.0;
           s8[u] += v; q8[u] += v * v;
         }
       }
-      if (sn < p.ne) {
-        double* pr = p.stats + ((long)(mt * R + sl) * 2) * p.N + sn;
+      if (sn < pe.ne) {
+        double* pr = pe.stats + ((long)(mt * R + sl) * 2) * pe.N + sn;
         pr[0] = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
-        pr[p.N] = ((q8[0] + q8[1]) + (q8[2] + q8[3])) + ((q8[4] + q8[5]) + (q8[6] + q8[7]));
+        pr[pe.N] = ((q8[0] + q8[1]) + (q8[2] + q8[3])) + ((q8[4] + q8[5]) + (q8[6] + q8[7]));
       }
     }
     constexpr int CQ = BN / 4, RPP = 256 / CQ;    // float4 columns per row, rows per pass
@@ -766,22 +770,22 @@ __global__ __launch_bounds__(256, VAR == 6 ? 3 : 2) void conv_igemm_kernel(ConvP
       // row, the per-thread byte offset is computed once and the row advance rides in the scalar offset.  The general
       // code below spends ~45 VALU instructions per row segment on 64-bit addresses, bounds and out_row -- 700 per thread
       // on a 128x128 tile, more than one per MFMA of an 8-chunk 1x1 layer, and VALU cycles are matrix-pipe cycles here.
-      const int nend = n0 + BN < p.ne ? n0 + BN : p.ne;
-      const bool side1 = n0 >= p.nsplit;
-      if (p.os == 1 && m0 + BM <= p.M && (side1 || nend <= p.nsplit)) {
+      const int nend = n0 + BN < pe.ne ? n0 + BN : pe.ne;
+      const bool side1 = n0 >= pe.nsplit;
+      if (pe.os == 1 && m0 + BM <= pe.M && (side1 || nend <= pe.nsplit)) {
         constexpr int NR = BM / RPP;
-        float* dbase = side1 ? p.y2 + ((long)m0 * p.ldy2 + (n0 - p.nsplit)) : p.y + ((long)m0 * p.ldy + n0);
-        const unsigned ld = (unsigned)(side1 ? p.ldy2 : p.ldy);
+        float* dbase = side1 ? pe.y2 + ((long)m0 * pe.ldy2 + (n0 - pe.nsplit)) : pe.y + ((long)m0 * pe.ldy + n0);
+        const unsigned ld = (unsigned)(side1 ? pe.ldy2 : pe.ldy);
         const segsde_rsrc rd = segsde_make_rsrc(dbase);
-        const unsigned vo = n < p.ne ? ((unsigned)rr * ld + 4u * cq) * 4u : SEGSDE_OOB;
+        const unsigned vo = n < pe.ne ? ((unsigned)rr * ld + 4u * cq) * 4u : SEGSDE_OOB;
         const unsigned step = (unsigned)RPP * ld * 4u;
-        const bool ag = p.agy && !side1;
-        const segsde_rsrc ra = segsde_make_rsrc(ag ? p.agy + ((long)m0 * p.agld + n0) : p.zero);
-        const unsigned voa = (ag && n < p.ne) ? ((unsigned)rr * (unsigned)p.agld + 4u * cq) * 4u : SEGSDE_OOB;
-        const unsigned stepa = (unsigned)RPP * (unsigned)p.agld * 4u;
+        const bool ag = pe.agy && !side1;
+        const segsde_rsrc ra = segsde_make_rsrc(ag ? pe.agy + ((long)m0 * pe.agld + n0) : pe.zero);
+        const unsigned voa = (ag && n < pe.ne) ? ((unsigned)rr * (unsigned)pe.agld + 4u * cq) * 4u : SEGSDE_OOB;
+        const unsigned stepa = (unsigned)RPP * (unsigned)pe.agld * 4u;
         const float* cp = Ct + rr * BN + 4 * cq;
         float4 o[NR];
-        if (p.accum) {
+        if (pe.accum) {
           unsigned so = 0;
 #pragma unroll
           for (int t = 0; t < NR; ++t) { o[t] = segsde_buffer_load4(rd, vo, so); so += step; }
@@ -792,58 +796,58 @@ __global__ __launch_bounds__(256, VAR == 6 ? 3 : 2) void conv_igemm_kernel(ConvP
           float4 v = *reinterpret_cast<const float4*>(cp + t * RPP * BN);
           if (ag) {
             const float4 yv = segsde_buffer_load4(ra, voa, soa);
-            v.x *= segsde_act_grad_from_out(yv.x, p.agkind); v.y *= segsde_act_grad_from_out(yv.y, p.agkind);
-            v.z *= segsde_act_grad_from_out(yv.z, p.agkind); v.w *= segsde_act_grad_from_out(yv.w, p.agkind);
+            v.x *= segsde_act_grad_from_out(yv.x, pe.agkind); v.y *= segsde_act_grad_from_out(yv.y, pe.agkind);
+            v.z *= segsde_act_grad_from_out(yv.z, pe.agkind); v.w *= segsde_act_grad_from_out(yv.w, pe.agkind);
           }
-          if (p.accum) { v.x += o[t].x; v.y += o[t].y; v.z += o[t].z; v.w += o[t].w; }
+          if (pe.accum) { v.x += o[t].x; v.y += o[t].y; v.z += o[t].z; v.w += o[t].w; }
           segsde_buffer_store4(rd, vo, so, v);
           so += step; soa += stepa;
         }
         return;
       }
     }
-    if (n < p.ne) {
+    if (n < pe.ne) {
       float* dst; long ld; int nn;
-      if (n < p.nsplit) { dst = p.y; ld = p.ldy; nn = n; }
-      else { dst = p.y2; ld = p.ldy2; nn = n - p.nsplit; }
-      if (p.accum) {
+      if (n < pe.nsplit) { dst = pe.y; ld = pe.ldy; nn = n; }
+      else { dst = pe.y2; ld = pe.ldy2; nn = n - pe.nsplit; }
+      if (pe.accum) {
         // y += tile: every read-modify-write of a row segment depends on a global load; issue all of a thread's loads
         // first (the accumulators are in LDS by now, registers are free) so that their latency is paid once, not
         // BM / RPP times in a row -- on the 8-chunk 1x1 data-gradients this epilogue was a third of the tile's time
         constexpr int NR = BM / RPP;
         float4 o[NR];
-        const float* ag = (p.agy && n < p.nsplit) ? p.agy + nn : nullptr;
+        const float* ag = (pe.agy && n < pe.nsplit) ? pe.agy + nn : nullptr;
 #pragma unroll
         for (int t = 0; t < NR; ++t) {
           const int m = m0 + rr + t * RPP;
           o[t] = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (m < p.M) o[t] = *reinterpret_cast<const float4*>(dst + out_row(p, m) * ld + nn);
+          if (m < pe.M) o[t] = *reinterpret_cast<const float4*>(dst + out_row(pe, m) * ld + nn);
         }
 #pragma unroll
         for (int t = 0; t < NR; ++t) {
           const int ml = rr + t * RPP, m = m0 + ml;
-          if (m < p.M) {
+          if (m < pe.M) {
             float4 v = *reinterpret_cast<const float4*>(Ct + ml * BN + 4 * cq);
             if (ag) {
-              const float4 yv = *reinterpret_cast<const float4*>(ag + out_row(p, m) * p.agld);
-              v.x *= segsde_act_grad_from_out(yv.x, p.agkind); v.y *= segsde_act_grad_from_out(yv.y, p.agkind);
-              v.z *= segsde_act_grad_from_out(yv.z, p.agkind); v.w *= segsde_act_grad_from_out(yv.w, p.agkind);
+              const float4 yv = *reinterpret_cast<const float4*>(ag + out_row(pe, m) * pe.agld);
+              v.x *= segsde_act_grad_from_out(yv.x, pe.agkind); v.y *= segsde_act_grad_from_out(yv.y, pe.agkind);
+              v.z *= segsde_act_grad_from_out(yv.z, pe.agkind); v.w *= segsde_act_grad_from_out(yv.w, pe.agkind);
             }
             v.x += o[t].x; v.y += o[t].y; v.z += o[t].z; v.w += o[t].w;
-            *reinterpret_cast<float4*>(dst + out_row(p, m) * ld + nn) = v;
+            *reinterpret_cast<float4*>(dst + out_row(pe, m) * ld + nn) = v;
           }
         }
-      } else if (p.agy && n < p.nsplit) {
-        const float* ag = p.agy + nn;
+      } else if (pe.agy && n < pe.nsplit) {
+        const float* ag = pe.agy + nn;
 #pragma unroll 4
         for (int ml = rr; ml < BM; ml += RPP) {
           const int m = m0 + ml;
-          if (m < p.M) {
-            const long row = out_row(p, m);
+          if (m < pe.M) {
+            const long row = out_row(pe, m);
             float4 v = *reinterpret_cast<const float4*>(Ct + ml * BN + 4 * cq);
-            const float4 yv = *reinterpret_cast<const float4*>(ag + row * p.agld);
-            v.x *= segsde_act_grad_from_out(yv.x, p.agkind); v.y *= segsde_act_grad_from_out(yv.y, p.agkind);
-            v.z *= segsde_act_grad_from_out(yv.z, p.agkind); v.w *= segsde_act_grad_from_out(yv.w, p.agkind);
+            const float4 yv = *reinterpret_cast<const float4*>(ag + row * pe.agld);
+            v.x *= segsde_act_grad_from_out(yv.x, pe.agkind); v.y *= segsde_act_grad_from_out(yv.y, pe.agkind);
+            v.z *= segsde_act_grad_from_out(yv.z, pe.agkind); v.w *= segsde_act_grad_from_out(yv.w, pe.agkind);
             *reinterpret_cast<float4*>(dst + row * ld + nn) = v;
           }
         }
@@ -851,8 +855,8 @@ __global__ __launch_bounds__(256, VAR == 6 ? 3 : 2) void conv_igemm_kernel(ConvP
 #pragma unroll 4
         for (int ml = rr; ml < BM; ml += RPP) {
           const int m = m0 + ml;
-          if (m < p.M) {
-            float4* q = reinterpret_cast<float4*>(dst + out_row(p, m) * ld + nn);
+          if (m < pe.M) {
+            float4* q = reinterpret_cast<float4*>(dst + out_row(pe, m) * ld + nn);
             *q = *reinterpret_cast<const float4*>(Ct + ml * BN + 4 * cq);
           }
         }
@@ -866,40 +870,40 @@ __global__ __launch_bounds__(256, VAR == 6 ? 3 : 2) void conv_igemm_kernel(ConvP
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int n = n0 + (wn * TN + j) * 32 + col;
-    if (n >= p.ne) continue;
-    const float bias = p.bias ? p.bias[n] : 0.f;
+    if (n >= pe.ne) continue;
+    const float bias = pe.bias ? pe.bias[n] : 0.f;
     float* dst; long ld; int nn;
-    if (n < p.nsplit) { dst = p.y; ld = p.ldy; nn = n; }
-    else { dst = p.y2; ld = p.ldy2; nn = n - p.nsplit; }
+    if (n < pe.nsplit) { dst = pe.y; ld = pe.ldy; nn = n; }
+    else { dst = pe.y2; ld = pe.ldy2; nn = n - pe.nsplit; }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-      if (p.sum2x2) {
+      if (pe.sum2x2) {
         // data-gradient through the nearest x2 upsample: channels of source 0 are summed over each 2x2 block in
         // registers and stored at half resolution; skip-connection channels are stored per pixel
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int m = m0 + (wm * TM + i) * 32 + 8 * g + 4 * rhalf;
-          if (m >= p.M) continue;
-          if (n < p.nsplit) {
+          if (m >= pe.M) continue;
+          if (n < pe.nsplit) {
             float v = (acc[i][j][4 * g] + acc[i][j][4 * g + 1]) + (acc[i][j][4 * g + 2] + acc[i][j][4 * g + 3]);
-            if (p.agy) v *= segsde_act_grad_from_out(p.agy[(long)(m >> 2) * p.agld + nn], p.agkind);
+            if (pe.agy) v *= segsde_act_grad_from_out(pe.agy[(long)(m >> 2) * pe.agld + nn], pe.agkind);
             dst[(long)(m >> 2) * ld + nn] = v;
           } else {
             int b, hb, wb; bool ok;
-            decode_m(p, m, b, hb, wb, ok);
-            float* q = dst + ((long)(b * p.Ho + hb) * p.Wo + wb) * ld + nn;   // sub-pixel 0 of the block
+            decode_m(pe, m, b, hb, wb, ok);
+            float* q = dst + ((long)(b * pe.Ho + hb) * pe.Wo + wb) * ld + nn;   // sub-pixel 0 of the block
             q[0] = acc[i][j][4 * g]; q[ld] = acc[i][j][4 * g + 1];
-            q[(long)p.Wo * ld] = acc[i][j][4 * g + 2]; q[(long)p.Wo * ld + ld] = acc[i][j][4 * g + 3];
+            q[(long)pe.Wo * ld] = acc[i][j][4 * g + 2]; q[(long)pe.Wo * ld + ld] = acc[i][j][4 * g + 3];
           }
         }
       } else {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * rhalf;
-          if (m < p.M) {
-            float v = segsde_act(acc[i][j][r] + bias, p.act);
-            if (p.agy && n < p.nsplit) v *= segsde_act_grad_from_out(p.agy[out_row(p, m) * p.agld + nn], p.agkind);
-            dst[out_row(p, m) * ld + nn] = v;
+          if (m < pe.M) {
+            float v = segsde_act(acc[i][j][r] + bias, pe.act);
+            if (pe.agy && n < pe.nsplit) v *= segsde_act_grad_from_out(pe.agy[out_row(pe, m) * pe.agld + nn], pe.agkind);
+            dst[out_row(pe, m) * ld + nn] = v;
           }
         }
       }
@@ -1584,6 +1588,7 @@ int launch_igemm(const ConvP& p, hipStream_t stream) {
     if constexpr (BN >= 64) {
       if (tune().var == 4) return launch_igemm_mode<BM, BN, WM, WN, 4, 16, 4>(p, stream);
     }
+    if (tune().var == 7) return launch_igemm_mode<BM, BN, WM, WN, 4, 32, 7>(p, stream);
     if constexpr (BN == 64) {
       if (tune().var == 6) return launch_igemm_mode<BM, BN, WM, WN, 4, 16, 6>(p, stream);
     }

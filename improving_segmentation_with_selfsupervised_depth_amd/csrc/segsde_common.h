@@ -55,6 +55,24 @@ __device__ __forceinline__ void segsde_wait_vmcnt0() { asm volatile("s_waitcnt v
 template <int N> __device__ __forceinline__ void segsde_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 #endif
 
+// A fresh copy of the kernel's FIRST by-value argument, loaded from the kernel-argument segment at this point of the
+// program (scalar loads of the fields that are used): the optimiser cannot merge it with the copy live since kernel entry.
+#ifndef SEGSDE_REFRESH_KERNARG
+template <typename T>
+__device__ __forceinline__ T segsde_kernarg_here() {
+  auto k = __builtin_amdgcn_kernarg_segment_ptr();   // constant address space: uniform loads through it are scalar loads
+  asm volatile("" : "+s"(k));
+  static_assert(sizeof(T) % 4 == 0, "dword copy");
+  const __attribute__((address_space(4))) unsigned* src = (const __attribute__((address_space(4))) unsigned*)k;
+  T out;
+  unsigned* dst = reinterpret_cast<unsigned*>(&out);
+#pragma unroll
+  for (unsigned i = 0; i < sizeof(T) / 4; ++i) dst[i] = src[i];   // only the fields that are used survive
+  return out;
+}
+#define SEGSDE_REFRESH_KERNARG(T, arg) segsde_kernarg_here<T>()
+#endif
+
 // hides a VGPR value's provenance from the optimiser (no instruction is emitted)
 #ifndef SEGSDE_OPAQUE
 #define SEGSDE_OPAQUE(x) asm volatile("" : "+v"(x))

@@ -144,6 +144,7 @@ alignas(16) inline unsigned char emu_lds[160 * 1024];
 // raw buffer loads: range-checked against num_records on the per-lane offset, zeros when out of range
 #define SEGSDE_BUFFER_OPS 1
 #define SEGSDE_OPAQUE(x) ((void)(x))
+#define SEGSDE_REFRESH_KERNARG(T, arg) (arg)
 #define SEGSDE_OOB 0x80000000u
 struct segsde_rsrc { const char* base; unsigned n; };
 inline segsde_rsrc segsde_make_rsrc(const void* base, unsigned n = 0x7fffffffu) { return segsde_rsrc{static_cast<const char*>(base), n}; }

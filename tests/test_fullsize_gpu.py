@@ -28,6 +28,8 @@ GEOMS = [
     ("64->64 refl up @512x1024", 64, 0, True, 64, 3, 1, 1, True, "elu", (512, 1024)),
     ("128up+64->128 refl @256x512", 128, 64, True, 128, 3, 1, 1, True, "elu", (256, 512)),
     ("2048->256 d18 @32x64", 2048, 0, False, 256, 3, 18, 18, False, "none", (32, 64)),
+    # 1x1: GEMM rows are input pixels (no row decode); input 2.1 GB, output 4.3 GB
+    ("64->128 1x1 @512x1024", 64, 0, False, 128, 1, 1, 0, False, "none", (512, 1024)),
 ]
 
 
@@ -65,6 +67,20 @@ def test_conv_fullsize_sampled(geom):
         pos1 = SC.pick_positions(B16, Hh, W, 48, seed=3)
         want = SC.dgrad_samples(dy, wt, (Hh, W), C0, C0 + C1, False, 1, dil, pad, reflect, pos1)
         _cmp(torch.stack([dx1[p] for p in pos1]), want, name + " dgrad src1")
+    if k == 1:
+        # epilogue variants of the same launch at offsets beyond 2^31 bytes: accumulate onto an existing gradient, and
+        # the activation derivative of the tensor differentiated with respect to (expected values from the plain result)
+        base = torch.randn(B16, Hh, W, C0, device=dev, generator=gen)
+        want_acc = torch.stack([(base[p].double() + dx0[p].double()) for p in pos0])
+        acc, _ = H.conv_dgrad(g, dy, wd, wt, (Hh, W), accumulate_into=base)
+        assert acc is not None and acc.data_ptr() == base.data_ptr(), "this shape accumulates in place"
+        _cmp(torch.stack([acc[p] for p in pos0]), want_acc, name + " dgrad accumulate")
+        del acc, base
+        yact = torch.nn.functional.elu(x0)
+        der = torch.stack([torch.where(yact[p] > 0, torch.ones_like(yact[p]), yact[p] + 1.0).double() for p in pos0])
+        dz, _ = H.conv_dgrad(g, dy, wd, wt, (Hh, W), actgrad=(yact, "elu"))
+        _cmp(torch.stack([dz[p] for p in pos0]), want.cpu() * der.cpu(), name + " dgrad x ELU'(y)")
+        del dz, yact
     del dx0, dx1
     # ---- weight gradient (sampled taps; each one a reduction over all 16 x H x W output pixels)
     dw = H.conv_wgrad(g, x0, x1, dy)

@@ -40,6 +40,7 @@ def main():
         ("layer1 conv1 1x1 256->64 @128x256", 128, 256, 256, 0, False, 64, 1, 1, 1, 0, False),
         ("probe: 3x3 512->64 @128x256 (N=64 tile, long K)", 128, 256, 512, 0, False, 64, 3, 1, 1, 1, False),
         ("probe: 3x3 64->64 @512x1024 zero pad no up", 512, 1024, 64, 0, False, 64, 3, 1, 1, 1, False),
+        ("probe: 3x3 128->128 @128x256 zero pad (dec_up1_0 without reflection)", 128, 256, 128, 0, False, 128, 3, 1, 1, 1, False),
         ("probe: 1x1 4096->128 @128x256 (long K)", 128, 256, 4096, 0, False, 128, 1, 1, 1, 0, False),
         ("probe: 1x1 32->128 @512x1024 (short K)", 512, 1024, 32, 0, False, 128, 1, 1, 1, 0, False),
         ("layer2 conv2 3x3s2 128->128 @128x256", 128, 256, 128, 0, False, 128, 3, 2, 1, 1, False),
