@@ -587,11 +587,14 @@ __global__ __launch_bounds__(256, VAR == 6 ? 3 : 2) void conv_igemm_kernel(ConvP
         };
         auto comp = [](const float4& v, int c) { return c == 0 ? v.x : (c == 1 ? v.y : (c == 2 ? v.z : v.w)); };
         constexpr int DSTEP = (U - 2) / (AR + BR) > 0 ? (U - 2) / (AR + BR) : 1;
-        for (int kc = 0; kc < nchunks; ++kc) {
-          const int buf = kc & (NST - 1);
+        // one chunk; buf is a compile-time constant in the two-stage loop (unrolled by two below) so that the fragment
+        // reads and the LDS-DMA destinations use immediate offsets -- the 8 v_lshl_add_u32 per chunk that rebuilt the
+        // stage base were most of the loop's remaining VALU work
+        auto chunk = [&](int kc, auto buf_c) {
+          const int buf = buf_c;
           fread(buf, 0, 0);
           dma_begin();                     // past the last chunk: the last one is fetched again (harmless, waited for)
-          const unsigned stn = (unsigned)((kc + NST - 1) & (NST - 1)) * STG;
+          const unsigned stn = (unsigned)((buf + NST - 1) & (NST - 1)) * STG;
           if constexpr (VAR == 1) {
   #pragma unroll
             for (int i = 0; i < AR; ++i) dmaA(stn, i);
@@ -622,6 +625,14 @@ __global__ __launch_bounds__(256, VAR == 6 ? 3 : 2) void conv_igemm_kernel(ConvP
           dma_end(kc + NST < nchunks, false);
           segsde_wait_vmcnt<INFLIGHT>();   // chunk kc+1 has landed (later chunks may still be in flight)
           __syncthreads();
+        };
+        if constexpr (NST == 2 && VAR != 7) {   // var=7: A/B knob (round-2 loop before this unroll and the kernarg refresh)
+          for (int kc = 0; kc < nchunks; kc += 2) {
+            chunk(kc, std::integral_constant<int, 0>{});
+            if (kc + 1 < nchunks) chunk(kc + 1, std::integral_constant<int, 1>{});
+          }
+        } else {
+          for (int kc = 0; kc < nchunks; ++kc) chunk(kc, kc & (NST - 1));
         }
         if constexpr (INFLIGHT > 0) {      // the epilogue reuses the stages: nothing may still be landing
           segsde_wait_vmcnt0();
@@ -647,8 +658,8 @@ __global__ __launch_bounds__(256, VAR == 6 ? 3 : 2) void conv_igemm_kernel(ConvP
         for (int j = 0; j < TN; ++j) fb[slot][j] = *reinterpret_cast<const float4*>(Bp + j * 32 * LDT + 4 * ((2 * g + h) ^ sb));
       };
       auto comp = [](const float4& v, int c) { return c == 0 ? v.x : (c == 1 ? v.y : (c == 2 ? v.z : v.w)); };
-      for (int kc = 0; kc < nchunks; ++kc) {
-        const int buf = kc & 1;
+      auto rchunk = [&](int kc, auto buf_c) {   // stage index as a compile-time constant, as in the LDS-DMA loop
+        constexpr int buf = decltype(buf_c)::value;
         fread(buf, 0, 0);
         chunk_begin(kc + 2);
         float* Asn = smem + (buf ^ 1) * STAGE;
@@ -674,6 +685,10 @@ __global__ __launch_bounds__(256, VAR == 6 ? 3 : 2) void conv_igemm_kernel(ConvP
         }
         chunk_end(false);
         __syncthreads();
+      };
+      for (int kc = 0; kc < nchunks; kc += 2) {
+        rchunk(kc, std::integral_constant<int, 0>{});
+        if (kc + 1 < nchunks) rchunk(kc + 1, std::integral_constant<int, 1>{});
       }
     };
     if constexpr (ADJ) {
@@ -1250,8 +1265,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(ConvP p, const float
         for (int j = 0; j < TN; ++j) fd[slot][u][j] = St[dofs[j] + 2 * (4 * g + u) * BN];
       }
     };
-    for (int c = c_begin; c < c_end; ++c) {
-      const int buf = (c - c_begin) & 1;
+    // unrolled by two so that the stage index is a compile-time constant (immediate LDS offsets, no address VALU)
+    auto chunk = [&](int c, auto buf_c) {
+      constexpr int buf = decltype(buf_c)::value;
       fread(buf, 0, 0);
       tload();
 #pragma unroll
@@ -1268,6 +1284,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(ConvP p, const float
       }
       segsde_wait_vmcnt0();
       __syncthreads();
+    };
+    for (int c = c_begin; c < c_end; c += 2) {
+      chunk(c, std::integral_constant<int, 0>{});
+      if (c + 1 < c_end) chunk(c + 1, std::integral_constant<int, 1>{});
     }
   } else {
   gload(c_begin);
