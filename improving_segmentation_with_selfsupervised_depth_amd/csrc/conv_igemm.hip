@@ -405,12 +405,12 @@ __global__ __launch_bounds__(256, VAR == 6 ? 3 : 2) void conv_igemm_kernel(ConvP
     }
     // byte offsets of the tile rows' source pixels for tap (kh, kw) of one source (col = the thread's own column part, in
     // floats); with WADJ also the extra pre-images of the reflection adjoint (those need col = 4 * kqs)
-    auto compute_voff = [&](bool in0, int kh, int kw, unsigned* out, unsigned col, auto wadj_tag) {
+    auto compute_voff = [&](bool in0, int kh, int kw, unsigned col, auto wadj_tag, auto&& sink) {   // sink(i, offset, extra offset)
       constexpr bool WADJ = decltype(wadj_tag)::value;
       if (lin) {   // the tile's first image starts b0 * H * W pixels before the resource's base row
 #pragma unroll
         for (int i = 0; i < AR; ++i)
-          out[i] = rok[i] ? ((unsigned)(m0 + r0 + RP * i - b0 * p.d1) * s0.ld + col) * 4u : SEGSDE_OOB;
+          sink(i, rok[i] ? ((unsigned)(m0 + r0 + RP * i - b0 * p.d1) * s0.ld + col) * 4u : SEGSDE_OOB, SEGSDE_OOB);
         return;
       }
       const int dh = kh * p.dil - p.pad, dw = kw * p.dil - p.pad;
@@ -430,17 +430,19 @@ __global__ __launch_bounds__(256, VAR == 6 ? 3 : 2) void conv_igemm_kernel(ConvP
         const int wr = wi < 0 ? -wi : (wi >= p.W ? 2 * p.W - 2 - wi : wi);
         const bool hin = (unsigned)hi < (unsigned)p.H, win = (unsigned)wi < (unsigned)p.W;
         ok = ok && (refl || (hin && win));
-        out[i] = ok ? boff(refl ? hr : hi, refl ? wr : wi) : SEGSDE_OOB;
+        const unsigned vmain = ok ? boff(refl ? hr : hi, refl ? wr : wi) : SEGSDE_OOB;
+        unsigned vext = SEGSDE_OOB;
         if constexpr (WADJ) {
           const int eh = (rh[i] == 1 && dh == 1) ? 0 : ((rh[i] == p.H - 2 && dh == -1) ? p.H - 1 : -1);
           const int ew = (rw[i] == 1 && dw == 1) ? 0 : ((rw[i] == p.W - 2 && dw == -1) ? p.W - 1 : -1);
           const bool t1 = rok[i] && eh >= 0 && win, t2 = rok[i] && ew >= 0 && hin, t3 = rok[i] && eh >= 0 && ew >= 0;
-          voffX[i] = t1 ? boff(eh, wi) : (t2 ? boff(hi, ew) : SEGSDE_OOB);
+          vext = t1 ? boff(eh, wi) : (t2 ? boff(hi, ew) : SEGSDE_OOB);
           if (wave_corner) {
             voffX2[i] = (t1 && t2) ? boff(hi, ew) : SEGSDE_OOB;
             voffX3[i] = t3 ? boff(eh, ew) : SEGSDE_OOB;
           }
         }
+        sink(i, vmain, vext);
       }
     };
     // Tap table.  The ~120 VALU instructions of compute_voff used to run at every tap / source change -- every second
@@ -451,27 +453,42 @@ __global__ __launch_bounds__(256, VAR == 6 ? 3 : 2) void conv_igemm_kernel(ConvP
     // left out (that loop recomputes, it needs the extra pre-images anyway).
     unsigned* tab = reinterpret_cast<unsigned*>(smem + TAB0);
     const int ntaps = p.KH * p.KW;
-    auto tab_build = [&]() {
-      const int T = (p.C0 < p.Ctot ? 2 : 1) * ntaps;
+    // XTAB: the adjoint kernel's 128-wide tiles keep a second table bank with the border rows' extra pre-image, so that a
+    // bordered wave's tap change is table reads as well (every chunk ends in a barrier: the one wave per tile that
+    // recomputed ~250 VALU of offsets per tap set the pace).  The 128x64 tile would lose its third workgroup per CU to
+    // the 4.6 KB, and a wave that owns a corner-adjacent pixel (up to three extras) keeps recomputing.
+    constexpr bool XTAB = ADJ && BN >= 128 && VAR != 8;   // var=8: A/B knob
+    const bool xtab = XTAB && p.W >= 128;   // narrow images: every wave is bordered, building the second bank costs more than it saves
+    auto tab_build = [&](auto wadj_tag) {
+      constexpr bool WADJ = decltype(wadj_tag)::value;
+      if constexpr (WADJ && !XTAB) return;
+      if (WADJ && (wave_corner || !xtab)) return;
+      const int T = WADJ ? ntaps : (p.C0 < p.Ctot ? 2 : 1) * ntaps;
       for (int t = 1 + kq; t < T; t += KQ) {   // entry 0 is the first tap, computed directly and never revisited
         const bool in0 = t < ntaps;
         const int tt = in0 ? t : t - ntaps, kh = tt / p.KW, kw = tt - kh * p.KW;
-        unsigned o[AR];
-        compute_voff(in0, kh, kw, o, 0u, std::false_type{});
-#pragma unroll
-        for (int i = 0; i < AR; ++i) tab[t * BM + r0 + RP * i] = o[i];
+        compute_voff(in0, kh, kw, 0u, wadj_tag, [&](int i, unsigned v, unsigned vx) {
+          tab[t * BM + r0 + RP * i] = v;
+          if constexpr (WADJ) tab[(ntaps + t) * BM + r0 + RP * i] = vx;
+        });
       }
     };
     // direct: the table is not visible yet (prologue, before the first barrier)
     auto tap_update = [&](auto wadj_tag, bool direct) {
       constexpr bool WADJ = decltype(wadj_tag)::value;
       const bool in0 = cs.c0 < p.C0;
-      if (WADJ || direct) {
-        compute_voff(in0, cs.kh, cs.kw, voff, 4u * kqs, wadj_tag);
+      if (direct || (WADJ && (!xtab || wave_corner))) {
+        compute_voff(in0, cs.kh, cs.kw, 4u * kqs, wadj_tag, [&](int i, unsigned v, unsigned vx) {
+          voff[i] = v;
+          if constexpr (WADJ) voffX[i] = vx;
+        });
       } else {
         const unsigned* tp = tab + ((in0 ? 0 : ntaps) + cs.kh * p.KW + cs.kw) * BM + r0;
 #pragma unroll
-        for (int i = 0; i < AR; ++i) voff[i] = tp[RP * i] + 16u * kqs;
+        for (int i = 0; i < AR; ++i) {
+          voff[i] = tp[RP * i] + 16u * kqs;
+          if constexpr (WADJ) voffX[i] = tp[ntaps * BM + RP * i] + 16u * kqs;
+        }
       }
     };
     // The whole K loop exists twice in the adjoint kernel: waves that own no pixel next to the border run the plain
@@ -572,7 +589,7 @@ __global__ __launch_bounds__(256, VAR == 6 ? 3 : 2) void conv_igemm_kernel(ConvP
           for (int i = 0; i < BR; ++i) dmaB((unsigned)j * STG, i);
           dma_end(j + 1 < nchunks, true);
         }
-        tab_build();                                           // under the latency of the first loads
+        tab_build(wadj_tag);                                   // under the latency of the first loads
         segsde_wait_vmcnt<INFLIGHT>();                         // chunk 0 has landed
         __syncthreads();
         const int arow = wm * TM * 32 + (lane & 31), brow = wn * TN * 32 + (lane & 31), h = lane >> 5;
@@ -644,7 +661,7 @@ __global__ __launch_bounds__(256, VAR == 6 ? 3 : 2) void conv_igemm_kernel(ConvP
       load_chunk(0);
       storeA(smem); storeB(smem + BM * LDT);
       load_chunk(1);
-      if constexpr (!WADJ) tab_build();
+      tab_build(wadj_tag);
       __syncthreads();
 
       const int arow = wm * TM * 32 + (lane & 31), brow = wn * TN * 32 + (lane & 31), h = lane >> 5;
@@ -1588,7 +1605,7 @@ int launch_igemm_mode(const ConvP& p, hipStream_t stream) {
   const int nblk = segsde_cdiv(p.M, BM) * segsde_cdiv(p.ne - p.nb, BN);
   size_t smem = (VAR == 4 ? 4 : 2) * (size_t)(BM + BN) * BK * sizeof(float);
   if (smem < (size_t)BM * BN * sizeof(float)) smem = (size_t)BM * BN * sizeof(float);   // the staged epilogue's tile
-  if (MODE >= 2) smem += (size_t)(p.C0 < p.Ctot ? 2 : 1) * p.KH * p.KW * BM * sizeof(unsigned);   // tap table
+  if (MODE >= 2) smem += (size_t)(((MODE == 3 && BN >= 128) || p.C0 < p.Ctot) ? 2 : 1) * p.KH * p.KW * BM * sizeof(unsigned);   // tap table
   auto k = conv_igemm_kernel<BM, BN, WM, WN, MODE, BK, VAR>;
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   hipLaunchKernelGGL(k, dim3(nblk), dim3(256), smem, stream, p);
@@ -1599,7 +1616,8 @@ int launch_igemm_mode(const ConvP& p, hipStream_t stream) {
 template <int BM, int BN, int WM, int WN>
 int launch_igemm(const ConvP& p, hipStream_t stream) {
   if (igemm_fast_ok(p) && p.pad_mode == SEGSDE_PAD_REFLECT_ADJOINT && !(tune().adjfix && !p.sum2x2) && tune().adjfix < 2)
-    return tune().adjlds ? launch_igemm_mode<BM, BN, WM, WN, 3, 32>(p, stream) : launch_igemm_mode<BM, BN, WM, WN, 3, 32, 5>(p, stream);
+    return tune().var == 8 ? launch_igemm_mode<BM, BN, WM, WN, 3, 32, 8>(p, stream)
+           : (tune().adjlds ? launch_igemm_mode<BM, BN, WM, WN, 3, 32>(p, stream) : launch_igemm_mode<BM, BN, WM, WN, 3, 32, 5>(p, stream));
   if (tune().bk64 && bk64_ok(p)) return launch_igemm_mode<BM, BN, WM, WN, 2, 64>(p, stream);
   if (igemm_fast_ok(p) && tune().dma) {
     if (tune().var == 1) return launch_igemm_mode<BM, BN, WM, WN, 4, 32, 1>(p, stream);
