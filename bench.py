@@ -318,6 +318,20 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
+    if os.environ.get("SEGSDE_BENCH_ATEN_OPS") and rank == 0:
+        # diagnosis: which ATen operators (with shapes) still run inside a step -- everything on the hot path should be a
+        # kernel of this package
+        from torch.profiler import profile, ProfilerActivity
+        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as tp:
+            step()
+            barrier()
+        with open(os.environ["SEGSDE_BENCH_ATEN_OPS"], "w") as f:
+            ka = tp.key_averages(group_by_input_shape=True)
+            f.write(ka.table(sort_by="cuda_time_total", row_limit=80, max_name_column_width=60, max_shapes_column_width=90))
+            f.write("\n\nATen operators (device time total us, calls, input shapes)\n")
+            for e in sorted((e for e in ka if e.key.startswith("aten::")), key=lambda e: -e.device_time_total):
+                if e.device_time_total > 0:
+                    f.write("%-28s %10.1f %6d  %s\n" % (e.key, e.device_time_total, e.count, str(e.input_shapes)[:150]))
     torch.cuda.reset_peak_memory_stats(dev)
     prof = None if args.no_kernel_timing else []
     H.PROFILE = prof

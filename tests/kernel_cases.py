@@ -58,6 +58,12 @@ CONV_CASES = [
     # wide rows: some waves of a reflection-adjoint tile own no border pixel (LDS-DMA loop) while others do (register loop)
     ("fast_refl_w64", 1, 6, 64, 32, 0, False, 32, 3, 1, 1, 1, True, True, "elu"),
     ("fast_refl_w64_up_cat", 1, 4, 64, 32, 32, True, 64, 3, 1, 1, 1, True, True, "none"),
+    # full tiles whose columns lie entirely on one side of the concat split (buffer-store epilogue, both destinations)
+    ("fast_cat_sides", 1, 8, 16, 128, 128, False, 32, 3, 1, 1, 1, True, True, "none"),
+    # 1x1 with several small images per tile and a second tile that starts inside a later image (linear row path)
+    ("lin_1x1_multi", 4, 8, 8, 64, 0, False, 64, 1, 1, 1, 0, False, False, "none"),
+    # adjoint data-gradient on 128-wide tiles of an image 128 pixels wide: border rows' extras come from the second table bank
+    ("xtab_w128", 1, 4, 128, 128, 0, False, 128, 3, 1, 1, 1, True, False, "none"),
     # disparity heads: single output channel -> dedicated stencil kernels (C = 64 / 128 / 256)
     ("disp_c64", 2, 9, 11, 64, 0, False, 1, 3, 1, 1, 1, True, True, "sigmoid"),
     ("disp_c128_tiny", 1, 3, 5, 128, 0, False, 1, 3, 1, 1, 1, True, True, "sigmoid"),
