@@ -9,7 +9,7 @@ from ctypes import c_int, c_long, c_float, c_void_p, c_size_t, c_uint64, c_int64
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SEGSDE_LIB") or os.path.join(_HERE, "libsegsde_hip.so")   # override: kernel experiments
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _LIB = None
 # Set only by the test-suite when it injects the host-interpreted build of the same kernel sources
@@ -53,7 +53,8 @@ _SIGS = {
     "segsde_upsample2x_backward": (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, c_int, P]),
     "segsde_resize_bilinear_forward": (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, c_int, c_int, c_int, c_int, P]),
     "segsde_resize_bilinear_backward": (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, c_int, c_int, c_int, c_int, P]),
-    "segsde_global_avgpool_forward": (c_int, [P, c_int, c_int, c_long, c_int, P, P]),
+    "segsde_global_avgpool_workspace": (c_size_t, [c_int, c_long, c_int]),
+    "segsde_global_avgpool_forward": (c_int, [P, c_int, c_int, c_long, c_int, P, P, c_size_t, P]),
     "segsde_global_avgpool_backward": (c_int, [P, c_int, c_long, c_int, P, c_int, P]),
     "segsde_gate_forward": (c_int, [P, P, c_long, P, P]),
     "segsde_gate_backward": (c_int, [P, P, P, c_long, P, P, P]),

@@ -1024,7 +1024,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(ConvP p, const float
   // padding -- so that a chunk's tile loads cost ~10 VALU instructions per thread instead of ~180 (fp32 MFMA and VALU
   // share issue cycles on gfx950).  voff = Htab[h*stride + kh*dil] + Wtab[(w0 + row)*stride + kw*dil] + channel; the
   // image base and the dY row base ride in per-chunk buffer resources (scalar work only).
-  constexpr unsigned TAB_MARK = 0x20000000u;     // = num_records of the resources: one image is < 512 MB (host check)
+  constexpr unsigned TAB_MARK = 0x40000000u;     // = num_records of the resources: one image is at most 1 GB (host check);
+                                                 // two markers + a legitimate offset stay below 2^32 (no wrap-around)
   unsigned* tabs = reinterpret_cast<unsigned*>(smem + 2 * STAGE);
   const int He = (p.Ho - 1) * p.stride + (p.KH - 1) * p.dil + 1, We = (p.Wo - 1) * p.stride + (p.KW - 1) * p.dil + 1;
   unsigned thaddr = 0, twaddr[AI], tcc = 0, voffD[DI];
@@ -1807,7 +1808,7 @@ int wgrad_mode(const ConvP& p, const float* dy, int lddy) {
   const long e0 = (long)p.B * (p.H >> p.up0) * (p.W >> p.up0) * p.ld0, e1 = (long)p.B * p.H * p.W * p.ld1;
   const bool fast = vec_ok(p) && e0 < (1L << 31) && e1 < (1L << 31);   // the dY side may be scalar (odd Cout)
   const long i0 = (long)(p.H >> p.up0) * (p.W >> p.up0) * p.ld0 * 4, i1 = (long)p.H * p.W * p.ld1 * 4;
-  const bool table = p.Wo % BP == 0 && i0 < (1L << 29) && i1 < (1L << 29) && (long)BP * lddy * 4 < (1L << 30);
+  const bool table = p.Wo % BP == 0 && i0 <= (1L << 30) && i1 <= (1L << 30) && (long)BP * lddy * 4 < (1L << 30);
   if (fast && vec && table) return 2;
   if (fast) return 3;
   return vec ? 1 : 0;

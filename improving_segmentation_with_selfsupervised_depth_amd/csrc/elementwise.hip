@@ -465,29 +465,45 @@ __global__ __launch_bounds__(256) void resize_bwd_kernel(const float* dy, int ld
 }
 
 // ------------------------------------------------------------------ global average pool
-__global__ __launch_bounds__(256) void gap_fwd_kernel(const float* x, int ldx, long HW, int C, double scale, float* y, int ldy) {
-  // y[b][c] = scale * sum over the image's HW pixels; one block per (b, 64-channel slab), 4 row lanes, eight independent
-  // accumulators per lane (a single chain of HW/4 dependent loads was pure latency: 216 us for 2048 pixels)
+__global__ __launch_bounds__(256) void gap_fwd_kernel(const float* x, int ldx, long HW, int C, double scale, float* y, int ldy,
+                                                      double* part) {
+  // y[b][c] = scale * sum over the image's HW pixels; one block per (b, 64-channel slab, pixel slice), 4 row lanes, eight
+  // independent accumulators per lane (a single chain of HW/4 dependent loads was pure latency: 216 us for 2048 pixels).
+  // gridDim.z > 1 (few images x few channels, e.g. batch 2 at 1024x2048: 4 blocks used to read 134 MB): every slice leaves
+  // its double partial sum in part[b][z][c]; gap_finalize_kernel adds the slices in fixed order.
   SEGSDE_SMEM;
   double* sh = reinterpret_cast<double*>(segsde_smem);
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-  const int c = blockIdx.y * SLAB + tx, b = blockIdx.x;
+  const int c = blockIdx.y * SLAB + tx, b = blockIdx.x, nz = gridDim.z;
+  const long per = (HW + nz - 1) / nz, m_lo = per * blockIdx.z, m_hi = m_lo + per < HW ? m_lo + per : HW;
   double s8[8];
 #pragma unroll
   for (int u = 0; u < 8; ++u) s8[u] = 0.0;
   if (c < C) {
     const float* xb = x + (long)b * HW * ldx + c;
-    for (long m = ty; m < HW; m += RLANES * 8) {
+    for (long m = m_lo + ty; m < m_hi; m += RLANES * 8) {
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         const long mm = m + (long)u * RLANES;
-        if (mm < HW) s8[u] += (double)xb[mm * ldx];
+        if (mm < m_hi) s8[u] += (double)xb[mm * ldx];
       }
     }
   }
   sh[ty * SLAB + tx] = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
   __syncthreads();
-  if (ty == 0 && c < C) y[(long)b * ldy + c] = (float)((sh[tx] + sh[SLAB + tx] + sh[2 * SLAB + tx] + sh[3 * SLAB + tx]) * scale);
+  if (ty == 0 && c < C) {
+    const double t = sh[tx] + sh[SLAB + tx] + sh[2 * SLAB + tx] + sh[3 * SLAB + tx];
+    if (nz == 1) y[(long)b * ldy + c] = (float)(t * scale);
+    else part[((long)b * nz + blockIdx.z) * C + c] = t;
+  }
+}
+__global__ __launch_bounds__(256) void gap_finalize_kernel(const double* part, int nz, int B, int C, double scale, float* y, int ldy) {
+  const long e = blockIdx.x * 256L + threadIdx.x;
+  if (e >= (long)B * C) return;
+  const int b = (int)(e / C), c = (int)(e - (long)b * C);
+  double t = 0.0;
+  for (int z = 0; z < nz; ++z) t += part[((long)b * nz + z) * C + c];
+  y[(long)b * ldy + c] = (float)(t * scale);
 }
 __global__ __launch_bounds__(256) void gap_bwd_kernel(const float* dy, int B, long HW, int C, float* dx, int lddx) {
   const long total = (long)B * HW * C;
@@ -755,7 +771,7 @@ extern "C" int segsde_resize_bilinear_backward(const float* dy, int lddy, int B,
   if (Hi == 1 && Wi == 1) {
     // a 1x1 source is broadcast by the forward pass (ASPP image-pooling branch): its gradient is the plain per-image sum
     hipLaunchKernelGGL(gap_fwd_kernel, dim3(B, (C + SLAB - 1) / SLAB), dim3(256), RLANES * SLAB * sizeof(double), ST(stream),
-                       dy, lddy, (long)Ho * Wo, C, 1.0, dx, lddx);
+                       dy, lddy, (long)Ho * Wo, C, 1.0, dx, lddx, (double*)nullptr);
     SEGSDE_CHECK_LAUNCH();
     return 0;
   }
@@ -764,11 +780,35 @@ extern "C" int segsde_resize_bilinear_backward(const float* dy, int lddy, int B,
   SEGSDE_CHECK_LAUNCH();
   return 0;
 }
-extern "C" int segsde_global_avgpool_forward(const float* x, int ldx, int B, long HW, int C, float* y, void* stream) {
+namespace {
+// pixel slices per image so that the launch has about a thousand blocks (1: the single-kernel path)
+int gap_slices(int B, long HW, int C) {
+  const long blocks = (long)B * ((C + SLAB - 1) / SLAB);
+  long nz = (1024 + blocks - 1) / blocks;
+  const long maxz = HW / (RLANES * 8 * 4);        // at least four trips of the inner loop per slice
+  if (nz > maxz) nz = maxz;
+  if (nz > 256) nz = 256;
+  return nz < 1 ? 1 : (int)nz;
+}
+}  // namespace
+extern "C" size_t segsde_global_avgpool_workspace(int B, long HW, int C) {
+  const int nz = gap_slices(B, HW, C);
+  return nz > 1 ? (size_t)B * nz * C * sizeof(double) : 0;
+}
+extern "C" int segsde_global_avgpool_forward(const float* x, int ldx, int B, long HW, int C, float* y, void* ws, size_t ws_bytes,
+                                             void* stream) {
   if (!x || !y) return SEGSDE_ERR_NULL;
-  hipLaunchKernelGGL(gap_fwd_kernel, dim3(B, (C + SLAB - 1) / SLAB), dim3(256), RLANES * SLAB * sizeof(double), ST(stream),
-                     x, ldx, HW, C, 1.0 / (double)HW, y, C);
+  if (B <= 0 || HW <= 0 || C <= 0) return SEGSDE_ERR_SHAPE;
+  const int nz = gap_slices(B, HW, C);
+  if (nz > 1 && (!ws || ws_bytes < segsde_global_avgpool_workspace(B, HW, C))) return SEGSDE_ERR_WORKSPACE;
+  hipLaunchKernelGGL(gap_fwd_kernel, dim3(B, (C + SLAB - 1) / SLAB, nz), dim3(256), RLANES * SLAB * sizeof(double), ST(stream),
+                     x, ldx, HW, C, 1.0 / (double)HW, y, C, (double*)ws);
   SEGSDE_CHECK_LAUNCH();
+  if (nz > 1) {
+    hipLaunchKernelGGL(gap_finalize_kernel, dim3(segsde_cdiv((long)B * C, 256)), dim3(256), 0, ST(stream), (const double*)ws, nz,
+                       B, C, 1.0 / (double)HW, y, C);
+    SEGSDE_CHECK_LAUNCH();
+  }
   return 0;
 }
 extern "C" int segsde_global_avgpool_backward(const float* dy, int B, long HW, int C, float* dx, int lddx, void* stream) {

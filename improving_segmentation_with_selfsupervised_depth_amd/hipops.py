@@ -369,7 +369,11 @@ def resize_bilinear_backward(dy, in_hw, align_corners=False):
 def global_avgpool(x):
     B, H, W, C = x.shape
     y = torch.empty((B, 1, 1, C), dtype=torch.float32, device=x.device)
-    check(_lib.lib().segsde_global_avgpool_forward(_p(_f32(x)), nhwc_ld(x), B, H * W, C, _p(y), _stream(x)), "gap_fwd")
+    L = _lib.lib()
+    nws = int(L.segsde_global_avgpool_workspace(B, H * W, C))   # > 0: few images x few channels, the pixels are sliced
+    ws = _ws(nws, x) if nws else None
+    check(L.segsde_global_avgpool_forward(_p(_f32(x)), nhwc_ld(x), B, H * W, C, _p(y), _p(ws) if nws else None, nws,
+                                          _stream(x)), "gap_fwd")
     return y
 
 

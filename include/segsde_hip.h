@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SEGSDE_ABI_VERSION 5
+#define SEGSDE_ABI_VERSION 6
 
 enum { SEGSDE_ERR_NULL = -1, SEGSDE_ERR_SHAPE = -2, SEGSDE_ERR_WORKSPACE = -3, SEGSDE_ERR_UNSUPPORTED = -4 };
 enum { SEGSDE_ACT_NONE = 0, SEGSDE_ACT_RELU = 1, SEGSDE_ACT_ELU = 2, SEGSDE_ACT_SIGMOID = 3 };
@@ -154,7 +154,9 @@ int segsde_resize_bilinear_forward(const float* x, int ldx, int B, int Hi, int W
 int segsde_resize_bilinear_backward(const float* dy, int lddy, int B, int Hi, int Wi, int C, float* dx, int lddx, int Ho,
                                     int Wo, int align_corners, void* stream);
 /* nn.AdaptiveAvgPool2d(1) / out.mean(3).mean(2) (pose_decoder.py:49) and adjoint */
-int segsde_global_avgpool_forward(const float* x, int ldx, int B, long HW, int C, float* y, void* stream);
+size_t segsde_global_avgpool_workspace(int B, long HW, int C);   /* bytes; 0: the launch needs none */
+int segsde_global_avgpool_forward(const float* x, int ldx, int B, long HW, int C, float* y, void* ws, size_t ws_bytes,
+                                  void* stream);
 int segsde_global_avgpool_backward(const float* dy, int B, long HW, int C, float* dx, int lddx, void* stream);
 /* SelfAttention gate y = f * sigmoid(a) (models/model_parts.py:44-46) and adjoint */
 int segsde_gate_forward(const float* f, const float* a, long n, float* y, void* stream);

@@ -248,6 +248,9 @@ def run_misc_cases(device):
     yo = H.global_avgpool(d(nhwc(x.detach())))
     assert_close(nchw(yo), y, what="gap fwd")
     assert_close(nchw(H.global_avgpool_backward(d(nhwc(gy)), (3, 5, 6, 70))), x.grad, what="gap bwd")
+    # few images x few channels over many pixels: the pixel range is sliced over blocks, partial sums in a workspace
+    x = torch.randn(1, 20, 37, 41, generator=gen) + 3.0
+    assert_close(nchw(H.global_avgpool(d(nhwc(x)))), x.mean((2, 3), keepdim=True), rtol=1e-6, what="gap fwd sliced")
     # gate
     f = torch.randn(2, 4, 5, 8, generator=gen).requires_grad_(True)
     a = torch.randn(2, 4, 5, 8, generator=gen).requires_grad_(True)

@@ -30,12 +30,16 @@ GEOMS = [
     ("2048->256 d18 @32x64", 2048, 0, False, 256, 3, 18, 18, False, "none", (32, 64)),
     # 1x1: GEMM rows are input pixels (no row decode); input 2.1 GB, output 4.3 GB
     ("64->128 1x1 @512x1024", 64, 0, False, 128, 1, 1, 0, False, "none", (512, 1024)),
+    # the cfg5 crop size at its batch of 2: one image of the 64-channel tensor is exactly 2^29 bytes (the table-driven
+    # weight-gradient's per-image offsets reach 512 MB)
+    ("64->64 refl up @1024x2048 batch 2", 64, 0, True, 64, 3, 1, 1, True, "elu", (1024, 2048), 2),
 ]
 
 
 @pytest.mark.parametrize("geom", GEOMS, ids=[g[0] for g in GEOMS])
 def test_conv_fullsize_sampled(geom):
-    name, C0, C1, up0, Cout, k, dil, pad, reflect, act, (Hh, W) = geom
+    name, C0, C1, up0, Cout, k, dil, pad, reflect, act, (Hh, W) = geom[:11]
+    B16 = geom[11] if len(geom) > 11 else 16
     dev = "cuda"
     gen = torch.Generator(device=dev).manual_seed(3)
     h0, w0 = (Hh // 2, W // 2) if up0 else (Hh, W)
