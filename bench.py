@@ -274,7 +274,7 @@ def main():
     from improving_segmentation_with_selfsupervised_depth_amd.models.layers import weight_pack_scope
 
     def step():
-        with weight_pack_scope():      # weights change only in optimizer.step(): every forward of the step shares the packs
+        with weight_pack_scope(model):  # weights change only in optimizer.step(): packed once per step, in one launch
             return step_body()
 
     def step_body():

@@ -9,12 +9,18 @@ from ctypes import c_int, c_long, c_float, c_void_p, c_size_t, c_uint64, c_int64
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SEGSDE_LIB") or os.path.join(_HERE, "libsegsde_hip.so")   # override: kernel experiments
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 _LIB = None
 # Set only by the test-suite when it injects the host-interpreted build of the same kernel sources
 # (see tests/emu.py); the product never sets it.
 HOST_POINTERS_OK = False
+
+
+class PackJob(ctypes.Structure):
+    """mirror of ``segsde_pack_job`` (include/segsde_hip.h)"""
+    _fields_ = [("w", c_void_p), ("fwd", c_void_p), ("dgrad", c_void_p)] + [(n, c_int) for n in (
+        "O", "I", "KH", "KW", "block0", "reserved")]
 
 
 class ConvDesc(ctypes.Structure):
@@ -37,6 +43,7 @@ _SIGS = {
     "segsde_conv2d_wgrad": (c_int, [POINTER(ConvDesc), P, P, P, c_int, P, P, c_size_t, P]),
     "segsde_pack_weight": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "segsde_pack_weight_both": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P]),
+    "segsde_pack_weight_both_multi": (c_int, [P, c_int, c_int, P]),
     "segsde_reflect_dgrad_fix": (c_int, [P, c_int, P, P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "segsde_bn_stats_workspace": (c_size_t, [c_long, c_int]),
     "segsde_bn_stats": (c_int, [P, c_int, c_long, c_int, P, P, P, P, c_float, c_float, P, P, c_size_t, P]),

@@ -1922,6 +1922,37 @@ extern "C" int segsde_pack_weight_both(const float* w_oihw, float* out_fwd, floa
   return 0;
 }
 
+namespace {
+// every convolution weight of a model in ONE launch (a step re-packs ~160 weights: one ~10 us launch each otherwise)
+__global__ __launch_bounds__(256) void pack_weight_multi_kernel(const segsde_pack_job* jobs, int njobs) {
+  int lo = 0, hi = njobs;                       // jobs[j].block0 <= blockIdx.x < jobs[j + 1].block0 (sentinel at njobs)
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if ((int)blockIdx.x >= jobs[mid].block0) lo = mid; else hi = mid;
+  }
+  const segsde_pack_job j = jobs[lo];
+  const int nblk = jobs[lo + 1].block0 - j.block0, lb = (int)blockIdx.x - j.block0;
+  const int total = j.O * j.I * j.KH * j.KW;
+  for (int e = lb * 256 + threadIdx.x; e < total; e += nblk * 256) {
+    const int kw = e % j.KW; int t = e / j.KW;
+    const int kh = t % j.KH; t /= j.KH;
+    const int i = t % j.I, o = t / j.I;
+    const float v = j.w[e];
+    j.fwd[((o * j.KH + kh) * j.KW + kw) * j.I + i] = v;
+    j.dgrad[((i * j.KH + (j.KH - 1 - kh)) * j.KW + (j.KW - 1 - kw)) * j.O + o] = v;
+  }
+}
+}  // namespace
+
+extern "C" int segsde_pack_weight_both_multi(const segsde_pack_job* jobs_device, int njobs, int total_blocks, void* stream) {
+  if (!jobs_device) return SEGSDE_ERR_NULL;
+  if (njobs <= 0 || total_blocks <= 0) return SEGSDE_ERR_SHAPE;
+  hipLaunchKernelGGL(pack_weight_multi_kernel, dim3(total_blocks), dim3(256), 0, static_cast<hipStream_t>(stream), jobs_device,
+                     njobs);
+  SEGSDE_CHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" int segsde_reflect_dgrad_fix(const float* dy, int lddy, const float* wdpack, float* dx, int lddx, float* dx2,
                                         int lddx2, int nsplit, int B, int H, int W, int Cin, int Cout, void* stream) {
   if (!dy || !wdpack || !dx) return SEGSDE_ERR_NULL;

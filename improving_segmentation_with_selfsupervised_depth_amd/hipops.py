@@ -109,6 +109,41 @@ def pack_weight_both(w_oihw):
     return outf, outd
 
 
+_MULTI_PACK = {}     # (device, weight pointers / shapes) -> (job table on the device, flat pack buffer, [(fwd view, dgrad view)])
+
+
+def pack_weights_multi(weights):
+    """[(forward pack, data-gradient pack)] of many OIHW weights in ONE launch.  The packs are views into one flat buffer
+    that is reused by the next call with the same weights (same storage, same shapes): valid until then -- what a training
+    step needs (models/layers.weight_pack_scope), not something to keep."""
+    ws = [_f32(w.detach()) for w in weights]
+    assert ws and all(w.is_contiguous() and w.dim() == 4 for w in ws)
+    dev = ws[0].device
+    key = (dev, tuple((w.data_ptr(), tuple(w.shape)) for w in ws))
+    hit = _MULTI_PACK.get(key)
+    if hit is None:
+        if len(_MULTI_PACK) > 8:            # weights were re-allocated (load_state_dict into new storage ...): start over
+            _MULTI_PACK.clear()
+        total = sum(w.numel() for w in ws)
+        flat = torch.empty(2 * total, dtype=torch.float32, device=dev)
+        jobs = (_lib.PackJob * (len(ws) + 1))()
+        views, off, blk = [], 0, 0
+        for i, w in enumerate(ws):
+            O, I, KH, KW = w.shape
+            n = w.numel()
+            f, d = flat[off:off + n].view(O, KH, KW, I), flat[off + n:off + 2 * n].view(I, KH, KW, O)
+            off += 2 * n
+            jobs[i] = _lib.PackJob(w.data_ptr(), f.data_ptr(), d.data_ptr(), O, I, KH, KW, blk, 0)
+            blk += max(1, min(64, (n + 2047) // 2048))       # ~8 elements per thread, at most 64 blocks per weight
+            views.append((f, d))
+        jobs[len(ws)] = _lib.PackJob(None, None, None, 0, 0, 0, 0, blk, 0)
+        raw = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8).to(dev)
+        hit = _MULTI_PACK[key] = (raw, flat, views, len(ws), blk)
+    raw, flat, views, n, blk = hit
+    check(_lib.lib().segsde_pack_weight_both_multi(_p(raw), n, blk, _stream(flat)), "pack_weight_both_multi")
+    return views
+
+
 def conv_forward(g, x0, x1, wpack, bias, act="none", want_stats=False):
     """y = act(conv(cat[up?(x0), x1]) + bias).  x0: [B,H0,W0,C0] (H0 = H/2 if g.up0), x1: [B,H,W,C1] or None.
     want_stats: also return the per-tile statistics partials of y for the BatchNorm that follows ([rows,2,Cout] doubles,

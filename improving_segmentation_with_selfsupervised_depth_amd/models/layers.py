@@ -29,12 +29,31 @@ class weight_pack_scope:
     ``load_state_dict``, but not ``param.data[:] = ...`` (how the reference's own EMA update writes, train.py:353-357), which
     is why nothing is cached outside a scope."""
 
+    def __init__(self, model=None):
+        """model: optionally the module whose convolutions the scope is about to run -- their weights are then packed up
+        front in ONE launch instead of one launch per convolution at its first forward (a training step re-packs every
+        weight: ~160 launches of ~10 us for the ResNet-101 joint model)"""
+        self._model = model
+
     def __enter__(self):
         self._outer = _PACK_SCOPE[0]
         if not self._outer:                # a nested scope joins the enclosing one
             _PACK_SCOPE[1] += 1
             _PACK_SCOPE[0] = _PACK_SCOPE[1]
+            if self._model is not None:
+                self._prepack(self._model, _PACK_SCOPE[0])
         return self
+
+    @staticmethod
+    def _prepack(model, scope_id):
+        convs = [m for m in model.modules() if isinstance(m, Conv2d) and m.weight.is_contiguous()
+                 and m.weight.dtype == torch.float32 and m.in_channels % 4 == 0]   # (stems pad their weight per call)
+        if not convs:
+            return
+        packs = H.pack_weights_multi([m.weight for m in convs])
+        for m, pk in zip(convs, packs):
+            w = m.weight
+            m._packs, m._pack_key = pk, (scope_id, w._version, w.data_ptr(), w.device)
 
     def __exit__(self, *exc):
         _PACK_SCOPE[0] = self._outer

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SEGSDE_ABI_VERSION 6
+#define SEGSDE_ABI_VERSION 7
 
 enum { SEGSDE_ERR_NULL = -1, SEGSDE_ERR_SHAPE = -2, SEGSDE_ERR_WORKSPACE = -3, SEGSDE_ERR_UNSUPPORTED = -4 };
 enum { SEGSDE_ACT_NONE = 0, SEGSDE_ACT_RELU = 1, SEGSDE_ACT_ELU = 2, SEGSDE_ACT_SIGMOID = 3 };
@@ -93,6 +93,14 @@ int segsde_pack_weight(const float* w_oihw, float* out, int O, int I, int KH, in
 /* both packs of one weight tensor in a single launch (training forward: the data-gradient pack is kept for backward) */
 int segsde_pack_weight_both(const float* w_oihw, float* out_fwd, float* out_dgrad, int O, int I, int KH, int KW,
                             void* stream);
+/* The same for many weights in one launch (a training step re-packs every convolution weight of the model).  jobs_device:
+ * njobs + 1 entries in DEVICE memory; entry j packs one weight with blocks [block0, next entry's block0) of the launch, the
+ * last entry is a sentinel whose block0 is total_blocks. */
+typedef struct segsde_pack_job {
+  const float* w; float* fwd; float* dgrad;
+  int O, I, KH, KW, block0, reserved;
+} segsde_pack_job;
+int segsde_pack_weight_both_multi(const segsde_pack_job* jobs_device, int njobs, int total_blocks, void* stream);
 
 /* Adds to dx the gradient that entered the mirrored padding cells of a reflection-padded 3x3 stride-1 conv
  * (autograd of nn.ReflectionPad2d(1), models/monodepth_layers.py:134,140); wdpack = segsde_pack_weight(for_dgrad=1).

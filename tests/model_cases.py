@@ -431,6 +431,34 @@ def run_weight_pack_scope(device):
             yc.sum().backward()                      # backward uses the packs of ITS forward
         conv(xg)
         assert len(calls) == 5                       # outside again: per call
+        # weight_pack_scope(model): every convolution weight of the model packed up front in ONE launch; the packs equal
+        # the per-weight ones bit for bit, the forwards / backwards inside the scope use them (no further pack launch),
+        # a weight update inside the scope is still noticed, and the next scope re-packs into the same buffer
+        net = torch.nn.Sequential(Conv2d(8, 16, 3, padding=1), Conv2d(16, 12, 1), Conv2d(12, 8, 3, padding=2, dilation=2)).to(device)
+        wants = [real(m.weight) for m in net]
+        n0 = len(calls)
+        with weight_pack_scope(net):
+            for m, (wf, wd) in zip(net, wants):
+                assert torch.equal(m._packs[0], wf) and torch.equal(m._packs[1], wd)
+            h = xg
+            for m in net:
+                h = m(h)
+            h.sum().backward()
+            assert len(calls) == n0, "no per-convolution pack inside a pre-packed scope"
+            with torch.no_grad():
+                net[1].weight.add_(1.0)
+            net[1](net[0](xg))
+            assert len(calls) == n0 + 1
+        with weight_pack_scope(net):
+            assert torch.equal(net[1]._packs[0], real(net[1].weight)[0])
+        ref = xg
+        for m in net:
+            ref = m(ref)
+        with weight_pack_scope(net):
+            h = xg
+            for m in net:
+                h = m(h)
+        assert torch.equal(h, ref)
     finally:
         Hh_.pack_weight_both = real
 
