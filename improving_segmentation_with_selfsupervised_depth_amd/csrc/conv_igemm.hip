@@ -607,8 +607,10 @@ __global__ __launch_bounds__(256, VAR == 6 ? 3 : 2) void conv_igemm_kernel(ConvP
         // one chunk; buf is a compile-time constant in the two-stage loop (unrolled by two below) so that the fragment
         // reads and the LDS-DMA destinations use immediate offsets -- the 8 v_lshl_add_u32 per chunk that rebuilt the
         // stage base were most of the loop's remaining VALU work
-        auto chunk = [&](int kc, auto buf_c) {
+        auto chunk = [&](int kc, auto buf_c, auto first_c) {
           const int buf = buf_c;
+          constexpr bool FIRST = decltype(first_c)::value;   // the tile's first chunk: its first k-step starts from zero
+                                                             // accumulators (inline constant) instead of 64 v_mov up front
           fread(buf, 0, 0);
           dma_begin();                     // past the last chunk: the last one is fetched again (harmless, waited for)
           const unsigned stn = (unsigned)((buf + NST - 1) & (NST - 1)) * STG;
@@ -627,7 +629,8 @@ __global__ __launch_bounds__(256, VAR == 6 ? 3 : 2) void conv_igemm_kernel(ConvP
             for (int i = 0; i < TM; ++i)
   #pragma unroll
               for (int j = 0; j < TN; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(comp(fa[g & 1][i], st), comp(fb[g & 1][j], st), acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(comp(fa[g & 1][i], st), comp(fb[g & 1][j], st),
+                                                                 (FIRST && u == 0) ? f32x16{} : acc[i][j], 0, 0, 0);
             if constexpr (VAR != 1) {
   #pragma unroll
               for (int i = 0; i < AR; ++i)
@@ -644,12 +647,14 @@ __global__ __launch_bounds__(256, VAR == 6 ? 3 : 2) void conv_igemm_kernel(ConvP
           __syncthreads();
         };
         if constexpr (NST == 2 && VAR != 7) {   // var=7: A/B knob (round-2 loop before this unroll and the kernarg refresh)
-          for (int kc = 0; kc < nchunks; kc += 2) {
-            chunk(kc, std::integral_constant<int, 0>{});
-            if (kc + 1 < nchunks) chunk(kc + 1, std::integral_constant<int, 1>{});
+          chunk(0, std::integral_constant<int, 0>{}, std::true_type{});
+          if (1 < nchunks) chunk(1, std::integral_constant<int, 1>{}, std::false_type{});
+          for (int kc = 2; kc < nchunks; kc += 2) {
+            chunk(kc, std::integral_constant<int, 0>{}, std::false_type{});
+            if (kc + 1 < nchunks) chunk(kc + 1, std::integral_constant<int, 1>{}, std::false_type{});
           }
         } else {
-          for (int kc = 0; kc < nchunks; ++kc) chunk(kc, kc & (NST - 1));
+          for (int kc = 0; kc < nchunks; ++kc) chunk(kc, kc & (NST - 1), std::false_type{});
         }
         if constexpr (INFLIGHT > 0) {      // the epilogue reuses the stages: nothing may still be landing
           segsde_wait_vmcnt0();
