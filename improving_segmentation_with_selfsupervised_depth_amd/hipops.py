@@ -134,7 +134,7 @@ def pack_weights_multi(weights):
             f, d = flat[off:off + n].view(O, KH, KW, I), flat[off + n:off + 2 * n].view(I, KH, KW, O)
             off += 2 * n
             jobs[i] = _lib.PackJob(w.data_ptr(), f.data_ptr(), d.data_ptr(), O, I, KH, KW, blk, 0)
-            blk += max(1, min(64, (n + 2047) // 2048))       # ~8 elements per thread, at most 64 blocks per weight
+            blk += max(1, min(2048, (n + 1023) // 1024))     # ~4 elements per thread (the writes of the flipped pack are scattered)
             views.append((f, d))
         jobs[len(ws)] = _lib.PackJob(None, None, None, 0, 0, 0, 0, blk, 0)
         raw = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8).to(dev)
