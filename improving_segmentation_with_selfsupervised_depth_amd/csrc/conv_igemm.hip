@@ -1930,6 +1930,8 @@ extern "C" int segsde_pack_weight_both(const float* w_oihw, float* out_fwd, floa
 namespace {
 // every convolution weight of a model in ONE launch (a step re-packs ~160 weights: one ~10 us launch each otherwise)
 __global__ __launch_bounds__(256) void pack_weight_multi_kernel(const segsde_pack_job* jobs, int njobs) {
+  SEGSDE_SMEM;
+  float* tile = reinterpret_cast<float*>(segsde_smem);   // [o][i][tap] of one 32 x 32 (output, input) channel block
   int lo = 0, hi = njobs;                       // jobs[j].block0 <= blockIdx.x < jobs[j + 1].block0 (sentinel at njobs)
   while (hi - lo > 1) {
     const int mid = (lo + hi) >> 1;
@@ -1937,7 +1939,29 @@ __global__ __launch_bounds__(256) void pack_weight_multi_kernel(const segsde_pac
   }
   const segsde_pack_job j = jobs[lo];
   const int nblk = jobs[lo + 1].block0 - j.block0, lb = (int)blockIdx.x - j.block0;
-  const int total = j.O * j.I * j.KH * j.KW;
+  const int T = j.KH * j.KW;
+  if (T <= 9 && j.reserved == 1) {
+    // transposing path (reserved == 1: the host gave this job ceil(O/32) * ceil(I/32) blocks): the block's 32 x 32 x T
+    // weights are read as 32 runs of 32*T consecutive floats and leave as 128-byte runs along I (forward pack) and along
+    // O (flipped data-gradient pack) -- the element-per-thread path below writes the flipped pack 4 bytes at a time
+    const int nit = (j.I + 31) >> 5, o0 = (lb / nit) << 5, i0 = (lb % nit) << 5;
+    const int nI = j.I - i0 < 32 ? j.I - i0 : 32, nO = j.O - o0 < 32 ? j.O - o0 : 32, run = nI * T;
+    for (int e = threadIdx.x; e < 32 * run; e += 256) {
+      const int ol = e / run, r = e - ol * run;
+      if (ol < nO) tile[ol * (32 * T) + r] = j.w[((long)(o0 + ol) * j.I + i0) * T + r];     // r = il * T + t
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 32 * T * 32; e += 256) {
+      const int il = e & 31, t = (e >> 5) % T, ol = (e >> 5) / T;
+      if (il < nI && ol < nO) j.fwd[((long)(o0 + ol) * T + t) * j.I + i0 + il] = tile[ol * (32 * T) + il * T + t];
+    }
+    for (int e = threadIdx.x; e < 32 * T * 32; e += 256) {
+      const int ol = e & 31, t = (e >> 5) % T, il = (e >> 5) / T;
+      if (il < nI && ol < nO) j.dgrad[((long)(i0 + il) * T + (T - 1 - t)) * j.O + o0 + ol] = tile[ol * (32 * T) + il * T + t];
+    }
+    return;
+  }
+  const int total = j.O * j.I * T;
   for (int e = lb * 256 + threadIdx.x; e < total; e += nblk * 256) {
     const int kw = e % j.KW; int t = e / j.KW;
     const int kh = t % j.KH; t /= j.KH;
@@ -1952,7 +1976,7 @@ __global__ __launch_bounds__(256) void pack_weight_multi_kernel(const segsde_pac
 extern "C" int segsde_pack_weight_both_multi(const segsde_pack_job* jobs_device, int njobs, int total_blocks, void* stream) {
   if (!jobs_device) return SEGSDE_ERR_NULL;
   if (njobs <= 0 || total_blocks <= 0) return SEGSDE_ERR_SHAPE;
-  hipLaunchKernelGGL(pack_weight_multi_kernel, dim3(total_blocks), dim3(256), 0, static_cast<hipStream_t>(stream), jobs_device,
+  hipLaunchKernelGGL(pack_weight_multi_kernel, dim3(total_blocks), dim3(256), 32 * 32 * 9 * sizeof(float), static_cast<hipStream_t>(stream), jobs_device,
                      njobs);
   SEGSDE_CHECK_LAUNCH();
   return 0;

@@ -133,8 +133,9 @@ def pack_weights_multi(weights):
             n = w.numel()
             f, d = flat[off:off + n].view(O, KH, KW, I), flat[off + n:off + 2 * n].view(I, KH, KW, O)
             off += 2 * n
-            jobs[i] = _lib.PackJob(w.data_ptr(), f.data_ptr(), d.data_ptr(), O, I, KH, KW, blk, 0)
-            blk += max(1, min(2048, (n + 1023) // 1024))     # ~4 elements per thread (the writes of the flipped pack are scattered)
+            tiled = KH * KW <= 9                              # one block per 32 x 32 channel block, transposed through LDS
+            jobs[i] = _lib.PackJob(w.data_ptr(), f.data_ptr(), d.data_ptr(), O, I, KH, KW, blk, 1 if tiled else 0)
+            blk += ((O + 31) // 32) * ((I + 31) // 32) if tiled else max(1, min(2048, (n + 1023) // 1024))
             views.append((f, d))
         jobs[len(ws)] = _lib.PackJob(None, None, None, 0, 0, 0, 0, blk, 0)
         raw = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8).to(dev)

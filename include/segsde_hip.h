@@ -95,7 +95,9 @@ int segsde_pack_weight_both(const float* w_oihw, float* out_fwd, float* out_dgra
                             void* stream);
 /* The same for many weights in one launch (a training step re-packs every convolution weight of the model).  jobs_device:
  * njobs + 1 entries in DEVICE memory; entry j packs one weight with blocks [block0, next entry's block0) of the launch, the
- * last entry is a sentinel whose block0 is total_blocks. */
+ * last entry is a sentinel whose block0 is total_blocks.  reserved = 1 selects the transposing path for a weight with at
+ * most 9 taps: the job must then own exactly ceil(O/32) * ceil(I/32) blocks (one per 32 x 32 channel block); reserved = 0:
+ * any number of blocks, one element per thread and trip. */
 typedef struct segsde_pack_job {
   const float* w; float* fwd; float* dgrad;
   int O, I, KH, KW, block0, reserved;
