@@ -558,10 +558,12 @@ __global__ __launch_bounds__(256) void scale_channels_kernel(const float* x, int
 }
 __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* x, int B, int C, int H, int W, float mean, float sd,
                                                            float* y, int ldy) {
-  const long HW = (long)H * W, total = (long)B * HW * C;
+  // every one of the ldy channels of a pixel is written (channels past C: zeros -- the padded network input needs no
+  // separate memset), so the stores of a wave are one contiguous run
+  const long HW = (long)H * W, total = (long)B * HW * ldy;
   for (long e = blockIdx.x * 256L + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
-    const int c = (int)(e % C); const long m = e / C; const long b = m / HW, p = m - b * HW;
-    y[m * ldy + c] = (x[(b * C + c) * HW + p] - mean) / sd;
+    const int c = (int)(e % ldy); const long m = e / ldy; const long b = m / HW, p = m - b * HW;
+    y[e] = c < C ? (x[(b * C + c) * HW + p] - mean) / sd : 0.f;
   }
 }
 __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* x, int ldx, int B, int C, int H, int W, float* y) {
@@ -863,7 +865,7 @@ extern "C" int segsde_scale_channels(const float* x, int ldx, int B, long HW, in
 extern "C" int segsde_nchw_to_nhwc(const float* x, int B, int C, int H, int W, float mean, float sd, float* y, int ldy,
                                    void* stream) {
   if (!x || !y) return SEGSDE_ERR_NULL;
-  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(ew_blocks((long)B * C * H * W)), dim3(256), 0, ST(stream), x, B, C, H, W,
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(ew_blocks((long)B * ldy * H * W)), dim3(256), 0, ST(stream), x, B, C, H, W,
                      mean, sd, y, ldy);
   SEGSDE_CHECK_LAUNCH();
   return 0;

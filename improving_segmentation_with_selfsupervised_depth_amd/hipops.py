@@ -478,10 +478,7 @@ def nchw_to_nhwc(x, mean=0.0, std=1.0, pad_to=1):
     x = _f32(x).contiguous()
     B, C, H, W = x.shape
     Cp = -(-C // pad_to) * pad_to
-    if Cp == C:
-        y = torch.empty((B, H, W, C), dtype=torch.float32, device=x.device)
-    else:
-        y = torch.zeros((B, H, W, Cp), dtype=torch.float32, device=x.device)
+    y = torch.empty((B, H, W, Cp), dtype=torch.float32, device=x.device)     # the kernel writes the zero channels too
     check(_lib.lib().segsde_nchw_to_nhwc(_p(x), B, C, H, W, float(mean), float(std), _p(y), Cp, _stream(x)), "nchw_to_nhwc")
     return y
 

@@ -181,7 +181,8 @@ int segsde_copy_channels(const float* src, int lds, float* dst, int ldd, long M,
  * with scale = 0 or 1/(1-p) per (sample, channel); the same call is its adjoint. */
 int segsde_scale_channels(const float* x, int ldx, int B, long HW, int C, const float* scale, float* y, int ldy, void* stream);
 /* NCHW image -> NHWC with the encoder's input normalisation (x - mean) / std (models/resnet_encoder.py:92);
- * mean = 0, std = 1 gives a plain layout change.  nhwc_to_nchw is the inverse layout change. */
+ * mean = 0, std = 1 gives a plain layout change.  All ldy channels of every pixel are written: channels C..ldy-1 become
+ * zero (the 3 / 6-channel network input padded to 4 / 8).  nhwc_to_nchw is the inverse layout change. */
 int segsde_nchw_to_nhwc(const float* x, int B, int C, int H, int W, float mean, float std, float* y, int ldy, void* stream);
 int segsde_nhwc_to_nchw(const float* x, int ldx, int B, int C, int H, int W, float* y, void* stream);
 

@@ -270,6 +270,12 @@ def run_misc_cases(device):
     assert torch.equal(buf[..., 4:12].cpu(), src) and float(buf[..., :4].abs().sum()) == 0
     img = torch.rand(2, 3, 6, 10, generator=gen)
     assert_close(nchw(H.nchw_to_nhwc(d(img), 0.45, 0.225)), (img - 0.45) / 0.225, rtol=1e-6, atol=1e-6, what="img norm")
+    for _ in range(2):      # padded to 4 channels: the kernel itself writes the zero channel (the output is torch.empty)
+        padded = H.nchw_to_nhwc(d(img), 0.45, 0.225, pad_to=4)
+        assert padded.shape[-1] == 4 and float(padded[..., 3].abs().max()) == 0.0
+        assert_close(nchw(padded[..., :3]), (img - 0.45) / 0.225, rtol=1e-6, atol=1e-6, what="img norm, padded")
+        padded.fill_(7.0)   # the next call probably gets this very block back from the caching allocator
+        del padded
     t = torch.randn(2, 6, 10, 7, generator=gen)
     assert torch.equal(H.nhwc_to_nchw(d(t)).cpu(), nchw(t))
     assert torch.equal(H.nchw_to_nhwc(d(nchw(t))).cpu(), t)
