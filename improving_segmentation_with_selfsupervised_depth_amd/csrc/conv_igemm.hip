@@ -1747,6 +1747,9 @@ extern "C" int segsde_conv2d_dgrad_actgrad(const segsde_conv_desc* d, const floa
         q.in_div = 1;
         // source row of loop tap kh' for sub-grid row i:  i + (ph + kh0*dil - pad)/2 + kh'*dil   (exact division)
         q.pad = -((ph + kh0 * d->dil - d->pad) / 2);
+        // the loader has one padding value for both axes: a class whose column offset differs from its row offset
+        // (dilation 3 with stride 2: no model of the reference has it) sends the whole problem to the generic path
+        if (q.pad != -((pw + kw0 * d->dil - d->pad) / 2)) ok = false;
         q.os = 2; q.oph = ph; q.opw = pw; q.OHf = d->Ho; q.OWf = d->Wo;
         q.Ho = nI; q.Wo = nJ; q.M = d->B * nI * nJ;
         set_divs(q);

@@ -46,6 +46,8 @@ CONV_CASES = [
     ("fast_dil3", 1, 12, 10, 64, 0, False, 32, 3, 1, 3, 3, False, False, "none"),
     ("fast_s2", 2, 11, 14, 32, 0, False, 64, 3, 2, 1, 1, False, False, "none"),
     ("fast_s2_even", 1, 8, 12, 64, 0, False, 32, 3, 2, 1, 1, False, True, "none"),
+    # stride 2 with dilation 3: row and column offsets of the mixed parity classes differ -> generic data-gradient
+    ("fast_s2_dil3", 2, 11, 10, 32, 0, False, 64, 3, 2, 3, 3, False, False, "none"),
     ("fast_1x1", 2, 7, 9, 96, 0, False, 160, 1, 1, 1, 0, False, True, "none"),
     ("fast_1x1_s2", 1, 8, 10, 64, 0, False, 32, 1, 2, 1, 0, False, False, "none"),
     ("fast64_refl_up_cat", 1, 8, 12, 64, 128, True, 64, 3, 1, 1, 1, True, True, "elu"),
@@ -77,6 +79,31 @@ CONV_CASES = [
     ("disp_strip_c128_zero", 1, 5, 16, 128, 0, False, 1, 3, 1, 1, 1, False, True, "none"),
     ("disp_strip_c256", 1, 4, 16, 256, 0, False, 1, 3, 1, 1, 1, True, False, "sigmoid"),
 ]
+
+
+def random_conv_case(rng, i):
+    """a random convolution geometry (numpy RandomState): odd sizes, partial tiles, several images per tile, both padding
+    modes, strides, dilations, upsample + concat -- the shapes the fixed list above does not hold"""
+    k = int(rng.choice([1, 3, 3, 3]))
+    reflect = bool(k == 3 and rng.rand() < 0.5)
+    stride = 1 if reflect else int(rng.choice([1, 1, 1, 2]))
+    dil = 1 if (reflect or k == 1) else int(rng.choice([1, 1, 2, 3]))
+    pad = 0 if k == 1 else dil
+    up0 = bool(stride == 1 and rng.rand() < 0.35)
+    C0 = int(rng.choice([32, 64, 64, 96, 128, 256]))
+    C1 = int(rng.choice([0, 0, 32, 64, 128])) if (stride == 1 and k == 3) else 0
+    Cout = int(rng.choice([32, 64, 64, 128, 128, 160, 192, 256, 19, 48]))
+    Hh, W = int(rng.randint(6, 70)), int(rng.randint(6, 160))
+    if rng.rand() < 0.3:
+        W = int(rng.choice([32, 64, 128, 160]))          # table-driven weight gradient, second table bank of the adjoint
+    if up0:
+        Hh, W = Hh + (Hh & 1), W + (W & 1)
+    B = int(rng.choice([1, 2, 3, 5]))
+    bias = bool(rng.rand() < 0.5)
+    act = str(rng.choice(["none", "none", "elu"]))     # (no ReLU: a sign flip of a pre-activation next to zero between two
+    #                                                       correct implementations changes the mask the gradient is checked with)
+    return ("stress%03d" % i, B, Hh, W, C0, C1, up0, Cout, k, stride, dil, pad, reflect, bias, act)
+
 
 
 def conv_reference(case, x0, x1, w, b):

@@ -25,6 +25,15 @@ def test_conv(case):
     KC.run_conv_case(case, "cuda")
 
 
+def test_conv_random_geometries():
+    """60 random geometries (fixed seed; tools/stress_conv.py runs more): forward, fused statistics, both data gradients and
+    the weight gradient against torch autograd on the CPU"""
+    import numpy as np
+    rng = np.random.RandomState(2024)
+    for i in range(60):
+        KC.run_conv_case(KC.random_conv_case(rng, i), "cuda", seed=i)
+
+
 BIG_CONV = [
     ("big_refl_up_cat", 2, 64, 96, 64, 32, True, 64, 3, 1, 1, 1, True, True, "elu"),
     ("big_dil6", 2, 32, 64, 128, 0, False, 256, 3, 1, 6, 6, False, False, "none"),
