@@ -1,5 +1,7 @@
 """Kernel parity cases shared by the CPU run (kernel sources interpreted by tests/hipemu) and the GPU run
 (`-m gpu`, real libsegsde_hip.so through the C ABI).  The checker is plain PyTorch fp32 on CPU / the oracle."""
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -93,7 +95,8 @@ def random_conv_case(rng, i):
     C0 = int(rng.choice([32, 64, 64, 96, 128, 256]))
     C1 = int(rng.choice([0, 0, 32, 64, 128])) if (stride == 1 and k == 3) else 0
     Cout = int(rng.choice([32, 64, 64, 128, 128, 160, 192, 256, 19, 48]))
-    Hh, W = int(rng.randint(6, 70)), int(rng.randint(6, 160))
+    big = 3 if os.environ.get("STRESS_BIG") else 1
+    Hh, W = int(rng.randint(6, 70 * big)), int(rng.randint(6, 160 * big))
     if rng.rand() < 0.3:
         W = int(rng.choice([32, 64, 128, 160]))          # table-driven weight gradient, second table bank of the adjoint
     if up0:
