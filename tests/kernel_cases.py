@@ -185,9 +185,9 @@ def run_conv_case(case, device, seed=0):
 # ---------------------------------------------------------------------------------------------
 # BatchNorm / activation / pooling / resize
 # ---------------------------------------------------------------------------------------------
-def run_bn_case(device, C=24, act="relu", residual=True, train=True, drop_p=0.0, seed=0):
+def run_bn_case(device, C=24, act="relu", residual=True, train=True, drop_p=0.0, seed=0, shape=(3, 5, 7)):
     gen = torch.Generator().manual_seed(seed)
-    B, Hh, W = 3, 5, 7
+    B, Hh, W = shape
     x = torch.randn(B, C, Hh, W, generator=gen) * 2 + 0.5
     res = torch.randn(B, C, Hh, W, generator=gen) if residual else None
     gamma = torch.rand(C, generator=gen) + 0.5

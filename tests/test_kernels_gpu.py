@@ -25,6 +25,20 @@ def test_conv(case):
     KC.run_conv_case(case, "cuda")
 
 
+def test_bn_random_shapes():
+    """BatchNorm statistics / apply / backward at random sizes (channel counts that are no multiple of 4 or 64, pixel counts
+    that leave partial row blocks, tens of thousands of rows per channel) against torch autograd on the CPU.  No ReLU here:
+    an output within rounding distance of zero may get the other sign from two correct implementations, and the mask of
+    the gradient check is taken from ours (the fixed-size cases cover ReLU)."""
+    import numpy as np
+    rng = np.random.RandomState(11)
+    for i in range(24):
+        C = int(rng.choice([3, 19, 24, 64, 100, 128, 256, 513, 1024]))
+        shape = (int(rng.randint(1, 5)), int(rng.randint(3, 70)), int(rng.randint(3, 90)))
+        KC.run_bn_case("cuda", C=C, act=str(rng.choice(["none", "elu"])), residual=bool(rng.rand() < 0.5),
+                       train=bool(rng.rand() < 0.8), seed=i, shape=shape)
+
+
 def test_conv_random_geometries():
     """60 random geometries (fixed seed; tools/stress_conv.py runs more): forward, fused statistics, both data gradients and
     the weight gradient against torch autograd on the CPU"""
