@@ -185,6 +185,35 @@ def run_conv_case(case, device, seed=0):
 # ---------------------------------------------------------------------------------------------
 # BatchNorm / activation / pooling / resize
 # ---------------------------------------------------------------------------------------------
+def run_dgrad_epilogue_variants(case, device, seed=0):
+    """the data-gradient's epilogue variants against its own plain result: accumulate onto an existing gradient
+    (single-source, non-upsampled convolutions) and the derivative of the activation whose output the convolution read"""
+    name, B, Hh, W, C0, C1, up0, Cout, k, stride, dil, pad, reflect, bias, act = case
+    if C0 < 4 or Cout == 1:
+        return
+    gen = torch.Generator().manual_seed(1000 + seed)
+    g = H.ConvGeom(C0, Cout, k, stride, dil, pad, reflect, C1, up0)
+    w = (torch.randn(Cout, C0 + C1, k, k, generator=gen) * 0.2).to(device)
+    wd = H.pack_weight(w, True)
+    Ho, Wo = g.out_hw(Hh, W)
+    dz = torch.randn(B, Ho, Wo, Cout, generator=gen).to(device)
+    dx0, dx1 = H.conv_dgrad(g, dz, wd, w, (Hh, W))
+    h0, w0 = (Hh // 2, W // 2) if up0 else (Hh, W)
+    ysaved = F.elu(torch.randn(B, h0, w0, C0, generator=gen)).to(device)
+    der = torch.where(ysaved > 0, torch.ones_like(ysaved), ysaved + 1.0)
+    ag0, ag1 = H.conv_dgrad(g, dz, wd, w, (Hh, W), actgrad=(ysaved, "elu"))
+    assert_close(ag0, dx0 * der, rtol=1e-5, atol=1e-6, what=name + " dgrad x ELU'")
+    if dx1 is not None:
+        assert torch.equal(ag1, dx1), name + " dgrad of the skip source is not touched by the activation derivative"
+    if not up0 and not C1:
+        base = torch.randn(B, Hh, W, C0, generator=gen).to(device)
+        want = base + dx0
+        acc, _ = H.conv_dgrad(g, dz, wd, w, (Hh, W), accumulate_into=base)
+        if acc is None:          # this shape cannot accumulate in the epilogue: the caller adds
+            acc = base + dx0
+        assert_close(acc, want, rtol=1e-6, atol=1e-6, what=name + " dgrad accumulate")
+
+
 def run_bn_case(device, C=24, act="relu", residual=True, train=True, drop_p=0.0, seed=0, shape=(3, 5, 7)):
     gen = torch.Generator().manual_seed(seed)
     B, Hh, W = shape

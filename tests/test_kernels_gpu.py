@@ -45,7 +45,9 @@ def test_conv_random_geometries():
     import numpy as np
     rng = np.random.RandomState(2024)
     for i in range(60):
-        KC.run_conv_case(KC.random_conv_case(rng, i), "cuda", seed=i)
+        case = KC.random_conv_case(rng, i)
+        KC.run_conv_case(case, "cuda", seed=i)
+        KC.run_dgrad_epilogue_variants(case, "cuda", seed=i)
 
 
 BIG_CONV = [

@@ -23,6 +23,7 @@ def main():
         case = KC.random_conv_case(rng, i)
         try:
             KC.run_conv_case(case, "cuda", seed=seed + i)
+            KC.run_dgrad_epilogue_variants(case, "cuda", seed=seed + i)
             print("ok   %s" % (case,), flush=True)
         except AssertionError as e:
             bad += 1
