@@ -39,9 +39,12 @@ def test_full_model_vs_reference_vectors(golden, name):
     MC.run_full_model("cuda", golden, name)
 
 
-@pytest.mark.parametrize("name", ["r50_mono", "r101_jsd", "r101_pad"])
-def test_big_models_vs_oracle(name):
-    """ResNet-50/101 (dilated layer4, ASPP) whole-model step at 64x128 against the CPU oracle on identical weights"""
+@pytest.mark.parametrize("name,shape", [("r50_mono", (2, 64, 128)), ("r101_jsd", (2, 64, 128)), ("r101_pad", (2, 64, 128)),
+                                        ("r50_mono", (3, 96, 160)), ("r101_jsd", (2, 96, 224))],
+                         ids=["r50_mono", "r101_jsd", "r101_pad", "r50_mono_3x96x160", "r101_jsd_2x96x224"])
+def test_big_models_vs_oracle(name, shape):
+    """ResNet-50/101 (dilated layer4, ASPP) whole-model step at 64x128 (and two other sizes / batches) against the CPU
+    oracle on identical weights"""
     from oracle import nets as N, photometric as P, segmix as S
     from improving_segmentation_with_selfsupervised_depth_amd.models import get_model
     from improving_segmentation_with_selfsupervised_depth_amd.loss import get_monodepth_loss
@@ -53,7 +56,7 @@ def test_big_models_vs_oracle(name):
     model.load_state_dict(sd, strict=True)
     model.cuda().train()
     MC.dropout_eval(model)
-    B, Hh, W = 2, 64, 128
+    B, Hh, W = shape
     inp = bench.synthetic_inputs(B, Hh, W, "cpu", 3)
     Kt = torch.tensor([[1.1 * W, 0, 0.5 * W, 0], [0, 1.1 * W, 0.5 * Hh, 0], [0, 0, 1, 0], [0, 0, 0, 1.0]])
     inp[("K", 0)] = Kt.unsqueeze(0).repeat(B, 1, 1)
