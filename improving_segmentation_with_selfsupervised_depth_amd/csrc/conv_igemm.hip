@@ -57,6 +57,7 @@ struct ConvP {
   // division of a GEMM row index (< 2^31) by the image size / row length without the ~30-instruction runtime division:
   // q = umulhi(n, magic) >> shift (set_divs).  d1 = Ho*Wo, d2 = Wo; for sum2x2 launches the 2x2-block counts.
   unsigned mg1, mg2; int sf1, sf2, d1, d2;
+  unsigned mgC, mgKW; int sfC, sfKW;   // the same for k / Ctot and tap / KW (generic gathers: decode_k)
   int lin;   // 1x1, stride 1, unpadded, one source at output resolution: GEMM row m IS pixel m of the input (no row decode)
 };
 
@@ -64,12 +65,17 @@ struct KInfo {  // decoded reduction index k -> tap + channel + source
   const float* src; int ld, Hs, Ws, shift, dh, dw, cc; bool valid;
 };
 
+// n / d for 0 <= n < 2^31 with the (magic, shift) pair of set_divs; d == 1 is flagged by magic == 0
+__device__ __forceinline__ int fast_div(int n, unsigned magic, int shift) {
+  return magic ? (int)(__umulhi((unsigned)n, magic) >> shift) : n;
+}
+
 __device__ __forceinline__ KInfo decode_k(const ConvP& p, int k) {
   KInfo t;
   t.valid = k < p.Ktot;
   const int kk = t.valid ? k : 0;
-  const int tap = kk / p.Ctot, c = kk - tap * p.Ctot;
-  const int kh = tap / p.KW, kw = tap - kh * p.KW;
+  const int tap = fast_div(kk, p.mgC, p.sfC), c = kk - tap * p.Ctot;
+  const int kh = fast_div(tap, p.mgKW, p.sfKW), kw = tap - kh * p.KW;
   t.dh = kh * p.dil - p.pad;
   t.dw = kw * p.dil - p.pad;
   if (c < p.C0) { t.src = p.x0; t.ld = p.ld0; t.cc = c; t.shift = p.up0; }
@@ -94,11 +100,6 @@ __device__ __forceinline__ long a_offset(const ConvP& p, const KInfo& t, int b, 
   }
   hi >>= t.shift; wi >>= t.shift;
   return ((long)(b * t.Hs + hi) * t.Ws + wi) * t.ld + t.cc;
-}
-
-// n / d for 0 <= n < 2^31 with the (magic, shift) pair of set_divs; d == 1 is flagged by magic == 0
-__device__ __forceinline__ int fast_div(int n, unsigned magic, int shift) {
-  return magic ? (int)(__umulhi((unsigned)n, magic) >> shift) : n;
 }
 
 __device__ __forceinline__ void decode_m(const ConvP& p, int m, int& b, int& hb, int& wb, bool& ok) {
@@ -154,6 +155,14 @@ __device__ __forceinline__ float4 fetch_a4(const ConvP& p, int k, int b, int hb,
   return v;
 }
 
+// float4 gather with the chunk's decoded (tap, channel) handed in: decode_k once per chunk and thread, not once per tile row
+__device__ __forceinline__ float4 fetch_a4_at(const ConvP& p, const KInfo& t, int b, int hb, int wb, bool row_ok) {
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (!row_ok || !t.valid) return v;
+  const long off = a_offset(p, t, b, hb, wb);
+  if (off >= 0) v = *reinterpret_cast<const float4*>(t.src + off);
+  return v;
+}
 template <bool VEC>
 __device__ __forceinline__ float4 fetch_w4(const ConvP& p, int n, int k) {
   float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -292,8 +301,14 @@ __global__ __launch_bounds__(256, VAR == 6 ? 3 : 2) void conv_igemm_kernel(ConvP
     const int kcl = kc < nchunks ? kc : nchunks - 1;
     {
       const int k = kcl * BK + 4 * kq;
+      if constexpr (VEC) {
+        const KInfo t = decode_k(p, k);
 #pragma unroll
-      for (int i = 0; i < AR; ++i) ra[i] = fetch_a4<VEC>(p, k, rb[i], rh[i], rw[i], rok[i]);
+        for (int i = 0; i < AR; ++i) ra[i] = fetch_a4_at(p, t, rb[i], rh[i], rw[i], rok[i]);
+      } else {
+#pragma unroll
+        for (int i = 0; i < AR; ++i) ra[i] = fetch_a4<VEC>(p, k, rb[i], rh[i], rw[i], rok[i]);
+      }
 #pragma unroll
       for (int i = 0; i < BR; ++i) rbv[i] = fetch_w4<VEC>(p, n0 + r0 + RP * i, k);
     }
@@ -1544,6 +1559,8 @@ void set_divs(ConvP& p) {
   p.d2 = p.sum2x2 ? (p.Wo >> 1) : p.Wo;
   magic_for(p.d1, p.mg1, p.sf1);
   magic_for(p.d2, p.mg2, p.sf2);
+  magic_for(p.Ctot, p.mgC, p.sfC);
+  magic_for(p.KW, p.mgKW, p.sfKW);
 }
 
 ConvP make_params(const segsde_conv_desc* d, const float* x0, const float* x1, const float* w, const float* bias,
