@@ -102,6 +102,19 @@ def random_conv_case(rng, i):
     if up0:
         Hh, W = Hh + (Hh & 1), W + (W & 1)
     B = int(rng.choice([1, 2, 3, 5]))
+    r = rng.rand()
+    if r < 0.08:        # network stems: 7x7 stride 2 on 3 / 4 / 6 / 8 channels
+        k, stride, dil, pad, reflect, up0, C1 = 7, 2, 1, 3, False, False, 0
+        C0, Cout = int(rng.choice([3, 4, 6, 8])), 64
+    elif r < 0.16:      # disparity heads (Cout = 1, stencil kernels) and class heads (skinny kernels)
+        C0, C1, up0, stride, dil = int(rng.choice([64, 128, 256])), 0, False, 1, 1
+        if rng.rand() < 0.5:
+            k, pad, reflect, Cout = 3, 1, bool(rng.rand() < 0.7), 1
+        else:
+            k, pad, reflect, Cout = 1, 0, False, int(rng.choice([19, 3, 22]))
+    elif r < 0.24:      # channel counts that are no multiple of 32 (float4 gather) or of 4 (scalar gather)
+        C0, C1, up0 = int(rng.choice([19, 20, 36, 12, 5])), 0, False
+        Cout = int(rng.choice([8, 19, 24, 40]))
     bias = bool(rng.rand() < 0.5)
     act = str(rng.choice(["none", "none", "elu"]))     # (no ReLU: a sign flip of a pre-activation next to zero between two
     #                                                       correct implementations changes the mask the gradient is checked with)
