@@ -917,6 +917,48 @@ __global__ __launch_bounds__(256, VAR == 6 ? 3 : 2) void conv_igemm_kernel(ConvP
     return;
   }
 
+  // Fused 2x2 sum (data-gradient through the nearest x2 upsample), full tile on the summed side of the split: the four
+  // members of a block are four registers of one lane (patch-major rows); the BM/4 x BN tile of sums goes through LDS and
+  // leaves as 16-byte buffer stores, the activation derivative (saved output at half resolution) is read the same way --
+  // the per-value path below pays 64-bit address arithmetic and a scattered 4-byte load + store for every sum
+  if (pe.sum2x2 && pe.vecout && m0 + BM <= pe.M && (n0 + BN < pe.ne ? n0 + BN : pe.ne) <= pe.nsplit) {
+    float* Ct = smem;                      // [BM / 4][BN] floats
+    {
+      const int col = lane & 31, rhalf = lane >> 5;
+      float* cw = Ct + (wm * TM * 8 + rhalf) * BN + wn * TN * 32 + col;
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+            cw[(i * 8 + 2 * g) * BN + j * 32] =
+                (acc[i][j][4 * g] + acc[i][j][4 * g + 1]) + (acc[i][j][4 * g + 2] + acc[i][j][4 * g + 3]);
+    }
+    __syncthreads();
+    constexpr int CQ = BN / 4, RPP = 256 / CQ, NR = (BM / 4) / RPP;
+    const int cq = tid % CQ, rr = tid / CQ, n = n0 + 4 * cq;
+    const unsigned ld = (unsigned)pe.ldy;
+    const segsde_rsrc rd = segsde_make_rsrc(pe.y + ((long)(m0 >> 2) * pe.ldy + n0));
+    const unsigned vo = n < pe.ne ? ((unsigned)rr * ld + 4u * cq) * 4u : SEGSDE_OOB;
+    const bool ag = pe.agy != nullptr;
+    const segsde_rsrc ra = segsde_make_rsrc(ag ? pe.agy + ((long)(m0 >> 2) * pe.agld + n0) : pe.zero);
+    const unsigned voa = (ag && n < pe.ne) ? ((unsigned)rr * (unsigned)pe.agld + 4u * cq) * 4u : SEGSDE_OOB;
+    unsigned so = 0, soa = 0;
+#pragma unroll
+    for (int t = 0; t < NR; ++t) {
+      float4 v = *reinterpret_cast<const float4*>(Ct + (rr + t * RPP) * BN + 4 * cq);
+      if (ag) {
+        const float4 yv = segsde_buffer_load4(ra, voa, soa);
+        v.x *= segsde_act_grad_from_out(yv.x, pe.agkind); v.y *= segsde_act_grad_from_out(yv.y, pe.agkind);
+        v.z *= segsde_act_grad_from_out(yv.z, pe.agkind); v.w *= segsde_act_grad_from_out(yv.w, pe.agkind);
+      }
+      segsde_buffer_store4(rd, vo, so, v);
+      so += (unsigned)RPP * ld * 4u; soa += (unsigned)RPP * (unsigned)pe.agld * 4u;
+    }
+    return;
+  }
+
   // epilogue: bias + activation, channel-split store (concat data-gradients go to two tensors)
   const int col = lane & 31, rhalf = lane >> 5;
 #pragma unroll
