@@ -392,6 +392,7 @@ __global__ __launch_bounds__(256, VAR == 6 ? 3 : 2) void conv_igemm_kernel(ConvP
     const segsde_rsrc rsw = segsde_make_rsrc(p.w);
     unsigned voff[AR], voffB[BR];
     bool wave_bord = false, wave_corner = false;
+    int bflag[AR];
     {
       int anyb = 0, anyc = 0;
 #pragma unroll
@@ -399,6 +400,7 @@ __global__ __launch_bounds__(256, VAR == 6 ? 3 : 2) void conv_igemm_kernel(ConvP
         rb[i] -= b0;
         const bool br = rok[i] && (rh[i] == 1 || rh[i] == p.H - 2), bc = rok[i] && (rw[i] == 1 || rw[i] == p.W - 2);
         anyb |= (br || bc) ? 1 : 0; anyc |= (br && bc) ? 1 : 0;
+        bflag[i] = !rok[i] ? 0 : ((rh[i] == 1 ? 1 : 0) | (rh[i] == p.H - 2 ? 2 : 0) | (rw[i] == 1 ? 4 : 0) | (rw[i] == p.W - 2 ? 8 : 0));
       }
       if constexpr (ADJ) { wave_bord = __any(anyb) != 0; wave_corner = __any(anyc) != 0; }
     }
@@ -474,25 +476,45 @@ __global__ __launch_bounds__(256, VAR == 6 ? 3 : 2) void conv_igemm_kernel(ConvP
     // the 4.6 KB, and a wave that owns a corner-adjacent pixel (up to three extras) keeps recomputing.
     constexpr bool XTAB = ADJ && BN >= 128 && VAR != 8;   // var=8: A/B knob
     const bool xtab = XTAB && p.W >= 128;   // narrow images: every wave is bordered, building the second bank costs more than it saves
+    // The extra pre-image of a border row from its MAIN offset (adjoint: 3x3, pad 1, one source at full resolution): row 1
+    // with the tap dh = +1 reads row 2 and also collects row 0, two rows up; row H-2 with dh = -1 two rows down; columns
+    // likewise.  A bordered wave of a tile without the second table bank does this per tap: a compare, a select and an
+    // add per row and axis instead of the ~250 VALU of the full compute_voff.  bflag[i]: bit 0 row 1, bit 1 row H-2,
+    // bit 2 column 1, bit 3 column W-2 (a corner-adjacent pixel has a row and a column bit: those waves recompute).
+    auto extra_from_main = [&](int kh, int kw) {
+      const int rbit = kh == 2 ? 1 : (kh == 0 ? 2 : 0), cbit = kw == 2 ? 4 : (kw == 0 ? 8 : 0);
+      const unsigned rstep = 2u * s0.Ws * s0.ld * 4u, cstep = 2u * s0.ld * 4u;
+      const unsigned rdelta = kh == 2 ? 0u - rstep : rstep, cdelta = kw == 2 ? 0u - cstep : cstep;
+#pragma unroll
+      for (int i = 0; i < AR; ++i) {
+        const bool live = (int)voff[i] >= 0;           // the main pre-image exists (not the out-of-range marker)
+        voffX[i] = (live && (bflag[i] & rbit)) ? voff[i] + rdelta : ((live && (bflag[i] & cbit)) ? voff[i] + cdelta : SEGSDE_OOB);
+      }
+    };
+    const bool tiny = ADJ && (p.H < 3 || p.W < 3);   // row 1 is also row H-2's neighbour: the main pre-image can be missing
     auto tab_build = [&](auto wadj_tag) {
       constexpr bool WADJ = decltype(wadj_tag)::value;
-      if constexpr (WADJ && !XTAB) return;
-      if (WADJ && (wave_corner || !xtab)) return;
+      if (WADJ && (wave_corner || tiny)) return;
+      const bool with_x = WADJ && xtab;
       const int T = WADJ ? ntaps : (p.C0 < p.Ctot ? 2 : 1) * ntaps;
       for (int t = 1 + kq; t < T; t += KQ) {   // entry 0 is the first tap, computed directly and never revisited
         const bool in0 = t < ntaps;
         const int tt = in0 ? t : t - ntaps, kh = tt / p.KW, kw = tt - kh * p.KW;
-        compute_voff(in0, kh, kw, 0u, wadj_tag, [&](int i, unsigned v, unsigned vx) {
-          tab[t * BM + r0 + RP * i] = v;
-          if constexpr (WADJ) tab[(ntaps + t) * BM + r0 + RP * i] = vx;
-        });
+        if (with_x) {
+          compute_voff(in0, kh, kw, 0u, wadj_tag, [&](int i, unsigned v, unsigned vx) {
+            tab[t * BM + r0 + RP * i] = v;
+            if constexpr (XTAB) tab[(ntaps + t) * BM + r0 + RP * i] = vx;
+          });
+        } else {
+          compute_voff(in0, kh, kw, 0u, std::false_type{}, [&](int i, unsigned v, unsigned) { tab[t * BM + r0 + RP * i] = v; });
+        }
       }
     };
     // direct: the table is not visible yet (prologue, before the first barrier)
     auto tap_update = [&](auto wadj_tag, bool direct) {
       constexpr bool WADJ = decltype(wadj_tag)::value;
       const bool in0 = cs.c0 < p.C0;
-      if (direct || (WADJ && (!xtab || wave_corner))) {
+      if (direct || (WADJ && (wave_corner || tiny))) {
         compute_voff(in0, cs.kh, cs.kw, 4u * kqs, wadj_tag, [&](int i, unsigned v, unsigned vx) {
           voff[i] = v;
           if constexpr (WADJ) voffX[i] = vx;
@@ -500,9 +522,14 @@ __global__ __launch_bounds__(256, VAR == 6 ? 3 : 2) void conv_igemm_kernel(ConvP
       } else {
         const unsigned* tp = tab + ((in0 ? 0 : ntaps) + cs.kh * p.KW + cs.kw) * BM + r0;
 #pragma unroll
-        for (int i = 0; i < AR; ++i) {
-          voff[i] = tp[RP * i] + 16u * kqs;
-          if constexpr (WADJ) voffX[i] = tp[ntaps * BM + RP * i] + 16u * kqs;
+        for (int i = 0; i < AR; ++i) voff[i] = tp[RP * i] + 16u * kqs;
+        if constexpr (WADJ) {
+          if (xtab) {
+#pragma unroll
+            for (int i = 0; i < AR; ++i) voffX[i] = tp[ntaps * BM + RP * i] + 16u * kqs;
+          } else {
+            extra_from_main(cs.kh, cs.kw);
+          }
         }
       }
     };
@@ -923,6 +950,19 @@ __global__ __launch_bounds__(256, VAR == 6 ? 3 : 2) void conv_igemm_kernel(ConvP
   // the per-value path below pays 64-bit address arithmetic and a scattered 4-byte load + store for every sum
   if (pe.sum2x2 && pe.vecout && m0 + BM <= pe.M && (n0 + BN < pe.ne ? n0 + BN : pe.ne) <= pe.nsplit) {
     float* Ct = smem;                      // [BM / 4][BN] floats
+    constexpr int CQ = BN / 4, RPP = 256 / CQ, NR = (BM / 4) / RPP;
+    const int cq = tid % CQ, rr = tid / CQ, n = n0 + 4 * cq;
+    // the saved activation outputs are requested first: they do not depend on the accumulators, and their latency then
+    // overlaps the trip of the sums through LDS
+    const bool ag = pe.agy != nullptr;
+    const segsde_rsrc ra = segsde_make_rsrc(ag ? pe.agy + ((long)(m0 >> 2) * pe.agld + n0) : pe.zero);
+    const unsigned voa = (ag && n < pe.ne) ? ((unsigned)rr * (unsigned)pe.agld + 4u * cq) * 4u : SEGSDE_OOB;
+    float4 yv[NR];
+    if (ag) {
+      unsigned soa = 0;
+#pragma unroll
+      for (int t = 0; t < NR; ++t) { yv[t] = segsde_buffer_load4(ra, voa, soa); soa += (unsigned)RPP * (unsigned)pe.agld * 4u; }
+    }
     {
       const int col = lane & 31, rhalf = lane >> 5;
       float* cw = Ct + (wm * TM * 8 + rhalf) * BN + wn * TN * 32 + col;
@@ -936,25 +976,19 @@ __global__ __launch_bounds__(256, VAR == 6 ? 3 : 2) void conv_igemm_kernel(ConvP
                 (acc[i][j][4 * g] + acc[i][j][4 * g + 1]) + (acc[i][j][4 * g + 2] + acc[i][j][4 * g + 3]);
     }
     __syncthreads();
-    constexpr int CQ = BN / 4, RPP = 256 / CQ, NR = (BM / 4) / RPP;
-    const int cq = tid % CQ, rr = tid / CQ, n = n0 + 4 * cq;
     const unsigned ld = (unsigned)pe.ldy;
     const segsde_rsrc rd = segsde_make_rsrc(pe.y + ((long)(m0 >> 2) * pe.ldy + n0));
     const unsigned vo = n < pe.ne ? ((unsigned)rr * ld + 4u * cq) * 4u : SEGSDE_OOB;
-    const bool ag = pe.agy != nullptr;
-    const segsde_rsrc ra = segsde_make_rsrc(ag ? pe.agy + ((long)(m0 >> 2) * pe.agld + n0) : pe.zero);
-    const unsigned voa = (ag && n < pe.ne) ? ((unsigned)rr * (unsigned)pe.agld + 4u * cq) * 4u : SEGSDE_OOB;
-    unsigned so = 0, soa = 0;
+    unsigned so = 0;
 #pragma unroll
     for (int t = 0; t < NR; ++t) {
       float4 v = *reinterpret_cast<const float4*>(Ct + (rr + t * RPP) * BN + 4 * cq);
       if (ag) {
-        const float4 yv = segsde_buffer_load4(ra, voa, soa);
-        v.x *= segsde_act_grad_from_out(yv.x, pe.agkind); v.y *= segsde_act_grad_from_out(yv.y, pe.agkind);
-        v.z *= segsde_act_grad_from_out(yv.z, pe.agkind); v.w *= segsde_act_grad_from_out(yv.w, pe.agkind);
+        v.x *= segsde_act_grad_from_out(yv[t].x, pe.agkind); v.y *= segsde_act_grad_from_out(yv[t].y, pe.agkind);
+        v.z *= segsde_act_grad_from_out(yv[t].z, pe.agkind); v.w *= segsde_act_grad_from_out(yv[t].w, pe.agkind);
       }
       segsde_buffer_store4(rd, vo, so, v);
-      so += (unsigned)RPP * ld * 4u; soa += (unsigned)RPP * (unsigned)pe.agld * 4u;
+      so += (unsigned)RPP * ld * 4u;
     }
     return;
   }
