@@ -46,7 +46,8 @@ class weight_pack_scope:
 
     @staticmethod
     def _prepack(model, scope_id):
-        convs = [m for m in model.modules() if isinstance(m, Conv2d) and m.weight.is_contiguous()
+        from .. import _lib
+        convs = [m for m in model.modules() if isinstance(m, Conv2d) and (m.weight.is_cuda or _lib.HOST_POINTERS_OK) and m.weight.is_contiguous()
                  and m.weight.dtype == torch.float32 and m.in_channels % 4 == 0]   # (stems pad their weight per call)
         if not convs:
             return
