@@ -354,6 +354,8 @@ def run_misc_cases(device):
     # colsum with a pitch
     wide = torch.randn(50, 40, generator=gen).to(device)
     assert_close(H.colsum(wide[:, 8:24]), wide[:, 8:24].cpu().sum(0), what="colsum")
+    one = torch.randn(2, 64, 64, 1, generator=gen) + 0.3     # a single column (bias gradient of a disparity head)
+    assert_close(H.colsum(d(one)), one.double().sum().float().reshape(1), rtol=1e-5, what="colsum of one column")
 
 
 # ---------------------------------------------------------------------------------------------
