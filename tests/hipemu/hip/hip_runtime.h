@@ -50,6 +50,7 @@ struct alignas(16) float4 { float x, y, z, w; };
 struct int2 { int x, y; };
 struct alignas(16) int4 { int x, y, z, w; };
 struct uchar4 { unsigned char x, y, z, w; };
+inline uchar4 make_uchar4(unsigned char x, unsigned char y, unsigned char z, unsigned char w) { return uchar4{x, y, z, w}; }
 inline float4 make_float4(float a, float b, float c, float d) { return float4{a, b, c, d}; }
 inline float2 make_float2(float a, float b) { return float2{a, b}; }
 

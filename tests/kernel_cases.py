@@ -301,6 +301,9 @@ def run_misc_cases(device):
     assert torch.equal(nchw(yo).cpu(), y.detach())
     dx = H.maxpool_backward(d(nhwc(gy)), idx, (2, 9, 11, 12))
     assert_close(nchw(dx), x.grad, what="maxpool bwd")
+    x6 = F.relu(torch.randn(1, 6, 8, 7, generator=gen))          # channel count off the four-channel kernels
+    yo6, idx6 = H.maxpool_forward(d(nhwc(x6)))
+    assert torch.equal(nchw(yo6).cpu(), F.max_pool2d(x6, 3, 2, 1)), "maxpool, scalar kernel"
     # bilinear resize, both conventions, up and down, and 1x1 -> HxW (ASPP pooling)
     for (hi, wi, ho, wo, ac) in [(5, 7, 10, 14, False), (5, 7, 11, 13, True), (8, 12, 4, 6, False), (1, 1, 6, 9, False),
                                  (4, 8, 32, 64, False), (6, 6, 6, 6, False)]:
