@@ -527,6 +527,47 @@ __global__ __launch_bounds__(256) void gap_fwd_kernel(const float* x, int ldx, l
     else part[((long)b * nz + blockIdx.z) * C + c] = t;
   }
 }
+// the same with four channels per thread (16-byte loads): 16 channel quads x 16 row lanes per block, four independent
+// accumulator sets per lane
+__global__ __launch_bounds__(256) void gap_fwd4_kernel(const float* x, int ldx, long HW, int C, double scale, float* y, int ldy,
+                                                       double* part) {
+  SEGSDE_SMEM;
+  double* sh = reinterpret_cast<double*>(segsde_smem);   // [16 row lanes][64 channels]
+  const int tq = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int c = blockIdx.y * SLAB + 4 * tq, b = blockIdx.x, nz = gridDim.z;
+  const long per = (HW + nz - 1) / nz, m_lo = per * blockIdx.z, m_hi = m_lo + per < HW ? m_lo + per : HW;
+  double s[4][4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s[u][j] = 0.0;
+  if (c < C) {
+    const float* xb = x + (long)b * HW * ldx + c;
+    for (long m = m_lo + ty; m < m_hi; m += 16 * 4) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const long mm = m + (long)u * 16;
+        if (mm < m_hi) {
+          const float4 v = *reinterpret_cast<const float4*>(xb + mm * ldx);
+          s[u][0] += (double)v.x; s[u][1] += (double)v.y; s[u][2] += (double)v.z; s[u][3] += (double)v.w;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) sh[ty * SLAB + 4 * tq + j] = (s[0][j] + s[1][j]) + (s[2][j] + s[3][j]);
+  __syncthreads();
+  if (threadIdx.x < SLAB) {
+    const int cc = blockIdx.y * SLAB + threadIdx.x;
+    if (cc < C) {
+      double t = 0.0;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) t += sh[r * SLAB + threadIdx.x];
+      if (nz == 1) y[(long)b * ldy + cc] = (float)(t * scale);
+      else part[((long)b * nz + blockIdx.z) * C + cc] = t;
+    }
+  }
+}
 __global__ __launch_bounds__(256) void gap_finalize_kernel(const double* part, int nz, int B, int C, double scale, float* y, int ldy) {
   const long e = blockIdx.x * 256L + threadIdx.x;
   if (e >= (long)B * C) return;
@@ -807,8 +848,12 @@ extern "C" int segsde_resize_bilinear_backward(const float* dy, int lddy, int B,
   if (!dy || !dx) return SEGSDE_ERR_NULL;
   if (Hi == 1 && Wi == 1) {
     // a 1x1 source is broadcast by the forward pass (ASPP image-pooling branch): its gradient is the plain per-image sum
-    hipLaunchKernelGGL(gap_fwd_kernel, dim3(B, (C + SLAB - 1) / SLAB), dim3(256), RLANES * SLAB * sizeof(double), ST(stream),
-                       dy, lddy, (long)Ho * Wo, C, 1.0, dx, lddx, (double*)nullptr);
+    if (C % 4 == 0 && lddy % 4 == 0 && al16(dy))
+      hipLaunchKernelGGL(gap_fwd4_kernel, dim3(B, (C + SLAB - 1) / SLAB), dim3(256), 16 * SLAB * sizeof(double), ST(stream), dy,
+                         lddy, (long)Ho * Wo, C, 1.0, dx, lddx, (double*)nullptr);
+    else
+      hipLaunchKernelGGL(gap_fwd_kernel, dim3(B, (C + SLAB - 1) / SLAB), dim3(256), RLANES * SLAB * sizeof(double), ST(stream),
+                         dy, lddy, (long)Ho * Wo, C, 1.0, dx, lddx, (double*)nullptr);
     SEGSDE_CHECK_LAUNCH();
     return 0;
   }
@@ -838,8 +883,13 @@ extern "C" int segsde_global_avgpool_forward(const float* x, int ldx, int B, lon
   if (B <= 0 || HW <= 0 || C <= 0) return SEGSDE_ERR_SHAPE;
   const int nz = gap_slices(B, HW, C);
   if (nz > 1 && (!ws || ws_bytes < segsde_global_avgpool_workspace(B, HW, C))) return SEGSDE_ERR_WORKSPACE;
-  hipLaunchKernelGGL(gap_fwd_kernel, dim3(B, (C + SLAB - 1) / SLAB, nz), dim3(256), RLANES * SLAB * sizeof(double), ST(stream),
-                     x, ldx, HW, C, 1.0 / (double)HW, y, C, (double*)ws);
+  if (C % 4 == 0 && ldx % 4 == 0 && al16(x)) {
+    hipLaunchKernelGGL(gap_fwd4_kernel, dim3(B, (C + SLAB - 1) / SLAB, nz), dim3(256), 16 * SLAB * sizeof(double), ST(stream), x,
+                       ldx, HW, C, 1.0 / (double)HW, y, C, (double*)ws);
+  } else {
+    hipLaunchKernelGGL(gap_fwd_kernel, dim3(B, (C + SLAB - 1) / SLAB, nz), dim3(256), RLANES * SLAB * sizeof(double), ST(stream),
+                       x, ldx, HW, C, 1.0 / (double)HW, y, C, (double*)ws);
+  }
   SEGSDE_CHECK_LAUNCH();
   if (nz > 1) {
     hipLaunchKernelGGL(gap_finalize_kernel, dim3(segsde_cdiv((long)B * C, 256)), dim3(256), 0, ST(stream), (const double*)ws, nz,

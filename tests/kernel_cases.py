@@ -315,6 +315,9 @@ def run_misc_cases(device):
         assert_close(nchw(yo), y, what="resize fwd %s" % ((hi, wi, ho, wo, ac),))
         dx = H.resize_bilinear_backward(d(nhwc(gy)), (hi, wi), ac)
         assert_close(nchw(dx), x.grad, what="resize bwd %s" % ((hi, wi, ho, wo, ac),))
+    gy = torch.randn(2, 8, 6, 9, generator=gen)      # 1x1 source with a channel count of the four-channel kernel
+    assert_close(nchw(H.resize_bilinear_backward(d(nhwc(gy)), (1, 1), False)), gy.sum((2, 3), keepdim=True), rtol=1e-5, atol=1e-6,
+                 what="resize bwd to 1x1, 8 channels")
     # global average pool
     x = torch.randn(3, 70, 5, 6, generator=gen).requires_grad_(True)
     y = x.mean((2, 3), keepdim=True)
@@ -326,6 +329,8 @@ def run_misc_cases(device):
     # few images x few channels over many pixels: the pixel range is sliced over blocks, partial sums in a workspace
     x = torch.randn(1, 20, 37, 41, generator=gen) + 3.0
     assert_close(nchw(H.global_avgpool(d(nhwc(x)))), x.mean((2, 3), keepdim=True), rtol=1e-6, what="gap fwd sliced")
+    x = torch.randn(3, 72, 5, 6, generator=gen) - 1.0          # four channels per thread, one slice
+    assert_close(nchw(H.global_avgpool(d(nhwc(x)))), x.mean((2, 3), keepdim=True), rtol=1e-6, atol=1e-7, what="gap fwd, 4 channels per thread")
     # gate
     f = torch.randn(2, 4, 5, 8, generator=gen).requires_grad_(True)
     a = torch.randn(2, 4, 5, 8, generator=gen).requires_grad_(True)
