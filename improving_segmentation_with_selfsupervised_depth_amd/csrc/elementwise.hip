@@ -631,7 +631,23 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* x, int B
                                                            float* y, int ldy) {
   // every one of the ldy channels of a pixel is written (channels past C: zeros -- the padded network input needs no
   // separate memset), so the stores of a wave are one contiguous run
-  const long HW = (long)H * W, total = (long)B * HW * ldy;
+  const long HW = (long)H * W;
+  if (ldy <= 8 && (ldy & 3) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0) {
+    // network inputs (3 / 6 planes -> 4 / 8 channels): one pixel per thread -- neighbouring threads read neighbouring
+    // pixels of each plane and store neighbouring 16 / 32-byte pixels
+    const long npix = (long)B * HW;
+    for (long m = blockIdx.x * 256L + threadIdx.x; m < npix; m += (long)gridDim.x * 256) {
+      const long b = m / HW, p = m - b * HW;
+      float v[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) v[c] = (c < C && c < ldy) ? (x[(b * C + c) * HW + p] - mean) / sd : 0.f;
+      float4* q = reinterpret_cast<float4*>(y + m * ldy);
+      q[0] = make_float4(v[0], v[1], v[2], v[3]);
+      if (ldy == 8) q[1] = make_float4(v[4], v[5], v[6], v[7]);
+    }
+    return;
+  }
+  const long total = (long)B * HW * ldy;
   for (long e = blockIdx.x * 256L + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
     const int c = (int)(e % ldy); const long m = e / ldy; const long b = m / HW, p = m - b * HW;
     y[e] = c < C ? (x[(b * C + c) * HW + p] - mean) / sd : 0.f;

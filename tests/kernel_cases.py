@@ -356,6 +356,10 @@ def run_misc_cases(device):
         assert_close(nchw(padded[..., :3]), (img - 0.45) / 0.225, rtol=1e-6, atol=1e-6, what="img norm, padded")
         padded.fill_(7.0)   # the next call probably gets this very block back from the caching allocator
         del padded
+    img6 = torch.rand(2, 6, 5, 7, generator=gen)       # a pose-network pair: 6 planes -> 8 channels
+    p8 = H.nchw_to_nhwc(d(img6), 0.45, 0.225, pad_to=8)
+    assert p8.shape[-1] == 8 and float(p8[..., 6:].abs().max()) == 0.0
+    assert_close(nchw(p8[..., :6]), (img6 - 0.45) / 0.225, rtol=1e-6, atol=1e-6, what="img norm, 6 -> 8 channels")
     t = torch.randn(2, 6, 10, 7, generator=gen)
     assert torch.equal(H.nhwc_to_nchw(d(t)).cpu(), nchw(t))
     assert torch.equal(H.nchw_to_nhwc(d(nchw(t))).cpu(), t)
