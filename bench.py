@@ -111,6 +111,24 @@ def param_groups(model, opt):
     return torch.optim.SGD([{"params": enc, "lr": 1e-3}, {"params": rest}], lr=1e-2, momentum=0.9, weight_decay=5e-4)
 
 
+def csrc_sha256():
+    """fingerprint of the kernel sources: committed PMC summaries carry it, a summary of other sources is refused"""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    base = os.path.join(ROOT, "improving_segmentation_with_selfsupervised_depth_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(base, "*.hip")) + glob.glob(os.path.join(base, "*.h"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
+def newest_profile(pattern):
+    import glob
+    c = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
+    return c[-1] if c else None
+
+
 def cpu_model_name():
     try:
         for line in open("/proc/cpuinfo"):
@@ -255,6 +273,10 @@ def main():
     optimizer = param_groups(model, opt_name)
     loss_obj = get_monodepth_loss(loss_cfg(B, Hh, W), is_train=True)
     reducer = GradAllReducer(model, always=force_reducer) if (world > 1 or force_reducer) else None
+    # identical initial parameters (seed 42 above + the reducer's broadcast), then INDEPENDENT dropout / tie-break
+    # / augmentation streams per replica
+    from improving_segmentation_with_selfsupervised_depth_amd.ddp import seed_per_rank
+    rank_seed = seed_per_rank(42, rank)
     inputs = synthetic_inputs(B, Hh, W, dev, 1234 + rank, with_labels=cfg.get("segmentation_name") is not None)
     clip = 10.0 if opt_name == "sgd" else None
     unlabeled = args.workload == "cfg5"
@@ -265,6 +287,15 @@ def main():
         for p_ in ema_model.parameters():
             p_.detach_()
         unlabeled_inputs = synthetic_inputs(B, Hh, W, dev, 4321 + rank, with_labels=False)
+        # exp-212 (experiments.py:343-357) sets mix_use_gt: samples of the unlabeled loader that carry a label hand their
+        # one-hot ground truth to the mix instead of the teacher's softmax (train.py:667-672).  Half of the batch is
+        # flagged, with one-hot planes in the loader's dtype / layout (int64 [19,H,W], all zero on ignored pixels).
+        g_ = torch.Generator().manual_seed(777 + rank)
+        lbl_u = torch.randint(0, 19, (B, Hh, W), generator=g_)
+        lbl_u[torch.rand(B, Hh, W, generator=g_) < 0.05] = 19
+        unlabeled_inputs["onehot_lbl"] = torch.nn.functional.one_hot(lbl_u, 21)[..., :19].permute(0, 3, 1, 2).contiguous().to(dev)
+        unlabeled_inputs["is_labeled"] = (torch.arange(B) % 2 == 0).to(dev)
+        del lbl_u
     it = [0]
 
     def nosync():
@@ -296,7 +327,7 @@ def main():
             L_u, mono_u = T.train_step_segmentation_unlabeled(
                 model, ema_model, loss_obj, unlabeled_inputs, mix_mask="depthcomp", depthmix_online_depth=True,
                 monodepth_lambda=1.0, consistency_weight=1.0, backward_first_pseudo_label=False, depthcomp_margin=0.03,
-                depthcomp_foreground_threshold=0.0, color_jitter=True, blur=True, reducer=reducer)
+                depthcomp_foreground_threshold=0.0, color_jitter=True, blur=True, reducer=reducer, mix_use_gt=True)
             total = total.detach() + L_u.detach() + mono_u.detach()
         else:
             total.backward()
@@ -335,32 +366,44 @@ def main():
     torch.cuda.reset_peak_memory_stats(dev)
     prof = None if args.no_kernel_timing else []
     H.PROFILE = prof
+    # per-step times without a host synchronisation inside the timed region: one HIP event per step boundary on the
+    # launch stream (the device executes the steps back to back; the host runs ahead)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for i in range(args.steps):
         last = step()
+        marks[i + 1].record()
     barrier()
     dt = time.perf_counter() - t0
     H.PROFILE = None
+    step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
+    med_ms = float(np.median(step_ms))
     if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        t = torch.tensor([dt, med_ms], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t[0])
+        dt, med_ms = float(t[0]), float(t[1])
     loss_val = float(last.detach())
 
     if rank == 0:
-        ms = dt / args.steps * 1e3
-        value = B * world * args.steps / dt
+        # the metric is global batch / MEDIAN step time (the reference's Time/Image convention, robust against
+        # a stray slow step); the mean over the barrier-bracketed region is reported next to it
+        ms_mean = dt / args.steps * 1e3
+        ms = med_ms
+        value = B * world / (med_ms * 1e-3)
         res = {"metric": "train images/sec, ResNet-101 joint seg+depth @512x1024" if args.workload.startswith("cfg3")
                else ("train labeled images/sec, ResNet-101 joint seg+depth + DepthMix @1024x2048" if unlabeled
                      else "train images/sec (%s)" % args.workload),
                "value": value, "unit": "img/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-               "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+               "ms_per_step": ms, "ms_per_step_mean": ms_mean, "value_from_mean": B * world * args.steps / dt,
+               "ms_per_step_min": min(step_ms), "ms_per_step_max": max(step_ms), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
                "data": "synthetic", "config": {"workload": desc, "per_gpu_batch": B, "global_batch": B * world,
                                                "height": Hh, "width": W, "optimizer": opt_name,
                                                "parallelism": "dp%d" % world, "final_loss": loss_val,
                                                "ranks": dist.get_world_size() if dist.is_initialized() else 1,
                                                "backend": (dist.get_backend() + (" (RCCL)" if dist.get_backend() == "nccl" else "")) if dist.is_initialized() else None,
                                                "allreduce_launches": reducer.collectives if reducer is not None else 0,
+                                               "rng": "weights seed 42 on every rank, then seed %d = 42 + 1000 * (rank + 1) per rank" % rank_seed,
                                                "peak_memory_gb": torch.cuda.max_memory_allocated(dev) / 2 ** 30}}
         if unlabeled:
             res["config"]["images_per_step"] = {"labeled": B * world, "unlabeled": B * world}
@@ -371,8 +414,15 @@ def main():
         if prof:
             agg = {}
             layers = {}
+            hbm = {}
             for kind, flops, s, e, tag in prof:
                 t = s.elapsed_time(e) * 1e-3
+                if kind.startswith("hbm_"):       # `flops` holds the launch's algorithmic BYTES (operands once each)
+                    a = hbm.setdefault(kind[4:], [0.0, 0.0, 0])
+                    a[0] += flops
+                    a[1] += t
+                    a[2] += 1
+                    continue
                 a = agg.setdefault(kind, [0.0, 0.0, 0])
                 a[0] += flops
                 a[1] += t
@@ -403,30 +453,42 @@ def main():
             roof.update(achieved=fl / tt / 1e12, frac=fl / tt / 1e12 / PEAK_FP32_MATRIX_TFLOPS, launches=nl,
                         avg_launch_ms=tt / nl * 1e3, avg_launch_gflop=fl / nl / 1e9,
                         share_of_step=tt / dt, algorithmic_bytes_per_launch=abytes / nl)
-            # HBM-side traffic per launch: PMC counters cannot be read live, so this is the committed result of the
-            # rocprofv3 --pmc passes of this very command (tools/gpu_pmc.sh -> profiles/traffic_r02.json; FETCH_SIZE x2 +
-            # WRITE_SIZE, the gfx950 rule of MI355X_MICROARCH.md)
-            tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "traffic_r02.json")
+            # HBM-side traffic per launch and matrix-pipe busy fraction: PMC counters cannot be read live, so these are the
+            # committed results of the rocprofv3 --pmc passes of this very command (tools/gpu_pmc.sh -> profiles/traffic_rNN.json,
+            # pmc_rNN_mfma_busy.txt; FETCH_SIZE x2 + WRITE_SIZE, the gfx950 rule of MI355X_MICROARCH.md).  A summary collected
+            # from OTHER kernel sources (fingerprint mismatch) is refused: null + the reason, never a stale number.
+            sha = csrc_sha256()
             wg_traffic = None
-            if args.workload == "cfg3" and os.path.exists(tpath):
+            tpath = newest_profile("traffic_r*.json")
+            if args.workload == "cfg3" and tpath:
+                rel = os.path.relpath(tpath, ROOT)
                 try:
                     tj = json.load(open(tpath))
-                    kk = [k for k in tj["kernels"] if k.startswith("conv_igemm_kernel")][0]
-                    roof["traffic"] = tj["kernels"][kk]["bytes_per_launch"]
-                    roof["traffic_source"] = "profiles/traffic_r02.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py)"
-                    wg_traffic = tj["kernels"]["conv_wgrad_kernel"]["bytes_per_launch"]
-                except Exception:
-                    pass
-            # matrix-pipe busy fraction of the same kernels, from the committed SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE pass
-            mpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_r02_mfma_busy.txt")
-            if args.workload == "cfg3" and os.path.exists(mpath):
-                busy = {}
-                for line in open(mpath):
-                    if line.startswith("conv_"):
-                        f = line.split()
-                        busy[line[:72].strip()] = float(f[-1])
-                roof["mfma_busy"] = busy
-                roof["mfma_busy_source"] = "profiles/pmc_r02_mfma_busy.txt (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE)"
+                    if tj.get("csrc_sha256") != sha:
+                        roof["traffic_source"] = "%s refused: collected from other kernel sources (csrc_sha256 %s != %s); re-run tools/gpu_pmc.sh" % (
+                            rel, str(tj.get("csrc_sha256"))[:12], sha[:12])
+                    else:
+                        kk = [k for k in tj["kernels"] if k.startswith("conv_igemm_kernel")][0]
+                        roof["traffic"] = tj["kernels"][kk]["bytes_per_launch"]
+                        roof["traffic_source"] = rel + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py)"
+                        wg_traffic = tj["kernels"]["conv_wgrad_kernel"]["bytes_per_launch"]
+                        res["pmc_traffic_bytes_per_launch"] = {k: v["bytes_per_launch"] for k, v in tj["kernels"].items()}
+                except Exception as ex:
+                    roof["traffic_source"] = "%s unreadable: %r" % (rel, ex)
+            mpath = newest_profile("pmc_r*_mfma_busy.txt")
+            if args.workload == "cfg3" and mpath:
+                rel = os.path.relpath(mpath, ROOT)
+                lines = open(mpath).read().splitlines()
+                if not any(l.startswith("# csrc_sha256 " + sha) for l in lines):
+                    roof["mfma_busy_source"] = rel + " refused: collected from other kernel sources; re-run tools/gpu_pmc.sh"
+                else:
+                    busy = {}
+                    for line in lines:
+                        if line.startswith("conv_"):
+                            f = line.split()
+                            busy[line[:72].strip()] = float(f[-1])
+                    roof["mfma_busy"] = busy
+                    roof["mfma_busy_source"] = rel + " (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE)"
             roof["measured_peaks"] = MEASURED_PEAKS
             roof["frac_of_measured_peak"] = roof["achieved"] / MEASURED_PEAKS["mfma_f32_tflops"]
             if "conv_wgrad" in agg:
@@ -438,6 +500,14 @@ def main():
                                 "algorithmic_bytes_per_launch": wb / agg["conv_wgrad"][2], "traffic": wg_traffic}
             res["kernels"] = {k: {"tflops": v[0] / v[1] / 1e12, "seconds": v[1], "launches": v[2],
                                   "share_of_step": v[1] / dt} for k, v in agg.items()}
+            # every HBM-bound kernel family against the HBM roof -- algorithmic bytes (each operand of the
+            # launch once) / HIP-event time, as a fraction of the nominal 8 TB/s and of the measured 6.36 TB/s
+            res["hbm_kernels"] = {k: {"algorithmic_mb_per_step": v[0] / args.steps / 1e6, "ms_per_step": v[1] / args.steps * 1e3,
+                                      "launches_per_step": v[2] / args.steps, "achieved_gbs": v[0] / v[1] / 1e9,
+                                      "frac_of_8tbs": v[0] / v[1] / 8e12,
+                                      "frac_of_measured_hbm": v[0] / v[1] / (MEASURED_PEAKS["hbm_gbs"] * 1e9),
+                                      "share_of_step": v[1] / dt}
+                                  for k, v in sorted(hbm.items(), key=lambda kv: -kv[1][1])}
         else:
             roof.update(achieved=res["step_tflops"], frac=res["step_tflops"] / PEAK_FP32_MATRIX_TFLOPS)
         res["roofline"] = roof

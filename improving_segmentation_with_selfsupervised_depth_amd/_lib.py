@@ -9,7 +9,7 @@ from ctypes import c_int, c_long, c_float, c_void_p, c_size_t, c_uint64, c_int64
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SEGSDE_LIB") or os.path.join(_HERE, "libsegsde_hip.so")   # override: kernel experiments
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 _LIB = None
 # Set only by the test-suite when it injects the host-interpreted build of the same kernel sources
@@ -96,7 +96,7 @@ _SIGS = {
     "segsde_cross_entropy_backward": (c_int, [P, c_int, c_long, c_int, P, c_int64, P, P, P, P, c_int, P]),
     "segsde_mix": (c_int, [P, c_int, c_int, P, c_int, c_int, c_int, c_int, c_long, c_long, c_long, c_long, P, P]),
     "segsde_mix_labels": (c_int, [P, P, c_int, c_int, c_int, P, P]),
-    "segsde_depthcomp_mask": (c_int, [P, c_int, c_long, c_float, c_float, P, P]),
+    "segsde_depthcomp_mask": (c_int, [P, c_int, c_long, c_float, c_float, P, P, P]),
     "segsde_depth_threshold_mask": (c_int, [P, c_long, c_float, c_float, c_int, P, P]),
     "segsde_class_mask": (c_int, [P, c_long, P, c_int, P, P]),
     "segsde_confusion_update": (c_int, [P, c_long, c_long, c_long, P, P, c_int, c_long, c_int, P, P]),
@@ -105,6 +105,7 @@ _SIGS = {
     "segsde_color_jitter": (c_int, [P, c_int, c_long, P, POINTER(c_int), P, P]),
     "segsde_gaussian_blur": (c_int, [P, c_int, c_int, c_int, P, c_int, P, c_int, P, P, P]),
     "segsde_softmax_nhwc_to_nchw": (c_int, [P, c_int, c_int, c_long, c_int, P, P]),
+    "segsde_onehot_select": (c_int, [P, P, c_int, P, c_int, c_int, c_long, P]),
     "segsde_minmax_normalize_workspace": (c_size_t, [c_int, c_long]),
     "segsde_minmax_normalize": (c_int, [P, c_int, c_long, P, P, P, P, c_size_t, P]),
     "segsde_disp_to_depth": (c_int, [P, c_int, c_int, c_int, c_int, c_int, c_float, c_float, P, P]),

@@ -92,6 +92,18 @@ __global__ __launch_bounds__(256) void minmax_apply_kernel(const float* x, long 
     if (out_u8) out_u8[(long)b * HW + e] = (uint8_t)(v * 255.f);
   }
 }
+// mix_use_gt (train.py:667-672): for the samples of the unlabeled batch that carry a label, the teacher's softmax planes are
+// replaced by the one-hot ground truth (the loader's int64 [C][H][W] planes, all zero on ignored pixels) before the
+// argmax / mix / pseudo-label.  The per-sample switch is read from a DEVICE flag array: no host round trip; unlabeled
+// samples are left untouched (their blocks return at once), so the result is bit-exact in both branches.
+template <typename T>
+__global__ __launch_bounds__(256) void onehot_select_kernel(float* prob, const T* onehot, const uint8_t* is_labeled, long CHW) {
+  const int b = blockIdx.y;
+  if (!is_labeled[b]) return;
+  float* pb = prob + (long)b * CHW;
+  const T* ob = onehot + (long)b * CHW;
+  for (long e = blockIdx.x * 256L + threadIdx.x; e < CHW; e += (long)gridDim.x * 256) pb[e] = (float)ob[e];
+}
 inline int plane_blocks(long HW) { long nb = (HW + 255) / 256; return (int)(nb < 1 ? 1 : (nb > 512 ? 512 : nb)); }
 }  // namespace
 
@@ -102,6 +114,26 @@ extern "C" int segsde_softmax_nhwc_to_nchw(const float* logits, int ld, int B, l
   nb = nb > 2048 ? 2048 : nb;
   hipLaunchKernelGGL(softmax_nhwc_to_nchw_kernel, dim3((unsigned)nb, B), dim3(256), (size_t)SM_PIX * C * sizeof(float),
                      ST(stream), logits, ld, HW, C, out);
+  SEGSDE_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int segsde_onehot_select(float* prob_nchw, const void* onehot, int onehot_dtype, const uint8_t* is_labeled, int B,
+                                    int C, long HW, void* stream) {
+  if (!prob_nchw || !onehot || !is_labeled) return SEGSDE_ERR_NULL;
+  if (B <= 0 || C <= 0 || HW <= 0) return SEGSDE_ERR_SHAPE;
+  const long CHW = (long)C * HW;
+  long nb = (CHW + 1023) / 1024;
+  nb = nb > 4096 ? 4096 : nb;
+  const dim3 grid((unsigned)nb, B), block(256);
+  if (onehot_dtype == SEGSDE_DTYPE_I64)
+    hipLaunchKernelGGL(onehot_select_kernel<int64_t>, grid, block, 0, ST(stream), prob_nchw, (const int64_t*)onehot, is_labeled, CHW);
+  else if (onehot_dtype == SEGSDE_DTYPE_F32)
+    hipLaunchKernelGGL(onehot_select_kernel<float>, grid, block, 0, ST(stream), prob_nchw, (const float*)onehot, is_labeled, CHW);
+  else if (onehot_dtype == SEGSDE_DTYPE_U8)
+    hipLaunchKernelGGL(onehot_select_kernel<uint8_t>, grid, block, 0, ST(stream), prob_nchw, (const uint8_t*)onehot, is_labeled, CHW);
+  else
+    return SEGSDE_ERR_SHAPE;
   SEGSDE_CHECK_LAUNCH();
   return 0;
 }

@@ -167,10 +167,12 @@ __global__ __launch_bounds__(256) void mix_labels_kernel(const int64_t* mask, co
     out[e] = m * t[e] + (1 - m) * t[((b + 1) % B) * HW + p];
   }
 }
-__global__ __launch_bounds__(256) void depthcomp_kernel(const float* d, int B, long HW, float margin, float ft, int64_t* mask) {
+__global__ __launch_bounds__(256) void depthcomp_kernel(const float* d, int B, long HW, float margin, float ft_all,
+                                                        const float* ft_dev /*[B] or null*/, int64_t* mask) {
   const long total = (long)B * HW;
   for (long e = blockIdx.x * 256L + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
     const long b = e / HW, p = e - b * HW;
+    const float ft = ft_dev ? ft_dev[b] : ft_all;    // train.py:592-599: one foreground threshold PER IMAGE when a range is configured
     const float own = d[e], other = d[((b + 1) % B) * HW + p];
     const float thr = other - margin;
     const int64_t fg = own >= thr ? 1 : 0;
@@ -357,12 +359,12 @@ extern "C" int segsde_mix_labels(const int64_t* mask, const int64_t* target, int
   SEGSDE_CHECK_LAUNCH();
   return 0;
 }
-extern "C" int segsde_depthcomp_mask(const float* depths, int B, long HW, float margin, float fg_threshold, int64_t* mask,
-                                     void* stream) {
+extern "C" int segsde_depthcomp_mask(const float* depths, int B, long HW, float margin, float fg_threshold,
+                                     const float* fg_threshold_per_sample, int64_t* mask, void* stream) {
   if (!depths || !mask) return SEGSDE_ERR_NULL;
   if (B < 1 || HW <= 0) return SEGSDE_ERR_SHAPE;
   hipLaunchKernelGGL(depthcomp_kernel, dim3(flat_blocks((long)B * HW)), dim3(256), 0, ST(stream), depths, B, HW, margin,
-                     fg_threshold, mask);
+                     fg_threshold, fg_threshold_per_sample, mask);
   SEGSDE_CHECK_LAUNCH();
   return 0;
 }

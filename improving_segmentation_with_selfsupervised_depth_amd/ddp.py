@@ -16,8 +16,14 @@ Design notes
     ``with reducer.no_sync():`` (hooks then do nothing).  A step that forgets to do so is still reduced correctly --
     a hook that fires twice for one parameter marks its bucket dirty and ``finish()`` re-reduces it from the
     accumulated ``p.grad`` -- it only loses the overlap (and warns once);
-  * the averaged bucket is scaled once in place and copied back with one multi-tensor launch per bucket (the flat
-    buffers are never aliased by ``p.grad``: an in-flight collective cannot be disturbed by a later accumulation);
+  * the averaged bucket is scaled once in place and ``p.grad`` is then RE-POINTED at its slice of the bucket (no copy
+    back).  With ``zero_grad(set_to_none=True)`` (torch's default) the next step's gradients are fresh tensors again, so an
+    in-flight collective can never be disturbed by a later accumulation and the dirty-bucket path below keeps working;
+    with ``set_to_none=False`` the gradients accumulate straight into the bucket and ``p.grad`` moves out of it when it is
+    handed over (one copy per step in either mode; round 2 had two);
+  * which parameters are live is agreed on ACROSS ranks (one small MAX all-reduce of a bitmap per step): ranks whose
+    losses touched different parameters (a data-dependent branch, a skipped batch) still issue identical collectives
+    instead of hanging;
   * BatchNorm statistics stay per replica, exactly like N independent runs of the single-GPU reference.
 """
 import contextlib
@@ -25,6 +31,23 @@ import warnings
 
 import torch
 import torch.distributed as dist
+
+
+def seed_per_rank(base_seed, rank=None):
+    """replicas start from IDENTICAL parameters (construct the model under one common seed, then
+    ``GradAllReducer`` broadcasts rank 0's) but draw INDEPENDENT dropout masks, auto-mask tie-break noise and augmentation
+    parameters: call this after the model is built.  Seeds the torch CPU generator (dropout counter seeds are drawn from it),
+    every device generator, numpy and ``random`` with ``base_seed + 1000 * (rank + 1)``; returns that seed."""
+    import random
+
+    import numpy as np
+    if rank is None:
+        rank = dist.get_rank() if dist.is_initialized() else 0
+    seed = int(base_seed) + 1000 * (int(rank) + 1)
+    torch.manual_seed(seed)
+    np.random.seed(seed % (2 ** 31))
+    random.seed(seed)
+    return seed
 
 
 class _Bucket:
@@ -47,11 +70,20 @@ class _Bucket:
         p = self.params[i]
         return self.flat[self.offsets[i]:self.offsets[i] + p.numel()]
 
+    def aliased(self, i):
+        g = self.params[i].grad
+        return g is not None and g.data_ptr() == self.slot(i).data_ptr()
+
     def pack(self, i):
         p = self.params[i]
         s = self.slot(i)
         if p.grad is None:
             s.zero_()
+        elif self.aliased(i):
+            # zero_grad(set_to_none=False) kept last step's bucket view as p.grad and this step accumulated into it: the
+            # bucket already holds the data.  p.grad moves out (one copy, as in the other branch) so that a later
+            # accumulation cannot disturb the collective and the dirty-bucket path still sees the full local gradient.
+            p.grad = p.grad.clone()
         else:
             s.copy_(p.grad.reshape(-1))
 
@@ -72,6 +104,13 @@ class GradAllReducer:
         self._warned = False
         self.collectives = 0       # diagnostics / tests: all_reduce launches so far
         self.rebuilds = 0
+        self.live_syncs = 0        # bitmap agreements on the live-parameter set
+        self._next = 0             # buckets are launched strictly in index order (identical order on every rank)
+        # control channel: a gloo group of its own for the per-step agreement (host-side facts only -- which p.grad exist --
+        # so no device synchronisation, and its collective cannot interleave differently with the bucket all-reduces on
+        # different ranks because it lives on another communicator)
+        ranks = dist.get_process_group_ranks(process_group) if (process_group is not None and self.world > 1) else None
+        self._ctl = dist.new_group(ranks=ranks, backend="gloo") if self.world > 1 else None
         self.broadcast_parameters()
 
     @property
@@ -109,6 +148,7 @@ class GradAllReducer:
         if cur:
             self.buckets.append(_Bucket(cur, device))
         self._where = {}
+        self._next = 0
         for b in self.buckets:
             for i, p in enumerate(b.params):
                 self._where[p] = (b, i)
@@ -120,6 +160,15 @@ class GradAllReducer:
     def _launch(self, b):
         b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         self.collectives += 1
+
+    def _launch_ready(self):
+        """Collectives of one group must be issued in the same order on every rank.  Gradient-ready order is not that: a
+        rank whose loss skipped a branch completes its buckets in another order (or not at all).  So bucket k starts only
+        after buckets 0..k-1 have started; an incomplete one holds the later ones back until finish() fills it in.  In the
+        common case (bucket order = reverse registration order = ready order) nothing waits."""
+        while self._next < len(self.buckets) and self.buckets[self._next].pending == 0:
+            self._launch(self.buckets[self._next])
+            self._next += 1
 
     def _on_grad(self, p):
         if not self._sync:
@@ -134,48 +183,75 @@ class GradAllReducer:
         b.ready[i] = True
         b.pending -= 1
         if b.pending == 0:
-            self._launch(b)
+            self._launch_ready()
 
     def finish(self):
         """call after the last backward() of the step, before clipping / the optimizer step"""
         if not self.active:
             return
-        live = [p for p in self.module.parameters() if p.requires_grad and p.grad is not None]
-        if self.buckets is None or any(p not in self._where for p in live):
-            # first step, or a parameter received its first gradient: (re)build the buckets over everything that has
-            # ever had a gradient, and reduce this step without overlap
+        cand = [p for p in self.module.parameters() if p.requires_grad]
+        live = [p for p in cand if p.grad is not None]
+        rebuild = self.buckets is None or any(p not in self._where for p in live)
+        nb = len(self.buckets) if self.buckets is not None else 0
+        dirty = [1 if b.dirty else 0 for b in self.buckets] if nb else []
+        if self.world > 1:
+            # the decision, the parameter set and the dirty buckets must be the same on every rank, or the collectives
+            # diverge and the job hangs: one MAX all-reduce of [rebuild?, has-gradient bitmap, dirty bitmap] per step on the
+            # control channel (CPU tensor, < 1 KB).  Unconditional: a rank cannot know that ANOTHER rank saw a new parameter.
+            flags = torch.tensor([1 if rebuild else 0] + [1 if (p.grad is not None or p in self._where) else 0 for p in cand]
+                                 + dirty, dtype=torch.int32)
+            dist.all_reduce(flags, op=dist.ReduceOp.MAX, group=self._ctl)
+            self.live_syncs += 1
+            fl = flags.tolist()
+            pbits = fl[1:1 + len(cand)]
+            rebuild = bool(fl[0]) or any(f and p not in self._where for f, p in zip(pbits, cand))
+            union = [p for f, p in zip(pbits, cand) if f]
+            dirty = fl[1 + len(cand):]
+        else:
+            union = [p for p in cand if p.grad is not None or p in self._where]
+        if not union:
+            return                       # nothing has a gradient yet on any rank (e.g. a skipped batch on the first step)
+        if rebuild:
+            # first step, or a parameter received its first gradient (on any rank): (re)build the buckets over everything
+            # that has ever had a gradient, and reduce this step without overlap
             if self.buckets is not None:
                 for b in self.buckets:
                     if b.work is not None:
                         b.work.wait()
                         b.work = None
-            known = set(self._where)
-            used = [p for p in self.module.parameters() if p.requires_grad and (p.grad is not None or p in known)]
-            self._build(used)
+            self._build(union)
+        # pass 1, index order like the hooks: whatever has not started yet (incomplete because a gradient did not show up in
+        # the last backward, held back behind an incomplete one, overlap off, or fresh after a rebuild)
         for b in self.buckets:
-            if b.dirty:
-                if not self._warned:
-                    warnings.warn("GradAllReducer: backward() ran more than once in this step outside no_sync(); the "
-                                  "affected buckets are reduced again after the last backward (correct, not overlapped)")
-                    self._warned = True
-                if b.work is not None:
-                    b.work.wait()
-                    b.work = None
-                b.reset()
-            if b.work is None:   # incomplete (a gradient did not show up in the last backward), dirty, or overlap off
+            if b.work is None:
                 for i in range(len(b.params)):
                     if not b.ready[i]:
                         b.pack(i)
                 self._launch(b)
+        # pass 2: buckets that went stale on ANY rank (a second un-synchronised backward) are reduced again from the
+        # accumulated p.grad -- after every first-pass launch, so that the issue order is the same on all ranks
+        if not rebuild:
+            for b, d in zip(self.buckets, dirty):
+                if d:
+                    if b.dirty and not self._warned:
+                        warnings.warn("GradAllReducer: backward() ran more than once in this step outside no_sync(); the "
+                                      "affected buckets are reduced again after the last backward (correct, not overlapped)")
+                        self._warned = True
+                    b.work.wait()
+                    b.reset()
+                    for i in range(len(b.params)):
+                        b.pack(i)
+                    self._launch(b)
         inv = 1.0 / self.world
         for b in self.buckets:
             b.work.wait()
             b.work = None
             if inv != 1.0:
                 b.flat.mul_(inv)
-            # identical programs on every rank (pure data parallelism, SURVEY.md 8e): a parameter without a gradient
-            # this step has none on any rank and keeps grad=None, as in the single-GPU reference
-            idx = [i for i, p in enumerate(b.params) if p.grad is not None]
-            if idx:
-                torch._foreach_copy_([b.params[i].grad for i in idx], [b.slot(i).view_as(b.params[i]) for i in idx])
+            # every bucket member receives the averaged gradient on every rank (a parameter that had none locally this step
+            # still gets the other ranks' average: replicas stay identical).  No copy back: p.grad is re-pointed at its
+            # slice of the bucket; the optimizer reads the bucket.
+            for i, p in enumerate(b.params):
+                p.grad = b.slot(i).view_as(p)
             b.reset()
+        self._next = 0

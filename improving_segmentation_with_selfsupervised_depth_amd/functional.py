@@ -84,8 +84,10 @@ class ConvFn(Function):
         ctx.x0_act, ctx.act_box = x0_act, act_box
         x0 = _c(x0) if x0.stride(-1) != 1 else x0
         ctx.wd = None
+        ctx.wd_gen = None
         if packs is not None:
             wp, ctx.wd = packs                          # the owning module's cache (valid for this version of the weight)
+            ctx.wd_gen = getattr(ctx.wd, "_segsde_gen", None)   # multi-pack buffers are rewritten by the next prepack
         elif ctx.needs_input_grad[0] or (x1 is not None and ctx.needs_input_grad[1]):
             wp, ctx.wd = H.pack_weight_both(weight)     # the data-gradient pack is needed by backward: one launch for both
         else:
@@ -110,12 +112,17 @@ class ConvFn(Function):
         dbias = None
         if need_b:
             stash = ctx.act_box.pop("dbias", None) if ctx.act_box is not None else None
-            # the bias gradient ActGradFn reduced in its pass is valid only if nothing else was added to its dz since
-            dbias = stash[1] if (stash is not None and stash[0] == dz.data_ptr()) else H.colsum(dz)
+            # the bias gradient ActGradFn reduced in its pass is valid only if this IS its dz and nothing was added to it since
+            # (autograd may accumulate a second contribution into the same buffer in place: the version counter moves)
+            same = stash is not None and stash[0].data_ptr() == dz.data_ptr() and stash[0]._version == stash[1] == dz._version
+            dbias = stash[2] if same else H.colsum(dz)
         actgrad = (x0, ctx.x0_act) if ctx.x0_act is not None else None
         dx0 = dx1 = dw = None
         if ctx.needs_input_grad[0] or (x1 is not None and ctx.needs_input_grad[1]):
             wd = ctx.wd if ctx.wd is not None else H.pack_weight(weight, True)
+            if ctx.wd_gen is not None and getattr(wd, "_segsde_gen", None) != ctx.wd_gen:
+                raise RuntimeError("the weight packs of this graph were rebuilt by a later weight_pack_scope(model): a graph "
+                                   "must be consumed before the next prepack of the same weights")
             dx0 = None
             box = ctx.grad_box
             if box is not None and box.get("g") is not None and x1 is None:
@@ -158,7 +165,7 @@ class ActGradFn(Function):
         ActGradFn.passes += 1
         dz, dbias = H.act_backward(_c(dy), y, ctx.act, need_dbias=bool(ctx.box.get("need_dbias")))
         if dbias is not None:
-            ctx.box["dbias"] = (dz.data_ptr(), dbias)
+            ctx.box["dbias"] = (dz, dz._version, dbias)
         return dz, None, None
 
 

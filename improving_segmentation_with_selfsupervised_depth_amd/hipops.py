@@ -13,8 +13,9 @@ from ._lib import ConvDesc, check
 
 ACT = {"none": 0, "relu": 1, "elu": 2, "sigmoid": 3}
 
-# Optional live kernel timing (bench.py): when set to a list, every implicit-GEMM launch is bracketed by HIP events
-# recorded on the stream the kernel is launched on; entries are (kind, algorithmic_flops, start_event, end_event).
+# Optional live kernel timing (bench.py): when set to a list, every implicit-GEMM launch -- and every launch (group) of the
+# HBM-bound kernel families, kind "hbm_*" -- is bracketed by HIP events recorded on the stream the kernel is launched on;
+# entries are (kind, algorithmic flops (conv_*) or algorithmic bytes (hbm_*: the operands once each), start, end, tag).
 PROFILE = None
 
 
@@ -139,8 +140,11 @@ def pack_weights_multi(weights):
             views.append((f, d))
         jobs[len(ws)] = _lib.PackJob(None, None, None, 0, 0, 0, 0, blk, 0)
         raw = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8).to(dev)
-        hit = _MULTI_PACK[key] = (raw, flat, views, len(ws), blk)
-    raw, flat, views, n, blk = hit
+        hit = _MULTI_PACK[key] = [raw, flat, views, len(ws), blk, 0]
+    raw, flat, views, n, blk, gen = hit
+    hit[5] = gen = gen + 1
+    for f, d in views:       # a graph that still holds the previous contents must not run its data-gradients (ConvFn.backward checks)
+        d._segsde_gen = gen
     check(_lib.lib().segsde_pack_weight_both_multi(_p(raw), n, blk, _stream(flat)), "pack_weight_both_multi")
     return views
 
@@ -287,9 +291,9 @@ def bn_stats(x, running_mean, running_var, momentum, eps, update_running=True, n
     invstd = torch.empty_like(mean)
     nb = L.segsde_bn_stats_workspace(M, C)
     ws = _ws(nb, x)
-    check(L.segsde_bn_stats(_p(_f32(x)), ld, M, C, _p(mean), _p(invstd), _p(running_mean if update_running else None),
+    _timed('hbm_bn_stats', 4.0 * M * C, x, lambda: check(L.segsde_bn_stats(_p(_f32(x)), ld, M, C, _p(mean), _p(invstd), _p(running_mean if update_running else None),
                             _p(running_var if update_running else None), float(momentum), float(eps),
-                            _p(num_batches_tracked), _p(ws), nb, _stream(x)), "bn_stats")
+                            _p(num_batches_tracked), _p(ws), nb, _stream(x)), "bn_stats"))
     return mean, invstd
 
 
@@ -322,8 +326,8 @@ def bn_apply(x, mean, invstd, gamma, beta, residual=None, act="none", drop_p=0.0
     M, C, ld = _rows(x)
     y = torch.empty(x.shape, dtype=torch.float32, device=x.device) if out is None else out
     ldr = _rows(residual)[2] if residual is not None else 0
-    check(_lib.lib().segsde_bn_apply(_p(x), ld, M, C, _p(mean), _p(invstd), _p(gamma), _p(beta), _p(residual), ldr, _p(y),
-                                     _rows(y)[2], ACT[act], float(drop_p), int(seed), _stream(x)), "bn_apply")
+    _timed('hbm_bn_apply', (8.0 + (4.0 if residual is not None else 0.0)) * M * C, x, lambda: check(_lib.lib().segsde_bn_apply(_p(x), ld, M, C, _p(mean), _p(invstd), _p(gamma), _p(beta), _p(residual), ldr, _p(y),
+                                     _rows(y)[2], ACT[act], float(drop_p), int(seed), _stream(x)), "bn_apply"))
     return y
 
 
@@ -338,9 +342,9 @@ def bn_backward(dy, y, x, mean, invstd, gamma, act="none", drop_p=0.0, seed=0, b
     dres = torch.empty(x.shape, dtype=torch.float32, device=x.device) if need_dres else None
     nb = L.segsde_bn_backward_workspace(M, C)
     ws = _ws(nb, x)
-    check(L.segsde_bn_backward(_p(_f32(dy)), _rows(dy)[2], _p(y), _rows(y)[2] if y is not None else ldx, _p(x), ldx, M, C,
+    _timed('hbm_bn_backward', (8.0 + (4.0 if y is not None else 0.0) + (4.0 if need_dx else 0.0) + (4.0 if need_dres else 0.0)) * M * C + 8.0 * M * C, x, lambda: check(L.segsde_bn_backward(_p(_f32(dy)), _rows(dy)[2], _p(y), _rows(y)[2] if y is not None else ldx, _p(x), ldx, M, C,
                                _p(mean), _p(invstd), _p(gamma), _p(beta), ACT[act], float(drop_p), int(seed), int(batch_stats), _p(dgamma), _p(dbeta),
-                               _p(dx), C, _p(dres), C, _p(ws), nb, _stream(x)), "bn_backward")
+                               _p(dx), C, _p(dres), C, _p(ws), nb, _stream(x)), "bn_backward"))
     return dx, dres, dgamma, dbeta
 
 
@@ -351,8 +355,8 @@ def act_backward(dy, y, act, need_dbias=False, need_dz=True):
     dbias = torch.empty(C, dtype=torch.float32, device=y.device) if need_dbias else None
     nb = L.segsde_colsum_workspace(M, C)
     ws = _ws(nb, y)
-    check(L.segsde_act_backward(_p(_f32(dy)), _rows(dy)[2], _p(y), ldy, M, C, ACT[act], _p(dz), C, _p(dbias), _p(ws), nb,
-                                _stream(y)), "act_backward")
+    _timed('hbm_act_backward', (8.0 + (4.0 if need_dz else 0.0)) * M * C, y, lambda: check(L.segsde_act_backward(_p(_f32(dy)), _rows(dy)[2], _p(y), ldy, M, C, ACT[act], _p(dz), C, _p(dbias), _p(ws), nb,
+                                _stream(y)), "act_backward"))
     return dz, dbias
 
 
@@ -376,7 +380,7 @@ def maxpool_forward(x):
     Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
     y = torch.empty((B, Ho, Wo, C), dtype=torch.float32, device=x.device)
     idx = torch.empty((B, Ho, Wo, C), dtype=torch.uint8, device=x.device)
-    check(_lib.lib().segsde_maxpool3x3s2_forward(_p(_f32(x)), B, H, W, C, _p(y), _p(idx), _stream(x)), "maxpool_fwd")
+    _timed('hbm_maxpool_fwd', 4.0 * x.numel() * 1.25 + 0.25 * x.numel(), x, lambda: check(_lib.lib().segsde_maxpool3x3s2_forward(_p(_f32(x)), B, H, W, C, _p(y), _p(idx), _stream(x)), "maxpool_fwd"))
     return y, idx
 
 
@@ -526,10 +530,10 @@ def warp_forward(disp, inv_K, K, T, src, min_depth, max_depth, want_grid=False, 
     color = torch.empty((B, 3, H, W), dtype=torch.float32, device=src.device)
     grid = torch.empty((B, H, W, 2), dtype=torch.float32, device=src.device) if want_grid else None
     depth = torch.empty((B, 1, H, W), dtype=torch.float32, device=src.device) if want_depth else None
-    check(_lib.lib().segsde_warp_forward(_p(_f32(disp.contiguous())), hs, ws, _p(_f32(inv_K.contiguous())),
+    _timed('hbm_warp_fwd', 4.0 * B * (hs * ws + (3 + 3 + (2 if want_grid else 0) + (1 if want_depth else 0)) * H * W), src, lambda: check(_lib.lib().segsde_warp_forward(_p(_f32(disp.contiguous())), hs, ws, _p(_f32(inv_K.contiguous())),
                                          _p(_f32(K.contiguous())), _p(_f32(T.contiguous())), _p(_f32(src.contiguous())),
                                          B, H, W, float(min_depth), float(max_depth), _p(color), _p(grid), _p(depth),
-                                         _stream(src)), "warp_fwd")
+                                         _stream(src)), "warp_fwd"))
     return color, grid, depth
 
 
@@ -570,9 +574,9 @@ def photometric_identity(src0, src1, target, no_ssim):
     """err(src_f, target), f = 0, 1 -> [B,2,H,W] (the auto-mask's identity terms, the same for every scale)"""
     B, _, Hh, W = target.shape
     ident = torch.empty((B, 2, Hh, W), dtype=torch.float32, device=target.device)
-    check(_lib.lib().segsde_photometric_identity(_p(_f32(src0.contiguous())), _p(_f32(src1.contiguous())),
+    _timed('hbm_photometric_identity', 4.0 * B * Hh * W * (9 + 2), target, lambda: check(_lib.lib().segsde_photometric_identity(_p(_f32(src0.contiguous())), _p(_f32(src1.contiguous())),
                                                  _p(_f32(target.contiguous())), B, Hh, W, int(no_ssim), _p(ident),
-                                                 _stream(target)), "photometric_identity")
+                                                 _stream(target)), "photometric_identity"))
     return ident
 
 
@@ -585,9 +589,9 @@ def photometric_forward(pred0, pred1, target, ident, noise, no_ssim, avg, want_s
     out = torch.empty(1, dtype=torch.float32, device=target.device)
     nb = L.segsde_photometric_workspace(B, Hh, W)
     ws_ = _ws(nb, target)
-    check(L.segsde_photometric_forward(_p(_f32(pred0.contiguous())), _p(_f32(pred1.contiguous())), _p(_f32(target.contiguous())),
+    _timed('hbm_photometric_fwd', B * Hh * W * (4.0 * (9 + (2 if ident is not None else 0) + (2 if noise is not None else 0) + (1 if isel is not None else 0)) + 1.0), target, lambda: check(L.segsde_photometric_forward(_p(_f32(pred0.contiguous())), _p(_f32(pred1.contiguous())), _p(_f32(target.contiguous())),
                                        _p(ident), _p(noise), B, Hh, W, int(no_ssim), int(avg), _p(sel), _p(isel), _p(out),
-                                       _p(ws_), nb, _stream(target)), "photometric_forward")
+                                       _p(ws_), nb, _stream(target)), "photometric_forward"))
     return out, sel, isel
 
 
@@ -601,12 +605,12 @@ def photometric_backward(pred0, pred1, target, sel, has_ident, disp, inv_K, K, T
     gup = torch.empty((B, Hh, W), dtype=torch.float32, device=target.device)
     nb = L.segsde_photometric_workspace(B, Hh, W)
     ws_ = _ws(nb, target)
-    check(L.segsde_photometric_backward(_p(pred0.contiguous()), _p(pred1.contiguous()), _p(target.contiguous()), _p(sel),
+    _timed('hbm_photometric_bwd', B * (Hh * W * (4.0 * (9 + 6 + 1) + 1.0) + 4.0 * hs * ws), target, lambda: check(L.segsde_photometric_backward(_p(pred0.contiguous()), _p(pred1.contiguous()), _p(target.contiguous()), _p(sel),
                                         2 if has_ident else 0, _p(disp.contiguous()), hs, ws, _p(inv_K.contiguous()),
                                         _p(K.contiguous()), _p(T0.contiguous()), _p(T1.contiguous()), _p(src0.contiguous()),
                                         _p(src1.contiguous()), B, Hh, W, float(min_depth), float(max_depth), int(no_ssim),
                                         int(avg), float(scale), _p(weight), _p(gup), _p(gT0), _p(gT1), _p(ws_), nb,
-                                        _stream(target)), "photometric_backward")
+                                        _stream(target)), "photometric_backward"))
     return gup
 
 
@@ -638,8 +642,8 @@ def smoothness_forward(disp, img):
     out = torch.empty(1, dtype=torch.float32, device=disp.device)
     nb = L.segsde_smoothness_workspace(B, h, w)
     ws_ = _ws(nb, disp)
-    check(L.segsde_smoothness_forward(_p(_f32(disp.contiguous())), _p(_f32(img.contiguous())), B, h, w, _p(mean), _p(out),
-                                      _p(ws_), nb, _stream(disp)), "smooth_fwd")
+    _timed('hbm_smooth_fwd', 16.0 * B * h * w, disp, lambda: check(L.segsde_smoothness_forward(_p(_f32(disp.contiguous())), _p(_f32(img.contiguous())), B, h, w, _p(mean), _p(out),
+                                      _p(ws_), nb, _stream(disp)), "smooth_fwd"))
     return out, mean
 
 
@@ -649,8 +653,8 @@ def smoothness_backward(disp, img, mean, scale, gdisp):
     L = _lib.lib()
     nb = L.segsde_smoothness_workspace(B, h, w)
     ws_ = _ws(nb, disp)
-    check(L.segsde_smoothness_backward(_p(disp.contiguous()), _p(img.contiguous()), _p(mean), B, h, w, float(scale),
-                                       _p(gdisp), _p(ws_), nb, _stream(disp)), "smooth_bwd")
+    _timed('hbm_smooth_bwd', 24.0 * B * h * w, disp, lambda: check(L.segsde_smoothness_backward(_p(disp.contiguous()), _p(img.contiguous()), _p(mean), B, h, w, float(scale),
+                                       _p(gdisp), _p(ws_), nb, _stream(disp)), "smooth_bwd"))
 
 
 # ----------------------------------------------------------------------------------------------
@@ -663,17 +667,17 @@ def cross_entropy_forward(logits_nhwc, target, ignore_index, class_weight=None, 
     nb = L.segsde_cross_entropy_workspace(M)
     ws_ = _ws(nb, logits_nhwc)
     assert target.dtype == torch.int64 and target.is_contiguous() and target.numel() == M
-    check(L.segsde_cross_entropy_forward(_p(_f32(logits_nhwc)), ld, M, C, _p(target), int(ignore_index), _p(class_weight),
-                                         _p(pixel_weights), _p(out), _p(ws_), nb, _stream(logits_nhwc)), "ce_fwd")
+    _timed('hbm_ce_fwd', M * (4.0 * C + 8.0), logits_nhwc, lambda: check(L.segsde_cross_entropy_forward(_p(_f32(logits_nhwc)), ld, M, C, _p(target), int(ignore_index), _p(class_weight),
+                                         _p(pixel_weights), _p(out), _p(ws_), nb, _stream(logits_nhwc)), "ce_fwd"))
     return out
 
 
 def cross_entropy_backward(logits_nhwc, target, ignore_index, scale, class_weight=None, pixel_weights=None):
     M, C, ld = _rows(logits_nhwc)
     dl = torch.empty(logits_nhwc.shape, dtype=torch.float32, device=logits_nhwc.device)
-    check(_lib.lib().segsde_cross_entropy_backward(_p(logits_nhwc), ld, M, C, _p(target), int(ignore_index),
+    _timed('hbm_ce_bwd', M * (8.0 * C + 8.0), logits_nhwc, lambda: check(_lib.lib().segsde_cross_entropy_backward(_p(logits_nhwc), ld, M, C, _p(target), int(ignore_index),
                                                    _p(class_weight), _p(pixel_weights), _p(_f32(scale)), _p(dl), C,
-                                                   _stream(logits_nhwc)), "ce_bwd")
+                                                   _stream(logits_nhwc)), "ce_bwd"))
     return dl
 
 
@@ -691,8 +695,8 @@ def mix(mask, x):
         raise TypeError("mask must be int64 or float32")
     mask = mask.contiguous()
     sb = x.stride(0) if B > 1 else C * H * W
-    check(_lib.lib().segsde_mix(_p(mask), is64, mask.shape[0], _p(_f32(x)), B, C, H, W, int(sb), int(x.stride(1)),
-                                int(x.stride(2)), int(x.stride(3)), _p(out), _stream(x)), "mix")
+    _timed('hbm_mix', B * H * W * (12.0 * C + (8.0 if is64 else 4.0)), x, lambda: check(_lib.lib().segsde_mix(_p(mask), is64, mask.shape[0], _p(_f32(x)), B, C, H, W, int(sb), int(x.stride(1)),
+                                int(x.stride(2)), int(x.stride(3)), _p(out), _stream(x)), "mix"))
     return out
 
 
@@ -705,10 +709,17 @@ def mix_labels(mask, target):
 
 
 def depthcomp_mask(depths, margin, fg_threshold):
+    """fg_threshold: a float for every image, or a DEVICE tensor [B] (one threshold per image, train.py:592-599)"""
     B = depths.shape[0]
     HW = depths[0].numel()
     mask = torch.empty((B,) + tuple(depths.shape[-2:]), dtype=torch.int64, device=depths.device)
-    check(_lib.lib().segsde_depthcomp_mask(_p(_f32(depths.contiguous())), B, HW, float(margin), float(fg_threshold), _p(mask),
+    per = None
+    if torch.is_tensor(fg_threshold):
+        per = _f32(fg_threshold.reshape(-1)).to(depths.device).contiguous()
+        if per.numel() != B:
+            raise ValueError("one foreground threshold per image: got %d for a batch of %d" % (per.numel(), B))
+    check(_lib.lib().segsde_depthcomp_mask(_p(_f32(depths.contiguous())), B, HW, float(margin),
+                                           0.0 if per is not None else float(fg_threshold), _p(per), _p(mask),
                                            _stream(depths)), "depthcomp_mask")
     return mask
 
@@ -788,8 +799,8 @@ def gaussian_blur(x, wy, wx):
     x = _f32(x).contiguous()
     B, C, Hh, W = x.shape
     tmp, y = torch.empty_like(x), torch.empty_like(x)
-    check(_lib.lib().segsde_gaussian_blur(_p(x), B * C, Hh, W, _p(_f32(wy.contiguous())), wy.numel(), _p(_f32(wx.contiguous())),
-                                          wx.numel(), _p(tmp), _p(y), _stream(x)), "gaussian_blur")
+    _timed('hbm_blur', 16.0 * x.numel(), x, lambda: check(_lib.lib().segsde_gaussian_blur(_p(x), B * C, Hh, W, _p(_f32(wy.contiguous())), wy.numel(), _p(_f32(wx.contiguous())),
+                                          wx.numel(), _p(tmp), _p(y), _stream(x)), "gaussian_blur"))
     return y
 
 
@@ -797,9 +808,30 @@ def softmax_to_nchw(logits_nhwc):
     """class softmax of NHWC logits [B,H,W,C] -> dense NCHW probabilities [B,C,H,W] (train.py:666)"""
     B, Hh, W, C = logits_nhwc.shape
     out = torch.empty((B, C, Hh, W), dtype=torch.float32, device=logits_nhwc.device)
-    check(_lib.lib().segsde_softmax_nhwc_to_nchw(_p(_f32(logits_nhwc)), nhwc_ld(logits_nhwc), B, Hh * W, C, _p(out),
-                                                 _stream(logits_nhwc)), "softmax_nhwc_to_nchw")
+    _timed('hbm_softmax', 8.0 * B * Hh * W * C, logits_nhwc, lambda: check(_lib.lib().segsde_softmax_nhwc_to_nchw(_p(_f32(logits_nhwc)), nhwc_ld(logits_nhwc), B, Hh * W, C, _p(out),
+                                                 _stream(logits_nhwc)), "softmax_nhwc_to_nchw"))
     return out
+
+
+def onehot_select_(prob_nchw, onehot, is_labeled):
+    """mix_use_gt (train.py:667-672), in place: ``prob[i] = onehot[i]`` for every sample with ``is_labeled[i]``.
+    prob: [B,C,H,W] fp32 dense; onehot: [B,C,H,W] int64 / float32 / uint8 (the loader's planes); is_labeled: [B]
+    bool / integer tensor (moved to the device as uint8, never read back)."""
+    B, C, Hh, W = prob_nchw.shape
+    if tuple(onehot.shape) != (B, C, Hh, W):
+        raise ValueError("onehot_lbl %s does not match the teacher softmax %s" % (tuple(onehot.shape), tuple(prob_nchw.shape)))
+    if not prob_nchw.is_contiguous() or prob_nchw.dtype != torch.float32:
+        raise ValueError("onehot_select_ works in place on a dense fp32 NCHW tensor")
+    code = {torch.float32: 0, torch.int64: 1, torch.uint8: 2, torch.bool: 2}.get(onehot.dtype)
+    if code is None:
+        onehot, code = onehot.to(torch.int64), 1
+    onehot = onehot.to(prob_nchw.device).contiguous()
+    flags = torch.as_tensor(is_labeled).reshape(-1).to(device=prob_nchw.device).ne(0).to(torch.uint8).contiguous()
+    if flags.numel() != B:
+        raise ValueError("is_labeled has %d entries for a batch of %d" % (flags.numel(), B))
+    check(_lib.lib().segsde_onehot_select(_p(prob_nchw), _p(onehot), code, _p(flags), B, C, Hh * W, _stream(prob_nchw)),
+          "onehot_select")
+    return prob_nchw
 
 
 def minmax_normalize(x, as_uint8=False):

@@ -120,9 +120,10 @@ def generate_mix_mask(mode, argmax_u_w, unlabeled_imgs, depths, depthcomp_margin
     if mode == "depthcomp":
         ft = depthcomp_foreground_threshold
         if isinstance(ft, (tuple, list)):
+            # train.py:592-599: an independent threshold per image, drawn on the device RNG; it stays on the device
             ft_l, ft_u = ft
             assert ft_u > ft_l
-            ft = float(torch.rand(1)) * (ft_u - ft_l) + ft_l
+            ft = torch.rand(B, device=dev) * (ft_u - ft_l) + ft_l
         return transformmasks.generate_depthcomp_mask(depths, depthcomp_margin, ft)
     if mode == "depth":
         masks = []
@@ -139,12 +140,14 @@ def train_step_segmentation_unlabeled(model, ema_model, monodepth_loss_calculato
                                       depthmix_online_depth=True, monodepth_lambda=1.0, consistency_weight=1.0,
                                       backward_first_pseudo_label=False, depthcomp_margin=0.03,
                                       depthcomp_foreground_threshold=0.0, color_jitter=False, blur=False, reducer=None,
-                                      last_backward=True):
+                                      last_backward=True, mix_use_gt=False):
     """Trainer.train_step_segmentation_unlabeled (train.py:653-724) with the ``self.*`` values as arguments: teacher
     forward -> softmax; student forward on the unmixed frames -> monodepth loss backward and the online depth; mix mask;
     DepthMix of images and teacher softmax; student forward on the mixed frames; pseudo-label loss backward.
     Returns (L_2 + L_1, mono_loss) like the reference.  ``reducer`` (ddp.GradAllReducer) keeps the gradient all-reduce
-    out of every backward() except the last one of the step (``last_backward``: the L_2 backward is that one)."""
+    out of every backward() except the last one of the step (``last_backward``: the L_2 backward is that one).
+    ``mix_use_gt`` (train.py:667-672, on in the exp-212 block, experiments.py:343-357): samples of the unlabeled batch with
+    ``unlabeled_inputs["is_labeled"][i]`` set take ``unlabeled_inputs["onehot_lbl"][i]`` instead of the teacher's softmax."""
     import contextlib
     import random
     from .loader import transformsgpu
@@ -185,46 +188,48 @@ def train_step_segmentation_unlabeled(model, ema_model, monodepth_loss_calculato
     with torch.no_grad():
         logits_u_w = ema_model(unlabeled_inputs)["semantics"]
     softmax_u_w = teacher_softmax(logits_u_w)
+    if mix_use_gt:
+        if "is_labeled" not in unlabeled_inputs or "onehot_lbl" not in unlabeled_inputs:
+            raise KeyError('mix_use_gt needs unlabeled_inputs["is_labeled"] and ["onehot_lbl"] (loader load_onehot, train.py:222)')
+        H.onehot_select_(softmax_u_w, unlabeled_inputs["onehot_lbl"], unlabeled_inputs["is_labeled"])
     argmax_u_w = None
     if isinstance(mix_mask, str) and mix_mask == "class":
         argmax_u_w = H.pseudo_label(softmax_u_w, 2.0, -1, want_weight=False)[0]
     # second step: student on the unaugmented frames -> online depth + monodepth loss (train.py:676-702)
     mono_loss, L_1 = 0, 0
-    scope = weight_pack_scope()        # both student passes run on the same weights: their convolutions pack once
-    scope.__enter__()
-    if depthmix_online_depth:
-        outputs_1 = model(unlabeled_inputs)
-        if monodepth_lambda > 0:
-            monodepth_loss_calculator.generate_images_pred(unlabeled_inputs, outputs_1)
-            mono_losses = monodepth_loss_calculator.compute_losses(unlabeled_inputs, outputs_1)
-            mono_loss = monodepth_lambda * mono_losses["loss"]
-            with nosync():
-                mono_loss.backward(retain_graph=backward_first_pseudo_label)
-            depths = normalize_online_depth(outputs_1[("disp", 0)])
-        else:
+    with weight_pack_scope():          # both student passes run on the same weights: their convolutions pack once
+        if depthmix_online_depth:
+            outputs_1 = model(unlabeled_inputs)
+            if monodepth_lambda > 0:
+                monodepth_loss_calculator.generate_images_pred(unlabeled_inputs, outputs_1)
+                mono_losses = monodepth_loss_calculator.compute_losses(unlabeled_inputs, outputs_1)
+                mono_loss = monodepth_lambda * mono_losses["loss"]
+                with nosync():
+                    mono_loss.backward(retain_graph=backward_first_pseudo_label)
+                depths = normalize_online_depth(outputs_1[("disp", 0)])
+            else:
+                depths = unlabeled_inputs["pseudo_depth"]
+            if backward_first_pseudo_label:
+                L_1, _ = calc_pseudo_label_loss(softmax_u_w, outputs_1["semantics"], consistency_weight)
+                with nosync():
+                    L_1.backward()
+            del outputs_1
+        elif "pseudo_depth" in unlabeled_inputs:
             depths = unlabeled_inputs["pseudo_depth"]
-        if backward_first_pseudo_label:
-            L_1, _ = calc_pseudo_label_loss(softmax_u_w, outputs_1["semantics"], consistency_weight)
-            with nosync():
-                L_1.backward()
-        del outputs_1
-    elif "pseudo_depth" in unlabeled_inputs:
-        depths = unlabeled_inputs["pseudo_depth"]
-    else:
-        depths = [None] * unlabeled_imgs.shape[0]
-    # third step: mix (train.py:704-724)
-    if torch.is_tensor(mix_mask):
-        MixMask = mix_mask                    # a precomputed mask (tests; pre-generated masks of a data pipeline)
-    else:
-        MixMask = generate_mix_mask(mix_mask, argmax_u_w, unlabeled_imgs, depths, depthcomp_margin,
-                                    depthcomp_foreground_threshold)
-    strong_parameters = {"Mix": MixMask, "ColorJitter": random.uniform(0, 1) if color_jitter else 0,
-                         "GaussianBlur": random.uniform(0, 1) if blur else 0}
-    inputs_u_s, _ = strong_transform(strong_parameters, data=unlabeled_imgs)
-    mixed_inputs = dict(unlabeled_inputs)
-    mixed_inputs[("color_aug", 0, 0)] = inputs_u_s
-    outputs = model(mixed_inputs)
-    scope.__exit__(None, None, None)
+        else:
+            depths = [None] * unlabeled_imgs.shape[0]
+        # third step: mix (train.py:704-724)
+        if torch.is_tensor(mix_mask):
+            MixMask = mix_mask                    # a precomputed mask (tests; pre-generated masks of a data pipeline)
+        else:
+            MixMask = generate_mix_mask(mix_mask, argmax_u_w, unlabeled_imgs, depths, depthcomp_margin,
+                                        depthcomp_foreground_threshold)
+        strong_parameters = {"Mix": MixMask, "ColorJitter": random.uniform(0, 1) if color_jitter else 0,
+                             "GaussianBlur": random.uniform(0, 1) if blur else 0}
+        inputs_u_s, _ = strong_transform(strong_parameters, data=unlabeled_imgs)
+        mixed_inputs = dict(unlabeled_inputs)
+        mixed_inputs[("color_aug", 0, 0)] = inputs_u_s
+        outputs = model(mixed_inputs)
     softmax_u_w_mixed, _ = strong_transform(strong_parameters, data=softmax_u_w)
     L_2, pseudo_label = calc_pseudo_label_loss(softmax_u_w_mixed, outputs["semantics"], consistency_weight)
     if last_backward:

@@ -25,10 +25,11 @@
 extern "C" {
 #endif
 
-#define SEGSDE_ABI_VERSION 7
+#define SEGSDE_ABI_VERSION 8
 
 enum { SEGSDE_ERR_NULL = -1, SEGSDE_ERR_SHAPE = -2, SEGSDE_ERR_WORKSPACE = -3, SEGSDE_ERR_UNSUPPORTED = -4 };
 enum { SEGSDE_ACT_NONE = 0, SEGSDE_ACT_RELU = 1, SEGSDE_ACT_ELU = 2, SEGSDE_ACT_SIGMOID = 3 };
+enum { SEGSDE_DTYPE_F32 = 0, SEGSDE_DTYPE_I64 = 1, SEGSDE_DTYPE_U8 = 2 };
 enum { SEGSDE_PAD_ZERO = 0, SEGSDE_PAD_REFLECT = 1, SEGSDE_PAD_REFLECT_ADJOINT = 2 };
 
 int segsde_abi_version(void);
@@ -253,8 +254,10 @@ int segsde_cross_entropy_backward(const float* logits, int ld, long M, int C, co
 int segsde_mix(const void* mask, int mask_is_int64, int Bm, const float* x, int B, int C, int H, int W, long sb, long sc,
                long sh, long sw, float* out, void* stream);
 int segsde_mix_labels(const int64_t* mask, const int64_t* target, int B, int H, int W, int64_t* out, void* stream);
-/* depthcomp: m_i = (d_i >= d_{(i+1)%B} - margin) * (d_i >= ft) -> int64 [B,H,W] (train.py:585-604, generalised partner) */
-int segsde_depthcomp_mask(const float* depths, int B, long HW, float margin, float fg_threshold, int64_t* mask, void* stream);
+/* depthcomp: m_i = (d_i >= d_{(i+1)%B} - margin) * (d_i >= ft_i) -> int64 [B,H,W] (train.py:585-604, generalised partner);
+ * ft_i = fg_threshold_per_sample[i] (nullable DEVICE [B]: the per-image draw of train.py:592-599) or fg_threshold for all. */
+int segsde_depthcomp_mask(const float* depths, int B, long HW, float margin, float fg_threshold,
+                          const float* fg_threshold_per_sample, int64_t* mask, void* stream);
 /* generate_depth_mask: depth >= thr (one threshold), or (depth >= min(t)) <= max(t) as the reference writes it */
 int segsde_depth_threshold_mask(const float* depth, long n, float t1, float t2, int two_thresholds, float* mask, void* stream);
 /* generate_class_mask: N[h,w] = #{k : pred[h,w] == classes[k]} */
@@ -283,6 +286,12 @@ int segsde_confusion_update(const float* logits, long sb, long sc, long sp, cons
 /* Teacher softmax of the unlabeled step, train.py:666 (torch.softmax(logits_u_w, dim=1)): NHWC logits rows (pitch ld)
  * -> class probabilities in NCHW planar layout, the layout segsde_mix / segsde_pseudo_label read. */
 int segsde_softmax_nhwc_to_nchw(const float* logits, int ld, int B, long HW, int C, float* out_nchw, void* stream);
+/* mix_use_gt, train.py:667-672 (``softmax_u_w[i] = unlabeled_inputs["onehot_lbl"][i]`` for every sample i of the unlabeled batch
+ * whose ``is_labeled[i]`` is set): prob_nchw [B,C,HW] is overwritten IN PLACE with the one-hot planes (the loader's layout and
+ * dtype, loader/sequence_segmentation_loader.py:237-246: int64 [C,H,W], all zero on ignored pixels; SEGSDE_DTYPE_*) of the
+ * flagged samples; is_labeled is a DEVICE uint8 [B] (no host synchronisation).  Unflagged samples are not touched. */
+int segsde_onehot_select(float* prob_nchw, const void* onehot, int onehot_dtype, const uint8_t* is_labeled, int B, int C,
+                         long HW, void* stream);
 /* Online-depth normalisation for the depthcomp mask, train.py:690-697, and the stored depth estimates of
  * DepthEstimator.prepare_depth_estimates, loader/depth_estimator.py:83-91: per sample b, out = (x - min_b) / (max_b - min_b)
  * (the reference's clamp to [min, max] is the identity); minmax (nullable) receives [B][2] = {min_b, max_b}; out_u8

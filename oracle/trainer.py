@@ -44,19 +44,34 @@ def calc_pseudo_label_loss(teacher_softmax, student_logits, consistency_weight, 
     return L_u, pseudo_label
 
 
+def use_gt(softmax_u_w, unlabeled_inputs):
+    """/root/reference/train.py:667-672 (``mix_use_gt``): labeled samples of the unlabeled batch take their one-hot label
+    planes (loader/sequence_segmentation_loader.py:237-246: int64, all zero on ignored pixels) instead of the teacher's
+    softmax; the assignment casts to the softmax's dtype."""
+    out = softmax_u_w.clone()
+    with torch.no_grad():
+        for i in range(out.shape[0]):
+            if bool(unlabeled_inputs["is_labeled"][i]):
+                out[i] = unlabeled_inputs["onehot_lbl"][i]
+    return out
+
+
 def train_step_segmentation_unlabeled(sd_student, sd_teacher, model_cfg, loss_oracle, unlabeled_inputs, margin=0.03,
                                       foreground_threshold=0.0, consistency_weight=1.0, monodepth_lambda=1.0,
-                                      tiebreak_noise=None, mask_override=None, dropout=False):
+                                      tiebreak_noise=None, mask_override=None, dropout=False, mix_use_gt=False):
     """/root/reference/train.py:653-724 with exp-212 flags (mix_mask "depthcomp", depthmix_online_depth True,
     backward_first_pseudo_label False, jitter / blur off): teacher forward -> softmax (:664-666); student forward on the
     unmixed frames -> monodepth loss backward (:679-689) and min-max normalised online disparity (:690-697); depthcomp
     mask (:585-604); mix of image and teacher softmax (:717-722); student forward on the mixed frames; pseudo-label loss
-    backward (:723-724).  ``sd_student`` leaves accumulate .grad.  Returns a dict of the intermediate tensors."""
+    backward (:723-724).  ``sd_student`` leaves accumulate .grad.  Returns a dict of the intermediate tensors.
+    ``mix_use_gt`` (:667-672, on in the exp-212 block experiments.py:343-357): the teacher softmax of every sample with
+    ``unlabeled_inputs["is_labeled"][i]`` is replaced by ``unlabeled_inputs["onehot_lbl"][i]`` before anything reads it."""
     from . import nets as N, segmix as S
     with torch.no_grad():
         out_t = N.model_forward({k: v.detach() for k, v in sd_teacher.items()}, model_cfg, dict(unlabeled_inputs), train=True,
                                 dropout=dropout, use_pose_net=False)
     softmax_u_w = torch.softmax(out_t["semantics"].detach(), dim=1)
+    softmax_u_w = use_gt(softmax_u_w, unlabeled_inputs) if mix_use_gt else softmax_u_w
     out_1 = N.model_forward(sd_student, model_cfg, dict(unlabeled_inputs), train=True, dropout=dropout)
     loss_oracle.generate_images_pred(unlabeled_inputs, out_1)
     mono = monodepth_lambda * loss_oracle.compute_losses(unlabeled_inputs, out_1, tiebreak_noise=tiebreak_noise)["loss"]

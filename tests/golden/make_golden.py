@@ -632,7 +632,68 @@ def gen_trainer():
     d.update(cm_logits=logits, cm_gt=gt, cm_pred=pred, cm_matrix=rs.confusion_matrix,
              cm_scores=np.array([sc["Overall Acc: \t"], sc["Mean Acc : \t"], sc["FreqW Acc : \t"], sc["Mean IoU : \t"]]),
              cm_cls_iu=np.array([cls_iu[i] for i in range(n)]))
-    save("trainer", d)
+    save("trainer", "usegt", d)
+
+
+def gen_usegt():
+    """The reference's OWN ``Trainer.train_step_segmentation_unlabeled`` (train.py:653-724) with ``mix_use_gt`` on, called
+    unbound with a stand-in ``self``: the teacher is a table of fixed logits, the student one 3x3 convolution on the mixed
+    image (so that the pseudo-label loss has a gradient to record), depths come from ``pseudo_depth``
+    (depthmix_online_depth off), mask "depthcomp".  Sample 0 is flagged labeled, sample 1 is not: the label planes of sample 1
+    are garbage that must never be read.  Stored: inputs, the mixed image the student saw, the mixed teacher distribution
+    and pseudo labels ``calc_pseudo_label_loss`` received / produced, L_2 and the student's gradients."""
+    import train as ref_train
+    gen = torch.Generator().manual_seed(77)
+    B, C, H, W = 2, 19, 12, 20
+    teacher_logits = 3.0 * torch.randn(B, C, H, W, generator=gen)
+    img = torch.rand(B, 3, H, W, generator=gen)
+    depth = torch.rand(B, 1, H, W, generator=gen)
+    lbl = torch.randint(0, C, (B, H, W), generator=gen)
+    lbl[0, :2, :5] = 250                                         # ignored pixels of the labeled sample: all-zero planes
+    dense = lbl.clone()
+    dense[dense == 250] = C
+    onehot = F.one_hot(dense, C + 2)[..., :C].permute(0, 3, 1, 2).contiguous()     # the loader's recipe (:237-242), int64
+    onehot[1] = torch.randint(0, 2, (C, H, W), generator=gen)    # unlabeled sample: never read
+    is_labeled = torch.tensor([True, False])
+    student = torch.nn.Conv2d(3, C, 3, padding=1)
+    with torch.no_grad():
+        student.weight.copy_(0.5 * torch.randn(student.weight.shape, generator=gen))
+        student.bias.copy_(0.1 * torch.randn(C, generator=gen))
+    seen = {}
+
+    class Teacher:
+        use_pose_net = True
+
+        def __call__(self, inputs):
+            return {"semantics": teacher_logits.clone()}
+
+    def student_model(inputs):
+        seen["mixed_img"] = inputs[("color_aug", 0, 0)].clone()
+        return {"semantics": student(inputs[("color_aug", 0, 0)])}
+
+    fake = types.SimpleNamespace(
+        ema_model=Teacher(), model=student_model, mix_use_gt=True, depthmix_online_depth=False, mix_mask="depthcomp",
+        depthcomp_margin=0.03, depthcomp_foreground_threshold=0.1, unlabeled_color_jitter=False, unlabeled_blur=False,
+        unlabeled_backward_first_pseudo_label=False, consistency_weight=1.0, device=torch.device("cpu"),
+        unlabeled_loader=types.SimpleNamespace(ignore_index=250), scaler=types.SimpleNamespace(scale=lambda x: x),
+        cfg={"training": {"batch_size": B, "monodepth_lambda": 1.0, "print_interval": 1000, "log_path": "/tmp"}})
+    fake.generate_mix_mask = types.MethodType(ref_train.Trainer.generate_mix_mask, fake)
+
+    def calc(teacher_softmax, student_logits):
+        seen["soft_mixed"] = teacher_softmax.clone()
+        L, lab = ref_train.Trainer.calc_pseudo_label_loss(fake, teacher_softmax, student_logits)
+        seen["pseudo_label"] = lab.clone()
+        return L, lab
+    fake.calc_pseudo_label_loss = calc
+    inputs = {("color_aug", 0, 0): img.clone(), "pseudo_depth": depth, "onehot_lbl": onehot, "is_labeled": is_labeled,
+              "filename": ["a", "b"]}
+    total, mono = ref_train.Trainer.train_step_segmentation_unlabeled(fake, inputs, 0)
+    assert mono == 0 and fake.ema_model.use_pose_net is False
+    d = dict(teacher_logits=teacher_logits, img=img, pseudo_depth=depth, onehot_lbl=onehot, is_labeled=is_labeled,
+             student_weight=student.weight.detach(), student_bias=student.bias.detach(), mixed_img=seen["mixed_img"],
+             soft_mixed=seen["soft_mixed"], pseudo_label=seen["pseudo_label"], L_2=total.detach(),
+             grad_weight=student.weight.grad, grad_bias=student.bias.grad, margin=np.float32(0.03), ft=np.float32(0.1))
+    save("usegt", d)
 
 
 def gen_poseall():
@@ -707,6 +768,6 @@ def gen_valtail():
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["loss", "geom", "ssim_smooth", "segmix", "blocks", "decoders", "encoder", "nets", "trainer",
-                             "valtail", "poseall"]
+                             "usegt", "valtail", "poseall"]
     for w in which:
         globals()["gen_" + w]()

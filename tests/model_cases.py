@@ -54,6 +54,31 @@ def check_param_grads(g, tag, module, rtol=1e-3):
             assert_close(p.grad.reshape(-1)[:4096], g["%s_gslice_%s" % (tag, k)], rtol=rtol, atol=1e-4, what=key)
 
 
+def gradients_vs_truth(named_params, g32, g64, what, med_floor=1e-3, max_floor=5e-2):
+    """The fp64-truth VECTOR criterion: for every parameter, ||g - g64|| / ||g64|| of the product must be as
+    small as the reference arithmetic's own fp32 error (oracle in fp32 vs the same oracle in fp64): median within 3x (or
+    ``med_floor``), worst within 5x (or ``max_floor``).  A wrong-direction gradient of the right length fails (a norm
+    comparison would not notice).  g32 / g64: name -> gradient (None / all-zero = no gradient)."""
+    e_prod, e_ref, presence = [], [], []
+    for k, p in named_params:
+        t = g64.get(k)
+        pg = p.grad
+        dead_t = t is None or float(t.abs().max()) == 0
+        if dead_t or pg is None:
+            if not (dead_t and (pg is None or float(pg.abs().max()) == 0)):
+                presence.append(k)
+            continue
+        den = float(t.norm()) + 1e-30
+        e_prod.append(float((pg.detach().double().cpu() - t).norm()) / den)
+        e_ref.append(float((g32[k].double() - t).norm()) / den)
+    assert not presence, (what, "gradient presence differs", presence[:6])
+    e_prod, e_ref = np.array(e_prod), np.array(e_ref)
+    print("%s: relative gradient error vs fp64 truth: product median %.2e max %.2e | fp32 reference arithmetic median %.2e max %.2e"
+          % (what, np.median(e_prod), e_prod.max(), np.median(e_ref), e_ref.max()))
+    assert np.median(e_prod) <= max(3 * np.median(e_ref), med_floor), (what, np.median(e_prod), np.median(e_ref))
+    assert e_prod.max() <= max(5 * e_ref.max(), max_floor), (what, e_prod.max(), e_ref.max())
+
+
 def run_blocks(device, golden):
     g = golden("blocks")
 
@@ -278,8 +303,10 @@ def run_full_model(device, golden, name):
           "max %.2e" % (name, np.median(e_prod), e_prod.max(), np.median(e_ref), e_ref.max()))
     assert np.median(e_prod) <= max(3 * np.median(e_ref), 1e-3), (np.median(e_prod), np.median(e_ref))
     assert e_prod.max() <= max(5 * e_ref.max(), 5e-2), (e_prod.max(), e_ref.max())
-    assert_close(params["models.encoder.encoder.conv1.weight"].grad, g[name + "_grad_conv1"], rtol=1e-2, atol=1e-3,
-                 what="conv1 grad")
+    # the one full gradient tensor the fixture stores: the vector criterion against the fp64 truth (reference's recorded fp32
+    # gradient as the yardstick), not a loose element-wise tolerance
+    k1 = "models.encoder.encoder.conv1.weight"
+    gradients_vs_truth([(k1, params[k1])], {k1: g[name + "_grad_conv1"]}, {k1: sdo[k1].grad}, name + " conv1 gradient")
     assert_close(model.models["encoder"].encoder.bn1.running_mean, g[name + "_bn1_running_mean_after"], rtol=1e-3,
                  atol=1e-5, what="bn1 running mean")
 
@@ -548,7 +575,7 @@ def run_reducer_real_model(device, backend, port=29533):
         dist.destroy_process_group()
 
 
-def run_unlabeled_step(device, size=(64, 128)):
+def run_unlabeled_step(device, size=(64, 128), mix_use_gt=False):
     """trainer.train_step_segmentation_unlabeled (the cfg5 sequence, train.py:653-724) vs the oracle's restatement on
     identical weights: teacher softmax, online depth + depthcomp mask, composites (bit-exact given the same mask),
     pseudo labels, both losses and the accumulated gradients of the two student passes."""
@@ -562,10 +589,16 @@ def run_unlabeled_step(device, size=(64, 128)):
     inp, inp_d = _bench_inputs(B, Hh, W, 5, device, with_labels=False)
     gen = torch.Generator().manual_seed(9)
     noise = {s: torch.randn(B, 2, Hh, W, generator=gen) for s in range(4)}
+    if mix_use_gt:   # train.py:667-672: sample 0 carries a label (one-hot planes in the loader's int64 layout), sample 1 does not
+        lbl = torch.randint(0, 19, (B, Hh, W), generator=gen)
+        lbl[torch.rand(B, Hh, W, generator=gen) < 0.05] = 19
+        inp["onehot_lbl"] = torch.nn.functional.one_hot(lbl, 21)[..., :19].permute(0, 3, 1, 2).contiguous()
+        inp["is_labeled"] = torch.tensor([True, False])
+        inp_d["onehot_lbl"], inp_d["is_labeled"] = inp["onehot_lbl"].to(device), inp["is_labeled"].to(device)
     sdo = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.clone())
            for k, v in sd_s.items()}
     lo = P.MonodepthLossOracle(**bench.loss_cfg(B, Hh, W)["training"]["monodepth_loss"], batch_size=B)
-    ref = OT.train_step_segmentation_unlabeled(sdo, sd_t, cfg, lo, inp, tiebreak_noise=noise)
+    ref = OT.train_step_segmentation_unlabeled(sdo, sd_t, cfg, lo, inp, tiebreak_noise=noise, mix_use_gt=mix_use_gt)
 
     student, teacher = get_model(cfg, 19), get_model(cfg, 19)
     student.load_state_dict(sd_s, strict=True)
@@ -577,9 +610,11 @@ def run_unlabeled_step(device, size=(64, 128)):
     lp = get_monodepth_loss(bench.loss_cfg(B, Hh, W), True)
     lp.tiebreak_noise = noise
     # (1) free-running: the product derives its own mask from its own online depth
-    L, mono = T.train_step_segmentation_unlabeled(student, teacher, lp, dict(inp_d), mix_mask="depthcomp")
+    L, mono = T.train_step_segmentation_unlabeled(student, teacher, lp, dict(inp_d), mix_mask="depthcomp", mix_use_gt=mix_use_gt)
     last = T.train_step_segmentation_unlabeled.last
     assert_close(last["softmax_u_w"], ref["softmax_u_w"], rtol=1e-3, atol=1e-5, what="teacher softmax")
+    if mix_use_gt:
+        assert torch.equal(last["softmax_u_w"][0].cpu(), inp["onehot_lbl"][0].float()), "labeled sample: one-hot planes, bit-exact"
     assert_close(last["depths"], ref["depths"], rtol=1e-3, atol=2e-4, what="normalised online disparity")
     agree = float((last["MixMask"].cpu() == ref["mask"]).float().mean())
     assert agree > 0.99, agree                       # comparisons at the margin may flip on a handful of pixels
@@ -587,20 +622,28 @@ def run_unlabeled_step(device, size=(64, 128)):
     # (2) continue from the oracle's mask: composites are bit-exact, losses / gradients comparable
     student.zero_grad(set_to_none=True)
     student.load_state_dict(sd_s, strict=True)       # BN running stats back to the start
-    L, mono = T.train_step_segmentation_unlabeled(student, teacher, lp, dict(inp_d), mix_mask=ref["mask"].to(device))
+    L, mono = T.train_step_segmentation_unlabeled(student, teacher, lp, dict(inp_d), mix_mask=ref["mask"].to(device),
+                                                  mix_use_gt=mix_use_gt)
     last = T.train_step_segmentation_unlabeled.last
     assert torch.equal(last["inputs_u_s"].cpu(), ref["img_mixed"])
     assert float((last["pseudo_label"].cpu() == ref["pseudo_label"]).float().mean()) > 0.99
     assert_close(mono, ref["mono_loss"], rtol=1e-3, what="unlabeled mono loss")
     assert_close(L, ref["L_2"], rtol=1e-3, what="pseudo-label loss")
-    bad = []
-    for k, p in student.named_parameters():
-        go = sdo[k].grad
-        if go is None or p.grad is None:
-            if not (go is None and p.grad is None) and not (go is not None and float(go.abs().max()) == 0 and p.grad is None):
-                bad.append((k, "presence"))
-            continue
-        n_o, n_p = float(go.norm()), float(p.grad.norm())
-        if abs(n_o - n_p) > 3e-2 * n_o + 1e-6:
-            bad.append((k, n_o, n_p))
-    assert not bad, bad[:8]
+    # gradients accumulated over the two student passes: vector criterion against the oracle run in float64 (same mask, so
+    # the discrete choices agree), with the fp32 oracle as the yardstick
+    g32 = {k: v.grad for k, v in sdo.items() if v.is_floating_point() and v.requires_grad}
+    g64 = _unlabeled_truth(sd_s, sd_t, cfg, inp, noise, ref["mask"], B, Hh, W, mix_use_gt)
+    gradients_vs_truth(list(student.named_parameters()), g32, g64, "unlabeled step" + (" (mix_use_gt)" if mix_use_gt else ""))
+
+
+def _unlabeled_truth(sd_s, sd_t, cfg, inp, noise, mask, B, Hh, W, mix_use_gt):
+    import bench
+    from oracle import photometric as P, trainer as OT
+    cast = lambda v: v.double() if torch.is_tensor(v) and v.is_floating_point() else v
+    sd64 = {k: (cast(v.clone()).requires_grad_(True) if v.is_floating_point() and "running" not in k else cast(v.clone()))
+            for k, v in sd_s.items()}
+    lo64 = P.MonodepthLossOracle(**bench.loss_cfg(B, Hh, W)["training"]["monodepth_loss"], batch_size=B)
+    OT.train_step_segmentation_unlabeled(sd64, {k: cast(v) for k, v in sd_t.items()}, cfg, lo64, {k: cast(v) for k, v in inp.items()},
+                                         tiebreak_noise={s_: n.double() for s_, n in noise.items()}, mask_override=mask,
+                                         mix_use_gt=mix_use_gt)
+    return {k: v.grad for k, v in sd64.items() if v.is_floating_point() and v.requires_grad}

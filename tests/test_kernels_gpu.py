@@ -99,6 +99,10 @@ def test_trainer_rows(golden):
     KC.run_trainer_cases("cuda", golden)
 
 
+def test_mix_use_gt_vs_reference(golden):
+    KC.run_mix_use_gt_cases("cuda", golden)
+
+
 def test_depthmix_teacher_kernels():
     KC.run_depthmix_teacher_cases("cuda")
 

@@ -452,3 +452,24 @@ def test_pose_model_input_all_vs_reference(golden):
     loss.backward()
     close(sd["models.pose_encoder.encoder.conv1.weight"].grad, g["grad_pose_conv1"], rtol=2e-3, atol=1e-7)
     close(sd["models.pose.net.3.weight"].grad, g["grad_pose_last"], rtol=2e-3, atol=1e-7)
+
+
+def test_mix_use_gt_vs_reference(golden):
+    """oracle/trainer.py::use_gt + segmix.mix / depthcomp_mask + calc_pseudo_label_loss reproduce what the reference's own
+    Trainer.train_step_segmentation_unlabeled (mix_use_gt on, train.py:653-724) handed to / got from its pieces"""
+    from oracle import trainer as OT, segmix as S
+    g = golden("usegt")
+    soft = torch.softmax(g["teacher_logits"], dim=1)
+    soft = OT.use_gt(soft, {"is_labeled": g["is_labeled"], "onehot_lbl": g["onehot_lbl"]})
+    assert torch.equal(soft[0], g["onehot_lbl"][0].float())
+    mask = S.depthcomp_mask(g["pseudo_depth"], float(g["margin"]), float(g["ft"]))
+    mixed, _ = S.mix(mask, data=g["img"])
+    assert torch.equal(mixed, g["mixed_img"])
+    soft_mixed, _ = S.mix(mask, data=soft)
+    assert torch.equal(soft_mixed, g["soft_mixed"])
+    w, b = g["student_weight"].detach().clone().requires_grad_(True), g["student_bias"].detach().clone().requires_grad_(True)
+    L, lab = OT.calc_pseudo_label_loss(soft_mixed, torch.nn.functional.conv2d(mixed, w, b, padding=1), 1.0)
+    assert torch.equal(lab, g["pseudo_label"])
+    torch.testing.assert_close(L, g["L_2"], rtol=1e-6, atol=0)
+    L.backward()
+    torch.testing.assert_close(w.grad, g["grad_weight"], rtol=1e-5, atol=1e-8)

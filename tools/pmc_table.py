@@ -29,7 +29,11 @@ def main():
         t[1] += 1
     counters.sort()
     key = "GRBM_GUI_ACTIVE" if "GRBM_GUI_ACTIVE" in counters else counters[0]
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import csrc_sha256
     lines = ["# per-kernel PMC sums from %s (rocprofv3 --pmc %s)" % (db, " ".join(counters)),
+             "# csrc_sha256 %s   (bench.py refuses this summary once the kernel sources change)" % csrc_sha256(),
              "%-72s %8s " % ("kernel", "launches") + " ".join("%22s" % c for c in counters) +
              ("   MfmaUtil" if "SQ_VALU_MFMA_BUSY_CYCLES" in counters and "GRBM_GUI_ACTIVE" in counters else "")]
     for k, a in sorted(agg.items(), key=lambda kv: -kv[1].get(key, [0, 0])[0])[:32]:
