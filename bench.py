@@ -415,7 +415,7 @@ def main():
             agg = {}
             layers = {}
             hbm = {}
-            for kind, flops, s, e, tag in prof:
+            for kind, flops, s, e, tag, executed in prof:
                 t = s.elapsed_time(e) * 1e-3
                 if kind.startswith("hbm_"):       # `flops` holds the launch's algorithmic BYTES (operands once each)
                     a = hbm.setdefault(kind[4:], [0.0, 0.0, 0])
@@ -423,20 +423,23 @@ def main():
                     a[1] += t
                     a[2] += 1
                     continue
-                a = agg.setdefault(kind, [0.0, 0.0, 0])
+                a = agg.setdefault(kind, [0.0, 0.0, 0, 0.0])
                 a[0] += flops
                 a[1] += t
                 a[2] += 1
-                b = layers.setdefault((kind, tag), [0.0, 0.0, 0])
+                a[3] += executed
+                b = layers.setdefault((kind, tag), [0.0, 0.0, 0, 0.0])
                 b[0] += flops
                 b[1] += t
                 b[2] += 1
+                b[3] += executed
             if os.environ.get("SEGSDE_BENCH_LAYERS"):
                 with open(os.environ["SEGSDE_BENCH_LAYERS"], "w") as f:
                     f.write("# per-layer conv launches over %d timed steps (HIP events on the launch stream)\n" % args.steps)
                     for (kind, tag), v in sorted(layers.items(), key=lambda kv: -kv[1][1]):
-                        f.write("%-11s %-40s n=%4d  %8.2f ms/step  %6.1f TF  %5.2f%% of step\n" % (
-                            kind, tag, v[2], v[1] / args.steps * 1e3, v[0] / v[1] / 1e12, 100 * v[1] / dt))
+                        f.write("%-11s %-45s n=%4d  %8.2f ms/step  %6.1f TF  %5.2f%% of step%s\n" % (
+                            kind, tag, v[2], v[1] / args.steps * 1e3, v[0] / v[1] / 1e12, 100 * v[1] / dt,
+                            "" if v[3] == v[0] else "  (executed %.1f TF)" % (v[3] / v[1] / 1e12)))
             # algorithmic bytes of a conv launch: its input(s), weights and output once each (fp32), from the geometry tag
             def tag_bytes(tag):
                 m = re.match(r"(\d+)\+(\d+)->(\d+) k(\d+) s(\d+) d(\d+) (\d+)x(\d+)( up)?", tag)
@@ -450,6 +453,13 @@ def main():
             fl = sum(agg[k][0] for k in ("conv_fwd", "conv_dgrad") if k in agg)
             tt = sum(agg[k][1] for k in ("conv_fwd", "conv_dgrad") if k in agg)
             nl = sum(agg[k][2] for k in ("conv_fwd", "conv_dgrad") if k in agg)
+            ex = sum(agg[k][3] for k in ("conv_fwd", "conv_dgrad") if k in agg)
+            # `achieved` / `frac` count ALGORITHMIC work (2 * MAC of the convolution as the reference defines it).
+            # The upsample-folded decoder convolutions issue fewer multiply-adds than that (4 instead of 9 taps on the
+            # nearest-upsampled channels, an exact regrouping of the same sums): the matrix pipe's own utilisation is
+            # `executed_achieved` / `executed_frac`, which can never exceed 1.
+            roof.update(executed_achieved=ex / tt / 1e12, executed_frac=ex / tt / 1e12 / PEAK_FP32_MATRIX_TFLOPS,
+                        executed_over_algorithmic=ex / fl)
             roof.update(achieved=fl / tt / 1e12, frac=fl / tt / 1e12 / PEAK_FP32_MATRIX_TFLOPS, launches=nl,
                         avg_launch_ms=tt / nl * 1e3, avg_launch_gflop=fl / nl / 1e9,
                         share_of_step=tt / dt, algorithmic_bytes_per_launch=abytes / nl)
@@ -496,10 +506,12 @@ def main():
                 res["wgrad"] = {"kernel": "conv_wgrad_kernel (pixel-reduction GEMM, split + deterministic reduce)",
                                 "achieved": agg["conv_wgrad"][0] / agg["conv_wgrad"][1] / 1e12,
                                 "frac": agg["conv_wgrad"][0] / agg["conv_wgrad"][1] / 1e12 / PEAK_FP32_MATRIX_TFLOPS,
+                                "executed_achieved": agg["conv_wgrad"][3] / agg["conv_wgrad"][1] / 1e12,
+                                "executed_frac": agg["conv_wgrad"][3] / agg["conv_wgrad"][1] / 1e12 / PEAK_FP32_MATRIX_TFLOPS,
                                 "launches": agg["conv_wgrad"][2],
                                 "algorithmic_bytes_per_launch": wb / agg["conv_wgrad"][2], "traffic": wg_traffic}
-            res["kernels"] = {k: {"tflops": v[0] / v[1] / 1e12, "seconds": v[1], "launches": v[2],
-                                  "share_of_step": v[1] / dt} for k, v in agg.items()}
+            res["kernels"] = {k: {"tflops": v[0] / v[1] / 1e12, "executed_tflops": v[3] / v[1] / 1e12, "seconds": v[1],
+                                  "launches": v[2], "share_of_step": v[1] / dt} for k, v in agg.items()}
             # every HBM-bound kernel family against the HBM roof -- algorithmic bytes (each operand of the
             # launch once) / HIP-event time, as a fraction of the nominal 8 TB/s and of the measured 6.36 TB/s
             res["hbm_kernels"] = {k: {"algorithmic_mb_per_step": v[0] / args.steps / 1e6, "ms_per_step": v[1] / args.steps * 1e3,

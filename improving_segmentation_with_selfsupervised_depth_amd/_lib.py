@@ -41,6 +41,11 @@ _SIGS = {
     "segsde_bn_stats_from_partials": (c_int, [P, c_long, c_long, c_int, P, P, P, P, c_float, c_float, P, P, c_size_t, P]),
     "segsde_conv2d_wgrad_workspace": (c_size_t, [POINTER(ConvDesc)]),
     "segsde_conv2d_wgrad": (c_int, [POINTER(ConvDesc), P, P, P, c_int, P, P, c_size_t, P]),
+    "segsde_upfold_pack": (c_int, [P, c_int, c_int, c_int, P, P, P]),
+    "segsde_conv2d_forward_upfold": (c_int, [POINTER(ConvDesc), P, P, P, P, P, P, P]),
+    "segsde_conv2d_dgrad_upfold": (c_int, [POINTER(ConvDesc), P, c_int, P, P, P, P, P, P, c_int, c_int, P]),
+    "segsde_conv2d_wgrad_upfold_workspace": (c_size_t, [POINTER(ConvDesc)]),
+    "segsde_conv2d_wgrad_upfold": (c_int, [POINTER(ConvDesc), P, P, P, c_int, P, P, c_size_t, P]),
     "segsde_pack_weight": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "segsde_pack_weight_both": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P]),
     "segsde_pack_weight_both_multi": (c_int, [P, c_int, c_int, P]),

@@ -59,7 +59,14 @@ struct ConvP {
   unsigned mg1, mg2; int sf1, sf2, d1, d2;
   unsigned mgC, mgKW; int sfC, sfKW;   // the same for k / Ctot and tap / KW (generic gathers: decode_k)
   int lin;   // 1x1, stride 1, unpadded, one source at output resolution: GEMM row m IS pixel m of the input (no row decode)
+  // Upsample-folded sub-problems (segsde_conv2d_*_upfold, FAST / table-driven paths only): padw = the column padding (the
+  // parity classes of a folded 3x3 pad rows and columns differently; = pad everywhere else); wtap = floats between two taps
+  // of a packed weight row (= Ctot unless the launch reads a channel slice of wider rows); pad_mode SEGSDE_PAD_CLAMP_ =
+  // out-of-range taps read the nearest border pixel (what mirrored padding of a nearest-upsampled image amounts to on the
+  // low-resolution grid); osfast = a strided sub-grid store (os > 1) whose tiles lie inside one sub-grid row.
+  int padw, wtap, osfast;
 };
+constexpr int SEGSDE_PAD_CLAMP_ = 3;   // internal (never crosses the ABI)
 
 struct KInfo {  // decoded reduction index k -> tap + channel + source
   const float* src; int ld, Hs, Ws, shift, dh, dw, cc; bool valid;
@@ -430,11 +437,14 @@ __global__ __launch_bounds__(256, VAR == 6 ? 3 : 2) void conv_igemm_kernel(ConvP
           sink(i, rok[i] ? ((unsigned)(m0 + r0 + RP * i - b0 * p.d1) * s0.ld + col) * 4u : SEGSDE_OOB, SEGSDE_OOB);
         return;
       }
-      const int dh = kh * p.dil - p.pad, dw = kw * p.dil - p.pad;
+      const int dh = kh * p.dil - p.pad, dw = kw * p.dil - p.padw;
       const int sh = in0 ? s0.shift : 0;
       const unsigned ld = in0 ? s0.ld : s1.ld, Ws = in0 ? s0.Ws : s1.Ws, bst = in0 ? s0.bstride : s1.bstride;
       const int ds = p.in_div >> 1;   // data-gradient of a stride-2 conv: only even coordinates carry a value
-      const bool refl = p.pad_mode == SEGSDE_PAD_REFLECT;
+      // clamp padding (upsample-folded class launches) is a compile-time variant, VAR = 9: as one more run-time flag it cost the
+      // K loops their last free SGPRs (the LDS-DMA operands no longer got scalar registers)
+      constexpr bool clampm = VAR == 9;
+      const bool refl = !clampm && p.pad_mode == SEGSDE_PAD_REFLECT;
 #pragma unroll
       for (int i = 0; i < AR; ++i) {
         auto boff = [&](int hh, int ww) {
@@ -443,11 +453,12 @@ __global__ __launch_bounds__(256, VAR == 6 ? 3 : 2) void conv_igemm_kernel(ConvP
         int hi = rh[i] + dh, wi = rw[i] + dw;
         bool ok = rok[i] && (((hi | wi) & ds) == 0);
         hi >>= ds; wi >>= ds;
-        const int hr = hi < 0 ? -hi : (hi >= p.H ? 2 * p.H - 2 - hi : hi);
-        const int wr = wi < 0 ? -wi : (wi >= p.W ? 2 * p.W - 2 - wi : wi);
+        const int hr = clampm ? (hi < 0 ? 0 : (hi >= p.H ? p.H - 1 : hi)) : (hi < 0 ? -hi : (hi >= p.H ? 2 * p.H - 2 - hi : hi));
+        const int wr = clampm ? (wi < 0 ? 0 : (wi >= p.W ? p.W - 1 : wi)) : (wi < 0 ? -wi : (wi >= p.W ? 2 * p.W - 2 - wi : wi));
         const bool hin = (unsigned)hi < (unsigned)p.H, win = (unsigned)wi < (unsigned)p.W;
-        ok = ok && (refl || (hin && win));
-        const unsigned vmain = ok ? boff(refl ? hr : hi, refl ? wr : wi) : SEGSDE_OOB;
+        const bool mapped = refl || clampm;
+        ok = ok && (mapped || (hin && win));
+        const unsigned vmain = ok ? boff(mapped ? hr : hi, mapped ? wr : wi) : SEGSDE_OOB;
         unsigned vext = SEGSDE_OOB;
         if constexpr (WADJ) {
           const int eh = (rh[i] == 1 && dh == 1) ? 0 : ((rh[i] == p.H - 2 && dh == -1) ? p.H - 1 : -1);
@@ -541,7 +552,7 @@ __global__ __launch_bounds__(256, VAR == 6 ? 3 : 2) void conv_igemm_kernel(ConvP
       bool more; segsde_rsrc rsa; unsigned soffA, soffB;
       auto chunk_begin = [&](int kc) {
         more = kc + 1 < nchunks;   // chunks past the end reload the last one (cs stops advancing there) and are discarded
-        soffB = (unsigned)(((p.kh0 + p.khs * cs.kh) * p.KWf + p.kw0 + p.kws * cs.kw) * p.Ctot + cs.c0) * 4u;
+        soffB = (unsigned)(((p.kh0 + p.khs * cs.kh) * p.KWf + p.kw0 + p.kws * cs.kw) * p.wtap + cs.c0) * 4u;
         const bool in0 = cs.c0 < p.C0;
         rsa = segsde_make_rsrc(in0 ? base0 : base1);
         soffA = (unsigned)(in0 ? cs.c0 : cs.c0 - p.C0) * 4u;
@@ -604,7 +615,7 @@ __global__ __launch_bounds__(256, VAR == 6 ? 3 : 2) void conv_igemm_kernel(ConvP
         constexpr unsigned PASS = RP * LDT * 4, BOFF = BM * LDT * 4, STG = STAGE * 4;
         // weight-row byte offset of the chunk being fetched: consecutive chunks are consecutive 128-byte pieces of the
         // packed row except across a tap change of a parity-class sub-problem, where it is recomputed from the tap
-        unsigned wbyte = (unsigned)((p.kh0 * p.KWf + p.kw0) * p.Ctot) * 4u;
+        unsigned wbyte = (unsigned)((p.kh0 * p.KWf + p.kw0) * p.wtap) * 4u;
         auto dma_begin = [&]() {
           const bool in0 = cs.c0 < p.C0;
           rsa = segsde_make_rsrc(in0 ? base0 : base1);
@@ -615,7 +626,7 @@ __global__ __launch_bounds__(256, VAR == 6 ? 3 : 2) void conv_igemm_kernel(ConvP
           if (adv) {
             cs.advance(p, BK);
             wbyte += BK * 4u;
-            if (cs.c0 == 0) wbyte = (unsigned)(((p.kh0 + p.khs * cs.kh) * p.KWf + p.kw0 + p.kws * cs.kw) * p.Ctot) * 4u;
+            if (cs.c0 == 0) wbyte = (unsigned)(((p.kh0 + p.khs * cs.kh) * p.KWf + p.kw0 + p.kws * cs.kw) * p.wtap) * 4u;
             if (cs.c0 == 0 || cs.c0 == p.C0) tap_update(wadj_tag, direct);
           }
         };
@@ -809,7 +820,10 @@ __global__ __launch_bounds__(256, VAR == 6 ? 3 : 2) void conv_igemm_kernel(ConvP
             for (int r = 0; r < 16; ++r) cw[(i * 32 + (r & 3) + 8 * (r >> 2)) * BN + j * 32] = f(acc[i][j][r] + bias);
         }
       };
-      if (pe.act == SEGSDE_ACT_ELU) put([](float v) { return v > 0.f ? v : __expf(fminf(v, 0.f)) - 1.f; });
+      // an accumulating launch (the skip-source half of an upsample-folded convolution) activates AFTER adding what the
+      // destination holds: only the bias goes in here
+      if (pe.accum) put([](float v) { return v; });
+      else if (pe.act == SEGSDE_ACT_ELU) put([](float v) { return v > 0.f ? v : __expf(fminf(v, 0.f)) - 1.f; });
       else if (pe.act == SEGSDE_ACT_RELU) put([](float v) { return fmaxf(v, 0.f); });
       else if (pe.act == SEGSDE_ACT_SIGMOID) put([](float v) { return segsde_act(v, SEGSDE_ACT_SIGMOID); });
       else put([](float v) { return v; });
@@ -851,17 +865,20 @@ __global__ __launch_bounds__(256, VAR == 6 ? 3 : 2) void conv_igemm_kernel(ConvP
       // on a 128x128 tile, more than one per MFMA of an 8-chunk 1x1 layer, and VALU cycles are matrix-pipe cycles here.
       const int nend = n0 + BN < pe.ne ? n0 + BN : pe.ne;
       const bool side1 = n0 >= pe.nsplit;
-      if (pe.os == 1 && m0 + BM <= pe.M && (side1 || nend <= pe.nsplit)) {
+      if ((pe.os == 1 || pe.osfast) && m0 + BM <= pe.M && (side1 || nend <= pe.nsplit)) {
         constexpr int NR = BM / RPP;
-        float* dbase = side1 ? pe.y2 + ((long)m0 * pe.ldy2 + (n0 - pe.nsplit)) : pe.y + ((long)m0 * pe.ldy + n0);
-        const unsigned ld = (unsigned)(side1 ? pe.ldy2 : pe.ldy);
+        // strided sub-grid (osfast: the tile lies inside one sub-grid row): consecutive GEMM rows are os destination rows apart
+        const long row0 = pe.os == 1 ? (long)m0 : out_row(pe, m0);
+        float* dbase = side1 ? pe.y2 + (row0 * pe.ldy2 + (n0 - pe.nsplit)) : pe.y + (row0 * pe.ldy + n0);
+        const unsigned ld = (unsigned)(side1 ? pe.ldy2 : pe.ldy) * (unsigned)pe.os;
         const segsde_rsrc rd = segsde_make_rsrc(dbase);
         const unsigned vo = n < pe.ne ? ((unsigned)rr * ld + 4u * cq) * 4u : SEGSDE_OOB;
         const unsigned step = (unsigned)RPP * ld * 4u;
         const bool ag = pe.agy && !side1;
-        const segsde_rsrc ra = segsde_make_rsrc(ag ? pe.agy + ((long)m0 * pe.agld + n0) : pe.zero);
-        const unsigned voa = (ag && n < pe.ne) ? ((unsigned)rr * (unsigned)pe.agld + 4u * cq) * 4u : SEGSDE_OOB;
-        const unsigned stepa = (unsigned)RPP * (unsigned)pe.agld * 4u;
+        const unsigned agl = (unsigned)pe.agld * (unsigned)pe.os;
+        const segsde_rsrc ra = segsde_make_rsrc(ag ? pe.agy + (row0 * pe.agld + n0) : pe.zero);
+        const unsigned voa = (ag && n < pe.ne) ? ((unsigned)rr * agl + 4u * cq) * 4u : SEGSDE_OOB;
+        const unsigned stepa = (unsigned)RPP * agl * 4u;
         const float* cp = Ct + rr * BN + 4 * cq;
         float4 o[NR];
         if (pe.accum) {
@@ -878,7 +895,15 @@ __global__ __launch_bounds__(256, VAR == 6 ? 3 : 2) void conv_igemm_kernel(ConvP
             v.x *= segsde_act_grad_from_out(yv.x, pe.agkind); v.y *= segsde_act_grad_from_out(yv.y, pe.agkind);
             v.z *= segsde_act_grad_from_out(yv.z, pe.agkind); v.w *= segsde_act_grad_from_out(yv.w, pe.agkind);
           }
-          if (pe.accum) { v.x += o[t].x; v.y += o[t].y; v.z += o[t].z; v.w += o[t].w; }
+          if (pe.accum) {
+            v.x += o[t].x; v.y += o[t].y; v.z += o[t].z; v.w += o[t].w;
+            if (pe.act == SEGSDE_ACT_ELU) {
+              v.x = v.x > 0.f ? v.x : __expf(fminf(v.x, 0.f)) - 1.f; v.y = v.y > 0.f ? v.y : __expf(fminf(v.y, 0.f)) - 1.f;
+              v.z = v.z > 0.f ? v.z : __expf(fminf(v.z, 0.f)) - 1.f; v.w = v.w > 0.f ? v.w : __expf(fminf(v.w, 0.f)) - 1.f;
+            } else if (pe.act != SEGSDE_ACT_NONE) {
+              v.x = segsde_act(v.x, pe.act); v.y = segsde_act(v.y, pe.act); v.z = segsde_act(v.z, pe.act); v.w = segsde_act(v.w, pe.act);
+            }
+          }
           segsde_buffer_store4(rd, vo, so, v);
           so += step; soa += stepa;
         }
@@ -913,6 +938,12 @@ __global__ __launch_bounds__(256, VAR == 6 ? 3 : 2) void conv_igemm_kernel(ConvP
               v.z *= segsde_act_grad_from_out(yv.z, pe.agkind); v.w *= segsde_act_grad_from_out(yv.w, pe.agkind);
             }
             v.x += o[t].x; v.y += o[t].y; v.z += o[t].z; v.w += o[t].w;
+            if (pe.act == SEGSDE_ACT_ELU) {      // same expression as the staged path (accumulate, then activate)
+              v.x = v.x > 0.f ? v.x : __expf(fminf(v.x, 0.f)) - 1.f; v.y = v.y > 0.f ? v.y : __expf(fminf(v.y, 0.f)) - 1.f;
+              v.z = v.z > 0.f ? v.z : __expf(fminf(v.z, 0.f)) - 1.f; v.w = v.w > 0.f ? v.w : __expf(fminf(v.w, 0.f)) - 1.f;
+            } else if (pe.act != SEGSDE_ACT_NONE) {
+              v.x = segsde_act(v.x, pe.act); v.y = segsde_act(v.y, pe.act); v.z = segsde_act(v.z, pe.act); v.w = segsde_act(v.w, pe.act);
+            }
             *reinterpret_cast<float4*>(dst + out_row(pe, m) * ld + nn) = v;
           }
         }
@@ -1132,18 +1163,18 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(ConvP p, const float
   const unsigned tWs0 = (unsigned)(p.W >> p.up0), tld0 = (unsigned)p.ld0, tld1 = (unsigned)p.ld1;
   const size_t tbs0 = (size_t)(p.H >> p.up0) * tWs0 * tld0, tbs1 = (size_t)p.H * p.W * tld1;
   if constexpr (SIMPLE) {
-    const bool refl = p.pad_mode == SEGSDE_PAD_REFLECT;
+    const bool refl = p.pad_mode == SEGSDE_PAD_REFLECT || p.pad_mode == SEGSDE_PAD_CLAMP_, clampm = p.pad_mode == SEGSDE_PAD_CLAMP_;
     for (int j = tid; j < He; j += 256) {
       const int hi = j - p.pad;
       const bool ok = refl || (unsigned)hi < (unsigned)p.H;
-      const int hr = hi < 0 ? -hi : (hi >= p.H ? 2 * p.H - 2 - hi : hi);
+      const int hr = clampm ? (hi < 0 ? 0 : (hi >= p.H ? p.H - 1 : hi)) : (hi < 0 ? -hi : (hi >= p.H ? 2 * p.H - 2 - hi : hi));
       tabs[j] = ok ? (unsigned)(hr >> p.up0) * tWs0 * tld0 * 4u : TAB_MARK;
       tabs[He + We + j] = ok ? (unsigned)hr * (unsigned)p.W * tld1 * 4u : TAB_MARK;
     }
     for (int j = tid; j < We; j += 256) {
-      const int wi = j - p.pad;
+      const int wi = j - p.padw;
       const bool ok = refl || (unsigned)wi < (unsigned)p.W;
-      const int wr = wi < 0 ? -wi : (wi >= p.W ? 2 * p.W - 2 - wi : wi);
+      const int wr = clampm ? (wi < 0 ? 0 : (wi >= p.W ? p.W - 1 : wi)) : (wi < 0 ? -wi : (wi >= p.W ? 2 * p.W - 2 - wi : wi));
       tabs[He + j] = ok ? (unsigned)(wr >> p.up0) * tld0 * 4u : TAB_MARK;
       tabs[2 * He + We + j] = ok ? (unsigned)wr * tld1 * 4u : TAB_MARK;
     }
@@ -1161,7 +1192,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(ConvP p, const float
 #pragma unroll
     for (int i = 0; i < DI; ++i) {
       const int e = tid + 256 * i, row = e / DQ, nq = e - row * DQ;
-      voffD[i] = n0 + 4 * nq < p.N ? (unsigned)(row * lddy + n0 + 4 * nq) * 4u : SEGSDE_OOB;
+      voffD[i] = n0 + 4 * nq < p.N ? (unsigned)(row * p.os * lddy + n0 + 4 * nq) * 4u : SEGSDE_OOB;   // os > 1: dY on a strided sub-grid
     }
     int b_, h_, w_; bool ok_;
     decode_m(p, c_begin * BP < p.M ? c_begin * BP : 0, b_, h_, w_, ok_);
@@ -1204,8 +1235,18 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(ConvP p, const float
       }
     }
   };
+  // first dY row of the chunk at (cb, chh, cw): pixel c * BP of the plain problem; for the class launches of an
+  // upsample-folded weight gradient (os = 2) the pixels of a chunk are every second pixel of row os * chh + oph of the
+  // full-resolution gradient image
+  auto dybase = [&](int c) -> const float* {
+    if (p.os == 1) return dy + (size_t)c * BP * lddy;
+    // 32-bit pixel index (B * H * W < 2^31, host check), ONE widening multiply: stays on the scalar unit (a 64 x 32-bit
+    // product would go through the vector ALU and leave the buffer resource in VGPRs)
+    const unsigned pix = (unsigned)((cb * p.OHf + p.os * chh + p.oph) * p.OWf + p.os * cw + p.opw);
+    return dy + (size_t)pix * (unsigned)lddy;
+  };
   auto dload = [&](int c) {
-    const segsde_rsrc rd_ = segsde_make_rsrc(dy + (size_t)c * BP * lddy, c < nchunks_total ? 0x7fffffffu : 0u);
+    const segsde_rsrc rd_ = segsde_make_rsrc(dybase(c), c < nchunks_total ? 0x7fffffffu : 0u);
 #pragma unroll
     for (int i = 0; i < DI; ++i) rd[i] = segsde_buffer_load4(rd_, voffD[i], 0u);
     cw += BP;
@@ -1352,7 +1393,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(ConvP p, const float
           *reinterpret_cast<float4*>(At + row * BKT + 4 * kq) = ra[i];
         }
       }
-      const segsde_rsrc rd_ = segsde_make_rsrc(dy + (size_t)c * BP * lddy, live ? 0x7fffffffu : 0u);
+      const segsde_rsrc rd_ = segsde_make_rsrc(dybase(c), live ? 0x7fffffffu : 0u);
 #pragma unroll
       for (int i = 0; i < DI; ++i)
         segsde_buffer_load4_lds(rd_, voffD[i], 0u, lds0 + stage + (unsigned)((BP * BKT + ((256 / DQ) * i + (64 / DQ) * wv) * BN) * 4));
@@ -1476,7 +1517,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(ConvP p, const float
 
 // dW[o][c][kh][kw] (OIHW, the state_dict layout) = sum_z part[z][(kh*KW+kw)*Ctot + c][o], fixed order
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* part, int splits, int Ktot, int N, int Ctot,
-                                                           int taps, int srcC0, float* dw) {
+                                                           int taps, int srcC0, float* dw, int CtotDst, int cOff) {
   // 32 output elements x 8 split-lanes per block; each lane sums every 8th slab (4 independent chains), fixed order
   SEGSDE_SMEM;
   float* sh = reinterpret_cast<float*>(segsde_smem);
@@ -1500,7 +1541,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* part, in
     const int k = (int)(e / N), n = (int)(e - (long)k * N);
     int tap, c;
     wgrad_k_decode(k, Ctot, taps, srcC0, tap, c);
-    dw[((long)n * Ctot + c) * taps + tap] = s;
+    dw[((long)n * CtotDst + cOff + c) * taps + tap] = s;   // (CtotDst, cOff): the channels of a slice of a wider OIHW tensor
   }
 }
 
@@ -1661,6 +1702,7 @@ ConvP make_params(const segsde_conv_desc* d, const float* x0, const float* x1, c
   p.agy = nullptr; p.agld = 0; p.agkind = 0;
   p.lin = d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && d->in_div <= 1 && !d->up0 && !d->sum2x2 && d->C1 == 0 &&
           d->H == d->Ho && d->W == d->Wo;
+  p.padw = p.pad; p.wtap = p.Ctot; p.osfast = 0;
   return p;
 }
 
@@ -1717,6 +1759,8 @@ int launch_igemm(const ConvP& p, hipStream_t stream) {
   if (igemm_fast_ok(p) && p.pad_mode == SEGSDE_PAD_REFLECT_ADJOINT && !(tune().adjfix && !p.sum2x2) && tune().adjfix < 2)
     return tune().var == 8 ? launch_igemm_mode<BM, BN, WM, WN, 3, 32, 8>(p, stream)
            : (tune().adjlds ? launch_igemm_mode<BM, BN, WM, WN, 3, 32>(p, stream) : launch_igemm_mode<BM, BN, WM, WN, 3, 32, 5>(p, stream));
+  if (p.pad_mode == SEGSDE_PAD_CLAMP_)   // upsample-folded class launches (host guarantees the FAST conditions)
+    return igemm_fast_ok(p) ? launch_igemm_mode<BM, BN, WM, WN, 4, 32, 9>(p, stream) : SEGSDE_ERR_UNSUPPORTED;
   if (tune().bk64 && bk64_ok(p)) return launch_igemm_mode<BM, BN, WM, WN, 2, 64>(p, stream);
   if (igemm_fast_ok(p) && tune().dma) {
     if (tune().var == 1) return launch_igemm_mode<BM, BN, WM, WN, 4, 32, 1>(p, stream);
@@ -1840,9 +1884,7 @@ extern "C" int segsde_conv2d_dgrad_actgrad(const segsde_conv_desc* d, const floa
         q.in_div = 1;
         // source row of loop tap kh' for sub-grid row i:  i + (ph + kh0*dil - pad)/2 + kh'*dil   (exact division)
         q.pad = -((ph + kh0 * d->dil - d->pad) / 2);
-        // the loader has one padding value for both axes: a class whose column offset differs from its row offset
-        // (dilation 3 with stride 2: no model of the reference has it) sends the whole problem to the generic path
-        if (q.pad != -((pw + kw0 * d->dil - d->pad) / 2)) ok = false;
+        q.padw = -((pw + kw0 * d->dil - d->pad) / 2);   // (per-axis padding: round 3)
         q.os = 2; q.oph = ph; q.opw = pw; q.OHf = d->Ho; q.OWf = d->Wo;
         q.Ho = nI; q.Wo = nJ; q.M = d->B * nI * nJ;
         set_divs(q);
@@ -1909,7 +1951,7 @@ int wgrad_mode(const ConvP& p, const float* dy, int lddy) {
   const long e0 = (long)p.B * (p.H >> p.up0) * (p.W >> p.up0) * p.ld0, e1 = (long)p.B * p.H * p.W * p.ld1;
   const bool fast = vec_ok(p) && e0 < (1L << 31) && e1 < (1L << 31);   // the dY side may be scalar (odd Cout)
   const long i0 = (long)(p.H >> p.up0) * (p.W >> p.up0) * p.ld0 * 4, i1 = (long)p.H * p.W * p.ld1 * 4;
-  const bool table = p.Wo % BP == 0 && i0 <= (1L << 30) && i1 <= (1L << 30) && (long)BP * lddy * 4 < (1L << 30);
+  const bool table = p.Wo % BP == 0 && i0 <= (1L << 30) && i1 <= (1L << 30) && (long)BP * p.os * lddy * 4 < (1L << 30);
   if (fast && vec && table) return 2;
   if (fast) return 3;
   return vec ? 1 : 0;
@@ -1996,8 +2038,312 @@ extern "C" int segsde_conv2d_wgrad(const segsde_conv_desc* d, const float* x0, c
   if (e) return e;
   const long total = (long)p.Ktot * p.N;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(segsde_cdiv(total, 32)), dim3(256), 1024, s, workspace, splits,
-                     p.Ktot, p.N, p.Ctot, d->KH * d->KW, (wgrad_mode(p, dy, lddy) == 2 && p.C1 > 0) ? p.C0 : 0, dw_oihw);
+                     p.Ktot, p.N, p.Ctot, d->KH * d->KW, (wgrad_mode(p, dy, lddy) == 2 && p.C1 > 0) ? p.C0 : 0, dw_oihw, p.Ctot, 0);
   SEGSDE_CHECK_LAUNCH();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Upsample-folded 3x3 convolutions (round 3)
+// ---------------------------------------------------------------------------------------------------
+// models/depth_decoder.py:93-101 runs Conv3x3 (ReflectionPad2d(1) + 3x3, monodepth_layers.py:127-142) on
+// [upsample(x) | skip]: nearest x2 upsampling followed by a 3x3 window.  On the upsampled channels the nine taps of an
+// output pixel (2i+py, 2j+px) land on only 2x2 DISTINCT low-resolution pixels -- rows {i-1, i} for py = 0 and {i, i+1} for
+// py = 1, columns likewise -- and the mirrored padding of the upsampled image is clamping on the low-resolution grid (row -1
+// mirrors to row 1 = low-resolution row 0).  So per parity class (py, px) the upsampled half of the convolution is a 2x2
+// convolution of the LOW-resolution tensor with pre-summed weights  Wf[class][th][tw] = sum_{kh in S(py,th)} sum_{kw in
+// S(px,tw)} W[kh][kw],  S(0,0) = {0}, S(0,1) = {1,2}, S(1,0) = {0,1}, S(1,1) = {2}:  4 instead of 9 multiply-adds per
+// upsampled channel, an exact identity up to the association of the weight sums.  The three directions become
+//   forward : 4 class launches (2x2, clamp padding, low-resolution source, strided sub-grid store) + the ordinary 3x3 on the
+//             skip channels, which accumulates onto them and applies bias + activation;
+//   dgrad   : d/d(low-resolution x) = a 4x4 stride-2 convolution of dY (16 (class, tap) pairs instead of 36 tap visits per
+//             2x2 block) + the clamp adjoint on the border pixels (upfold_dgrad_fix_kernel); d/d(skip) = the ordinary
+//             reflection-adjoint data-gradient restricted to the skip channels;
+//   wgrad   : 4 class launches (K = 2*2*C0 columns each, dY read on the strided sub-grid), unfolded into the 3x3 taps by
+//             upfold_wgrad_reduce_kernel (dW[kh][kw] = sum over the four classes of the folded tap it belongs to) + the
+//             ordinary weight gradient of the skip channels.
+namespace {
+__device__ __host__ inline int upfold_th(int py, int kh) { return py == 0 ? (kh == 0 ? 0 : 1) : (kh == 2 ? 1 : 0); }
+
+// OIHW [Cout][Ctot][3][3] -> wf [4][Cout][2][2][C0] (forward / fix-up) and wd [C0][4][4][Cout] (data-gradient: tap a of the
+// 4x4 stride-2 kernel stands for (class parity, folded tap) = (1,1), (0,1), (1,0), (0,0) for a = 0..3, rows and columns alike)
+__global__ __launch_bounds__(256) void upfold_pack_kernel(const float* w, int Cout, int C0, int Ctot, float* wf, float* wd) {
+  const long total = 4L * Cout * 4 * C0;
+  for (long e = blockIdx.x * 256L + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const int c = (int)(e % C0); long t = e / C0;
+    const int tw = (int)(t & 1), th = (int)((t >> 1) & 1); t >>= 2;
+    const int n = (int)(t % Cout), cls = (int)(t / Cout);
+    const int py = cls >> 1, px = cls & 1;
+    const float* wp = w + ((long)n * Ctot + c) * 9;
+    float sum = 0.f;
+    for (int kh = 0; kh < 3; ++kh) {
+      if (upfold_th(py, kh) != th) continue;
+      float r = 0.f;
+      for (int kw = 0; kw < 3; ++kw)
+        if (upfold_th(px, kw) == tw) r += wp[kh * 3 + kw];
+      sum += r;
+    }
+    wf[e] = sum;
+    const int a = 3 - 2 * th - py, b = 3 - 2 * tw - px;
+    wd[(((long)c * 4 + a) * 4 + b) * Cout + n] = sum;
+  }
+}
+
+// clamp adjoint of the folded data-gradient: a low-resolution border pixel (row 0 / H2-1, column 0 / W2-1) also receives
+// what its clamped taps read -- row 0 through tap a = 3 from dY row 0 (class py = 0, folded tap th = 0 of output row 0),
+// row H2-1 through a = 0 from dY row H-1; columns alike.  One thread per (border pixel, channel); dY values are wave-uniform,
+// the forward-folded weights are read channel-contiguous.  agy (nullable): the saved activation output the gradient is
+// multiplied with (same rule as the main launch's epilogue).
+__global__ __launch_bounds__(256) void upfold_dgrad_fix_kernel(const float* dy, int lddy, const float* wf, float* dx, int lddx,
+                                                               int B, int H2, int W2, int C0, int Cout, const float* agy,
+                                                               int agld, int agkind) {
+  const int nbord = H2 >= 2 ? 2 * W2 + 2 * (H2 - 2) : W2;
+  const long total = (long)B * nbord * C0;
+  const int H = 2 * H2, W = 2 * W2;
+  for (long e = blockIdx.x * 256L + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const int c = (int)(e % C0); long t = e / C0;
+    const int q = (int)(t % nbord), b = (int)(t / nbord);
+    int i, j;
+    if (q < W2) { i = 0; j = q; }
+    else if (q < 2 * W2) { i = H2 - 1; j = q - W2; }
+    else { const int r = q - 2 * W2; i = 1 + (r >> 1); j = (r & 1) ? W2 - 1 : 0; }
+    float acc = 0.f;
+    for (int a = 0; a < 4; ++a) {
+      const int rm = 2 * i - 1 + a;
+      const int rx = (i == 0 && a == 3) ? 0 : ((i == H2 - 1 && a == 0) ? H - 1 : -1);
+      const int py = (a & 1) ? 0 : 1, th = a >= 2 ? 0 : 1;          // a = 3 - 2 th - py
+      for (int bb = 0; bb < 4; ++bb) {
+        const int cm = 2 * j - 1 + bb;
+        const int cx = (j == 0 && bb == 3) ? 0 : ((j == W2 - 1 && bb == 0) ? W - 1 : -1);
+        if (rx < 0 && cx < 0) continue;
+        const int px = (bb & 1) ? 0 : 1, tw = bb >= 2 ? 0 : 1;
+        const float* wrow = wf + (((long)(py * 2 + px) * Cout) * 4 + th * 2 + tw) * C0 + c;
+        for (int v = 0; v < 3; ++v) {      // (extra row, main column), (main row, extra column), (extra row, extra column)
+          const int r = v == 1 ? rm : rx, sc = v == 0 ? cm : cx;
+          if (r < 0 || r >= H || sc < 0 || sc >= W) continue;
+          const float* dp = dy + ((long)(b * H + r) * W + sc) * lddy;
+          float part = 0.f;
+          for (int n = 0; n < Cout; ++n) part += dp[n] * wrow[(long)n * 4 * C0];
+          acc += part;
+        }
+      }
+    }
+    const long pix = (long)(b * H2 + i) * W2 + j;
+    if (agy) acc *= segsde_act_grad_from_out(agy[pix * agld + c], agkind);
+    dx[pix * lddx + c] += acc;
+  }
+}
+
+// dW[n][c][kh][kw] (c < C0, OIHW with CtotDst channels) = sum over the four classes and the splits of the folded tap's partial
+// slab part[class][z][(th*2 + tw) * C0 + c][n]: fixed order (class-major, then splits), deterministic
+__global__ __launch_bounds__(256) void upfold_wgrad_reduce_kernel(const float* part, int splits, int C0, int N, float* dw,
+                                                                  int CtotDst) {
+  const long total = (long)N * C0 * 9;
+  const long slab = 4L * C0 * N;
+  for (long e = blockIdx.x * 256L + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    // e indexes (c, tap, n) with n fastest so that the slab reads coalesce
+    const int n = (int)(e % N); long t = e / N;
+    const int tap = (int)(t % 9), c = (int)(t / 9);
+    const int kh = tap / 3, kw = tap - kh * 3;
+    float s = 0.f;
+    for (int cls = 0; cls < 4; ++cls) {
+      const int th = upfold_th(cls >> 1, kh), tw = upfold_th(cls & 1, kw);
+      const float* src = part + (long)cls * splits * slab + ((long)(th * 2 + tw) * C0 + c) * N + n;
+      float s0 = 0.f, s1 = 0.f;
+      int z = 0;
+      for (; z + 1 < splits; z += 2) { s0 += src[(long)z * slab]; s1 += src[(long)(z + 1) * slab]; }
+      if (z < splits) s0 += src[(long)z * slab];
+      s += s0 + s1;
+    }
+    dw[((long)n * CtotDst + c) * 9 + tap] = s;
+  }
+}
+
+bool upfold_shape_ok(const segsde_conv_desc* d) {
+  return d->up0 && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->dil == 1 && d->pad == 1 && d->pad_mode == SEGSDE_PAD_REFLECT &&
+         d->H == d->Ho && d->W == d->Wo && !(d->H & 1) && !(d->W & 1) && d->H >= 4 && d->W >= 4 && d->C0 % 32 == 0 &&
+         d->C1 % 32 == 0 && d->Cout % 4 == 0 && d->in_div <= 1 && !d->sum2x2 && !d->accumulate;
+}
+
+// class launch of the forward fold: 2x2 clamp-padded convolution of the low-resolution source, stored to sub-grid (py, px)
+ConvP upfold_class_fwd(const segsde_conv_desc* d, const float* x0, const float* wf, const float* bias, float* y, int py, int px) {
+  segsde_conv_desc c = *d;
+  c.H = d->H / 2; c.W = d->W / 2; c.Ho = c.H; c.Wo = c.W; c.up0 = 0; c.C1 = 0; c.ld1 = 0; c.KH = 2; c.KW = 2;
+  c.pad = 1 - py; c.pad_mode = SEGSDE_PAD_ZERO; c.nsplit = 0; c.ldy2 = 0;
+  if (d->C1) c.act = 0;                               // bias + activation belong to the launch that completes the sum
+  ConvP q = make_params(&c, x0, nullptr, wf + (long)(py * 2 + px) * d->Cout * 4 * d->C0, d->C1 ? nullptr : bias, y, nullptr);
+  q.pad_mode = SEGSDE_PAD_CLAMP_; q.padw = 1 - px;
+  q.os = 2; q.oph = py; q.opw = px; q.OHf = d->H; q.OWf = d->W;
+  q.osfast = (c.Wo % 128 == 0) ? 1 : 0;
+  q.lin = 0;
+  return q;
+}
+int launch_by_n(const ConvP& q, hipStream_t s) {
+  if (q.N <= 32) return launch_igemm<128, 32, 4, 1>(q, s);
+  if (q.N <= 64) return launch_igemm<128, 64, 2, 2>(q, s);
+  if (q.N % 128 > 0 && q.N % 128 <= 64) {
+    ConvP a = q, b = q;
+    a.ne = q.N - q.N % 128; b.nb = a.ne;
+    if (int e = launch_igemm<128, 128, 2, 2>(a, s)) return e;
+    return (b.ne - b.nb <= 32) ? launch_igemm<128, 32, 4, 1>(b, s) : launch_igemm<128, 64, 2, 2>(b, s);
+  }
+  return launch_igemm<128, 128, 2, 2>(q, s);
+}
+}  // namespace
+
+extern "C" int segsde_upfold_pack(const float* w_oihw, int Cout, int C0, int Ctot, float* wfold, float* wdfold, void* stream) {
+  if (!w_oihw || !wfold || !wdfold) return SEGSDE_ERR_NULL;
+  if (Cout <= 0 || C0 <= 0 || Ctot < C0) return SEGSDE_ERR_SHAPE;
+  const long total = 16L * Cout * C0;
+  hipLaunchKernelGGL(upfold_pack_kernel, dim3(min(2048, segsde_cdiv(total, 256))), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     w_oihw, Cout, C0, Ctot, wfold, wdfold);
+  SEGSDE_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int segsde_conv2d_forward_upfold(const segsde_conv_desc* d, const float* x0, const float* x1, const float* wpack,
+                                            const float* wfold, const float* bias, float* y, void* stream) {
+  if (int e = validate(d)) return e;
+  if (!x0 || !wpack || !wfold || !y || (d->C1 && !x1)) return SEGSDE_ERR_NULL;
+  if (!upfold_shape_ok(d) || d->ldy % 4 || !aligned16(y) || !aligned16(wfold)) return SEGSDE_ERR_UNSUPPORTED;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  ConvP cls[4];
+  for (int k = 0; k < 4; ++k) {
+    cls[k] = upfold_class_fwd(d, x0, wfold, bias, y, k >> 1, k & 1);
+    if (!igemm_fast_ok(cls[k]) || !cls[k].vecout) return SEGSDE_ERR_UNSUPPORTED;
+  }
+  ConvP r;
+  if (d->C1) {
+    // the skip channels: the ordinary reflection-padded 3x3 over source 1 alone, reading its channel slice of the packed rows,
+    // added onto the class launches' sums; bias and activation are applied here
+    segsde_conv_desc c = *d;
+    c.C0 = d->C1; c.C1 = 0; c.ld0 = d->ld1; c.ld1 = 0; c.up0 = 0; c.accumulate = 1; c.nsplit = 0; c.ldy2 = 0;
+    r = make_params(&c, x1, nullptr, wpack + d->C0, bias, y, nullptr);
+    r.wtap = d->C0 + d->C1; r.Kfull = 9 * (d->C0 + d->C1);
+    if (!igemm_fast_ok(r) || !r.vecout || (long)r.N * r.Kfull * 4 >= (1L << 31)) return SEGSDE_ERR_UNSUPPORTED;
+  }
+  for (int k = 0; k < 4; ++k)
+    if (int e = launch_by_n(cls[k], s)) return e;
+  if (d->C1)
+    if (int e = launch_by_n(r, s)) return e;
+  return 0;
+}
+
+extern "C" int segsde_conv2d_dgrad_upfold(const segsde_conv_desc* d, const float* dy, int lddy, const float* wdpack,
+                                          const float* wfold, const float* wdfold, float* dx0, float* dx1,
+                                          const float* act_out, int act_ld, int act_kind, void* stream) {
+  // d: the FORWARD geometry (H x W virtual input, C0 upsampled + C1 skip channels, Cout).  dx0 [B,H/2,W/2,C0] dense (nullable),
+  // dx1 [B,H,W,C1] dense (nullable); act_out: the saved activation output dx0 is differentiated through (nullable)
+  if (int e = validate(d)) return e;
+  if (!dy || !wdpack || !wfold || !wdfold || (!dx0 && !dx1)) return SEGSDE_ERR_NULL;
+  if (!upfold_shape_ok(d) || lddy % 4 || !aligned16(dy) || d->Cout % 32) return SEGSDE_ERR_UNSUPPORTED;
+  if (act_out && (act_kind < SEGSDE_ACT_RELU || act_kind > SEGSDE_ACT_SIGMOID || act_ld < d->C0 || (act_ld % 4) || !aligned16(act_out)))
+    return SEGSDE_ERR_UNSUPPORTED;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int H2 = d->H / 2, W2 = d->W / 2;
+  ConvP q, r;
+  if (dx0) {
+    segsde_conv_desc c = *d;            // 4x4 stride-2 zero-padded convolution of dY -> low-resolution gradient
+    c.C0 = d->Cout; c.C1 = 0; c.ld0 = lddy; c.ld1 = 0; c.up0 = 0; c.Ho = H2; c.Wo = W2; c.Cout = d->C0; c.ldy = d->C0; c.ldy2 = 0;
+    c.nsplit = 0; c.KH = 4; c.KW = 4; c.stride = 2; c.dil = 1; c.pad = 1; c.pad_mode = SEGSDE_PAD_ZERO; c.act = 0;
+    q = make_params(&c, dy, nullptr, wdfold, nullptr, dx0, nullptr);
+    if (act_out) { q.agy = act_out; q.agld = act_ld; q.agkind = act_kind; }
+    if (!igemm_fast_ok(q) || !q.vecout) return SEGSDE_ERR_UNSUPPORTED;
+  }
+  if (dx1 && d->C1) {
+    segsde_conv_desc c = *d;            // reflection-adjoint data-gradient of the skip channels: rows C0.. of the dgrad pack
+    c.C0 = d->Cout; c.C1 = 0; c.ld0 = lddy; c.ld1 = 0; c.up0 = 0; c.Cout = d->C1; c.ldy = d->C1; c.ldy2 = 0; c.nsplit = 0;
+    c.pad_mode = SEGSDE_PAD_REFLECT_ADJOINT; c.act = 0;
+    if (int e = validate(&c)) return e;
+    r = make_params(&c, dy, nullptr, wdpack + (long)d->C0 * 9 * d->Cout, nullptr, dx1, nullptr);
+    if (!igemm_fast_ok(r) || !r.vecout) return SEGSDE_ERR_UNSUPPORTED;
+  }
+  if (dx0) {
+    if (int e = launch_by_n(q, s)) return e;
+    const long total = (long)d->B * (2 * W2 + 2 * H2) * d->C0;
+    hipLaunchKernelGGL(upfold_dgrad_fix_kernel, dim3(min(8192, segsde_cdiv(total, 256))), dim3(256), 0, s, dy, lddy, wfold, dx0,
+                       d->C0, d->B, H2, W2, d->C0, d->Cout, act_out, act_ld, act_kind);
+    SEGSDE_CHECK_LAUNCH();
+  }
+  if (dx1 && d->C1)
+    if (int e = launch_by_n(r, s)) return e;
+  return 0;
+}
+
+namespace {
+struct UpfoldWgradPlan { segsde_conv_desc cls, skip; int bn, splits, cps, bn1, splits1, cps1; size_t ws_fold, ws_skip; };
+bool upfold_wgrad_plan(const segsde_conv_desc* d, UpfoldWgradPlan& pl) {
+  if (!upfold_shape_ok(d)) return false;
+  pl.cls = *d;
+  pl.cls.H = d->H / 2; pl.cls.W = d->W / 2; pl.cls.Ho = pl.cls.H; pl.cls.Wo = pl.cls.W; pl.cls.up0 = 0; pl.cls.C1 = 0; pl.cls.ld1 = 0;
+  pl.cls.KH = 2; pl.cls.KW = 2; pl.cls.pad = 1; pl.cls.pad_mode = SEGSDE_PAD_ZERO; pl.cls.act = 0;
+  int bkt;
+  wgrad_plan(&pl.cls, bkt, pl.bn, pl.splits, pl.cps);
+  pl.ws_fold = 4 * (size_t)pl.splits * 4 * d->C0 * d->Cout * sizeof(float);
+  pl.ws_skip = 0;
+  if (d->C1) {
+    pl.skip = *d;
+    pl.skip.C0 = d->C1; pl.skip.C1 = 0; pl.skip.ld0 = d->ld1; pl.skip.ld1 = 0; pl.skip.up0 = 0; pl.skip.act = 0;
+    wgrad_plan(&pl.skip, bkt, pl.bn1, pl.splits1, pl.cps1);
+    pl.ws_skip = (size_t)pl.splits1 * 9 * d->C1 * d->Cout * sizeof(float);
+  }
+  return true;
+}
+template <typename... A>
+int launch_wgrad_by_bn(int bn, A... a) {
+  if (bn == 32) return launch_wgrad<128, 32, 4, 1>(a...);
+  if (bn == 64) return launch_wgrad<128, 64, 2, 2>(a...);
+  return launch_wgrad<128, 128, 2, 2>(a...);
+}
+}  // namespace
+
+extern "C" size_t segsde_conv2d_wgrad_upfold_workspace(const segsde_conv_desc* d) {
+  UpfoldWgradPlan pl;
+  if (validate(d) || !upfold_wgrad_plan(d, pl)) return 0;
+  return pl.ws_fold + pl.ws_skip;
+}
+
+extern "C" int segsde_conv2d_wgrad_upfold(const segsde_conv_desc* d, const float* x0, const float* x1, const float* dy, int lddy,
+                                          float* dw_oihw, float* workspace, size_t workspace_bytes, void* stream) {
+  if (int e = validate(d)) return e;
+  if (!x0 || !dy || !dw_oihw || !workspace || (d->C1 && !x1)) return SEGSDE_ERR_NULL;
+  UpfoldWgradPlan pl;
+  if (!upfold_wgrad_plan(d, pl)) return SEGSDE_ERR_UNSUPPORTED;
+  if (workspace_bytes < pl.ws_fold + pl.ws_skip) return SEGSDE_ERR_WORKSPACE;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int Ctot = d->C0 + d->C1;
+  ConvP cls[4];
+  const size_t slab = (size_t)pl.splits * 4 * d->C0 * d->Cout;
+  for (int k = 0; k < 4; ++k) {
+    const int py = k >> 1, px = k & 1;
+    segsde_conv_desc c = pl.cls;
+    c.pad = 1 - py;
+    ConvP q = make_params(&c, x0, nullptr, dy, nullptr, workspace + k * slab, nullptr);
+    q.pad_mode = SEGSDE_PAD_CLAMP_; q.padw = 1 - px;
+    q.os = 2; q.oph = py; q.opw = px; q.OHf = d->H; q.OWf = d->W;
+    if (wgrad_mode(q, dy, lddy) != 2) return SEGSDE_ERR_UNSUPPORTED;   // the table-driven loader is the one that knows sub-grids
+    cls[k] = q;
+  }
+  ConvP r;
+  if (d->C1) {
+    r = make_params(&pl.skip, x1, nullptr, dy, nullptr, workspace + 4 * slab, nullptr);
+  }
+  for (int k = 0; k < 4; ++k)
+    if (int e = launch_wgrad_by_bn(pl.bn, cls[k], dy, lddy, workspace + k * slab, pl.splits, pl.cps, s)) return e;
+  {
+    const long total = (long)d->Cout * d->C0 * 9;
+    hipLaunchKernelGGL(upfold_wgrad_reduce_kernel, dim3(min(4096, segsde_cdiv(total, 256))), dim3(256), 0, s, workspace, pl.splits,
+                       d->C0, d->Cout, dw_oihw, Ctot);
+    SEGSDE_CHECK_LAUNCH();
+  }
+  if (d->C1) {
+    float* ws1 = workspace + 4 * slab;
+    if (int e = launch_wgrad_by_bn(pl.bn1, r, dy, lddy, ws1, pl.splits1, pl.cps1, s)) return e;
+    const long total = (long)r.Ktot * r.N;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(segsde_cdiv(total, 32)), dim3(256), 1024, s, ws1, pl.splits1, r.Ktot, r.N, r.Ctot, 9, 0,
+                       dw_oihw, Ctot, d->C0);
+    SEGSDE_CHECK_LAUNCH();
+  }
   return 0;
 }
 

@@ -92,11 +92,15 @@ class ConvFn(Function):
             wp, ctx.wd = H.pack_weight_both(weight)     # the data-gradient pack is needed by backward: one launch for both
         else:
             wp = H.pack_weight(weight, False)
+        ctx.fold = None
         if stats_out is not None:
             y, part = H.conv_forward(g, x0, x1, wp, bias, act, want_stats=True)
             stats_out.append(part)
         else:
-            y = H.conv_forward(g, x0, x1, wp, bias, act)
+            if H.upfold_ok(g) and x0.is_contiguous() and (x1 is None or x1.is_contiguous()):
+                # decoder Conv3x3 on [upsample(x0) | x1]: the upsample-folded route (4 taps instead of 9 on the upsampled channels)
+                ctx.fold = H.upfold_pack(weight, g.C0)
+            y = H.conv_forward(g, x0, x1, wp, bias, act, wfold=None if ctx.fold is None else ctx.fold[0])
         ctx.g, ctx.act = g, act
         ctx.in_hw = (x0.shape[1] * (2 if g.up0 else 1), x0.shape[2] * (2 if g.up0 else 1))
         ctx.has_bias = bias is not None
@@ -130,7 +134,8 @@ class ConvFn(Function):
                 if dx0 is not None:
                     box["fused"] = True      # dx0 IS the residual-path gradient, now holding the sum
             if dx0 is None:
-                dx0, dx1 = H.conv_dgrad(g, dz, wd, weight.detach(), ctx.in_hw, actgrad=actgrad)
+                dx0, dx1 = H.conv_dgrad(g, dz, wd, weight.detach(), ctx.in_hw, actgrad=actgrad, fold=ctx.fold,
+                                        need0=ctx.needs_input_grad[0], need1=x1 is not None and ctx.needs_input_grad[1])
                 if box is not None and box.get("publish") and box.get("g") is None and x1 is None and not g.up0 \
                         and dx0.is_contiguous():
                     box["g"] = dx0           # FanoutFn: the next consumer's data-gradient is accumulated onto this tensor

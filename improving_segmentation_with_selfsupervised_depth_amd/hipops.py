@@ -5,6 +5,7 @@ every arithmetic step is a call into libsegsde_hip.so.  Activations are NHWC fp3
 last dimension is contiguous (a channel slice of a wider buffer is fine: its pixel pitch ``ld`` is passed on).
 """
 import ctypes
+import os
 
 import torch
 
@@ -19,15 +20,45 @@ ACT = {"none": 0, "relu": 1, "elu": 2, "sigmoid": 3}
 PROFILE = None
 
 
-def _timed(kind, flops, like, launch, tag=""):
+def _timed(kind, flops, like, launch, tag="", executed=None):
+    """executed: the multiply-add work the launch really issues when that is less than the algorithmic figure (the
+    upsample-folded convolutions); defaults to ``flops``"""
     if PROFILE is None or not like.is_cuda:
         return launch()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
     r = launch()
     e.record()
-    PROFILE.append((kind, flops, s, e, tag))
+    PROFILE.append((kind, flops, s, e, tag, flops if executed is None else executed))
     return r
+
+
+# Upsample-folded route of the decoder's Conv3x3 on [upsample(x) | skip] (csrc/conv_igemm.hip, "Upsample-folded 3x3
+# convolutions"): SEGSDE_UPFOLD=0 keeps the plain 9-tap route (A/B measurements, debugging)
+UPFOLD = os.environ.get("SEGSDE_UPFOLD", "1") != "0"
+UPFOLD_TAKEN = {"fwd": 0, "dgrad": 0, "wgrad": 0}    # diagnostics / tests: launches that took the folded route
+
+
+def upfold_ok(g):
+    return (UPFOLD and g.up0 and g.reflect and g.k == 3 and g.stride == 1 and g.dil == 1 and g.pad == 1 and g.C0 % 32 == 0
+            and g.C1 % 32 == 0 and g.Cout % 32 == 0)
+
+
+def upfold_pack(w_oihw, C0):
+    """(wfold [4][Cout][2][2][C0], wdfold [C0][4][4][Cout]) of an OIHW 3x3 weight whose first C0 input channels see a
+    nearest-upsampled source: the pre-summed 2x2 taps of the four output parity classes / the 4x4 stride-2 kernel of the
+    low-resolution data-gradient"""
+    w = _f32(w_oihw.detach()).contiguous()
+    Cout, Ctot, KH, KW = w.shape
+    assert KH == 3 and KW == 3 and 0 < C0 <= Ctot
+    wf = torch.empty((4, Cout, 2, 2, C0), dtype=torch.float32, device=w.device)
+    wd = torch.empty((C0, 4, 4, Cout), dtype=torch.float32, device=w.device)
+    check(_lib.lib().segsde_upfold_pack(_p(w), Cout, C0, Ctot, _p(wf), _p(wd), _stream(w)), "upfold_pack")
+    return wf, wd
+
+
+def _fold_frac(g):
+    return (4.0 * g.C0 + 9.0 * g.C1) / (9.0 * (g.C0 + g.C1))
 
 
 def _tag(g, H, W):
@@ -149,7 +180,7 @@ def pack_weights_multi(weights):
     return views
 
 
-def conv_forward(g, x0, x1, wpack, bias, act="none", want_stats=False):
+def conv_forward(g, x0, x1, wpack, bias, act="none", want_stats=False, wfold=None):
     """y = act(conv(cat[up?(x0), x1]) + bias).  x0: [B,H0,W0,C0] (H0 = H/2 if g.up0), x1: [B,H,W,C1] or None.
     want_stats: also return the per-tile statistics partials of y for the BatchNorm that follows ([rows,2,Cout] doubles,
     or None when this shape cannot fuse them) -> (y, partials)."""
@@ -165,6 +196,15 @@ def conv_forward(g, x0, x1, wpack, bias, act="none", want_stats=False):
                  stride=g.stride, dil=g.dil, pad=g.pad, pad_mode=PAD_REFLECT if g.reflect else PAD_ZERO, in_div=1,
                  act=ACT[act], sum2x2=0)
     flops = 2.0 * B * Ho * Wo * g.Cout * g.Cin * g.k * g.k
+    if wfold is not None and not want_stats:
+        rc = _timed("conv_fwd", flops, x0, lambda: _lib.lib().segsde_conv2d_forward_upfold(
+            ctypes.byref(d), _p(_f32(x0)), _p(x1), _p(wpack), _p(wfold), _p(bias), _p(y), _stream(x0)), _tag(g, H, W) + " fold",
+            executed=flops * _fold_frac(g))
+        if rc == 0:
+            UPFOLD_TAKEN["fwd"] += 1
+            return y
+        if rc != -4:
+            check(rc, "conv2d_forward_upfold")
     part = None
     if want_stats and bias is None and act == "none":
         rows = int(_lib.lib().segsde_conv2d_stats_rows(ctypes.byref(d)))
@@ -176,7 +216,7 @@ def conv_forward(g, x0, x1, wpack, bias, act="none", want_stats=False):
     return (y, part) if want_stats else y
 
 
-def conv_dgrad(g, dy, wdpack, w_oihw, in_hw, need0=True, need1=True, accumulate_into=None, actgrad=None):
+def conv_dgrad(g, dy, wdpack, w_oihw, in_hw, need0=True, need1=True, accumulate_into=None, actgrad=None, fold=None):
     """Data gradient(s) of conv_forward w.r.t. (x0, x1).  dy: [B,Ho,Wo,Cout]; in_hw = (H, W) of the virtual input.
     Returns (dx0, dx1); dx0 is at the *stored* resolution of x0 (2x2-summed when g.up0).
     accumulate_into: a dense [B,H,W,C0] tensor that already holds another gradient of x0 (single-source, non-upsampled
@@ -224,6 +264,25 @@ def conv_dgrad(g, dy, wdpack, w_oihw, in_hw, need0=True, need1=True, accumulate_
             return None, None
         check(rc, "conv2d dgrad (accumulate)")
         return acc, None
+    if g.up0 and fold is not None and accumulate_into is None:
+        # upsample-folded route: low-resolution gradient as a 4x4 stride-2 convolution of dy (+ clamp adjoint on the border),
+        # skip-channel gradient as the ordinary reflection adjoint over its own channels
+        wfold, wdfold = fold
+        dx0 = torch.empty((B, H // 2, W // 2, g.C0), dtype=torch.float32, device=dy.device) if need0 else None
+        dx1f = dx1 if need1 else None
+        if dx0 is None and dx1f is None:
+            return None, None
+        df = ConvDesc(B=B, H=H, W=W, C0=g.C0, C1=g.C1, ld0=g.C0, ld1=g.C1, up0=1, Ho=Ho, Wo=Wo, Cout=Cout, ldy=Cout, ldy2=0,
+                      nsplit=0, KH=3, KW=3, stride=1, dil=1, pad=1, pad_mode=PAD_REFLECT, in_div=1, act=0, sum2x2=0)
+        fr = ((4.0 * g.C0 if need0 else 0.0) + (9.0 * g.C1 if need1 else 0.0)) / (9.0 * g.Cin)
+        rc = _timed("conv_dgrad", flops, dy, lambda: L.segsde_conv2d_dgrad_upfold(
+            ctypes.byref(df), _p(_f32(dy)), nhwc_ld(dy), _p(wdpack), _p(wfold), _p(wdfold), _p(dx0), _p(dx1f),
+            _p(ag_y) if dx0 is not None else None, ag_ld, ag_kind, _stream(dy)), _tag(g, H, W) + " fold", executed=flops * fr)
+        if rc == 0:
+            UPFOLD_TAKEN["dgrad"] += 1
+            return dx0, dx1f
+        if rc != -4:
+            check(rc, "conv2d_dgrad_upfold")
     if g.up0:
         # fused: the 2x2 sum of the upsample adjoint happens in the GEMM epilogue (no full-resolution gradient tensor)
         dx0 = torch.empty((B, H // 2, W // 2, g.C0), dtype=torch.float32, device=dy.device)
@@ -263,10 +322,22 @@ def conv_wgrad(g, x0, x1, dy):
                  up0=int(g.up0), Ho=Ho, Wo=Wo, Cout=Cout, ldy=Cout, ldy2=0, nsplit=0, KH=g.k, KW=g.k, stride=g.stride,
                  dil=g.dil, pad=g.pad, pad_mode=PAD_REFLECT if g.reflect else PAD_ZERO, in_div=1, act=0, sum2x2=0)
     L = _lib.lib()
-    nbytes = L.segsde_conv2d_wgrad_workspace(ctypes.byref(d))
-    ws = _ws(nbytes, dy)
     dw = torch.empty((Cout, g.Cin, g.k, g.k), dtype=torch.float32, device=dy.device)
     flops = 2.0 * B * Ho * Wo * Cout * g.Cin * g.k * g.k
+    if upfold_ok(g):
+        nbytes = L.segsde_conv2d_wgrad_upfold_workspace(ctypes.byref(d))
+        if nbytes:
+            ws = _ws(nbytes, dy)
+            rc = _timed("conv_wgrad", flops, dy, lambda: L.segsde_conv2d_wgrad_upfold(
+                ctypes.byref(d), _p(x0), _p(x1), _p(_f32(dy)), nhwc_ld(dy), _p(dw), _p(ws), nbytes, _stream(dy)),
+                _tag(g, H, W) + " fold", executed=flops * _fold_frac(g))
+            if rc == 0:
+                UPFOLD_TAKEN["wgrad"] += 1
+                return dw
+            if rc != -4:
+                check(rc, "conv2d_wgrad_upfold")
+    nbytes = L.segsde_conv2d_wgrad_workspace(ctypes.byref(d))
+    ws = _ws(nbytes, dy)
     _timed("conv_wgrad", flops, dy, lambda: check(L.segsde_conv2d_wgrad(
         ctypes.byref(d), _p(x0), _p(x1), _p(_f32(dy)), nhwc_ld(dy), _p(dw), _p(ws), nbytes, _stream(dy)), "conv2d_wgrad"),
         _tag(g, H, W))

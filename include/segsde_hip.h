@@ -89,6 +89,29 @@ size_t segsde_conv2d_wgrad_workspace(const segsde_conv_desc* d);
 int segsde_conv2d_wgrad(const segsde_conv_desc* d, const float* x0, const float* x1, const float* dy, int lddy,
                         float* dw_oihw, float* workspace, size_t workspace_bytes, void* stream);
 
+/* Upsample-folded route of Conv3x3 on [upsample(x0) | x1] (models/depth_decoder.py:93-101 with ReflectionPad2d(1) + 3x3,
+ * monodepth_layers.py:127-142; d: up0 = 1, 3x3, stride 1, pad 1, SEGSDE_PAD_REFLECT): on the nearest-upsampled channels the
+ * nine taps of an output pixel touch only 2x2 distinct low-resolution pixels, so per output parity class the upsampled half is
+ * a 2x2 convolution of the low-resolution tensor with pre-summed weights (4 instead of 9 multiply-adds per upsampled channel;
+ * mirrored padding becomes clamping).  Same results as the plain route up to the association of the sums; every entry returns
+ * SEGSDE_ERR_UNSUPPORTED for shapes it does not take (the caller then uses the plain entry points).
+ *   pack    : w_oihw [Cout][Ctot][3][3] -> wfold [4][Cout][2][2][C0] (forward classes (py, px) = (0,0),(0,1),(1,0),(1,1)) and
+ *             wdfold [C0][4][4][Cout] (the 4x4 stride-2 kernel of the low-resolution data-gradient)
+ *   forward : wpack = segsde_pack_weight(for_dgrad=0) of the same weight (its skip-channel slice is read in place)
+ *   dgrad   : d = the FORWARD geometry; dy [B,H,W,Cout] pitch lddy; wdpack = segsde_pack_weight(for_dgrad=1); dx0
+ *             [B,H/2,W/2,C0] dense (nullable), dx1 [B,H,W,C1] dense (nullable); act_out (nullable): saved activation output
+ *             (pitch act_ld, kind SEGSDE_ACT_*) whose derivative multiplies dx0, as in segsde_conv2d_dgrad_actgrad
+ *   wgrad   : dw_oihw [Cout][Ctot][3][3], deterministic (fixed-order reduction of the split partials) */
+int segsde_upfold_pack(const float* w_oihw, int Cout, int C0, int Ctot, float* wfold, float* wdfold, void* stream);
+int segsde_conv2d_forward_upfold(const segsde_conv_desc* d, const float* x0, const float* x1, const float* wpack,
+                                 const float* wfold, const float* bias, float* y, void* stream);
+int segsde_conv2d_dgrad_upfold(const segsde_conv_desc* d, const float* dy, int lddy, const float* wdpack, const float* wfold,
+                               const float* wdfold, float* dx0, float* dx1, const float* act_out, int act_ld, int act_kind,
+                               void* stream);
+size_t segsde_conv2d_wgrad_upfold_workspace(const segsde_conv_desc* d);
+int segsde_conv2d_wgrad_upfold(const segsde_conv_desc* d, const float* x0, const float* x1, const float* dy, int lddy,
+                               float* dw_oihw, float* workspace, size_t workspace_bytes, void* stream);
+
 /* OIHW -> [O][KH][KW][I] (for_dgrad=0) or [I][KH][KW][O] spatially flipped (for_dgrad=1). */
 int segsde_pack_weight(const float* w_oihw, float* out, int O, int I, int KH, int KW, int for_dgrad, void* stream);
 /* both packs of one weight tensor in a single launch (training forward: the data-gradient pack is kept for backward) */
