@@ -221,7 +221,7 @@ def test_finish_without_any_gradient_is_a_no_op():
         dist.destroy_process_group()
 
 
-def _worker_real_model(rank, world, port, q):
+def _worker_real_model(rank, world, port, q, device="cpu"):
     """the real ResNet-18 joint seg+depth model of this package (kernels through the host interpreter) on two gloo ranks with
     DIFFERENT inputs: the bucketed, hook-driven reducer must leave on every rank the mean of the two ranks' local gradients
     (checked against a plain per-parameter all-reduce of the un-reduced run), and the per-rank RNG streams must differ"""
@@ -231,8 +231,11 @@ def _worker_real_model(rank, world, port, q):
     os.environ["MASTER_PORT"] = str(port)
     torch.set_num_threads(4)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    import emu
-    emu.install()
+    if device == "cpu":
+        import emu
+        emu.install()
+    else:
+        torch.cuda.set_device(0)          # both ranks on the box's one GPU; the collectives run over gloo
     import bench
     import model_cases as MC
     from oracle import nets as N
@@ -243,14 +246,14 @@ def _worker_real_model(rank, world, port, q):
     cfg = MC.contract_cfgs()["cfgs"]["r18_jsd"]
     sd = N.build_state_dict(cfg, 19, seed=3 + rank, randomize_bn=True)       # ranks start DIFFERENT: the broadcast must fix it
     B, Hh, W = 2, 32, 64
-    _, inp = MC._bench_inputs(B, Hh, W, 17 + rank, "cpu")                    # a different shard per rank
+    _, inp = MC._bench_inputs(B, Hh, W, 17 + rank, device)                   # a different shard per rank
     gen = torch.Generator().manual_seed(4)
     noise = {s: torch.randn(B, 2, Hh, W, generator=gen) for s in range(4)}
 
     def make():
         m = get_model(cfg, 19)
         m.load_state_dict(sd, strict=True)
-        m.train()
+        m.to(device).train()
         lo = get_monodepth_loss(bench.loss_cfg(B, Hh, W), True)
         lo.tiebreak_noise = noise
         return m, lo
@@ -305,14 +308,14 @@ def _worker_real_model(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_real_model_two_ranks_gloo_interpreter():
+def run_real_model_two_ranks(device, timeout):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 36500 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_worker_real_model, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker_real_model, args=(r, 2, port, q, device)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted(q.get(timeout=900) for _ in procs)
+    res = sorted(q.get(timeout=timeout) for _ in procs)
     for p in procs:
         p.join(60)
     assert all(r[1] for r in res), "parameters differ after the broadcast"
@@ -320,3 +323,9 @@ def test_real_model_two_ranks_gloo_interpreter():
     assert res[0][3] == res[1][3] > 50
     assert res[0][4] and res[0][4] != res[1][4], "per-rank RNG: dropout seeds must differ between replicas"
     assert res[0][5] == res[1][5] > 1 and res[0][6] == res[1][6] == res[0][5]     # one collective per bucket (no_sync on backward one)
+
+
+@pytest.mark.skipif(not os.environ.get("SEGSDE_SLOW_TESTS"), reason="~30 min through the kernel interpreter: the same test runs on "
+                    "the GPU box in seconds (tests/test_models_gpu.py::test_real_model_two_ranks_one_gpu); set SEGSDE_SLOW_TESTS=1")
+def test_real_model_two_ranks_gloo_interpreter():
+    run_real_model_two_ranks("cpu", 3000)

@@ -368,3 +368,12 @@ def test_bench_selfspawn_two_ranks_one_device():
     assert res["config"]["allreduce_launches"] > 0 and res["config"]["global_batch"] == 2 * res["config"]["per_gpu_batch"]
     assert res["value"] > 0 and res["steps"] == 2 and res["scaling"] == "weak"
     assert "hbm_kernels" in res and "roofline" in res
+
+
+def test_real_model_two_ranks_one_gpu():
+    """cfg4's exchange step with the REAL model and two ranks: the ResNet-18 joint seg+depth model of this package on two
+    gloo ranks (both on this box's GPU, the real HIP library), different inputs per rank, the reference's two backward() calls
+    per step: broadcast makes the replicas identical, the hook-driven bucketed reducer leaves the mean of the two local
+    gradients on both, dropout seeds differ between replicas (tests/test_ddp_gloo.py::_worker_real_model)."""
+    import test_ddp_gloo as TD
+    TD.run_real_model_two_ranks("cuda", 600)
