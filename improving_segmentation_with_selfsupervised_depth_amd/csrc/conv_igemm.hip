@@ -65,6 +65,7 @@ struct ConvP {
   // out-of-range taps read the nearest border pixel (what mirrored padding of a nearest-upsampled image amounts to on the
   // low-resolution grid); osfast = a strided sub-grid store (os > 1) whose tiles lie inside one sub-grid row.
   int padw, wtap, osfast;
+  int submap;   // output rows are not rows m of the destination: out_row() maps them (strided sub-grids, single border rows / columns)
 };
 constexpr int SEGSDE_PAD_CLAMP_ = 3;   // internal (never crosses the ABI)
 
@@ -131,7 +132,7 @@ __device__ __forceinline__ void decode_m(const ConvP& p, int m, int& b, int& hb,
 
 // row index of output GEMM row m in the destination tensor (identity unless the launch writes a strided sub-grid)
 __device__ __forceinline__ long out_row(const ConvP& p, int m) {
-  if (p.os == 1) return m;
+  if (!p.submap) return m;
   const int b = fast_div(m, p.mg1, p.sf1), rem = m - b * p.d1, i = fast_div(rem, p.mg2, p.sf2), j = rem - i * p.d2;
   return ((long)b * p.OHf + p.os * i + p.oph) * p.OWf + p.os * j + p.opw;
 }
@@ -865,10 +866,10 @@ __global__ __launch_bounds__(256, VAR == 6 ? 3 : 2) void conv_igemm_kernel(ConvP
       // on a 128x128 tile, more than one per MFMA of an 8-chunk 1x1 layer, and VALU cycles are matrix-pipe cycles here.
       const int nend = n0 + BN < pe.ne ? n0 + BN : pe.ne;
       const bool side1 = n0 >= pe.nsplit;
-      if ((pe.os == 1 || pe.osfast) && m0 + BM <= pe.M && (side1 || nend <= pe.nsplit)) {
+      if ((!pe.submap || pe.osfast) && m0 + BM <= pe.M && (side1 || nend <= pe.nsplit)) {
         constexpr int NR = BM / RPP;
         // strided sub-grid (osfast: the tile lies inside one sub-grid row): consecutive GEMM rows are os destination rows apart
-        const long row0 = pe.os == 1 ? (long)m0 : out_row(pe, m0);
+        const long row0 = pe.submap ? out_row(pe, m0) : (long)m0;
         float* dbase = side1 ? pe.y2 + (row0 * pe.ldy2 + (n0 - pe.nsplit)) : pe.y + (row0 * pe.ldy + n0);
         const unsigned ld = (unsigned)(side1 ? pe.ldy2 : pe.ldy) * (unsigned)pe.os;
         const segsde_rsrc rd = segsde_make_rsrc(dbase);
@@ -1702,7 +1703,7 @@ ConvP make_params(const segsde_conv_desc* d, const float* x0, const float* x1, c
   p.agy = nullptr; p.agld = 0; p.agkind = 0;
   p.lin = d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && d->in_div <= 1 && !d->up0 && !d->sum2x2 && d->C1 == 0 &&
           d->H == d->Ho && d->W == d->Wo;
-  p.padw = p.pad; p.wtap = p.Ctot; p.osfast = 0;
+  p.padw = p.pad; p.wtap = p.Ctot; p.osfast = 0; p.submap = 0;
   return p;
 }
 
@@ -1885,7 +1886,7 @@ extern "C" int segsde_conv2d_dgrad_actgrad(const segsde_conv_desc* d, const floa
         // source row of loop tap kh' for sub-grid row i:  i + (ph + kh0*dil - pad)/2 + kh'*dil   (exact division)
         q.pad = -((ph + kh0 * d->dil - d->pad) / 2);
         q.padw = -((pw + kw0 * d->dil - d->pad) / 2);   // (per-axis padding: round 3)
-        q.os = 2; q.oph = ph; q.opw = pw; q.OHf = d->Ho; q.OWf = d->Wo;
+        q.os = 2; q.submap = 1; q.oph = ph; q.opw = pw; q.OHf = d->Ho; q.OWf = d->Wo;
         q.Ho = nI; q.Wo = nJ; q.M = d->B * nI * nJ;
         set_divs(q);
         if (!igemm_fast_ok(q)) ok = false;
@@ -2134,27 +2135,60 @@ __global__ __launch_bounds__(256) void upfold_dgrad_fix_kernel(const float* dy, 
   }
 }
 
+// the four corner pixels of an image collect (extra row, extra column) as well: dY at the full-resolution corner through the
+// corner tap of the 4x4 kernel.  One thread per (image, corner, channel).
+__global__ __launch_bounds__(256) void upfold_dgrad_corner_kernel(const float* dy, int lddy, const float* wdfold, float* dx, int lddx,
+                                                                  int B, int H2, int W2, int C0, int Cout, const float* agy,
+                                                                  int agld, int agkind) {
+  const int total = B * 4 * C0;
+  const int H = 2 * H2, W = 2 * W2;
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+    const int c = e % C0, t = e / C0, k = t & 3, b = t >> 2;
+    const int bot = k >> 1, rgt = k & 1;
+    const int i = bot ? H2 - 1 : 0, j = rgt ? W2 - 1 : 0, r = bot ? H - 1 : 0, sc = rgt ? W - 1 : 0;
+    const int a = bot ? 0 : 3, bb = rgt ? 0 : 3;
+    const float* dp = dy + ((long)(b * H + r) * W + sc) * lddy;
+    const float* wp = wdfold + (((long)c * 4 + a) * 4 + bb) * Cout;
+    float acc = 0.f;
+    for (int n = 0; n < Cout; ++n) acc += dp[n] * wp[n];
+    const long pix = (long)(b * H2 + i) * W2 + j;
+    if (agy) acc *= segsde_act_grad_from_out(agy[pix * agld + c], agkind);
+    dx[pix * lddx + c] += acc;
+  }
+}
+
 // dW[n][c][kh][kw] (c < C0, OIHW with CtotDst channels) = sum over the four classes and the splits of the folded tap's partial
 // slab part[class][z][(th*2 + tw) * C0 + c][n]: fixed order (class-major, then splits), deterministic
 __global__ __launch_bounds__(256) void upfold_wgrad_reduce_kernel(const float* part, int splits, int C0, int N, float* dw,
                                                                   int CtotDst) {
+  // 32 consecutive (c, tap, n) elements (n fastest: the slab reads coalesce) x 8 split-lanes per block, like wgrad_reduce_kernel
+  SEGSDE_SMEM;
+  float* sh = reinterpret_cast<float*>(segsde_smem);
   const long total = (long)N * C0 * 9;
   const long slab = 4L * C0 * N;
-  for (long e = blockIdx.x * 256L + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
-    // e indexes (c, tap, n) with n fastest so that the slab reads coalesce
-    const int n = (int)(e % N); long t = e / N;
-    const int tap = (int)(t % 9), c = (int)(t / 9);
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const long e = blockIdx.x * 32L + tx;
+  float acc = 0.f;
+  int n = 0, tap = 0, c = 0;
+  if (e < total) {
+    n = (int)(e % N); const long t = e / N;
+    tap = (int)(t % 9); c = (int)(t / 9);
     const int kh = tap / 3, kw = tap - kh * 3;
-    float s = 0.f;
     for (int cls = 0; cls < 4; ++cls) {
       const int th = upfold_th(cls >> 1, kh), tw = upfold_th(cls & 1, kw);
       const float* src = part + (long)cls * splits * slab + ((long)(th * 2 + tw) * C0 + c) * N + n;
       float s0 = 0.f, s1 = 0.f;
-      int z = 0;
-      for (; z + 1 < splits; z += 2) { s0 += src[(long)z * slab]; s1 += src[(long)(z + 1) * slab]; }
+      int z = ty;
+      for (; z + 8 < splits; z += 16) { s0 += src[(long)z * slab]; s1 += src[(long)(z + 8) * slab]; }
       if (z < splits) s0 += src[(long)z * slab];
-      s += s0 + s1;
+      acc += s0 + s1;
     }
+  }
+  sh[ty * 32 + tx] = acc;
+  __syncthreads();
+  if (ty == 0 && e < total) {
+    float s = 0.f;
+    for (int j = 0; j < 8; ++j) s += sh[j * 32 + tx];
     dw[((long)n * CtotDst + c) * 9 + tap] = s;
   }
 }
@@ -2173,7 +2207,7 @@ ConvP upfold_class_fwd(const segsde_conv_desc* d, const float* x0, const float* 
   if (d->C1) c.act = 0;                               // bias + activation belong to the launch that completes the sum
   ConvP q = make_params(&c, x0, nullptr, wf + (long)(py * 2 + px) * d->Cout * 4 * d->C0, d->C1 ? nullptr : bias, y, nullptr);
   q.pad_mode = SEGSDE_PAD_CLAMP_; q.padw = 1 - px;
-  q.os = 2; q.oph = py; q.opw = px; q.OHf = d->H; q.OWf = d->W;
+  q.os = 2; q.submap = 1; q.oph = py; q.opw = px; q.OHf = d->H; q.OWf = d->W;
   q.osfast = (c.Wo % 128 == 0) ? 1 : 0;
   q.lin = 0;
   return q;
@@ -2260,10 +2294,43 @@ extern "C" int segsde_conv2d_dgrad_upfold(const segsde_conv_desc* d, const float
   }
   if (dx0) {
     if (int e = launch_by_n(q, s)) return e;
-    const long total = (long)d->B * (2 * W2 + 2 * H2) * d->C0;
-    hipLaunchKernelGGL(upfold_dgrad_fix_kernel, dim3(min(8192, segsde_cdiv(total, 256))), dim3(256), 0, s, dy, lddy, wfold, dx0,
-                       d->C0, d->B, H2, W2, d->C0, d->Cout, act_out, act_ld, act_kind);
-    SEGSDE_CHECK_LAUNCH();
+    // Clamp adjoint.  The border pixels of the low-resolution gradient also collect what their clamped taps read: row 0 through
+    // the taps a = 3 from dY row 0, row H2-1 through a = 0 from dY row H-1, columns alike.  (extra row) x (main columns) is a
+    // 1x4 stride-2 convolution of ONE dY row into one low-resolution row, (main rows) x (extra column) a 4x1 one into one
+    // column: four small launches of the same matrix-core kernel that ADD onto the main launch's result (same fused activation
+    // derivative), reading their taps in place inside the 4x4 pack; (extra row) x (extra column) exists at the four corners.
+    // (The first version did all of this with one thread per border pixel and channel: 0.4 ms per layer.)
+    bool ok = true;
+    ConvP bl[4];
+    for (int k = 0; k < 4 && ok; ++k) {
+      const bool rowl = k < 2, far = k & 1;        // 0 top row, 1 bottom row, 2 left column, 3 right column
+      segsde_conv_desc c = *d;
+      c.C0 = d->Cout; c.C1 = 0; c.ld0 = lddy; c.ld1 = 0; c.up0 = 0; c.Cout = d->C0; c.ldy = d->C0; c.ldy2 = 0; c.nsplit = 0;
+      c.Ho = rowl ? 1 : H2; c.Wo = rowl ? W2 : 1; c.KH = rowl ? 1 : 4; c.KW = rowl ? 4 : 1; c.stride = 2; c.dil = 1;
+      c.pad = rowl ? (far ? -(d->H - 1) : 0) : 1; c.pad_mode = SEGSDE_PAD_ZERO; c.act = 0; c.accumulate = 1;
+      const int a = far ? 0 : 3;                   // the clamped tap
+      ConvP b = make_params(&c, dy, nullptr, wdfold + (long)(rowl ? a * 4 : a) * d->Cout, nullptr, dx0, nullptr);
+      b.padw = rowl ? 1 : (far ? -(d->W - 1) : 0);
+      b.Kfull = 16 * d->Cout; b.wtap = rowl ? d->Cout : 4 * d->Cout;
+      b.submap = 1; b.os = 1; b.OHf = H2; b.OWf = W2; b.oph = rowl ? (far ? H2 - 1 : 0) : 0; b.opw = rowl ? 0 : (far ? W2 - 1 : 0);
+      b.osfast = (rowl && W2 % 128 == 0) ? 1 : 0;
+      b.lin = 0;
+      if (act_out) { b.agy = act_out; b.agld = act_ld; b.agkind = act_kind; }
+      if (!igemm_fast_ok(b) || !b.vecout) ok = false;
+      bl[k] = b;
+    }
+    if (ok) {
+      for (int k = 0; k < 4; ++k)
+        if (int e = launch_by_n(bl[k], s)) return e;
+      hipLaunchKernelGGL(upfold_dgrad_corner_kernel, dim3(segsde_cdiv((long)d->B * 4 * d->C0, 256)), dim3(256), 0, s, dy, lddy, wdfold,
+                         dx0, d->C0, d->B, H2, W2, d->C0, d->Cout, act_out, act_ld, act_kind);
+      SEGSDE_CHECK_LAUNCH();
+    } else {
+      const long total = (long)d->B * (2 * W2 + 2 * H2) * d->C0;
+      hipLaunchKernelGGL(upfold_dgrad_fix_kernel, dim3(min(8192, segsde_cdiv(total, 256))), dim3(256), 0, s, dy, lddy, wfold, dx0,
+                         d->C0, d->B, H2, W2, d->C0, d->Cout, act_out, act_ld, act_kind);
+      SEGSDE_CHECK_LAUNCH();
+    }
   }
   if (dx1 && d->C1)
     if (int e = launch_by_n(r, s)) return e;
@@ -2332,7 +2399,7 @@ extern "C" int segsde_conv2d_wgrad_upfold(const segsde_conv_desc* d, const float
     if (int e = launch_wgrad_by_bn(pl.bn, cls[k], dy, lddy, workspace + k * slab, pl.splits, pl.cps, s)) return e;
   {
     const long total = (long)d->Cout * d->C0 * 9;
-    hipLaunchKernelGGL(upfold_wgrad_reduce_kernel, dim3(min(4096, segsde_cdiv(total, 256))), dim3(256), 0, s, workspace, pl.splits,
+    hipLaunchKernelGGL(upfold_wgrad_reduce_kernel, dim3(segsde_cdiv(total, 32)), dim3(256), 1024, s, workspace, pl.splits,
                        d->C0, d->Cout, dw_oihw, Ctot);
     SEGSDE_CHECK_LAUNCH();
   }

@@ -61,6 +61,17 @@ def test_conv_fullsize_sampled(geom):
         _cmp(torch.stack([ya[p] for p in pos]), torch.nn.functional.elu(want), name + " forward+ELU")
         del ya
     del y
+    fold = None
+    if H.upfold_ok(g):
+        # the upsample-folded route (what the models run) against the same float64 samples, border pixels included
+        fold = H.upfold_pack(wt, C0)
+        t0 = dict(H.UPFOLD_TAKEN)
+        pos_b = pos + [(0, 0, 0), (0, 0, W - 1), (B16 - 1, Hh - 1, 0), (B16 - 1, Hh - 1, W - 1), (1, 0, 5), (1, Hh - 1, 6), (B16 // 2, 7, 0), (B16 // 2, 8, W - 1)]
+        want_b = SC.conv_samples(x0, x1, up0, wt, bias, 1, dil, pad, reflect, pos_b)
+        yf = H.conv_forward(g, x0, x1, wp, bias, act, wfold=fold[0])
+        _cmp(torch.stack([yf[p] for p in pos_b]), torch.nn.functional.elu(want_b) if act == "elu" else want_b, name + " forward (folded)")
+        assert H.UPFOLD_TAKEN["fwd"] == t0["fwd"] + 1, "the folded forward fell back"
+        del yf
     # ---- data gradient
     dy = torch.randn(B16, Hh, W, Cout, device=dev, generator=gen)
     dx0, dx1 = H.conv_dgrad(g, dy, wd, wt, (Hh, W))
@@ -71,6 +82,16 @@ def test_conv_fullsize_sampled(geom):
         pos1 = SC.pick_positions(B16, Hh, W, 48, seed=3)
         want = SC.dgrad_samples(dy, wt, (Hh, W), C0, C0 + C1, False, 1, dil, pad, reflect, pos1)
         _cmp(torch.stack([dx1[p] for p in pos1]), want, name + " dgrad src1")
+    if fold is not None:
+        t0 = dict(H.UPFOLD_TAKEN)
+        f0, f1 = H.conv_dgrad(g, dy, wd, wt, (Hh, W), fold=fold)
+        assert H.UPFOLD_TAKEN["dgrad"] == t0["dgrad"] + 1, "the folded data-gradient fell back"
+        posb0 = pos0 + [(0, 0, 0), (0, 0, w0 - 1), (B16 - 1, h0 - 1, 0), (B16 - 1, h0 - 1, w0 - 1), (1, 0, 3), (1, h0 - 1, 4), (B16 // 2, 5, 0), (B16 // 2, 6, w0 - 1)]
+        wantb = SC.dgrad_samples(dy, wt, (Hh, W), 0, C0, up0, 1, dil, pad, reflect, posb0)
+        _cmp(torch.stack([f0[p] for p in posb0]), wantb, name + " dgrad src0 (folded, clamp adjoint on the border)")
+        if C1:
+            assert torch.equal(f1, dx1) or bool(((f1 - dx1).abs() <= 1e-4 * dx1.abs().max()).all()), name + " dgrad src1 (folded)"
+        del f0, f1
     if k == 1:
         # epilogue variants of the same launch at offsets beyond 2^31 bytes: accumulate onto an existing gradient, and
         # the activation derivative of the tensor differentiated with respect to (expected values from the plain result)
@@ -87,7 +108,9 @@ def test_conv_fullsize_sampled(geom):
         del dz, yact
     del dx0, dx1
     # ---- weight gradient (sampled taps; each one a reduction over all 16 x H x W output pixels)
+    t0 = dict(H.UPFOLD_TAKEN)
     dw = H.conv_wgrad(g, x0, x1, dy)
+    assert H.UPFOLD_TAKEN["wgrad"] == t0["wgrad"] + (1 if H.upfold_ok(g) else 0), "weight-gradient route"
     rng = np.random.RandomState(5)
     taps = [(0, 0, 0, 0), (Cout - 1, C0 + C1 - 1, k - 1, k - 1), (Cout - 1, 0, 0, k - 1), (0, C0 + C1 - 1, k - 1, 0)]
     if C1:

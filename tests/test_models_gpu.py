@@ -229,8 +229,13 @@ def test_depthmix_unlabeled_step_vs_oracle():
     inp_d2 = dict(inp_d); inp_d2[("color_aug", 0, 0)] = img
     student.use_pose_net = False
     o_s = student(inp_d2)
-    L, lab = T.calc_pseudo_label_loss(softm, o_s["semantics"], cw)
-    assert float((lab.cpu() == lab_o).float().mean()) > 0.99
+    assert_close(softm, softm_o, rtol=1e-3, atol=1e-5, what="mixed teacher distribution")
+    _, lab_own = T.calc_pseudo_label_loss(softm, o_s["semantics"].detach(), cw)
+    assert float((lab_own.cpu() == lab_o).float().mean()) > 0.99          # a near-tie of the teacher may flip a pixel's label
+    # the loss / gradient comparison continues from the ORACLE's distribution (like the mask above): identical pseudo labels,
+    # so that the vector criterion below measures arithmetic and not a handful of flipped labels
+    L, lab = T.calc_pseudo_label_loss(softm_o.cuda(), o_s["semantics"], cw)
+    assert torch.equal(lab.cpu(), lab_o)
     assert_close(L, L_o, rtol=1e-3, what="pseudo-label loss")
     L.backward()
     # vector criterion against the same student pass evaluated in float64 (identical mixed inputs / teacher distribution)
