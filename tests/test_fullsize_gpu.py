@@ -201,8 +201,10 @@ def test_cross_entropy_and_bn_fullsize():
         assert_close(y[p], want, rtol=1e-4, atol=1e-5, what="BN apply")
 
 
-def test_headline_model_two_steps_vs_oracle():
-    """cfg3 (ResNet-101 joint_seg_depth_dec, 512x1024, SGD + clip as bench.py runs it) at batch 2: forward, both losses,
+@pytest.mark.parametrize("workload", ["cfg3", "cfg3pad"], ids=["r101_jsd", "r101_pad"])
+def test_headline_model_two_steps_vs_oracle(workload):
+    """cfg3 (ResNet-101 joint_seg_depth_dec) and its mtl_pad variant (cfg5's model: PAD + SelfAttention distillation, intermediate
+    segmentation output), 512x1024, SGD + clip as bench.py runs them, at batch 2: forward, both losses,
     backward, clip_grad_norm, SGD step, and the loss of the SECOND step -- which depends on every gradient of the first --
     against the CPU oracle on identical weights, inputs and tie-break noise"""
     from oracle import nets as N, photometric as P, segmix as S
@@ -212,8 +214,15 @@ def test_headline_model_two_steps_vs_oracle():
     import bench
     import model_cases as MC
     B, Hh, W = 2, 512, 1024
-    cfg = bench.model_cfg("cfg3", Hh, W)
+    cfg = bench.model_cfg(workload, Hh, W)
     sd = N.build_state_dict(cfg, 19, seed=11, randomize_bn=False)
+
+    def seg_loss(out, lbl, ce):
+        # train.py:490-506: the intermediate (distillation-side) segmentation output of mtl_pad is averaged in
+        seg = ce(out["semantics"], lbl)
+        if "intermediate_semantics" in out:
+            seg = (seg + ce(out["intermediate_semantics"], lbl)) / 2
+        return seg
     inp = bench.synthetic_inputs(B, Hh, W, "cpu", 1234)
     gen = torch.Generator().manual_seed(12)
     noise = {s: torch.randn(B, 2, Hh, W, generator=gen) for s in range(4)}
@@ -236,7 +245,7 @@ def test_headline_model_two_steps_vs_oracle():
         out = N.model_forward(sdo, cfg, inp, train=True, dropout=False)
         lo.generate_images_pred(inp, out)
         mono = lo.compute_losses(inp, out, tiebreak_noise=noise)["loss"]
-        seg = S.cross_entropy2d(out["semantics"], inp["lbl"])
+        seg = seg_loss(out, inp["lbl"], S.cross_entropy2d)
         (mono + seg).backward()
         used = [v for _, v in leaves if v.grad is not None]
         gn = torch.nn.utils.clip_grad_norm_(used, 10.0)
@@ -258,7 +267,7 @@ def test_headline_model_two_steps_vs_oracle():
         out = model(inp_d)
         lp.generate_images_pred(inp_d, out)
         mono = lp.compute_losses(inp_d, out)["loss"]
-        seg = cross_entropy2d(out["semantics"], inp_d["lbl"])
+        seg = seg_loss(out, inp_d["lbl"], cross_entropy2d)
         (mono + seg).backward()
         gn = torch.nn.utils.clip_grad_norm_([p for p in model.parameters() if p.grad is not None], 10.0)
         opt.step()
