@@ -25,6 +25,7 @@
 #include "segsde_common.h"
 #include "conv_small.h"
 #include <cstdlib>
+#include <mutex>
 #include <cstring>
 
 namespace {
@@ -1087,9 +1088,16 @@ __device__ __forceinline__ void wgrad_k_decode(int k, int Ctot, int taps, int sr
 
 constexpr int BP = 32;  // pixels per staged chunk
 
+// Reduction of the split partials inside the weight-gradient kernel (round 3; 184 wgrad_reduce launches of ~14 us per step
+// before).  Every workgroup stores its partial slab, fences, and takes a ticket of its (k-tile, n-tile); the workgroup that
+// draws the LAST ticket sums all slabs of the tile in slab order -- the same order whichever workgroup does it, so the result
+// is deterministic -- writes OIHW and puts the ticket back to zero.  tickets == nullptr: partial slabs only (a separate
+// reduce kernel follows: the class launches of the upsample-folded route, SEGSDE_TUNE="wred=0").
+struct WRed { unsigned* tickets; float* dw; int CtotDst, cOff, taps, srcC0; };
+
 template <int BKT, int BN, int WM, int WN, int MODE>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(ConvP p, const float* dy, int lddy, float* part,
-                                                         int chunks_per_split) {
+                                                         int chunks_per_split, WRed wr) {
   // MODE 0: scalar gather, 1: float4 gather, 2: FAST A side + vector dY + rows at least 32 pixels wide (straight-line
   // loop), 3: FAST A side with the general row walk / scalar dY (odd Cout, tiny feature maps), 4: MODE 2 with the tile
   // loads writing LDS themselves (LDS-DMA, see the forward kernel)
@@ -1514,6 +1522,32 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(ConvP p, const float
         if (k < p.Ktot) out[(long)k * p.N + n] = acc[i][j][r];
       }
   }
+  if (!wr.tickets) return;
+  // ---- last workgroup of this (k-tile, n-tile) reduces the splits
+  __threadfence();                                   // release: the slab is visible device-wide before the ticket is drawn
+  __syncthreads();
+  unsigned* flag = reinterpret_cast<unsigned*>(smem);
+  const int nsplit_z = (int)gridDim.x / (nkt * nnt);
+  if (tid == 0) flag[0] = atomicAdd(&wr.tickets[nt * nkt + kt], 1u) == (unsigned)(nsplit_z - 1) ? 1u : 0u;
+  __syncthreads();
+  if (!flag[0]) return;
+  __threadfence();                                   // acquire: the other workgroups' slabs
+  const long slab = (long)p.Ktot * p.N;
+  for (int e = tid; e < BKT * BN; e += 256) {
+    const int kl = e / BN, nl = e - kl * BN, k = k0 + kl, n = n0 + nl;
+    if (k >= p.Ktot || n >= p.N) continue;
+    const float* src = part + (long)k * p.N + n;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int z = 0;
+    for (; z + 3 < nsplit_z; z += 4) {
+      s0 += src[(long)z * slab]; s1 += src[(long)(z + 1) * slab]; s2 += src[(long)(z + 2) * slab]; s3 += src[(long)(z + 3) * slab];
+    }
+    for (; z < nsplit_z; ++z) s0 += src[(long)z * slab];
+    int tap, c;
+    wgrad_k_decode(k, p.Ctot, wr.taps, wr.srcC0, tap, c);
+    wr.dw[((long)n * wr.CtotDst + wr.cOff + c) * wr.taps + tap] = (s0 + s1) + (s2 + s3);
+  }
+  if (tid == 0) wr.tickets[nt * nkt + kt] = 0u;      // ready for the next launch that is handed this slice
 }
 
 // dW[o][c][kh][kw] (OIHW, the state_dict layout) = sum_z part[z][(kh*KW+kw)*Ctot + c][o], fixed order
@@ -1630,7 +1664,7 @@ __global__ __launch_bounds__(256) void reflect_dgrad_fix_kernel(const float* dy,
 // experiment knob (environment SEGSDE_TUNE="bk64=1"), read once.  Measured on MI355X (profiles/ab_conv_r01.log):
 // BK=64 (139 KB LDS => 1 workgroup/CU, half the barriers) loses 15-25 % on the large layers against BK=32 with two
 // co-resident workgroups per CU, and start-up staggering of co-resident workgroups changes nothing.
-struct Tune { int bk64 = 0; int adjfix = 0; int wplan = 0; int wovh = 4; int nos2 = 0; int dma = 1; int var = 0; int wdma = 1; int adjlds = 1; };
+struct Tune { int bk64 = 0; int adjfix = 0; int wplan = 0; int wovh = 4; int nos2 = 0; int dma = 1; int var = 0; int wdma = 1; int adjlds = 1; int wred = 1; };
 const Tune& tune() {
   static Tune t = [] {
     Tune r;
@@ -1644,6 +1678,7 @@ const Tune& tune() {
       if (const char* q = strstr(e, "var=")) r.var = atoi(q + 4);         // experiment variants of the LDS-DMA loop
       if (const char* q = strstr(e, "adjl=")) r.adjlds = atoi(q + 5);     // 0: reflection-adjoint loop register-staged in every wave
       if (const char* q = strstr(e, "wlds=")) r.wdma = atoi(q + 5);       // 0: register-staged weight-gradient tile loads
+      if (const char* q = strstr(e, "wred=")) r.wred = atoi(q + 5);       // 0: split partials reduced by a separate kernel
     }
     return r;
   }();
@@ -1934,14 +1969,14 @@ extern "C" int segsde_conv2d_dgrad_actgrad(const segsde_conv_desc* d, const floa
 
 namespace {
 template <int BKT, int BN, int WM, int WN, int MODE>
-int launch_wgrad_mode(const ConvP& p, const float* dy, int lddy, float* ws, int splits, int cps, hipStream_t stream) {
+int launch_wgrad_mode(const ConvP& p, const float* dy, int lddy, float* ws, int splits, int cps, hipStream_t stream, WRed wr) {
   const dim3 grid(segsde_cdiv(p.Ktot, BKT) * segsde_cdiv(p.N, BN) * splits);
   size_t smem = 2 * (size_t)BP * (BKT + BN) * sizeof(float);
   if (MODE == 2 || MODE == 4)   // + the four offset tables (padded rows / columns of the two sources)
     smem += 2 * (size_t)((p.Ho - 1) * p.stride + (p.KH - 1) * p.dil + 1 + (p.Wo - 1) * p.stride + (p.KW - 1) * p.dil + 1) * sizeof(unsigned);
   auto k = conv_wgrad_kernel<BKT, BN, WM, WN, MODE>;
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-  hipLaunchKernelGGL(k, grid, dim3(256), smem, stream, p, dy, lddy, ws, cps);
+  hipLaunchKernelGGL(k, grid, dim3(256), smem, stream, p, dy, lddy, ws, cps, wr);
   SEGSDE_CHECK_LAUNCH();
   return 0;
 }
@@ -1959,15 +1994,23 @@ int wgrad_mode(const ConvP& p, const float* dy, int lddy) {
 }
 
 template <int BKT, int BN, int WM, int WN>
-int launch_wgrad(const ConvP& p, const float* dy, int lddy, float* ws, int splits, int cps, hipStream_t stream) {
+int launch_wgrad(const ConvP& p, const float* dy, int lddy, float* ws, int splits, int cps, hipStream_t stream, WRed wr = WRed{}) {
   switch (wgrad_mode(p, dy, lddy)) {
     case 2:
-      if (tune().wdma) return launch_wgrad_mode<BKT, BN, WM, WN, 4>(p, dy, lddy, ws, splits, cps, stream);
-      return launch_wgrad_mode<BKT, BN, WM, WN, 2>(p, dy, lddy, ws, splits, cps, stream);
-    case 3: return launch_wgrad_mode<BKT, BN, WM, WN, 3>(p, dy, lddy, ws, splits, cps, stream);
-    case 1: return launch_wgrad_mode<BKT, BN, WM, WN, 1>(p, dy, lddy, ws, splits, cps, stream);
-    default: return launch_wgrad_mode<BKT, BN, WM, WN, 0>(p, dy, lddy, ws, splits, cps, stream);
+      if (tune().wdma) return launch_wgrad_mode<BKT, BN, WM, WN, 4>(p, dy, lddy, ws, splits, cps, stream, wr);
+      return launch_wgrad_mode<BKT, BN, WM, WN, 2>(p, dy, lddy, ws, splits, cps, stream, wr);
+    case 3: return launch_wgrad_mode<BKT, BN, WM, WN, 3>(p, dy, lddy, ws, splits, cps, stream, wr);
+    case 1: return launch_wgrad_mode<BKT, BN, WM, WN, 1>(p, dy, lddy, ws, splits, cps, stream, wr);
+    default: return launch_wgrad_mode<BKT, BN, WM, WN, 0>(p, dy, lddy, ws, splits, cps, stream, wr);
   }
+}
+
+WRed make_wred(const ConvP& p, int bkt, int bn, float* dw, int CtotDst, int cOff, int taps, int srcC0) {
+  WRed wr{};
+  if (!tune().wred) return wr;
+  wr.tickets = segsde_ticket_slice(segsde_cdiv(p.Ktot, bkt) * segsde_cdiv(p.N, bn));
+  wr.dw = dw; wr.CtotDst = CtotDst; wr.cOff = cOff; wr.taps = taps; wr.srcC0 = srcC0;
+  return wr;
 }
 
 void wgrad_plan(const segsde_conv_desc* d, int& bkt, int& bn, int& splits, int& cps) {
@@ -2033,10 +2076,13 @@ extern "C" int segsde_conv2d_wgrad(const segsde_conv_desc* d, const float* x0, c
   int bkt, bn, splits, cps;
   wgrad_plan(d, bkt, bn, splits, cps);
   int e;
-  if (bn == 32) e = launch_wgrad<128, 32, 4, 1>(p, dy, lddy, workspace, splits, cps, s);
-  else if (bn == 64) e = launch_wgrad<128, 64, 2, 2>(p, dy, lddy, workspace, splits, cps, s);
-  else e = launch_wgrad<128, 128, 2, 2>(p, dy, lddy, workspace, splits, cps, s);
+  const int srcmaj = (wgrad_mode(p, dy, lddy) == 2 && p.C1 > 0) ? p.C0 : 0;
+  const WRed wr = make_wred(p, bkt, bn, dw_oihw, p.Ctot, 0, d->KH * d->KW, srcmaj);
+  if (bn == 32) e = launch_wgrad<128, 32, 4, 1>(p, dy, lddy, workspace, splits, cps, s, wr);
+  else if (bn == 64) e = launch_wgrad<128, 64, 2, 2>(p, dy, lddy, workspace, splits, cps, s, wr);
+  else e = launch_wgrad<128, 128, 2, 2>(p, dy, lddy, workspace, splits, cps, s, wr);
   if (e) return e;
+  if (wr.tickets) return 0;
   const long total = (long)p.Ktot * p.N;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(segsde_cdiv(total, 32)), dim3(256), 1024, s, workspace, splits,
                      p.Ktot, p.N, p.Ctot, d->KH * d->KW, (wgrad_mode(p, dy, lddy) == 2 && p.C1 > 0) ? p.C0 : 0, dw_oihw, p.Ctot, 0);
@@ -2396,7 +2442,7 @@ extern "C" int segsde_conv2d_wgrad_upfold(const segsde_conv_desc* d, const float
     r = make_params(&pl.skip, x1, nullptr, dy, nullptr, workspace + 4 * slab, nullptr);
   }
   for (int k = 0; k < 4; ++k)
-    if (int e = launch_wgrad_by_bn(pl.bn, cls[k], dy, lddy, workspace + k * slab, pl.splits, pl.cps, s)) return e;
+    if (int e = launch_wgrad_by_bn(pl.bn, cls[k], dy, lddy, workspace + k * slab, pl.splits, pl.cps, s, WRed{})) return e;
   {
     const long total = (long)d->Cout * d->C0 * 9;
     hipLaunchKernelGGL(upfold_wgrad_reduce_kernel, dim3(segsde_cdiv(total, 32)), dim3(256), 1024, s, workspace, pl.splits,
@@ -2405,7 +2451,9 @@ extern "C" int segsde_conv2d_wgrad_upfold(const segsde_conv_desc* d, const float
   }
   if (d->C1) {
     float* ws1 = workspace + 4 * slab;
-    if (int e = launch_wgrad_by_bn(pl.bn1, r, dy, lddy, ws1, pl.splits1, pl.cps1, s)) return e;
+    const WRed wr = make_wred(r, 128, pl.bn1, dw_oihw, Ctot, d->C0, 9, 0);
+    if (int e = launch_wgrad_by_bn(pl.bn1, r, dy, lddy, ws1, pl.splits1, pl.cps1, s, wr)) return e;
+    if (wr.tickets) return 0;
     const long total = (long)r.Ktot * r.N;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(segsde_cdiv(total, 32)), dim3(256), 1024, s, ws1, pl.splits1, r.Ktot, r.N, r.Ctot, 9, 0,
                        dw_oihw, Ctot, d->C0);

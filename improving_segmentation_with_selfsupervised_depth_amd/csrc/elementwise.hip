@@ -8,6 +8,8 @@
 // results are run-to-run reproducible.  Pure elementwise kernels take a float4 path when C, the pitches and
 // the base pointers allow it.
 #include "segsde_common.h"
+#include <cstdlib>
+#include <cstring>
 
 namespace {
 
@@ -37,8 +39,13 @@ __host__ __device__ inline int red_blocks(long M) {
 // TX channel lanes x TY = 256 / TX row lanes.  Wide tensors: TX = 64 / VW lanes of VW channels each.  Narrow ones (C < 64:
 // the 1-channel disparity heads, the 19-class logits) shrink TX to the next power of two >= C so that all 256 threads
 // stay busy -- with 64 channel lanes a 1-channel reduction ran on 4 threads per block.
+// Fin: finalize inside the reduction kernel (round 3; the separate pair_finalize launch cost ~7 us 190 times per step).  The
+// block that draws the LAST ticket of its channel group folds the group's partial rows -- in the same fixed lane order as
+// pair_finalize_kernel, so the result is bit-identical to the two-kernel path -- and writes the float sums.
+struct Fin { unsigned* tickets; float* out0; float* out1; };
+
 template <class Op, int VW, int TX>
-__global__ __launch_bounds__(256) void colreduce_kernel(Op op, long M, int C, double* part) {
+__global__ __launch_bounds__(256) void colreduce_kernel(Op op, long M, int C, double* part, Fin fin) {
   constexpr int TY = 256 / TX, CW = TX * VW;          // channels per block
   SEGSDE_SMEM;
   double* sh = reinterpret_cast<double*>(segsde_smem);  // [2][TY][CW]
@@ -66,27 +73,67 @@ __global__ __launch_bounds__(256) void colreduce_kernel(Op op, long M, int C, do
     part[((long)blockIdx.x * 2 + 0) * C + blockIdx.y * CW + cc] = a;
     part[((long)blockIdx.x * 2 + 1) * C + blockIdx.y * CW + cc] = b2;
   }
+  if (!fin.tickets) return;
+  __threadfence();
+  __syncthreads();
+  unsigned* flag = reinterpret_cast<unsigned*>(sh);
+  if (threadIdx.x == 0) flag[0] = atomicAdd(&fin.tickets[blockIdx.y], 1u) == (unsigned)(nb - 1) ? 1u : 0u;
+  __syncthreads();
+  const bool last = flag[0] != 0u;
+  __syncthreads();
+  if (!last) return;
+  __threadfence();
+  // pair_finalize_kernel's order: 16 partial-lanes (lane l takes rows l, l + 16, ...), then lanes 0..15 in sequence
+  constexpr int LPT = (16 * CW + 255) / 256;          // lane sums per thread
+  for (int t = threadIdx.x; t < 16 * CW; t += 256) {
+    const int l = t / CW, ch = t - l * CW, cg = blockIdx.y * CW + ch;
+    double a = 0.0, b2 = 0.0;
+    if (cg < C)
+      for (int i = l; i < nb; i += 16) { a += part[((long)i * 2) * C + cg]; b2 += part[((long)i * 2 + 1) * C + cg]; }
+    sh[l * CW + ch] = a; sh[(16 + l) * CW + ch] = b2;
+  }
+  (void)LPT;
+  __syncthreads();
+  if (cc < CW && blockIdx.y * CW + cc < C) {
+    double a = 0.0, b2 = 0.0;
+    for (int j = 0; j < 16; ++j) { a += sh[j * CW + cc]; b2 += sh[(16 + j) * CW + cc]; }
+    if (fin.out0) fin.out0[blockIdx.y * CW + cc] = (float)a;
+    if (fin.out1) fin.out1[blockIdx.y * CW + cc] = (float)b2;
+  }
+  if (threadIdx.x == 0) fin.tickets[blockIdx.y] = 0u;
 }
 
 template <class Op, int TX>
-void launch_colreduce_scalar(Op op, long M, int C, double* part, hipStream_t s) {
+void launch_colreduce_scalar(Op op, long M, int C, double* part, hipStream_t s, Fin fin) {
   const dim3 grid(red_blocks(M), (C + TX - 1) / TX);
-  hipLaunchKernelGGL((colreduce_kernel<Op, 1, TX>), grid, dim3(256), 2 * 256 * sizeof(double), s, op, M, C, part);
+  // LDS: [2][TY][TX] block partials, and [2][16][TX] lane sums of the in-kernel finalize
+  const size_t smem = 2 * (size_t)(256 > 16 * TX ? 256 : 16 * TX) * sizeof(double);
+  hipLaunchKernelGGL((colreduce_kernel<Op, 1, TX>), grid, dim3(256), smem, s, op, M, C, part, fin);
 }
 
+// fin: out0 / out1 (nullable) receive the two column sums as floats from the reduction kernel itself (its last block per
+// channel group); returns true in *done when it did (the caller then skips pair_finalize_kernel)
 template <class Op>
-int launch_colreduce(Op op, long M, int C, double* part, bool vec, hipStream_t s) {
+int launch_colreduce(Op op, long M, int C, double* part, bool vec, hipStream_t s, float* out0 = nullptr, float* out1 = nullptr,
+                     bool* done = nullptr) {
+  Fin fin{nullptr, out0, out1};
+  static const bool enabled = [] { const char* e = getenv("SEGSDE_TUNE"); return !(e && strstr(e, "cfin=0")); }();
+  if (done && enabled && (out0 || out1)) {
+    const int cw = vec ? SLAB : (C <= 1 ? 1 : C <= 2 ? 2 : C <= 4 ? 4 : C <= 8 ? 8 : C <= 16 ? 16 : C <= 32 ? 32 : 64);   // channels per block
+    fin.tickets = segsde_ticket_slice((C + cw - 1) / cw);             // one ticket per channel group (grid.y)
+  }
   if (vec) {
     const dim3 grid(red_blocks(M), (C + SLAB - 1) / SLAB);
-    hipLaunchKernelGGL((colreduce_kernel<Op, 4, SLAB / 4>), grid, dim3(256), 2 * 16 * SLAB * sizeof(double), s, op, M, C, part);
-  } else if (C <= 1) launch_colreduce_scalar<Op, 1>(op, M, C, part, s);
-  else if (C <= 2) launch_colreduce_scalar<Op, 2>(op, M, C, part, s);
-  else if (C <= 4) launch_colreduce_scalar<Op, 4>(op, M, C, part, s);
-  else if (C <= 8) launch_colreduce_scalar<Op, 8>(op, M, C, part, s);
-  else if (C <= 16) launch_colreduce_scalar<Op, 16>(op, M, C, part, s);
-  else if (C <= 32) launch_colreduce_scalar<Op, 32>(op, M, C, part, s);
-  else launch_colreduce_scalar<Op, 64>(op, M, C, part, s);
+    hipLaunchKernelGGL((colreduce_kernel<Op, 4, SLAB / 4>), grid, dim3(256), 2 * 16 * SLAB * sizeof(double), s, op, M, C, part, fin);
+  } else if (C <= 1) launch_colreduce_scalar<Op, 1>(op, M, C, part, s, fin);
+  else if (C <= 2) launch_colreduce_scalar<Op, 2>(op, M, C, part, s, fin);
+  else if (C <= 4) launch_colreduce_scalar<Op, 4>(op, M, C, part, s, fin);
+  else if (C <= 8) launch_colreduce_scalar<Op, 8>(op, M, C, part, s, fin);
+  else if (C <= 16) launch_colreduce_scalar<Op, 16>(op, M, C, part, s, fin);
+  else if (C <= 32) launch_colreduce_scalar<Op, 32>(op, M, C, part, s, fin);
+  else launch_colreduce_scalar<Op, 64>(op, M, C, part, s, fin);
   SEGSDE_CHECK_LAUNCH();
+  if (done) *done = fin.tickets != nullptr;
   return 0;
 }
 
@@ -706,6 +753,30 @@ __global__ __launch_bounds__(256) void bn_partials_reduce_kernel(const double* p
   }
 }
 
+// conv-epilogue partials -> mean / invstd / running statistics in ONE launch when the row count is moderate (the 32x64 and
+// 64x128 feature maps: 512 ... 2048 rows): 16 channels x 16 row-lanes per block, fixed order (two launches before)
+__global__ __launch_bounds__(256) void bn_stats_from_partials_kernel(const double* part, long rows, long M, int C, float eps,
+                                                                     float momentum, float* mean, float* invstd,
+                                                                     float* running_mean, float* running_var, int64_t* nbt) {
+  SEGSDE_SMEM;
+  double* sh = reinterpret_cast<double*>(segsde_smem);
+  const int c = blockIdx.x * 16 + (threadIdx.x & 15), pl = threadIdx.x >> 4;
+  if (nbt && blockIdx.x == 0 && threadIdx.x == 0) nbt[0] += 1;
+  double s, q;
+  combine_partials(part, (int)rows, C, c, pl, sh, s, q);
+  if (pl != 0 || c >= C) return;
+  const double mu = s / (double)M;
+  double var = q / (double)M - mu * mu;
+  if (var < 0.0) var = 0.0;
+  mean[c] = (float)mu;
+  invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+  if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mu;
+  if (running_var) {
+    const double unb = M > 1 ? var * (double)M / (double)(M - 1) : var;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+  }
+}
+
 namespace { constexpr int PARTIALS_NB = 64; }
 
 extern "C" size_t segsde_bn_stats_from_partials_workspace(int C) { return (size_t)PARTIALS_NB * 2 * (C > 0 ? C : 1) * sizeof(double); }
@@ -716,6 +787,12 @@ extern "C" int segsde_bn_stats_from_partials(const double* partials, long rows, 
   if (!partials || !mean || !invstd || !ws) return SEGSDE_ERR_NULL;
   if (rows <= 0 || M <= 0 || C <= 0) return SEGSDE_ERR_SHAPE;
   if (ws_bytes < segsde_bn_stats_from_partials_workspace(C)) return SEGSDE_ERR_WORKSPACE;
+  if (rows <= 2048) {
+    hipLaunchKernelGGL(bn_stats_from_partials_kernel, dim3((C + 15) / 16), dim3(256), 4096, ST(stream), partials, rows, M, C, eps,
+                       momentum, mean, invstd, running_mean, running_var, num_batches_tracked);
+    SEGSDE_CHECK_LAUNCH();
+    return 0;
+  }
   const int nb = rows < PARTIALS_NB ? (int)rows : PARTIALS_NB;
   hipLaunchKernelGGL(bn_partials_reduce_kernel, dim3(nb, (C + 63) / 64), dim3(256), 4096, ST(stream), partials, rows, C, nb,
                      (double*)ws);
@@ -766,10 +843,13 @@ extern "C" int segsde_bn_backward(const float* dy, int lddy, const float* y, int
   BnBwdOp op{dy, lddy, y, ldy, x, ldx, mean, invstd, act, C, drop_p, seed, gamma, beta};
   const bool vec = (C % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) && (lddy % 4 == 0) && al16p(x) && (!y || al16p(y)) && al16p(dy) &&
                    (!gamma || (al16p(gamma) && (!beta || al16p(beta)))) && al16p(mean) && al16p(invstd);
-  if (int e = launch_colreduce(op, M, C, (double*)ws, vec, ST(stream))) return e;
-  hipLaunchKernelGGL(pair_finalize_kernel, dim3((C + 15) / 16), dim3(256), 4096, ST(stream), (const double*)ws,
-                     red_blocks(M), C, dgamma, dbeta);
-  SEGSDE_CHECK_LAUNCH();
+  bool fin = false;
+  if (int e = launch_colreduce(op, M, C, (double*)ws, vec, ST(stream), dgamma, dbeta, &fin)) return e;
+  if (!fin) {
+    hipLaunchKernelGGL(pair_finalize_kernel, dim3((C + 15) / 16), dim3(256), 4096, ST(stream), (const double*)ws,
+                       red_blocks(M), C, dgamma, dbeta);
+    SEGSDE_CHECK_LAUNCH();
+  }
   if (dx || dres) {
     const bool v4 = vec && (!dx || ((lddx % 4 == 0) && al16p(dx))) && (!dres || ((lddres % 4 == 0) && al16p(dres)));
     if (v4)
@@ -793,8 +873,9 @@ extern "C" int segsde_act_backward(const float* dy, int lddy, const float* y, in
   ActBwdOp op{dy, lddy, y, ldy, dz, lddz, act};
   const bool vec = (C % 4 == 0) && (ldy % 4 == 0) && (lddy % 4 == 0) && al16p(y) && al16p(dy) &&
                    (!dz || ((lddz % 4 == 0) && al16p(dz)));
-  if (int e = launch_colreduce(op, M, C, (double*)ws, vec, ST(stream))) return e;
-  if (dbias) {
+  bool fin = false;
+  if (int e = launch_colreduce(op, M, C, (double*)ws, vec, ST(stream), dbias, nullptr, &fin)) return e;
+  if (dbias && !fin) {
     hipLaunchKernelGGL(pair_finalize_kernel, dim3((C + 15) / 16), dim3(256), 4096, ST(stream), (const double*)ws,
                        red_blocks(M), C, dbias, (float*)nullptr);
     SEGSDE_CHECK_LAUNCH();
@@ -808,10 +889,13 @@ extern "C" int segsde_colsum(const float* x, int ldx, long M, int C, float* out,
   if (ws_bytes < part_bytes(M, C)) return SEGSDE_ERR_WORKSPACE;
   ColsumOp op{x, ldx};
   const bool vec = (C % 4 == 0) && (ldx % 4 == 0) && al16p(x);
-  if (int e = launch_colreduce(op, M, C, (double*)ws, vec, ST(stream))) return e;
-  hipLaunchKernelGGL(pair_finalize_kernel, dim3((C + 15) / 16), dim3(256), 4096, ST(stream), (const double*)ws,
-                     red_blocks(M), C, out, (float*)nullptr);
-  SEGSDE_CHECK_LAUNCH();
+  bool fin = false;
+  if (int e = launch_colreduce(op, M, C, (double*)ws, vec, ST(stream), out, nullptr, &fin)) return e;
+  if (!fin) {
+    hipLaunchKernelGGL(pair_finalize_kernel, dim3((C + 15) / 16), dim3(256), 4096, ST(stream), (const double*)ws,
+                       red_blocks(M), C, out, (float*)nullptr);
+    SEGSDE_CHECK_LAUNCH();
+  }
   return 0;
 }
 

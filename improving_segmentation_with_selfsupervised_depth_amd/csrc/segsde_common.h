@@ -86,6 +86,11 @@ __device__ __forceinline__ T segsde_kernarg_here() {
 
 static inline int segsde_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// Tickets for "the last workgroup finishes the job" reductions (weight-gradient splits, column-sum finalize): a zeroed slice
+// of a device-resident ring for one launch (csrc/abi.hip); nullptr if it cannot be provided (the caller then uses its
+// two-kernel path).
+unsigned* segsde_ticket_slice(int n);
+
 // activation codes shared by conv epilogues, bn_apply and act_backward
 __device__ __forceinline__ float segsde_act(float v, int act) {
   if (act == SEGSDE_ACT_RELU) return v > 0.f ? v : 0.f;

@@ -97,7 +97,7 @@ class ConvFn(Function):
             y, part = H.conv_forward(g, x0, x1, wp, bias, act, want_stats=True)
             stats_out.append(part)
         else:
-            if H.upfold_ok(g) and x0.is_contiguous() and (x1 is None or x1.is_contiguous()):
+            if H.upfold_ok(g, 4 * x0.shape[0] * x0.shape[1] * x0.shape[2]) and x0.is_contiguous() and (x1 is None or x1.is_contiguous()):
                 # decoder Conv3x3 on [upsample(x0) | x1]: the upsample-folded route (4 taps instead of 9 on the upsampled channels)
                 ctx.fold = H.upfold_pack(weight, g.C0)
             y = H.conv_forward(g, x0, x1, wp, bias, act, wfold=None if ctx.fold is None else ctx.fold[0])

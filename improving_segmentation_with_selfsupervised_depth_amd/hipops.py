@@ -39,9 +39,18 @@ UPFOLD = os.environ.get("SEGSDE_UPFOLD", "1") != "0"
 UPFOLD_TAKEN = {"fwd": 0, "dgrad": 0, "wgrad": 0}    # diagnostics / tests: launches that took the folded route
 
 
-def upfold_ok(g):
-    return (UPFOLD and g.up0 and g.reflect and g.k == 3 and g.stride == 1 and g.dil == 1 and g.pad == 1 and g.C0 % 32 == 0
-            and g.C1 % 32 == 0 and g.Cout % 32 == 0)
+UPFOLD_MIN_SAVED_MACS = float(os.environ.get("SEGSDE_UPFOLD_MIN_MACS", "1e10"))
+
+
+def upfold_ok(g, pixels=None):
+    """pixels = B * H * W of the output (None: shape test only).  The folded route issues ~10 more launches per direction than
+    the plain one (pack, class launches, border launches): it is taken when the multiply-adds it saves -- 5 of 9 taps on the
+    C0 upsampled channels -- outweigh ~100 us of launches at ~130 TFLOP/s (cfg1's 2 x 256 x 512 layers stay on the plain route:
+    measured 28.9 vs 31.7 ms/step)."""
+    if not (UPFOLD and g.up0 and g.reflect and g.k == 3 and g.stride == 1 and g.dil == 1 and g.pad == 1 and g.C0 % 32 == 0
+            and g.C1 % 32 == 0 and g.Cout % 32 == 0):
+        return False
+    return pixels is None or 5.0 * pixels * g.C0 * g.Cout >= UPFOLD_MIN_SAVED_MACS
 
 
 def upfold_pack(w_oihw, C0):
@@ -324,7 +333,7 @@ def conv_wgrad(g, x0, x1, dy):
     L = _lib.lib()
     dw = torch.empty((Cout, g.Cin, g.k, g.k), dtype=torch.float32, device=dy.device)
     flops = 2.0 * B * Ho * Wo * Cout * g.Cin * g.k * g.k
-    if upfold_ok(g):
+    if upfold_ok(g, B * Ho * Wo):
         nbytes = L.segsde_conv2d_wgrad_upfold_workspace(ctypes.byref(d))
         if nbytes:
             ws = _ws(nbytes, dy)

@@ -13,6 +13,64 @@ from .. import hipops as H
 _ONES = {}
 
 
+class LazyOutputs(dict):
+    """The model's ``outputs`` dict with entries that are computed on first access.  ``MonodepthLoss.generate_images_pred``
+    registers the API-visible sampling grids ("sample", f, s) and depths ("depth", 0, s) here instead of materialising them
+    every step: the reference's train step never reads them (train.py:479-514; SURVEY.md 8b "may be produced lazily"), only
+    debug / evaluation code does.  Looks like a plain dict to everything else: ``in``, ``get``, iteration and ``len`` see the
+    lazy keys (iteration materialises them)."""
+
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        self._lazy = {}
+
+    def set_lazy(self, key, thunk):
+        dict.pop(self, key, None)
+        self._lazy[key] = thunk
+
+    def __missing__(self, key):
+        thunk = self._lazy.pop(key, None)
+        if thunk is None:
+            raise KeyError(key)
+        thunk()                                   # fills this key (and its siblings of the same launch)
+        return dict.__getitem__(self, key)
+
+    def __setitem__(self, key, value):
+        self._lazy.pop(key, None)
+        dict.__setitem__(self, key, value)
+
+    def __contains__(self, key):
+        return dict.__contains__(self, key) or key in self._lazy
+
+    def get(self, key, default=None):
+        return self[key] if key in self else default
+
+    def materialize(self):
+        for key in list(self._lazy):
+            if key in self._lazy:
+                self.__missing__(key)
+        return self
+
+    def keys(self):
+        return dict.keys(self.materialize())
+
+    def items(self):
+        return dict.items(self.materialize())
+
+    def values(self):
+        return dict.values(self.materialize())
+
+    def __iter__(self):
+        return dict.__iter__(self.materialize())
+
+    def __len__(self):
+        return dict.__len__(self) + len(self._lazy)
+
+    def update(self, *a, **k):
+        for key, v in dict(*a, **k).items():
+            self[key] = v
+
+
 def _one(dev):
     if dev not in _ONES:
         _ONES[dev] = torch.ones(1, dtype=torch.float32, device=dev)
@@ -125,16 +183,30 @@ class MonodepthLoss:
         assert tuple(outputs[("disp", 0)].shape[-2:]) == (self.height, self.width), \
             f'{outputs[("disp", 0)].shape[-2:]} should be {(self.height, self.width)} '
         cache = {}
+        lazy = isinstance(outputs, LazyOutputs)    # what this package's models return; a plain dict gets everything eagerly
         for s in self.scales:
             disp = outputs[("disp", s)].detach().contiguous()
             for i, f in enumerate(self.frame_ids[1:]):
                 T = outputs[("cam_T_cam", 0, f)].detach().float().contiguous()
                 color, grid, depth = H.warp_forward(disp, inputs[("inv_K", 0)], inputs[("K", 0)], T,
                                                     inputs[("color", f, 0)], self.min_depth, self.max_depth,
-                                                    want_grid=True, want_depth=(i == 0))
-                if i == 0:
-                    outputs[("depth", 0, s)] = depth
-                outputs[("sample", f, s)] = grid
+                                                    want_grid=not lazy, want_depth=(i == 0 and not lazy))
+                if lazy:
+                    def fill(disp=disp, T=T, f=f, s=s, i=i):
+                        _, g_, d_ = H.warp_forward(disp, inputs[("inv_K", 0)], inputs[("K", 0)], T, inputs[("color", f, 0)],
+                                                   self.min_depth, self.max_depth, want_grid=True, want_depth=(i == 0))
+                        dict.__setitem__(outputs, ("sample", f, s), g_)
+                        outputs._lazy.pop(("sample", f, s), None)
+                        if i == 0:
+                            dict.__setitem__(outputs, ("depth", 0, s), d_)
+                            outputs._lazy.pop(("depth", 0, s), None)
+                    outputs.set_lazy(("sample", f, s), fill)
+                    if i == 0:
+                        outputs.set_lazy(("depth", 0, s), fill)
+                else:
+                    if i == 0:
+                        outputs[("depth", 0, s)] = depth
+                    outputs[("sample", f, s)] = grid
                 outputs[("color", f, s)] = color
                 cache[("color", f, s)] = color
                 if not self.disable_automasking:

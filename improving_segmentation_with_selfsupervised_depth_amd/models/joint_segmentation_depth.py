@@ -49,7 +49,8 @@ class JointSegmentationMonodepth(nn.Module):
         return self.models["depth"](self.models["encoder"](x[("color", 0, 0)]))
 
     def forward(self, x):
-        outputs, inputs = {}, x
+        from ..loss.monodepth_loss import LazyOutputs
+        outputs, inputs = LazyOutputs(), x     # a dict; MonodepthLoss registers its API-visible grids / depths as lazy entries
         features = self.models["encoder"](inputs["color_aug", 0, 0])
         outputs["bottleneck"] = features[-1]
         if "mtl_decoder" in self.models:

@@ -41,6 +41,11 @@ inline hipError_t hipGetLastError() { return 0; }
 inline const char* hipGetErrorString(hipError_t) { return "emu"; }
 inline hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return 0; }
 inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return 0; }
+inline hipError_t hipMemset(void* p, int v, size_t n) { memset(p, v, n); return 0; }
+inline hipError_t hipMalloc(void** p, size_t n) { *p = malloc(n); return *p ? 0 : 2; }
+inline hipError_t hipGetDevice(int* d) { *d = 0; return 0; }
+inline hipError_t hipDeviceSynchronize() { return 0; }
+inline void __threadfence() {}
 enum hipMemcpyKind { hipMemcpyDeviceToDevice = 3 };
 inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memmove(d, s, n); return 0; }
 

@@ -641,6 +641,20 @@ def run_upfold_cases(device, cases=None):
                  (1, 6, 64, 32, 32, 32, "relu", True)]
     assert H.UPFOLD
     taken0 = dict(H.UPFOLD_TAKEN)
+    min_macs, H.UPFOLD_MIN_SAVED_MACS = H.UPFOLD_MIN_SAVED_MACS, 0.0     # the size gate would send these small cases to the plain route
+    try:
+        _run_upfold_cases(device, cases)
+    finally:
+        H.UPFOLD_MIN_SAVED_MACS = min_macs
+    n = len(cases)
+    took = {k: H.UPFOLD_TAKEN[k] - taken0[k] for k in taken0}
+    assert took["fwd"] == n and took["wgrad"] == 2 * n and took["dgrad"] >= 2 * n, ("a case fell back to the 9-tap route", took)
+    g = H.ConvGeom(32, 32, 3, 1, 1, 1, True, 0, True)
+    assert H.upfold_ok(g) and not H.upfold_ok(g, 2 * 64 * 64) and H.upfold_ok(g, 16 * 512 * 1024)   # the size gate
+
+
+def _run_upfold_cases(device, cases):
+    import torch.nn.functional as F
     for (B, Hh, W, C0, C1, Cout, act, bias) in cases:
         gen = torch.Generator().manual_seed(Hh * 1000 + W + C0)
         g = H.ConvGeom(C0, Cout, 3, 1, 1, 1, True, C1, True)
@@ -686,9 +700,6 @@ def run_upfold_cases(device, cases=None):
         assert_close(dw, wq.grad, rtol=1e-4, atol=1e-5, what=what + " dW")
         dw2 = H.conv_wgrad(g, X0, X1, Dy)
         assert torch.equal(dw, dw2), what + " dW deterministic"
-    n = len(cases)
-    took = {k: H.UPFOLD_TAKEN[k] - taken0[k] for k in taken0}
-    assert took["fwd"] == n and took["wgrad"] == 2 * n and took["dgrad"] >= 2 * n, ("a case fell back to the 9-tap route", took)
 
 
 def run_depthmix_teacher_cases(device):

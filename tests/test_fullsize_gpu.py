@@ -62,7 +62,7 @@ def test_conv_fullsize_sampled(geom):
         del ya
     del y
     fold = None
-    if H.upfold_ok(g):
+    if H.upfold_ok(g, B16 * Hh * W):
         # the upsample-folded route (what the models run) against the same float64 samples, border pixels included
         fold = H.upfold_pack(wt, C0)
         t0 = dict(H.UPFOLD_TAKEN)
@@ -110,7 +110,7 @@ def test_conv_fullsize_sampled(geom):
     # ---- weight gradient (sampled taps; each one a reduction over all 16 x H x W output pixels)
     t0 = dict(H.UPFOLD_TAKEN)
     dw = H.conv_wgrad(g, x0, x1, dy)
-    assert H.UPFOLD_TAKEN["wgrad"] == t0["wgrad"] + (1 if H.upfold_ok(g) else 0), "weight-gradient route"
+    assert H.UPFOLD_TAKEN["wgrad"] == t0["wgrad"] + (1 if H.upfold_ok(g, B16 * Hh * W) else 0), "weight-gradient route"
     rng = np.random.RandomState(5)
     taps = [(0, 0, 0, 0), (Cout - 1, C0 + C1 - 1, k - 1, k - 1), (Cout - 1, 0, 0, k - 1), (0, C0 + C1 - 1, k - 1, 0)]
     if C1:
@@ -252,6 +252,18 @@ def test_headline_model_two_steps_vs_oracle(workload):
         opt_o.step()
         ref.append((float(mono), float(seg), float(gn)))
         del out
+    # ---- the first step's gradient norm in float64 (the yardstick for the product's: DESIGN.md 4)
+    cast = lambda v: v.double() if v.is_floating_point() else v
+    sd64 = {k: (cast(v.clone()).requires_grad_(True) if v.is_floating_point() and "running" not in k else cast(v.clone()))
+            for k, v in sd.items()}
+    inp64 = {k: cast(v) for k, v in inp.items()}
+    lo64 = P.MonodepthLossOracle(**bench.loss_cfg(B, Hh, W)["training"]["monodepth_loss"], batch_size=B)
+    out64 = N.model_forward(sd64, cfg, inp64, train=True, dropout=False)
+    lo64.generate_images_pred(inp64, out64)
+    (lo64.compute_losses(inp64, out64, tiebreak_noise={s_: n.double() for s_, n in noise.items()})["loss"]
+     + seg_loss(out64, inp["lbl"], S.cross_entropy2d)).backward()
+    gn64 = float(torch.sqrt(sum((v.grad.double() ** 2).sum() for v in sd64.values() if v.is_floating_point() and v.grad is not None)))
+    del sd64, out64, lo64, inp64
     # ---- product (GPU)
     model = get_model(cfg, 19)
     model.load_state_dict(sd, strict=True)
@@ -279,7 +291,13 @@ def test_headline_model_two_steps_vs_oracle(workload):
             # losses: 1e-3.  Gradient norm: 1e-3 on the first step; the second step starts from weights that moved by a
             # clipped step of a norm-279 gradient (seg loss 11.2 -> 5.7), where fp32 re-association differences of the
             # first update are amplified -- its norm is only required to agree to 2 %
-            tol = 1e-3 if (i < 2 or step == 0) else 2e-2
+            if i == 2 and step == 0:
+                # against the float64 evaluation: as close to it as the reference's own fp32 arithmetic is (3x), or 1e-3
+                e_ref, e_prod = abs(ref[0][2] - gn64), abs(got[0][2] - gn64)
+                print("gradient norm step 0: float64 %.5f, fp32 oracle %.5f, product %.5f" % (gn64, ref[0][2], got[0][2]))
+                assert e_prod <= max(3 * e_ref, 1e-3 * gn64), (what, got[0][2], ref[0][2], gn64)
+                continue
+            tol = 1e-3 if i < 2 else 2e-2
             assert abs(got[step][i] - ref[step][i]) <= tol * abs(ref[step][i]), (step, what, got[step][i], ref[step][i])
 
 
