@@ -1088,11 +1088,14 @@ __device__ __forceinline__ void wgrad_k_decode(int k, int Ctot, int taps, int sr
 
 constexpr int BP = 32;  // pixels per staged chunk
 
-// Reduction of the split partials inside the weight-gradient kernel (round 3; 184 wgrad_reduce launches of ~14 us per step
-// before).  Every workgroup stores its partial slab, fences, and takes a ticket of its (k-tile, n-tile); the workgroup that
-// draws the LAST ticket sums all slabs of the tile in slab order -- the same order whichever workgroup does it, so the result
-// is deterministic -- writes OIHW and puts the ticket back to zero.  tickets == nullptr: partial slabs only (a separate
-// reduce kernel follows: the class launches of the upsample-folded route, SEGSDE_TUNE="wred=0").
+// Reduction of the split partials inside the weight-gradient kernel (round-3 EXPERIMENT, off by default: SEGSDE_TUNE="wred=1").
+// Every workgroup stores its partial slab, fences, and takes a ticket of its (k-tile, n-tile); the workgroup that draws the
+// LAST ticket sums all slabs of the tile in slab order -- the same order whichever workgroup does it, so the result is
+// deterministic -- writes OIHW and puts the ticket back to zero.  Correct (119 GPU tests), but MEASURED SLOWER: the
+// device-scope release fence every workgroup needs writes its XCD's whole L2 back (8 XCDs, no cross-XCD L2 coherence):
+// conv_wgrad 398 -> 648 us per launch, the step 334 -> 420 ms together with the same trick in the column reductions
+// (profiles/experiments_r03.md).  A kernel boundary pays that write-back once per launch; the 184 wgrad_reduce launches of
+// ~14 us stay.  tickets == nullptr (default): partial slabs only, a separate reduce kernel follows.
 struct WRed { unsigned* tickets; float* dw; int CtotDst, cOff, taps, srcC0; };
 
 template <int BKT, int BN, int WM, int WN, int MODE>
@@ -1664,7 +1667,7 @@ __global__ __launch_bounds__(256) void reflect_dgrad_fix_kernel(const float* dy,
 // experiment knob (environment SEGSDE_TUNE="bk64=1"), read once.  Measured on MI355X (profiles/ab_conv_r01.log):
 // BK=64 (139 KB LDS => 1 workgroup/CU, half the barriers) loses 15-25 % on the large layers against BK=32 with two
 // co-resident workgroups per CU, and start-up staggering of co-resident workgroups changes nothing.
-struct Tune { int bk64 = 0; int adjfix = 0; int wplan = 0; int wovh = 4; int nos2 = 0; int dma = 1; int var = 0; int wdma = 1; int adjlds = 1; int wred = 1; };
+struct Tune { int bk64 = 0; int adjfix = 0; int wplan = 0; int wovh = 4; int nos2 = 0; int dma = 1; int var = 0; int wdma = 1; int adjlds = 1; int wred = 0; };
 const Tune& tune() {
   static Tune t = [] {
     Tune r;
@@ -1678,7 +1681,7 @@ const Tune& tune() {
       if (const char* q = strstr(e, "var=")) r.var = atoi(q + 4);         // experiment variants of the LDS-DMA loop
       if (const char* q = strstr(e, "adjl=")) r.adjlds = atoi(q + 5);     // 0: reflection-adjoint loop register-staged in every wave
       if (const char* q = strstr(e, "wlds=")) r.wdma = atoi(q + 5);       // 0: register-staged weight-gradient tile loads
-      if (const char* q = strstr(e, "wred=")) r.wred = atoi(q + 5);       // 0: split partials reduced by a separate kernel
+      if (const char* q = strstr(e, "wred=")) r.wred = atoi(q + 5);       // 1: split partials reduced inside the kernel (measured: slower)
     }
     return r;
   }();

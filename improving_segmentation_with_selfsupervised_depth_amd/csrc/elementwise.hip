@@ -39,7 +39,7 @@ __host__ __device__ inline int red_blocks(long M) {
 // TX channel lanes x TY = 256 / TX row lanes.  Wide tensors: TX = 64 / VW lanes of VW channels each.  Narrow ones (C < 64:
 // the 1-channel disparity heads, the 19-class logits) shrink TX to the next power of two >= C so that all 256 threads
 // stay busy -- with 64 channel lanes a 1-channel reduction ran on 4 threads per block.
-// Fin: finalize inside the reduction kernel (round 3; the separate pair_finalize launch cost ~7 us 190 times per step).  The
+// Fin: finalize inside the reduction kernel (round-3 EXPERIMENT, off by default -- see launch_colreduce).  The
 // block that draws the LAST ticket of its channel group folds the group's partial rows -- in the same fixed lane order as
 // pair_finalize_kernel, so the result is bit-identical to the two-kernel path -- and writes the float sums.
 struct Fin { unsigned* tickets; float* out0; float* out1; };
@@ -117,7 +117,9 @@ template <class Op>
 int launch_colreduce(Op op, long M, int C, double* part, bool vec, hipStream_t s, float* out0 = nullptr, float* out1 = nullptr,
                      bool* done = nullptr) {
   Fin fin{nullptr, out0, out1};
-  static const bool enabled = [] { const char* e = getenv("SEGSDE_TUNE"); return !(e && strstr(e, "cfin=0")); }();
+  // off by default (SEGSDE_TUNE="cfin=1"): the device-scope fence costs more than the ~7 us finalize launch it replaces
+  // (colreduce<BnBwdOp> 53 -> 222 us per launch on the 8-XCD part; profiles/experiments_r03.md)
+  static const bool enabled = [] { const char* e = getenv("SEGSDE_TUNE"); return e && strstr(e, "cfin=1"); }();
   if (done && enabled && (out0 || out1)) {
     const int cw = vec ? SLAB : (C <= 1 ? 1 : C <= 2 ? 2 : C <= 4 ? 4 : C <= 8 ? 8 : C <= 16 ? 16 : C <= 32 ? 32 : 64);   // channels per block
     fin.tickets = segsde_ticket_slice((C + cw - 1) / cw);             // one ticket per channel group (grid.y)
@@ -753,8 +755,8 @@ __global__ __launch_bounds__(256) void bn_partials_reduce_kernel(const double* p
   }
 }
 
-// conv-epilogue partials -> mean / invstd / running statistics in ONE launch when the row count is moderate (the 32x64 and
-// 64x128 feature maps: 512 ... 2048 rows): 16 channels x 16 row-lanes per block, fixed order (two launches before)
+// conv-epilogue partials -> mean / invstd / running statistics in ONE launch when there are only a few partial rows:
+// 16 channels x 16 row-lanes per block, fixed order
 __global__ __launch_bounds__(256) void bn_stats_from_partials_kernel(const double* part, long rows, long M, int C, float eps,
                                                                      float momentum, float* mean, float* invstd,
                                                                      float* running_mean, float* running_var, int64_t* nbt) {
@@ -787,7 +789,7 @@ extern "C" int segsde_bn_stats_from_partials(const double* partials, long rows, 
   if (!partials || !mean || !invstd || !ws) return SEGSDE_ERR_NULL;
   if (rows <= 0 || M <= 0 || C <= 0) return SEGSDE_ERR_SHAPE;
   if (ws_bytes < segsde_bn_stats_from_partials_workspace(C)) return SEGSDE_ERR_WORKSPACE;
-  if (rows <= 2048) {
+  if (rows <= 64) {   // (tried for rows <= 2048: 16 serial row-lanes took 18.6 us against 8.7 + 4.8 us of the two parallel launches)
     hipLaunchKernelGGL(bn_stats_from_partials_kernel, dim3((C + 15) / 16), dim3(256), 4096, ST(stream), partials, rows, M, C, eps,
                        momentum, mean, invstd, running_mean, running_var, num_batches_tracked);
     SEGSDE_CHECK_LAUNCH();

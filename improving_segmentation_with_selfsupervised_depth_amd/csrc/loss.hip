@@ -653,8 +653,10 @@ __global__ __launch_bounds__(256) void photometric_bwd_kernel(PhotoBwdP a) {
   SEGSDE_SMEM;
   float* sm = reinterpret_cast<float*>(segsde_smem);      // [9][PB_H][PB_W] pixels, then [2][3][3][PC_H][PC_W] coefficients
   float* cf = sm + 9 * PB_H * PB_W;
-  float* geo = cf + 18 * PC_H * PC_W;                      // P0[12] pad P1[12] pad iK[16]
+  float* gpx = cf + 18 * PC_H * PC_W;                      // [6][PT_H][PT_W]: d err / d warped pixel per (frame, channel)
+  float* geo = gpx + 6 * PT_H * PT_W;                      // P0[12] pad P1[12] pad iK[16]
   double* sh = reinterpret_cast<double*>(geo + 48);
+  uint8_t* ssel = reinterpret_cast<uint8_t*>(sh + 4);      // [PC_H][PC_W]: selection of tile + 1 (255 outside the image)
   const int b = blockIdx.z, h0 = blockIdx.y * PT_H;
   const int H = a.H, W = a.W;
   const long HW = (long)H * W;
@@ -687,35 +689,46 @@ __global__ __launch_bounds__(256) void photometric_bwd_kernel(PhotoBwdP a) {
   __syncthreads();                                             // the previous tile's LDS reads are done (geo is visible)
   stage_tile(sm, sp, perp, tb, p0b, p1b, HW, w0 - 2, W);
   __syncthreads();
-  // ---- per-window-centre coefficients for tile + 1: d err_q / d x_cell = a + bx * x_cell + by * y_cell (times upstream)
+  // ---- per-window-centre coefficients for tile + 1: d err_q / d x_cell = a + bx * x_cell + by * y_cell (times upstream).
+  // Round 3: one thread per (column of tile + 1, frame, channel) WALKS DOWN the rows with rolling three-row sums -- each new
+  // staged row costs 3 + 3 LDS reads for the five row sums and a window is the sum of the last three row sums, instead of
+  // 9 + 9 reads per window centre (the 3x3 windows of vertically adjacent centres share two of their three rows).
+  // sel of tile + 1 is staged first (one byte per centre).
   for (int e = threadIdx.x; e < perc; e += 256) {
     const int qr = e / PC_W, qc = e - qr * PC_W;
     const int qh = h0 - 1 + qr, qw = w0 - 1 + qc;
-    float up[2] = {0.f, 0.f};
-    if (qh >= 0 && qh < H && qw >= 0 && qw < W) {
-      const int s = a.sel[(long)b * HW + (long)qh * W + qw];
-      if (a.avg) { if (s == a.ni) up[0] = up[1] = 0.5f * a.scale; }
-      else { if (s == a.ni) up[0] = a.scale; else if (s == a.ni + 1) up[1] = a.scale; }
-    }
+    ssel[e] = (qh >= 0 && qh < H && qw >= 0 && qw < W) ? a.sel[(long)b * HW + (long)qh * W + qw] : (uint8_t)255;
+  }
+  __syncthreads();
+  if (threadIdx.x < PC_W * 6) {
+    const int qc = threadIdx.x % PC_W, fc = threadIdx.x / PC_W, f = fc / 3, ch = fc - 3 * f;
+    float* o = cf + (fc * 3) * perc + qc;
+    if (a.no_ssim) {
+      for (int qr = 0; qr < PC_H; ++qr) { o[qr * PC_W] = 0.f; o[perc + qr * PC_W] = 0.f; o[2 * perc + qr * PC_W] = 0.f; }
+    } else {
+      const float* x = sm + (3 + fc) * perp + qc;        // planes 3..8 are pred0 c0..2, pred1 c0..2 = 3 + 3 f + ch
+      const float* y = sm + ch * perp + qc;
+      float rx[3], ry[3], rxx[3], ryy[3], rxy[3];
 #pragma unroll
-    for (int f = 0; f < 2; ++f) {
-      const float gq = up[f] * (0.85f / 3.f) * (-0.5f);
-#pragma unroll
-      for (int ch = 0; ch < 3; ++ch) {
+      for (int r = 0; r < PC_H + 2; ++r) {               // staged rows 0 .. PB_H-1; window of centre qr = rows qr .. qr+2
+        const float x0 = x[r * PB_W], x1 = x[r * PB_W + 1], x2 = x[r * PB_W + 2];
+        const float y0 = y[r * PB_W], y1 = y[r * PB_W + 1], y2 = y[r * PB_W + 2];
+        const int k = r % 3;
+        rx[k] = x0 + x1 + x2; ry[k] = y0 + y1 + y2;
+        rxx[k] = x0 * x0 + x1 * x1 + x2 * x2; ryy[k] = y0 * y0 + y1 * y1 + y2 * y2; rxy[k] = x0 * y0 + x1 * y1 + x2 * y2;
+        if (r < 2) continue;
+        const int qr = r - 2;
+        const int sl = ssel[qr * PC_W + qc];
+        float up = 0.f;
+        if (a.avg) { if (sl == a.ni) up = 0.5f * a.scale; }
+        else if (sl == a.ni + f) up = a.scale;
         float c0 = 0.f, c1 = 0.f, c2 = 0.f;
-        if (up[f] != 0.f && !a.no_ssim) {
-          const float* x = sm + (3 + 3 * f + ch) * perp;
-          const float* y = sm + ch * perp;
-          float sx = 0.f, sy = 0.f, sxx = 0.f, syy = 0.f, sxy = 0.f;
-#pragma unroll
-          for (int dh = -1; dh <= 1; ++dh)
-#pragma unroll
-            for (int dw = -1; dw <= 1; ++dw) {
-              const float xv = x[(qr + 1 + dh) * PB_W + qc + 1 + dw], yv = y[(qr + 1 + dh) * PB_W + qc + 1 + dw];
-              sx += xv; sy += yv; sxx += xv * xv; syy += yv * yv; sxy += xv * yv;
-            }
+        if (up != 0.f) {
+          const float sx = rx[0] + rx[1] + rx[2], sy = ry[0] + ry[1] + ry[2];
+          const float sxx = rxx[0] + rxx[1] + rxx[2], syy = ryy[0] + ryy[1] + ryy[2], sxy = rxy[0] + rxy[1] + rxy[2];
           // gradient path (not part of the bit-exact selection): reciprocal multiplies instead of IEEE divisions by 9
           constexpr float R9 = 1.f / 9.f;
+          const float gq = up * (0.85f / 3.f) * (-0.5f);
           const float mx = sx * R9, my = sy * R9;
           const float sig_x = sxx * R9 - mx * mx, sig_y = syy * R9 - my * my, sig_xy = sxy * R9 - mx * my;
           const float A1 = 2.f * mx * my + C1, A2 = 2.f * sig_xy + C2;
@@ -727,52 +740,60 @@ __global__ __launch_bounds__(256) void photometric_bwd_kernel(PhotoBwdP a) {
           c1 = m * (-rr * 2.f * B1);
           c2 = m * (2.f * A1);
         }
-        float* o = cf + ((f * 3 + ch) * 3) * perc + e;
-        o[0] = c0; o[perc] = c1; o[2 * perc] = c2;
+        o[qr * PC_W] = c0; o[perc + qr * PC_W] = c1; o[2 * perc + qr * PC_W] = c2;
       }
     }
   }
   __syncthreads();
-  // ---- per pixel: gather the 3x3 coefficient windows (reflection fold as multiplicities), L1 term, warp adjoint
+  // ---- d err / d warped pixel: the 3x3 gather of the coefficient windows (reflection fold as multiplicities) + the L1 term,
+  // again by column walkers: one thread per (tile column, frame, channel), rolling three-row sums of the column-weighted
+  // coefficient rows; the result goes to LDS for the pixel threads of the warp adjoint below
+  if (threadIdx.x < PT_W * 6) {
+    const int c_ = threadIdx.x % PT_W, fc = threadIdx.x / PT_W, f = fc / 3, ch = fc - 3 * f;
+    const int wq = w0 + c_;
+    // how often window centre p + d contains a padded cell that maps to p: the mirrored cell -1 (for w == 1) lies in the
+    // window of centre 0 only, the mirrored cell W (for w == W-2) in the window of centre W-1 only
+    const float mw0 = wq - 1 >= 0 ? (wq == 1 ? 2.f : 1.f) : 0.f, mw2 = wq + 1 <= W - 1 ? (wq == W - 2 ? 2.f : 1.f) : 0.f;
+    const float* o = cf + (fc * 3) * perc + c_;          // coefficient column c_ .. c_+2 <-> dw = -1 .. +1
+    float ra[3], rbx[3], rby[3];
+#pragma unroll
+    for (int qr = 0; qr < PC_H; ++qr) {                  // coefficient rows 0 .. PT_H+1 <-> image rows h0-1 ..
+      const float* q = o + qr * PC_W;
+      const int k = qr % 3;
+      ra[k] = mw0 * q[0] + q[1] + mw2 * q[2];
+      rbx[k] = mw0 * q[perc] + q[perc + 1] + mw2 * q[perc + 2];
+      rby[k] = mw0 * q[2 * perc] + q[2 * perc + 1] + mw2 * q[2 * perc + 2];
+      if (qr < 2) continue;
+      const int r_ = qr - 2, hq = h0 + r_;               // pixel row; its window rows are coefficient rows r_ .. r_+2
+      const float mh0 = hq - 1 >= 0 ? (hq == 1 ? 2.f : 1.f) : 0.f, mh2 = hq + 1 <= H - 1 ? (hq == H - 2 ? 2.f : 1.f) : 0.f;
+      const int k0 = r_ % 3, k1 = (r_ + 1) % 3, k2 = (r_ + 2) % 3;
+      const float sa = mh0 * ra[k0] + ra[k1] + mh2 * ra[k2];
+      const float sbx = mh0 * rbx[k0] + rbx[k1] + mh2 * rbx[k2];
+      const float sby = mh0 * rby[k0] + rby[k1] + mh2 * rby[k2];
+      const float xv = sm[(3 + fc) * perp + (r_ + 2) * PB_W + c_ + 2], yv = sm[ch * perp + (r_ + 2) * PB_W + c_ + 2];
+      const int sl = ssel[(r_ + 1) * PC_W + c_ + 1];
+      float upp = 0.f;
+      if (a.avg) { if (sl == a.ni) upp = 0.5f * a.scale; }
+      else if (sl == a.ni + f) upp = a.scale;
+      const float gl1 = upp * (a.no_ssim ? (1.f / 3.f) : (0.15f / 3.f));
+      const float df = yv - xv;   // d|t - x|/dx = -sign(t - x)
+      gpx[fc * (PT_W * PT_H) + r_ * PT_W + c_] = sa + sbx * xv + sby * yv + gl1 * (df > 0.f ? -1.f : (df < 0.f ? 1.f : 0.f));
+    }
+  }
+  __syncthreads();
+  // ---- per pixel: warp adjoint
   if (h < H && w < W) {
     const long p = (long)h * W + w;
-    // how often window centre p + d contains a padded cell that maps to p: the mirrored cell -1 (for h == 1) lies in the
-    // window of centre 0 only, the mirrored cell H (for h == H-2) in the window of centre H-1 only
-    float mh[3], mw[3];
-    mh[0] = h - 1 >= 0 ? (h == 1 ? 2.f : 1.f) : 0.f; mh[1] = 1.f; mh[2] = h + 1 <= H - 1 ? (h == H - 2 ? 2.f : 1.f) : 0.f;
-    mw[0] = w - 1 >= 0 ? (w == 1 ? 2.f : 1.f) : 0.f; mw[1] = 1.f; mw[2] = w + 1 <= W - 1 ? (w == W - 2 ? 2.f : 1.f) : 0.f;
-    const int s = a.sel[(long)b * HW + p];
-    float upp[2] = {0.f, 0.f};
-    if (a.avg) { if (s == a.ni) upp[0] = upp[1] = 0.5f * a.scale; }
-    else { if (s == a.ni) upp[0] = a.scale; else if (s == a.ni + 1) upp[1] = a.scale; }
     float gdisp = 0.f;
     const float* disp_b = a.disp + (long)b * a.hs * a.ws;
 #pragma unroll
     for (int f = 0; f < 2; ++f) {
       float gp[3];
       bool any = false;
-      const float gl1 = upp[f] * (a.no_ssim ? (1.f / 3.f) : (0.15f / 3.f));
 #pragma unroll
       for (int ch = 0; ch < 3; ++ch) {
-        const float xv = sm[(3 + 3 * f + ch) * perp + (r + 2) * PB_W + c + 2], yv = sm[ch * perp + (r + 2) * PB_W + c + 2];
-        float g = 0.f;
-        if (!a.no_ssim) {
-          const float* o = cf + ((f * 3 + ch) * 3) * perc + (r + 1) * PC_W + c + 1;
-          float sa = 0.f, sbx = 0.f, sby = 0.f;
-#pragma unroll
-          for (int dh = -1; dh <= 1; ++dh)
-#pragma unroll
-            for (int dw = -1; dw <= 1; ++dw) {
-              const float m = mh[dh + 1] * mw[dw + 1];
-              const int q = dh * PC_W + dw;
-              sa += m * o[q]; sbx += m * o[perc + q]; sby += m * o[2 * perc + q];
-            }
-          g = sa + sbx * xv + sby * yv;
-        }
-        const float df = yv - xv;   // d|t - x|/dx = -sign(t - x)
-        g += gl1 * (df > 0.f ? -1.f : (df < 0.f ? 1.f : 0.f));
-        gp[ch] = g;
-        any = any || (g != 0.f);
+        gp[ch] = gpx[(f * 3 + ch) * (PT_W * PT_H) + r * PT_W + c];
+        any = any || (gp[ch] != 0.f);
       }
       if (!any) continue;          // masked out here and in every neighbouring window: no contribution from this frame
       const float* P = geo + f * 16;
@@ -1069,7 +1090,7 @@ extern "C" int segsde_photometric_backward(const float* pred0, const float* pred
   a.tiles_per_block = photo_tiles_per_block(B, H, W);
   a.scale = scale; a.min_disp = 1.f / max_depth; a.max_disp = 1.f / min_depth;
   a.g_disp_up = g_disp_up; a.gP_part = (double*)ws_;
-  const size_t lds = (9 * PB_H * PB_W + 18 * PC_H * PC_W + 48) * sizeof(float) + 64;
+  const size_t lds = (9 * PB_H * PB_W + 18 * PC_H * PC_W + 6 * PT_H * PT_W + 48) * sizeof(float) + 64 + ((PC_H * PC_W + 15) / 16) * 16;
   hipLaunchKernelGGL(photometric_bwd_kernel, photo_grid(B, H, W), dim3(256), lds, ST(stream), a);
   SEGSDE_CHECK_LAUNCH();
   const int nblk = (int)(photo_blocks(B, H, W) / B);
