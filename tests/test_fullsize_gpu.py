@@ -350,7 +350,10 @@ def test_fused_photometric_fullsize_vs_stage_kernels():
                                   False, False, scale, w, gT1[0], gT1[1])
     sc = float(gup0.abs().max())
     assert sc > 0
-    assert_close(gup1, gup0, rtol=1e-4, atol=1e-5 * sc, what="d loss / d upsampled disparity")
+    # two different association orders of the same window sums (the fused backward rolls three-row sums down the columns, the
+    # stage chain gathers 9 taps per window): 3e-4 of the value + 3e-5 of the largest gradient (round 2, same order on both
+    # sides: 1e-4 / 1e-5; with the rolling sums 6 of 8.4 M elements sat at 1.2e-4 of their value)
+    assert_close(gup1, gup0, rtol=3e-4, atol=3e-5 * sc, what="d loss / d upsampled disparity")
     for j in range(2):
         assert_close(gT1[j], gT0[j], rtol=1e-4, atol=1e-5 * float(gT0[j].abs().max()), what="d loss / d T%d" % j)
 
