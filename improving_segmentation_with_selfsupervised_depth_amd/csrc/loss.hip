@@ -579,6 +579,22 @@ __device__ __forceinline__ float tile_error(const float* px, const float* py, in
   return no_ssim ? l1 : (0.85f * (ss / 3.f) + 0.15f * l1);
 }
 
+// XCD-aware block order for the tiled photometric kernels: the hardware deals consecutive workgroups round-robin over the
+// 8 XCDs, each with its own L2; after the remap every XCD owns a contiguous range of (image, tile row, strip) triples, so the
+// vertically adjacent strips that share two (forward: one) halo rows hit the same L2 instead of fetching them through eight
+// (PMC FETCH_SIZE before: 2.5x the algorithmic bytes of the backward launch)
+struct PhotoBlk { int bx, by, bz; };
+__device__ __forceinline__ PhotoBlk photo_block() {
+  const int nb = gridDim.x * gridDim.y * gridDim.z;
+  const int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+  const int t = segsde_xcd_remap(lin, nb);
+  PhotoBlk r;
+  r.bx = t % (int)gridDim.x;
+  const int q = t / (int)gridDim.x;
+  r.by = q % (int)gridDim.y; r.bz = q / (int)gridDim.y;
+  return r;
+}
+
 // IDENT = true : err planes of (src0, target), (src1, target) -> out_err [B,2,H,W]         (monodepth_loss.py:139-147)
 // IDENT = false: errors of the two warped frames + auto-mask minimum -> sel, identity_selection, block partial sums
 template <bool IDENT>
@@ -589,7 +605,8 @@ __global__ __launch_bounds__(256) void photometric_fwd_kernel(const float* pred0
   SEGSDE_SMEM;
   float* sm = reinterpret_cast<float*>(segsde_smem);           // [9][PF_H][PF_W]: target 0-2, pred0 3-5, pred1 6-8
   double* sh = reinterpret_cast<double*>(sm + 9 * PF_H * PF_W + ((9 * PF_H * PF_W) & 1));
-  const int b = blockIdx.z, h0 = blockIdx.y * PT_H;
+  const PhotoBlk pb = photo_block();
+  const int b = pb.bz, h0 = pb.by * PT_H;
   const long HW = (long)H * W;
   const float* tb = target + (long)b * 3 * HW;
   const float* p0b = pred0 + (long)b * 3 * HW;
@@ -600,7 +617,7 @@ __global__ __launch_bounds__(256) void photometric_fwd_kernel(const float* pred0
   const int h = h0 + r;
   const int ntx = (W + PT_W - 1) / PT_W;
   double acc = 0.0;
-  for (int tx = blockIdx.x * tiles_per_block; tx < ntx && tx < (int)(blockIdx.x + 1) * tiles_per_block; ++tx) {
+  for (int tx = pb.bx * tiles_per_block; tx < ntx && tx < (pb.bx + 1) * tiles_per_block; ++tx) {
     const int w0 = tx * PT_W, w = w0 + c;
     __syncthreads();                                           // the previous tile's window reads are done
     stage_tile(sm, sp, per, tb, p0b, p1b, HW, w0 - 1, W);
@@ -636,7 +653,7 @@ __global__ __launch_bounds__(256) void photometric_fwd_kernel(const float* pred0
   }
   if (!IDENT) {
     const double t = segsde_block_sum(acc, sh);
-    if (threadIdx.x == 0) part[((long)b * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = t;
+    if (threadIdx.x == 0) part[((long)b * gridDim.y + pb.by) * gridDim.x + pb.bx] = t;
   }
 }
 
@@ -657,7 +674,8 @@ __global__ __launch_bounds__(256) void photometric_bwd_kernel(PhotoBwdP a) {
   float* geo = gpx + 6 * PT_H * PT_W;                      // P0[12] pad P1[12] pad iK[16]
   double* sh = reinterpret_cast<double*>(geo + 48);
   uint8_t* ssel = reinterpret_cast<uint8_t*>(sh + 4);      // [PC_H][PC_W]: selection of tile + 1 (255 outside the image)
-  const int b = blockIdx.z, h0 = blockIdx.y * PT_H;
+  const PhotoBlk pb = photo_block();
+  const int b = pb.bz, h0 = pb.by * PT_H;
   const int H = a.H, W = a.W;
   const long HW = (long)H * W;
   {
@@ -684,7 +702,7 @@ __global__ __launch_bounds__(256) void photometric_bwd_kernel(PhotoBwdP a) {
   for (int f = 0; f < 2; ++f)
 #pragma unroll
     for (int i = 0; i < 12; ++i) acc[f][i] = 0.f;
-  for (int tx = blockIdx.x * a.tiles_per_block; tx < ntx && tx < (int)(blockIdx.x + 1) * a.tiles_per_block; ++tx) {
+  for (int tx = pb.bx * a.tiles_per_block; tx < ntx && tx < (pb.bx + 1) * a.tiles_per_block; ++tx) {
   const int w0 = tx * PT_W, w = w0 + c;
   __syncthreads();                                             // the previous tile's LDS reads are done (geo is visible)
   stage_tile(sm, sp, perp, tb, p0b, p1b, HW, w0 - 2, W);
@@ -833,7 +851,7 @@ __global__ __launch_bounds__(256) void photometric_bwd_kernel(PhotoBwdP a) {
     a.g_disp_up[(long)b * HW + p] = gdisp;
   }
   }   // tiles of the strip
-  const long blk = ((long)b * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+  const long blk = ((long)b * gridDim.y + pb.by) * gridDim.x + pb.bx;
 #pragma unroll
   for (int f = 0; f < 2; ++f)
 #pragma unroll
