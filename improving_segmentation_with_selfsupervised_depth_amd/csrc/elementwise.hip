@@ -8,6 +8,8 @@
 // results are run-to-run reproducible.  Pure elementwise kernels take a float4 path when C, the pitches and
 // the base pointers allow it.
 #include "segsde_common.h"
+#include <type_traits>
+#include <utility>
 #include <cstdlib>
 #include <cstring>
 
@@ -39,6 +41,11 @@ __host__ __device__ inline int red_blocks(long M) {
 // TX channel lanes x TY = 256 / TX row lanes.  Wide tensors: TX = 64 / VW lanes of VW channels each.  Narrow ones (C < 64:
 // the 1-channel disparity heads, the 19-class logits) shrink TX to the next power of two >= C so that all 256 threads
 // stay busy -- with 64 channel lanes a 1-channel reduction ran on 4 threads per block.
+// an Op may provide per-channel context (ctx<VW>(c)) that its row() takes: loaded once per thread instead of once per row
+template <class Op, int VW, class = void> struct has_ctx : std::false_type {};
+template <class Op, int VW>
+struct has_ctx<Op, VW, std::void_t<decltype(std::declval<const Op&>().template ctx<VW>(0))>> : std::true_type {};
+
 // Fin: finalize inside the reduction kernel (round-3 EXPERIMENT, off by default -- see launch_colreduce).  The
 // block that draws the LAST ticket of its channel group folds the group's partial rows -- in the same fixed lane order as
 // pair_finalize_kernel, so the result is bit-identical to the two-kernel path -- and writes the float sums.
@@ -58,8 +65,14 @@ __global__ __launch_bounds__(256) void colreduce_kernel(Op op, long M, int C, do
   double s0[VW], s1[VW];
 #pragma unroll
   for (int j = 0; j < VW; ++j) { s0[j] = 0.0; s1[j] = 0.0; }
-  if (c < C)
-    for (long m = r_begin + ty; m < r_end; m += TY) op.template row<VW>(m, c, s0, s1);
+  if (c < C) {
+    if constexpr (has_ctx<Op, VW>::value) {
+      const auto k = op.template ctx<VW>(c);
+      for (long m = r_begin + ty; m < r_end; m += TY) op.template row<VW>(m, c, k, s0, s1);
+    } else {
+      for (long m = r_begin + ty; m < r_end; m += TY) op.template row<VW>(m, c, s0, s1);
+    }
+  }
 #pragma unroll
   for (int j = 0; j < VW; ++j) {
     sh[ty * CW + tx * VW + j] = s0[j];
@@ -205,14 +218,27 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* x, int ldx, 
   const int CV = C / VW;
   const long total = M * CV;
   const float keep_scale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
-  for (long e = blockIdx.x * 256L + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+  // Round 3: when the grid stride is a multiple of the channel-vector count (power-of-two channel counts, host-chosen grid) a
+  // thread meets the SAME channels in every trip: mean / invstd / gamma / beta are loaded once, not four 16-byte loads next
+  // to every 16 bytes of data (those loads hit L1 but took 4/5 of the kernel's vector-memory issue slots: 5.0 TB/s before).
+  const long stride = (long)gridDim.x * 256;
+  const bool fixed_c = cv_shift >= 0 && (stride & (long)(CV - 1)) == 0;
+  VecF<VW> mu, is, ga, be;
+  if (fixed_c) {
+    const int c = (int)((blockIdx.x * 256L + threadIdx.x) & (long)(CV - 1)) * VW;
+    mu = ldv<VW>(mean + c); is = ldv<VW>(invstd + c);
+    if (gamma) { ga = ldv<VW>(gamma + c); be = ldv<VW>(beta + c); }
+  }
+  for (long e = blockIdx.x * 256L + threadIdx.x; e < total; e += stride) {
     // channel counts are powers of two on the whole ResNet / decoder path: shift + mask instead of a 64-bit division
     const long m = cv_shift >= 0 ? (e >> cv_shift) : e / CV;
     const int c = (int)(e - m * CV) * VW;
-    // per-channel parameters as one 16-byte load each (they were 16 scalar loads per float4 of data before)
-    const VecF<VW> xv = ldv<VW>(x + m * ldx + c), mu = ldv<VW>(mean + c), is = ldv<VW>(invstd + c);
-    VecF<VW> ga, be, rv, o;
-    if (gamma) { ga = ldv<VW>(gamma + c); be = ldv<VW>(beta + c); }
+    const VecF<VW> xv = ldv<VW>(x + m * ldx + c);
+    if (!fixed_c) {   // per-channel parameters as one 16-byte load each
+      mu = ldv<VW>(mean + c); is = ldv<VW>(invstd + c);
+      if (gamma) { ga = ldv<VW>(gamma + c); be = ldv<VW>(beta + c); }
+    }
+    VecF<VW> rv, o;
     if (res) rv = ldv<VW>(res + m * ldr + c);
 #pragma unroll
     for (int j = 0; j < VW; ++j) {
@@ -256,17 +282,23 @@ __device__ __forceinline__ float bn_dz_remask(float dy, float xh, float gamma, f
 struct BnBwdOp {
   const float* dy; int lddy; const float* y; int ldy; const float* x; int ldx; const float* mean; const float* invstd;
   int act, C; float drop_p; uint64_t seed; const float* gamma; const float* beta;
-  template <int VW> __device__ void row(long m, int c, double* s0, double* s1) const {
+  // per-channel parameters, loaded ONCE per thread (a thread of colreduce_kernel keeps its channels for all its rows)
+  template <int VW> struct Ctx { VecF<VW> mu, is, ga, be; };
+  template <int VW> __device__ Ctx<VW> ctx(int c) const {
+    Ctx<VW> k;
+    k.mu = ldv<VW>(mean + c); k.is = ldv<VW>(invstd + c);
+    if (!y && gamma) { k.ga = ldv<VW>(gamma + c); k.be = ldv<VW>(beta + c); }
+    return k;
+  }
+  template <int VW> __device__ void row(long m, int c, const Ctx<VW>& k, double* s0, double* s1) const {
     const VecF<VW> g = ldv<VW>(dy + m * lddy + c), xx = ldv<VW>(x + m * ldx + c);
-    VecF<VW> yy, ga, be;
+    VecF<VW> yy;
     if (y) yy = ldv<VW>(y + m * ldy + c);
-    else if (gamma) { ga = ldv<VW>(gamma + c); be = ldv<VW>(beta + c); }
-    const VecF<VW> mu = ldv<VW>(mean + c), is = ldv<VW>(invstd + c);   // per-channel parameters: one vector load each
 #pragma unroll
     for (int j = 0; j < VW; ++j) {
-      const float xh = (xx.v[j] - mu.v[j]) * is.v[j];
+      const float xh = (xx.v[j] - k.mu.v[j]) * k.is.v[j];
       const float dz = y ? bn_dz(g.v[j], yy.v[j], act, drop_p, seed, (uint64_t)(m * C + c + j))
-                         : bn_dz_remask(g.v[j], xh, gamma ? ga.v[j] : 1.f, gamma ? be.v[j] : 0.f, gamma != nullptr, act);
+                         : bn_dz_remask(g.v[j], xh, gamma ? k.ga.v[j] : 1.f, gamma ? k.be.v[j] : 0.f, gamma != nullptr, act);
       s0[j] += (double)dz * (double)xh; s1[j] += (double)dz;
     }
   }
@@ -293,15 +325,13 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* dy, int 
   const int CV = C / VW;
   const long total = M * CV;
   const float invM = 1.f / (float)M;
-  for (long e = blockIdx.x * 256L + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
-    const long m = cv_shift >= 0 ? (e >> cv_shift) : e / CV;
-    const int c = (int)(e - m * CV) * VW;
-    const VecF<VW> g = ldv<VW>(dy + m * lddy + c);
-    VecF<VW> xx, yy;
-    const bool remask = y == nullptr;
-    if (!remask) yy = ldv<VW>(y + m * ldy + c);
-    if ((dx && batch_stats) || remask) xx = ldv<VW>(x + m * ldx + c);
-    VecF<VW> dz, o, ga, be, mu, is, dg, db;
+  const bool remask = y == nullptr;
+  // per-channel parameters once per thread when every trip of the grid-stride loop meets the same channels (see bn_apply_kernel):
+  // up to six 16-byte parameter loads next to the two or three data loads of a trip before
+  const long stride = (long)gridDim.x * 256;
+  const bool fixed_c = cv_shift >= 0 && (stride & (long)(CV - 1)) == 0;
+  VecF<VW> ga, be, mu, is, dg, db;
+  auto load_params = [&](int c) {
     if (dx || remask) {
       is = ldv<VW>(invstd + c);
       if (gamma) ga = ldv<VW>(gamma + c);
@@ -309,6 +339,17 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* dy, int 
       if (batch_stats || remask) mu = ldv<VW>(mean + c);
       if (batch_stats && dx) { dg = ldv<VW>(dgamma + c); db = ldv<VW>(dbeta + c); }
     }
+  };
+  if (fixed_c) load_params((int)((blockIdx.x * 256L + threadIdx.x) & (long)(CV - 1)) * VW);
+  for (long e = blockIdx.x * 256L + threadIdx.x; e < total; e += stride) {
+    const long m = cv_shift >= 0 ? (e >> cv_shift) : e / CV;
+    const int c = (int)(e - m * CV) * VW;
+    const VecF<VW> g = ldv<VW>(dy + m * lddy + c);
+    VecF<VW> xx, yy;
+    if (!remask) yy = ldv<VW>(y + m * ldy + c);
+    if ((dx && batch_stats) || remask) xx = ldv<VW>(x + m * ldx + c);
+    VecF<VW> dz, o;
+    if (!fixed_c) load_params(c);
 #pragma unroll
     for (int j = 0; j < VW; ++j) {
       if (remask) dz.v[j] = bn_dz_remask(g.v[j], (xx.v[j] - mu.v[j]) * is.v[j], gamma ? ga.v[j] : 1.f, gamma ? be.v[j] : 0.f, gamma != nullptr, act);
@@ -712,6 +753,13 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* x, int l
 
 inline int pow2_shift(int v) { int s = 0; while ((1 << s) < v) ++s; return (1 << s) == v ? s : -1; }
 inline int ew_blocks(long total) { long nb = (total + 255) / 256; return (int)(nb < 1 ? 1 : (nb > 8192 ? 8192 : nb)); }
+// grid of a channel-vector kernel whose stride (blocks x 256) is a multiple of the CV channel vectors per row whenever CV is a
+// power of two (<= 256: any block count; 512, 1024, ...: the block count rounded up to a multiple of CV / 256)
+inline int ew_blocks_cv(long total, int cv) {
+  int nb = ew_blocks(total);
+  if (cv > 256 && (cv & (cv - 1)) == 0) { const int q = cv / 256; nb = ((nb + q - 1) / q) * q; }
+  return nb;
+}
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 #define ST(s) static_cast<hipStream_t>(s)
 
@@ -822,10 +870,10 @@ extern "C" int segsde_bn_apply(const float* x, int ldx, long M, int C, const flo
   const bool v4 = (C % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) && al16(x) && al16(y) &&
                   (!residual || ((ldr % 4 == 0) && al16(residual)));
   if (v4)
-    hipLaunchKernelGGL(bn_apply_kernel<4>, dim3(ew_blocks(M * C / 4)), dim3(256), 0, ST(stream), x, ldx, M, C, mean,
+    hipLaunchKernelGGL(bn_apply_kernel<4>, dim3(ew_blocks_cv(M * C / 4, C / 4)), dim3(256), 0, ST(stream), x, ldx, M, C, mean,
                        invstd, gamma, beta, residual, ldr, y, ldy, act, drop_p, seed, pow2_shift(C / 4));
   else
-    hipLaunchKernelGGL(bn_apply_kernel<1>, dim3(ew_blocks(M * C)), dim3(256), 0, ST(stream), x, ldx, M, C, mean, invstd,
+    hipLaunchKernelGGL(bn_apply_kernel<1>, dim3(ew_blocks_cv(M * C, C)), dim3(256), 0, ST(stream), x, ldx, M, C, mean, invstd,
                        gamma, beta, residual, ldr, y, ldy, act, drop_p, seed, pow2_shift(C));
   SEGSDE_CHECK_LAUNCH();
   return 0;
@@ -855,11 +903,11 @@ extern "C" int segsde_bn_backward(const float* dy, int lddy, const float* y, int
   if (dx || dres) {
     const bool v4 = vec && (!dx || ((lddx % 4 == 0) && al16p(dx))) && (!dres || ((lddres % 4 == 0) && al16p(dres)));
     if (v4)
-      hipLaunchKernelGGL(bn_bwd_apply_kernel<4>, dim3(ew_blocks(M * C / 4)), dim3(256), 0, ST(stream), dy, lddy, y, ldy, x,
+      hipLaunchKernelGGL(bn_bwd_apply_kernel<4>, dim3(ew_blocks_cv(M * C / 4, C / 4)), dim3(256), 0, ST(stream), dy, lddy, y, ldy, x,
                          ldx, M, C, mean, invstd, gamma, beta, act, drop_p, seed, batch_stats, (const float*)dgamma,
                          (const float*)dbeta, dx, lddx, dres, lddres, pow2_shift(C / 4));
     else
-      hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, dim3(ew_blocks(M * C)), dim3(256), 0, ST(stream), dy, lddy, y, ldy, x, ldx,
+      hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, dim3(ew_blocks_cv(M * C, C)), dim3(256), 0, ST(stream), dy, lddy, y, ldy, x, ldx,
                          M, C, mean, invstd, gamma, beta, act, drop_p, seed, batch_stats, (const float*)dgamma,
                          (const float*)dbeta, dx, lddx, dres, lddres, pow2_shift(C));
     SEGSDE_CHECK_LAUNCH();

@@ -109,8 +109,14 @@ class GradAllReducer:
         # control channel: a gloo group of its own for the per-step agreement (host-side facts only -- which p.grad exist --
         # so no device synchronisation, and its collective cannot interleave differently with the bucket all-reduces on
         # different ranks because it lives on another communicator)
-        ranks = dist.get_process_group_ranks(process_group) if (process_group is not None and self.world > 1) else None
-        self._ctl = dist.new_group(ranks=ranks, backend="gloo") if self.world > 1 else None
+        self._ctl = None
+        if self.world > 1:
+            ranks = dist.get_process_group_ranks(process_group) if process_group is not None else None
+            try:
+                self._ctl = dist.new_group(ranks=ranks, backend="gloo")
+            except Exception as ex:      # no usable TCP interface for gloo: keep going on local decisions (the pre-round-3 behaviour)
+                warnings.warn("GradAllReducer: no gloo control group (%r); ranks that see different parameter sets are not "
+                              "reconciled" % (ex,))
         self.broadcast_parameters()
 
     @property
@@ -194,7 +200,7 @@ class GradAllReducer:
         rebuild = self.buckets is None or any(p not in self._where for p in live)
         nb = len(self.buckets) if self.buckets is not None else 0
         dirty = [1 if b.dirty else 0 for b in self.buckets] if nb else []
-        if self.world > 1:
+        if self.world > 1 and self._ctl is not None:
             # the decision, the parameter set and the dirty buckets must be the same on every rank, or the collectives
             # diverge and the job hangs: one MAX all-reduce of [rebuild?, has-gradient bitmap, dirty bitmap] per step on the
             # control channel (CPU tensor, < 1 KB).  Unconditional: a rank cannot know that ANOTHER rank saw a new parameter.

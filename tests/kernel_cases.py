@@ -2,6 +2,7 @@
 (`-m gpu`, real libsegsde_hip.so through the C ABI).  The checker is plain PyTorch fp32 on CPU / the oracle."""
 import os
 
+import numpy as np
 import torch
 import torch.nn.functional as F
 
@@ -700,6 +701,53 @@ def _run_upfold_cases(device, cases):
         assert_close(dw, wq.grad, rtol=1e-4, atol=1e-5, what=what + " dW")
         dw2 = H.conv_wgrad(g, X0, X1, Dy)
         assert torch.equal(dw, dw2), what + " dW deterministic"
+
+
+def run_upfold_random(device, n=24, seed=7):
+    """random geometries of the upsample-folded route against the package's own 9-tap route (itself pinned on torch elsewhere):
+    odd tile counts, sub-grid rows that are not a multiple of the 128-row tile, partial last tiles, channel counts that mix
+    tile shapes (96, 160, 192), tiny maps.  Shapes the folded weight gradient does not take (rows not a multiple of 32 pixels
+    wide) must fall back silently and still be right."""
+    rng = np.random.RandomState(seed)
+    min_macs, H.UPFOLD_MIN_SAVED_MACS = H.UPFOLD_MIN_SAVED_MACS, 0.0
+    t0 = dict(H.UPFOLD_TAKEN)
+    try:
+        for it in range(n):
+            B = int(rng.randint(1, 4))
+            h2, w2 = int(rng.choice([2, 3, 5, 8, 13])), int(rng.choice([4, 7, 16, 32, 33, 64, 96, 128]))
+            C0, C1 = int(rng.choice([32, 64, 96])), int(rng.choice([0, 0, 32, 64]))
+            Cout = int(rng.choice([32, 64, 96, 160]))
+            act = str(rng.choice(["none", "elu"]))
+            Hh, W = 2 * h2, 2 * w2
+            g = H.ConvGeom(C0, Cout, 3, 1, 1, 1, True, C1, True)
+            gen = torch.Generator().manual_seed(1000 + it)
+            x0 = torch.randn(B, h2, w2, C0, generator=gen).to(device)
+            x1 = torch.randn(B, Hh, W, C1, generator=gen).to(device) if C1 else None
+            wt = (torch.randn(Cout, C0 + C1, 3, 3, generator=gen) * 0.1).to(device)
+            bs = torch.randn(Cout, generator=gen).to(device) if act != "none" else None
+            dy = torch.randn(B, Hh, W, Cout, generator=gen).to(device)
+            what = "upfold random #%d B%d %dx%d %d+%d->%d %s" % (it, B, Hh, W, C0, C1, Cout, act)
+            wp, wd = H.pack_weight_both(wt)
+            fold = H.upfold_pack(wt, C0)
+            assert_close(H.conv_forward(g, x0, x1, wp, bs, act, wfold=fold[0]), H.conv_forward(g, x0, x1, wp, bs, act),
+                         rtol=1e-4, atol=1e-5, what=what + " forward")
+            ys = torch.nn.functional.elu(torch.randn(B, h2, w2, C0, generator=gen)).to(device)
+            a0, a1 = H.conv_dgrad(g, dy, wd, wt, (Hh, W), fold=fold, actgrad=(ys, "elu"))
+            b0, b1 = H.conv_dgrad(g, dy, wd, wt, (Hh, W), actgrad=(ys, "elu"))
+            assert_close(a0, b0, rtol=1e-4, atol=1e-5, what=what + " d/dx0")
+            if C1:
+                assert_close(a1, b1, rtol=1e-4, atol=1e-5, what=what + " d/dx1")
+            dw_f = H.conv_wgrad(g, x0, x1, dy)
+            saved, H.UPFOLD = H.UPFOLD, False
+            try:
+                dw_9 = H.conv_wgrad(g, x0, x1, dy)
+            finally:
+                H.UPFOLD = saved
+            assert_close(dw_f, dw_9, rtol=1e-4, atol=1e-5, what=what + " dW")
+    finally:
+        H.UPFOLD_MIN_SAVED_MACS = min_macs
+    took = {k: H.UPFOLD_TAKEN[k] - t0[k] for k in t0}
+    assert took["fwd"] >= n // 2 and took["dgrad"] >= n // 2 and took["wgrad"] >= n // 6, took
 
 
 def run_depthmix_teacher_cases(device):

@@ -56,6 +56,10 @@ def test_upsample_folded_convolutions():
     KC.run_upfold_cases("cpu")
 
 
+def test_upsample_folded_random_geometries():
+    KC.run_upfold_random("cpu", n=6, seed=3)
+
+
 def test_depthmix_teacher_kernels():
     KC.run_depthmix_teacher_cases("cpu")
 

@@ -107,6 +107,10 @@ def test_upsample_folded_convolutions():
     KC.run_upfold_cases("cuda")
 
 
+def test_upsample_folded_random_geometries():
+    KC.run_upfold_random("cuda", n=40)
+
+
 def test_depthmix_teacher_kernels():
     KC.run_depthmix_teacher_cases("cuda")
 
