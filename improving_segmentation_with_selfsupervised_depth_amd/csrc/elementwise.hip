@@ -68,8 +68,10 @@ __global__ __launch_bounds__(256) void colreduce_kernel(Op op, long M, int C, do
   if (c < C) {
     if constexpr (has_ctx<Op, VW>::value) {
       const auto k = op.template ctx<VW>(c);
+#pragma unroll 4     // the loads of the next rows do not depend on the sums: unrolled, they are in flight together (same order of adds)
       for (long m = r_begin + ty; m < r_end; m += TY) op.template row<VW>(m, c, k, s0, s1);
     } else {
+#pragma unroll 4
       for (long m = r_begin + ty; m < r_end; m += TY) op.template row<VW>(m, c, s0, s1);
     }
   }
@@ -229,17 +231,8 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* x, int ldx, 
     mu = ldv<VW>(mean + c); is = ldv<VW>(invstd + c);
     if (gamma) { ga = ldv<VW>(gamma + c); be = ldv<VW>(beta + c); }
   }
-  for (long e = blockIdx.x * 256L + threadIdx.x; e < total; e += stride) {
-    // channel counts are powers of two on the whole ResNet / decoder path: shift + mask instead of a 64-bit division
-    const long m = cv_shift >= 0 ? (e >> cv_shift) : e / CV;
-    const int c = (int)(e - m * CV) * VW;
-    const VecF<VW> xv = ldv<VW>(x + m * ldx + c);
-    if (!fixed_c) {   // per-channel parameters as one 16-byte load each
-      mu = ldv<VW>(mean + c); is = ldv<VW>(invstd + c);
-      if (gamma) { ga = ldv<VW>(gamma + c); be = ldv<VW>(beta + c); }
-    }
-    VecF<VW> rv, o;
-    if (res) rv = ldv<VW>(res + m * ldr + c);
+  auto finish = [&](long m, int c, const VecF<VW>& xv, const VecF<VW>& rv) {
+    VecF<VW> o;
 #pragma unroll
     for (int j = 0; j < VW; ++j) {
       float t = (xv.v[j] - mu.v[j]) * is.v[j];
@@ -250,6 +243,36 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* x, int ldx, 
       o.v[j] = t;
     }
     stv<VW>(y + m * ldy + c, o);
+  };
+  long e = blockIdx.x * 256L + threadIdx.x;
+  if (fixed_c) {
+    // four trips at a time: their (independent) data loads are all in flight before the first result is needed -- one 16-byte
+    // load per thread and trip left too few bytes in flight for the HBM latency
+    const int c = (int)(e & (long)(CV - 1)) * VW;
+    for (; e + 3 * stride < total; e += 4 * stride) {
+      long m[4]; VecF<VW> xv[4], rv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { m[u] = (e + u * stride) >> cv_shift; xv[u] = ldv<VW>(x + m[u] * ldx + c); }
+      if (res) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) rv[u] = ldv<VW>(res + m[u] * ldr + c);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) finish(m[u], c, xv[u], rv[u]);
+    }
+  }
+  for (; e < total; e += stride) {
+    // channel counts are powers of two on the whole ResNet / decoder path: shift + mask instead of a 64-bit division
+    const long m = cv_shift >= 0 ? (e >> cv_shift) : e / CV;
+    const int c = (int)(e - m * CV) * VW;
+    const VecF<VW> xv = ldv<VW>(x + m * ldx + c);
+    if (!fixed_c) {   // per-channel parameters as one 16-byte load each
+      mu = ldv<VW>(mean + c); is = ldv<VW>(invstd + c);
+      if (gamma) { ga = ldv<VW>(gamma + c); be = ldv<VW>(beta + c); }
+    }
+    VecF<VW> rv;
+    if (res) rv = ldv<VW>(res + m * ldr + c);
+    finish(m, c, xv, rv);
   }
 }
 
@@ -341,15 +364,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* dy, int 
     }
   };
   if (fixed_c) load_params((int)((blockIdx.x * 256L + threadIdx.x) & (long)(CV - 1)) * VW);
-  for (long e = blockIdx.x * 256L + threadIdx.x; e < total; e += stride) {
-    const long m = cv_shift >= 0 ? (e >> cv_shift) : e / CV;
-    const int c = (int)(e - m * CV) * VW;
-    const VecF<VW> g = ldv<VW>(dy + m * lddy + c);
-    VecF<VW> xx, yy;
-    if (!remask) yy = ldv<VW>(y + m * ldy + c);
-    if ((dx && batch_stats) || remask) xx = ldv<VW>(x + m * ldx + c);
+  auto finish = [&](long m, int c, const VecF<VW>& g, const VecF<VW>& xx, const VecF<VW>& yy) {
     VecF<VW> dz, o;
-    if (!fixed_c) load_params(c);
 #pragma unroll
     for (int j = 0; j < VW; ++j) {
       if (remask) dz.v[j] = bn_dz_remask(g.v[j], (xx.v[j] - mu.v[j]) * is.v[j], gamma ? ga.v[j] : 1.f, gamma ? be.v[j] : 0.f, gamma != nullptr, act);
@@ -366,6 +382,32 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* dy, int 
     }
     if (dres) stv<VW>(dres + m * lddres + c, dz);
     if (dx) stv<VW>(dx + m * lddx + c, o);
+  };
+  long e = blockIdx.x * 256L + threadIdx.x;
+  if (fixed_c) {   // two trips at a time: all their data loads in flight together
+    const int c = (int)(e & (long)(CV - 1)) * VW;
+    for (; e + stride < total; e += 2 * stride) {
+      long m[2]; VecF<VW> g[2], xx[2], yy[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        m[u] = (e + u * stride) >> cv_shift;
+        g[u] = ldv<VW>(dy + m[u] * lddy + c);
+        if (!remask) yy[u] = ldv<VW>(y + m[u] * ldy + c);
+        if ((dx && batch_stats) || remask) xx[u] = ldv<VW>(x + m[u] * ldx + c);
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) finish(m[u], c, g[u], xx[u], yy[u]);
+    }
+  }
+  for (; e < total; e += stride) {
+    const long m = cv_shift >= 0 ? (e >> cv_shift) : e / CV;
+    const int c = (int)(e - m * CV) * VW;
+    const VecF<VW> g = ldv<VW>(dy + m * lddy + c);
+    VecF<VW> xx, yy;
+    if (!remask) yy = ldv<VW>(y + m * ldy + c);
+    if ((dx && batch_stats) || remask) xx = ldv<VW>(x + m * ldx + c);
+    if (!fixed_c) load_params(c);
+    finish(m, c, g, xx, yy);
   }
 }
 
