@@ -68,9 +68,11 @@ __global__ __launch_bounds__(256) void colreduce_kernel(Op op, long M, int C, do
   if (c < C) {
     if constexpr (has_ctx<Op, VW>::value) {
       const auto k = op.template ctx<VW>(c);
-#pragma unroll 4     // the loads of the next rows do not depend on the sums: unrolled, they are in flight together (same order of adds)
       for (long m = r_begin + ty; m < r_end; m += TY) op.template row<VW>(m, c, k, s0, s1);
     } else {
+      // the loads of the next rows do not depend on the sums: unrolled, they are in flight together (same order of adds).
+      // Bias-gradient column sums 86 -> 63 us, the single-column one 846 -> 273 us; the BatchNorm reduction above (three loads
+      // and a mask per row) lost 3 % with it and stays rolled.
 #pragma unroll 4
       for (long m = r_begin + ty; m < r_end; m += TY) op.template row<VW>(m, c, s0, s1);
     }
@@ -245,22 +247,8 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* x, int ldx, 
     stv<VW>(y + m * ldy + c, o);
   };
   long e = blockIdx.x * 256L + threadIdx.x;
-  if (fixed_c) {
-    // four trips at a time: their (independent) data loads are all in flight before the first result is needed -- one 16-byte
-    // load per thread and trip left too few bytes in flight for the HBM latency
-    const int c = (int)(e & (long)(CV - 1)) * VW;
-    for (; e + 3 * stride < total; e += 4 * stride) {
-      long m[4]; VecF<VW> xv[4], rv[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) { m[u] = (e + u * stride) >> cv_shift; xv[u] = ldv<VW>(x + m[u] * ldx + c); }
-      if (res) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) rv[u] = ldv<VW>(res + m[u] * ldr + c);
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) finish(m[u], c, xv[u], rv[u]);
-    }
-  }
+  // (four trips per thread at a time, all loads in flight together, measured SLOWER: 44.3 -> 49.0 us per launch; the column
+  // sums, which only load, gained from the same unrolling)
   for (; e < total; e += stride) {
     // channel counts are powers of two on the whole ResNet / decoder path: shift + mask instead of a 64-bit division
     const long m = cv_shift >= 0 ? (e >> cv_shift) : e / CV;
@@ -384,21 +372,6 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* dy, int 
     if (dx) stv<VW>(dx + m * lddx + c, o);
   };
   long e = blockIdx.x * 256L + threadIdx.x;
-  if (fixed_c) {   // two trips at a time: all their data loads in flight together
-    const int c = (int)(e & (long)(CV - 1)) * VW;
-    for (; e + stride < total; e += 2 * stride) {
-      long m[2]; VecF<VW> g[2], xx[2], yy[2];
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        m[u] = (e + u * stride) >> cv_shift;
-        g[u] = ldv<VW>(dy + m[u] * lddy + c);
-        if (!remask) yy[u] = ldv<VW>(y + m[u] * ldy + c);
-        if ((dx && batch_stats) || remask) xx[u] = ldv<VW>(x + m[u] * ldx + c);
-      }
-#pragma unroll
-      for (int u = 0; u < 2; ++u) finish(m[u], c, g[u], xx[u], yy[u]);
-    }
-  }
   for (; e < total; e += stride) {
     const long m = cv_shift >= 0 ? (e >> cv_shift) : e / CV;
     const int c = (int)(e - m * CV) * VW;
