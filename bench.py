@@ -364,6 +364,8 @@ def main():
                 if e.device_time_total > 0:
                     f.write("%-28s %10.1f %6d  %s\n" % (e.key, e.device_time_total, e.count, str(e.input_shapes)[:150]))
     torch.cuda.reset_peak_memory_stats(dev)
+    from improving_segmentation_with_selfsupervised_depth_amd import functional as Fn
+    Fn.fusion_report(reset=True)
     prof = None if args.no_kernel_timing else []
     H.PROFILE = prof
     # per-step times without a host synchronisation inside the timed region: one HIP event per step boundary on the
@@ -407,6 +409,9 @@ def main():
                                                "peak_memory_gb": torch.cuda.max_memory_allocated(dev) / 2 ** 30}}
         if unlabeled:
             res["config"]["images_per_step"] = {"labeled": B * world, "unlabeled": B * world}
+        # fusion hand-offs of the timed steps, per step (functional.FUSIONS): a hand-off that stopped working shows up as "missed"
+        res["fusions_per_step"] = {k: {kk: vv / args.steps for kk, vv in v.items()} for k, v in Fn.fusion_report().items()}
+        res["fusions_per_step"]["upsample_folded_launches"] = {k: v / (args.steps + args.warmup) for k, v in H.UPFOLD_TAKEN.items()}
         gflop_img = GFLOP_PER_IMG[args.workload]
         res["step_tflops"] = value * gflop_img / 1e3 / world
         roof = {"bound": "mfma", "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s", "traffic": None,

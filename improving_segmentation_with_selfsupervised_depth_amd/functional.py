@@ -10,6 +10,26 @@ from torch.autograd import Function
 from . import hipops as H
 
 
+# Fusion hand-offs travel as attributes / shared boxes next to the tensors (conv -> BatchNorm statistics partials, conv -> fused
+# activation backward, residual / fan-out gradient accumulation) and fall back to the unfused kernels when a view or an
+# in-place edit got in between.  The fallbacks are correct but slower, so every hand-off is COUNTED here: ``taken`` vs
+# ``missed`` per kind (bench.py prints the per-step numbers, tests pin them for the models of the path) -- a maintainer who
+# inserts an op between a convolution and its BatchNorm sees ``bn_stats.missed`` go up instead of silently losing 8 % of a step.
+FUSIONS = {}
+
+
+def fusion(kind, taken):
+    c = FUSIONS.setdefault(kind, [0, 0])
+    c[0 if taken else 1] += 1
+
+
+def fusion_report(reset=False):
+    out = {k: {"taken": v[0], "missed": v[1]} for k, v in sorted(FUSIONS.items())}
+    if reset:
+        FUSIONS.clear()
+    return out
+
+
 def _c(t):
     """dense NHWC tensor (grad tensors produced by our kernels already are)"""
     if t.is_contiguous():
@@ -120,7 +140,10 @@ class ConvFn(Function):
             # (autograd may accumulate a second contribution into the same buffer in place: the version counter moves)
             same = stash is not None and stash[0].data_ptr() == dz.data_ptr() and stash[0]._version == stash[1] == dz._version
             dbias = stash[2] if same else H.colsum(dz)
+            fusion("bias_grad_from_activation_pass", bool(same))
         actgrad = (x0, ctx.x0_act) if ctx.x0_act is not None else None
+        if actgrad is not None and ctx.needs_input_grad[0]:
+            fusion("activation_backward_in_dgrad_epilogue", True)
         dx0 = dx1 = dw = None
         if ctx.needs_input_grad[0] or (x1 is not None and ctx.needs_input_grad[1]):
             wd = ctx.wd if ctx.wd is not None else H.pack_weight(weight, True)
@@ -168,6 +191,7 @@ class ActGradFn(Function):
     def backward(ctx, dy):
         (y,) = ctx.saved_tensors
         ActGradFn.passes += 1
+        fusion("activation_backward_in_dgrad_epilogue", False)
         dz, dbias = H.act_backward(_c(dy), y, ctx.act, need_dbias=bool(ctx.box.get("need_dbias")))
         if dbias is not None:
             ctx.box["dbias"] = (dz, dz._version, dbias)
@@ -233,11 +257,13 @@ class SplitFn(Function):
         box.clear()
         if fused:
             SplitFn.fused_count += 1
+            fusion("residual_grad_accumulate", True)
             return g_main, None
         if g_main is None:
             return g_skip, None
         if g_skip is None:
             return g_main, None
+        fusion("residual_grad_accumulate", False)
         return g_main + g_skip, None
 
 
@@ -268,8 +294,11 @@ class FanoutFn(Function):
             if shared is not None and gi.data_ptr() == shared.data_ptr():
                 if used_shared:
                     FanoutFn.shared_count += 1
+                    fusion("fanout_grad_accumulate", True)
                     continue                 # the same accumulated tensor handed back by another consumer
                 used_shared = True
+            if total is not None:
+                fusion("fanout_grad_accumulate", False)
             total = gi if total is None else H.axpby(1.0, _c(total), 1.0, _c(gi))
         return total, None, None
 

@@ -155,5 +155,7 @@ class BatchNorm2d(nn.BatchNorm2d):
                 partials = None
             else:
                 producer._stats_wanted = True
+        if training:
+            Fn.fusion("bn_stats_from_conv_epilogue", partials is not None)
         return Fn.BNActFn.apply(x, self.weight, self.bias, residual, self.running_mean, self.running_var, training,
                                 momentum, self.eps, act, drop_p, seed, partials, grad_box, nbt)

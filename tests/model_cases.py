@@ -666,3 +666,25 @@ def _unlabeled_truth(sd_s, sd_t, cfg, inp, noise, mask, B, Hh, W, mix_use_gt):
                                          tiebreak_noise={s_: n.double() for s_, n in noise.items()}, mask_override=mask,
                                          mix_use_gt=mix_use_gt)
     return {k: v.grad for k, v in sd64.items() if v.is_floating_point() and v.requires_grad}
+
+
+def run_fusion_diagnostics(device):
+    """functional.FUSIONS makes the hand-off cliffs visible: conv -> BatchNorm statistics partials are counted as taken, and an op
+    a maintainer inserts between the two (here a harmless ``* 1.0``) shows up as ``missed`` -- same results, no silent slow path."""
+    from improving_segmentation_with_selfsupervised_depth_amd import functional as Fn
+    from improving_segmentation_with_selfsupervised_depth_amd.models import layers as L
+    torch.manual_seed(0)
+    conv = L.Conv2d(32, 64, 3, padding=1, bias=False).to(device)
+    bn = L.BatchNorm2d(64).to(device)
+    conv.train(); bn.train()
+    x = torch.randn(2, 16, 32, 32, device=device)
+    Fn.fusion_report(reset=True)
+    y1 = bn(conv(x), act="relu")
+    r1 = Fn.fusion_report(reset=True)
+    assert r1["bn_stats_from_conv_epilogue"] == {"taken": 1, "missed": 0}, r1
+    bn2 = L.BatchNorm2d(64).to(device)
+    bn2.train()
+    y2 = bn2(conv(x) * 1.0, act="relu")                 # the attribute does not survive the multiplication
+    r2 = Fn.fusion_report(reset=True)
+    assert r2["bn_stats_from_conv_epilogue"] == {"taken": 0, "missed": 1}, r2
+    assert_close(y2, y1, rtol=1e-5, atol=1e-6, what="fallback statistics give the same normalisation")

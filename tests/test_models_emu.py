@@ -64,3 +64,7 @@ def test_aspp_fanout_gradient_fusion():
 
 def test_decoder_activation_backward_is_fused():
     MC.run_decoder_activation_fusion("cpu")
+
+
+def test_fusion_handoffs_are_counted():
+    MC.run_fusion_diagnostics("cpu")

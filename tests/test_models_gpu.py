@@ -382,3 +382,7 @@ def test_real_model_two_ranks_one_gpu():
     gradients on both, dropout seeds differ between replicas (tests/test_ddp_gloo.py::_worker_real_model)."""
     import test_ddp_gloo as TD
     TD.run_real_model_two_ranks("cuda", 600)
+
+
+def test_fusion_handoffs_are_counted():
+    MC.run_fusion_diagnostics("cuda")
