@@ -103,12 +103,16 @@ def loss_cfg(B, H, W):
 
 def param_groups(model, opt):
     """train.py:67-101 with experiments.py:32-48: backbone lr 1e-3, everything else 1e-2 (sgd); adam 1e-4"""
+    # the stock torch optimisers; on the GPU their fused single-kernel implementation (same update rule, one pass over
+    # parameter / gradient / momentum instead of ~5 multi-tensor passes: ~0.7 ms of a cfg3 step).  SEGSDE_BENCH_FUSED_OPT=0: foreach
+    dev_ok = next(model.parameters()).is_cuda and os.environ.get("SEGSDE_BENCH_FUSED_OPT", "1") != "0"
+    extra = {"fused": True} if dev_ok else {}
     if opt == "adam":
-        return torch.optim.Adam(model.parameters(), lr=1e-4)
+        return torch.optim.Adam(model.parameters(), lr=1e-4, **extra)
     enc = list(model.models["encoder"].parameters())
     ids = {id(p) for p in enc}
     rest = [p for p in model.parameters() if id(p) not in ids]
-    return torch.optim.SGD([{"params": enc, "lr": 1e-3}, {"params": rest}], lr=1e-2, momentum=0.9, weight_decay=5e-4)
+    return torch.optim.SGD([{"params": enc, "lr": 1e-3}, {"params": rest}], lr=1e-2, momentum=0.9, weight_decay=5e-4, **extra)
 
 
 def csrc_sha256():
@@ -400,7 +404,8 @@ def main():
                "ms_per_step": ms, "ms_per_step_mean": ms_mean, "value_from_mean": B * world * args.steps / dt,
                "ms_per_step_min": min(step_ms), "ms_per_step_max": max(step_ms), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
                "data": "synthetic", "config": {"workload": desc, "per_gpu_batch": B, "global_batch": B * world,
-                                               "height": Hh, "width": W, "optimizer": opt_name,
+                                               "height": Hh, "width": W,
+                                               "optimizer": opt_name + (" (torch fused)" if getattr(optimizer, "defaults", {}).get("fused") else ""),
                                                "parallelism": "dp%d" % world, "final_loss": loss_val,
                                                "ranks": dist.get_world_size() if dist.is_initialized() else 1,
                                                "backend": (dist.get_backend() + (" (RCCL)" if dist.get_backend() == "nccl" else "")) if dist.is_initialized() else None,
