@@ -1678,7 +1678,7 @@ __global__ __launch_bounds__(256) void reflect_dgrad_fix_kernel(const float* dy,
 // experiment knob (environment SEGSDE_TUNE="bk64=1"), read once.  Measured on MI355X (profiles/ab_conv_r01.log):
 // BK=64 (139 KB LDS => 1 workgroup/CU, half the barriers) loses 15-25 % on the large layers against BK=32 with two
 // co-resident workgroups per CU, and start-up staggering of co-resident workgroups changes nothing.
-struct Tune { int bk64 = 0; int adjfix = 0; int wplan = 0; int wovh = 4; int nos2 = 0; int dma = 1; int var = 0; int wdma = 1; int adjlds = 1; int wred = 0; };
+struct Tune { int bk64 = 0; int adjfix = 0; int wplan = 0; int wovh = 4; int nos2 = 0; int dma = 1; int var = 0; int wdma = 1; int adjlds = 1; int wred = 0; int adjb = 1; };
 const Tune& tune() {
   static Tune t = [] {
     Tune r;
@@ -1692,6 +1692,7 @@ const Tune& tune() {
       if (const char* q = strstr(e, "var=")) r.var = atoi(q + 4);         // experiment variants of the LDS-DMA loop
       if (const char* q = strstr(e, "adjl=")) r.adjlds = atoi(q + 5);     // 0: reflection-adjoint loop register-staged in every wave
       if (const char* q = strstr(e, "wlds=")) r.wdma = atoi(q + 5);       // 0: register-staged weight-gradient tile loads
+      if (const char* q = strstr(e, "adjb=")) r.adjb = atoi(q + 5);       // 0: reflection adjoint inside the kernel (MODE 3) instead of zero-pad + border launches
       if (const char* q = strstr(e, "wred=")) r.wred = atoi(q + 5);       // 1: split partials reduced inside the kernel (measured: slower)
     }
     return r;
@@ -1852,6 +1853,85 @@ long stats_rows(const segsde_conv_desc* d, const ConvP& p) {
 }
 }  // namespace
 
+namespace {
+int launch_by_n(const ConvP& q, hipStream_t s) {
+  if (q.N <= 32) return launch_igemm<128, 32, 4, 1>(q, s);
+  if (q.N <= 64) return launch_igemm<128, 64, 2, 2>(q, s);
+  if (q.N % 128 > 0 && q.N % 128 <= 64) {
+    ConvP a = q, b = q;
+    a.ne = q.N - q.N % 128; b.nb = a.ne;
+    if (int e = launch_igemm<128, 128, 2, 2>(a, s)) return e;
+    return (b.ne - b.nb <= 32) ? launch_igemm<128, 32, 4, 1>(b, s) : launch_igemm<128, 64, 2, 2>(b, s);
+  }
+  return launch_igemm<128, 128, 2, 2>(q, s);
+}
+
+// corner terms of the reflection adjoint: pixel (1,1) / (1,W-2) / (H-2,1) / (H-2,W-2) also collects the gradient of the output
+// corner next to it through the tap that reached the doubly mirrored padding cell
+__global__ __launch_bounds__(256) void adjoint_corner_kernel(const float* dy, int lddy, const float* wd /*[N][9][C]*/, float* y, int ldy,
+                                                             float* y2, int ldy2, int nsplit, int B, int H, int W, int N, int C,
+                                                             const float* agy, int agld, int agkind, int accumulate_only) {
+  const int total = B * 4 * N;
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+    const int n = e % N, t = e / N, k = t & 3, b = t >> 2;
+    const int bot = k >> 1, rgt = k & 1;
+    const int i = bot ? H - 2 : 1, j = rgt ? W - 2 : 1, r = bot ? H - 1 : 0, sc = rgt ? W - 1 : 0;
+    const int tap = (bot ? 0 : 2) * 3 + (rgt ? 0 : 2);
+    const float* dp = dy + ((long)(b * H + r) * W + sc) * lddy;
+    const float* wp = wd + ((long)n * 9 + tap) * C;
+    float acc = 0.f;
+    for (int c = 0; c < C; ++c) acc += dp[c] * wp[c];
+    const long pix = (long)(b * H + i) * W + j;
+    if (agy && n < nsplit) acc *= segsde_act_grad_from_out(agy[pix * agld + n], agkind);
+    if (n < nsplit) y[pix * ldy + n] += acc; else y2[pix * ldy2 + (n - nsplit)] += acc;
+  }
+}
+
+// Reflection-pad data-gradient as the plain zero-padded data-gradient (LDS-DMA loop, no bordered waves) + the mirrored-padding
+// contributions as four small launches of the same kernel that ADD onto rows 1 / H-2 and columns 1 / W-2 (a 1x3 / 3x1
+// convolution of gradient row 0 / H-1, column 0 / W-1 with the taps that reached the padding) + the corner terms -- the same
+// construction as the clamp adjoint of the upsample-folded route.  (The in-kernel variant, MODE 3, runs the one wave per tile
+// that owns a border pixel on a register-staged loop with extra loads; every chunk ends in a barrier, so that wave set the
+// pace of half the tiles of a 512-pixel-wide image: 108-135 TFLOP/s against 139-145 for the forward of the same layers.)
+int launch_adjoint_by_borders(const ConvP& p, hipStream_t s) {
+  ConvP q = p;
+  q.pad_mode = SEGSDE_PAD_ZERO;
+  ConvP bl[4];
+  for (int k = 0; k < 4; ++k) {
+    const bool rowl = k < 2, far = k & 1;           // 0: row 1 <- gradient row 0, 1: row H-2 <- row H-1, 2: column 1 <- column 0, 3: column W-2 <- W-1
+    ConvP b = p;
+    b.pad_mode = SEGSDE_PAD_ZERO;
+    b.KH = rowl ? 1 : 3; b.KW = rowl ? 3 : 1;
+    b.Ho = rowl ? 1 : p.H; b.Wo = rowl ? p.W : 1; b.M = p.B * b.Ho * b.Wo;
+    b.pad = rowl ? (far ? -(p.H - 1) : 0) : 1;
+    b.padw = rowl ? 1 : (far ? -(p.W - 1) : 0);
+    b.Ktot = 3 * p.Ctot; b.Kfull = p.Kfull; b.KWf = b.KW;
+    b.wtap = rowl ? p.Ctot : 3 * p.Ctot;
+    const int tap0 = rowl ? (far ? 0 : 6) : (far ? 0 : 2);      // first of the three taps that reached the padding
+    b.w = p.w + (long)tap0 * p.Ctot;
+    b.kh0 = 0; b.khs = 1; b.kw0 = 0; b.kws = 1;
+    b.submap = 1; b.os = 1; b.OHf = p.H; b.OWf = p.W;
+    b.oph = rowl ? (far ? p.H - 2 : 1) : 0; b.opw = rowl ? 0 : (far ? p.W - 2 : 1);
+    b.osfast = (rowl && p.W % 128 == 0) ? 1 : 0;
+    b.accum = 1; b.lin = 0; b.stats = nullptr; b.bias = nullptr; b.act = 0;
+    set_divs(b);
+    if (!igemm_fast_ok(b) || !b.vecout) return SEGSDE_ERR_UNSUPPORTED;
+    bl[k] = b;
+  }
+  if (int e = launch_by_n(q, s)) return e;
+  for (int k = 0; k < 4; ++k)
+    if (int e = launch_by_n(bl[k], s)) return e;
+  hipLaunchKernelGGL(adjoint_corner_kernel, dim3(segsde_cdiv((long)p.B * 4 * p.N, 256)), dim3(256), 0, s, p.x0, p.ld0, p.w, p.y, p.ldy,
+                     p.y2, p.ldy2, p.nsplit, p.B, p.H, p.W, p.N, p.Ctot, p.agy, p.agld, p.agkind, 0);
+  SEGSDE_CHECK_LAUNCH();
+  return 0;
+}
+bool adjoint_by_borders_ok(const ConvP& p) {
+  return tune().adjb && p.pad_mode == SEGSDE_PAD_REFLECT_ADJOINT && igemm_fast_ok(p) && !p.sum2x2 && p.vecout && p.H >= 4 &&
+         p.W >= 4 && p.C1 == 0 && p.KH == 3 && p.KW == 3 && p.nb == 0 && p.ne == p.N;
+}
+}  // namespace
+
 extern "C" long segsde_conv2d_stats_rows(const segsde_conv_desc* d) {
   if (validate(d)) return 0;
   float dummy[4];
@@ -1963,6 +2043,10 @@ extern "C" int segsde_conv2d_dgrad_actgrad(const segsde_conv_desc* d, const floa
   if (d->sum2x2) {
     if ((d->Ho & 1) || (d->Wo & 1) || d->stride != 1 || d->act != 0 || bias) return SEGSDE_ERR_SHAPE;
     if (!igemm_fast_ok(p)) return SEGSDE_ERR_UNSUPPORTED;   // caller falls back to the two-pass path (full-res dgrad + 2x2 sum)
+  }
+  if (adjoint_by_borders_ok(p)) {
+    const int e = launch_adjoint_by_borders(p, s);
+    if (e != SEGSDE_ERR_UNSUPPORTED) return e;
   }
   int e;
   if (p.N <= 32) e = launch_igemm<128, 32, 4, 1>(p, s);
@@ -2272,17 +2356,6 @@ ConvP upfold_class_fwd(const segsde_conv_desc* d, const float* x0, const float* 
   q.lin = 0;
   return q;
 }
-int launch_by_n(const ConvP& q, hipStream_t s) {
-  if (q.N <= 32) return launch_igemm<128, 32, 4, 1>(q, s);
-  if (q.N <= 64) return launch_igemm<128, 64, 2, 2>(q, s);
-  if (q.N % 128 > 0 && q.N % 128 <= 64) {
-    ConvP a = q, b = q;
-    a.ne = q.N - q.N % 128; b.nb = a.ne;
-    if (int e = launch_igemm<128, 128, 2, 2>(a, s)) return e;
-    return (b.ne - b.nb <= 32) ? launch_igemm<128, 32, 4, 1>(b, s) : launch_igemm<128, 64, 2, 2>(b, s);
-  }
-  return launch_igemm<128, 128, 2, 2>(q, s);
-}
 }  // namespace
 
 extern "C" int segsde_upfold_pack(const float* w_oihw, int Cout, int C0, int Ctot, float* wfold, float* wdfold, void* stream) {
@@ -2392,8 +2465,11 @@ extern "C" int segsde_conv2d_dgrad_upfold(const segsde_conv_desc* d, const float
       SEGSDE_CHECK_LAUNCH();
     }
   }
-  if (dx1 && d->C1)
-    if (int e = launch_by_n(r, s)) return e;
+  if (dx1 && d->C1) {
+    int e = adjoint_by_borders_ok(r) ? launch_adjoint_by_borders(r, s) : SEGSDE_ERR_UNSUPPORTED;
+    if (e == SEGSDE_ERR_UNSUPPORTED) e = launch_by_n(r, s);
+    if (e) return e;
+  }
   return 0;
 }
 
