@@ -1692,7 +1692,7 @@ const Tune& tune() {
       if (const char* q = strstr(e, "var=")) r.var = atoi(q + 4);         // experiment variants of the LDS-DMA loop
       if (const char* q = strstr(e, "adjl=")) r.adjlds = atoi(q + 5);     // 0: reflection-adjoint loop register-staged in every wave
       if (const char* q = strstr(e, "wlds=")) r.wdma = atoi(q + 5);       // 0: register-staged weight-gradient tile loads
-      if (const char* q = strstr(e, "adjb=")) r.adjb = atoi(q + 5);       // 0: reflection adjoint inside the kernel (MODE 3) instead of zero-pad + border launches
+      if (const char* q = strstr(e, "adjb=")) r.adjb = atoi(q + 5);       // 0: reflection adjoint always inside the kernel (MODE 3); 1: zero-pad + border launches on the largest maps; 2: everywhere
       if (const char* q = strstr(e, "wred=")) r.wred = atoi(q + 5);       // 1: split partials reduced inside the kernel (measured: slower)
     }
     return r;
@@ -1927,7 +1927,10 @@ int launch_adjoint_by_borders(const ConvP& p, hipStream_t s) {
   return 0;
 }
 bool adjoint_by_borders_ok(const ConvP& p) {
-  return tune().adjb && p.pad_mode == SEGSDE_PAD_REFLECT_ADJOINT && igemm_fast_ok(p) && !p.sum2x2 && p.vecout && p.H >= 4 &&
+  // measured (profiles/experiments_r03.md): the five extra launches cost ~70 us per call -- a gain only on the largest maps
+  // (128 -> 64 @256x512 x 16: 5.63 -> 5.46 ms/step), a loss below (256 -> 256 @32x64: 0.69 -> 1.15); adjb=2 forces it everywhere
+  const bool big = (long)p.B * p.H * p.W >= (1L << 21) || tune().adjb == 2;
+  return tune().adjb && big && p.pad_mode == SEGSDE_PAD_REFLECT_ADJOINT && igemm_fast_ok(p) && !p.sum2x2 && p.vecout && p.H >= 4 &&
          p.W >= 4 && p.C1 == 0 && p.KH == 3 && p.KW == 3 && p.nb == 0 && p.ne == p.N;
 }
 }  // namespace
