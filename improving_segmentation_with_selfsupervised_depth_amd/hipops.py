@@ -116,8 +116,11 @@ def _ws(nbytes, like):
 class ConvGeom:
     """Static description of one convolution of the reference model (shared by fwd / dgrad / wgrad)."""
 
-    def __init__(self, C0, Cout, k, stride=1, dil=1, pad=0, reflect=False, C1=0, up0=False):
+    def __init__(self, C0, Cout, k, stride=1, dil=1, pad=0, reflect=False, C1=0, up0=False, cin_alg=None):
+        """cin_alg: input channels of the convolution as the REFERENCE defines it when the launch carries zero pad channels
+        (network stems: 3 -> 4, 6 -> 8): the algorithmic FLOP count of the bench uses it, the executed count the padded width"""
         self.C0, self.C1, self.Cout, self.k = int(C0), int(C1), int(Cout), int(k)
+        self.cin_alg = int(cin_alg) if cin_alg else None
         self.stride, self.dil, self.pad, self.reflect, self.up0 = int(stride), int(dil), int(pad), bool(reflect), bool(up0)
         if reflect and (self.k != 3 or self.stride != 1 or self.dil != 1 or self.pad != 1):
             raise NotImplementedError("reflection padding is implemented for the reference's 3x3/s1/p1 Conv3x3 only")
@@ -125,6 +128,10 @@ class ConvGeom:
     @property
     def Cin(self):
         return self.C0 + self.C1
+
+    @property
+    def CinAlg(self):
+        return self.cin_alg if self.cin_alg else self.C0 + self.C1
 
     def out_hw(self, H, W):
         e = self.dil * (self.k - 1) + 1
@@ -204,7 +211,8 @@ def conv_forward(g, x0, x1, wpack, bias, act="none", want_stats=False, wfold=Non
                  up0=int(g.up0), Ho=Ho, Wo=Wo, Cout=g.Cout, ldy=g.Cout, ldy2=0, nsplit=0, KH=g.k, KW=g.k,
                  stride=g.stride, dil=g.dil, pad=g.pad, pad_mode=PAD_REFLECT if g.reflect else PAD_ZERO, in_div=1,
                  act=ACT[act], sum2x2=0)
-    flops = 2.0 * B * Ho * Wo * g.Cout * g.Cin * g.k * g.k
+    flops = 2.0 * B * Ho * Wo * g.Cout * g.CinAlg * g.k * g.k
+    flops_x = flops * g.Cin / g.CinAlg      # executed: zero pad channels of a stem are multiplied too
     if wfold is not None and not want_stats:
         rc = _timed("conv_fwd", flops, x0, lambda: _lib.lib().segsde_conv2d_forward_upfold(
             ctypes.byref(d), _p(_f32(x0)), _p(x1), _p(wpack), _p(wfold), _p(bias), _p(y), _stream(x0)), _tag(g, H, W) + " fold",
@@ -221,7 +229,7 @@ def conv_forward(g, x0, x1, wpack, bias, act="none", want_stats=False, wfold=Non
             part = torch.empty((rows, 2, g.Cout), dtype=torch.float64, device=x0.device)
     _timed("conv_fwd", flops, x0, lambda: check(_lib.lib().segsde_conv2d_forward_stats(
         ctypes.byref(d), _p(_f32(x0)), _p(x1), _p(wpack), _p(bias), _p(y), None, _p(part), _stream(x0)), "conv2d_forward"),
-        _tag(g, H, W))
+        _tag(g, H, W), executed=flops_x)
     return (y, part) if want_stats else y
 
 
@@ -239,7 +247,7 @@ def conv_dgrad(g, dy, wdpack, w_oihw, in_hw, need0=True, need1=True, accumulate_
     assert Cout == g.Cout
     dx1 = torch.empty((B, H, W, g.C1), dtype=torch.float32, device=dy.device) if g.C1 else None
     L = _lib.lib()
-    flops = 2.0 * B * Ho * Wo * Cout * g.Cin * g.k * g.k
+    flops = 2.0 * B * Ho * Wo * Cout * g.CinAlg * g.k * g.k
     ag_y, ag_ld, ag_kind = None, 0, 0
     if actgrad is not None:
         ag_y, ag_kind = actgrad[0], ACT[actgrad[1]]
@@ -332,7 +340,8 @@ def conv_wgrad(g, x0, x1, dy):
                  dil=g.dil, pad=g.pad, pad_mode=PAD_REFLECT if g.reflect else PAD_ZERO, in_div=1, act=0, sum2x2=0)
     L = _lib.lib()
     dw = torch.empty((Cout, g.Cin, g.k, g.k), dtype=torch.float32, device=dy.device)
-    flops = 2.0 * B * Ho * Wo * Cout * g.Cin * g.k * g.k
+    flops = 2.0 * B * Ho * Wo * Cout * g.CinAlg * g.k * g.k
+    flops_x = flops * g.Cin / g.CinAlg
     if upfold_ok(g, B * Ho * Wo):
         nbytes = L.segsde_conv2d_wgrad_upfold_workspace(ctypes.byref(d))
         if nbytes:
@@ -349,7 +358,7 @@ def conv_wgrad(g, x0, x1, dy):
     ws = _ws(nbytes, dy)
     _timed("conv_wgrad", flops, dy, lambda: check(L.segsde_conv2d_wgrad(
         ctypes.byref(d), _p(x0), _p(x1), _p(_f32(dy)), nhwc_ld(dy), _p(dw), _p(ws), nbytes, _stream(dy)), "conv2d_wgrad"),
-        _tag(g, H, W))
+        _tag(g, H, W), executed=flops_x)
     return dw
 
 

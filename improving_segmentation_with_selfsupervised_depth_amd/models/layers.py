@@ -99,7 +99,7 @@ class Conv2d(nn.Conv2d):
             assert c0 + c1 == self.in_channels, (c0, c1, self.in_channels)
             packs = self._weight_packs(weight)
         g = ConvGeom(c0, self.out_channels, self.kernel_size[0], self.stride[0], self.dilation[0], self.padding[0],
-                     self.reflect, c1, up)
+                     self.reflect, c1, up, cin_alg=self.in_channels if (skip is None and c0 > self.in_channels) else None)
         # x may be the activated output of another convolution of this package (ConvBlock -> ELU): then this conv's
         # data-gradient applies the activation's derivative itself (conv epilogue) and hands the pre-activation gradient
         # straight to the producer -- see Fn.ActGradFn
