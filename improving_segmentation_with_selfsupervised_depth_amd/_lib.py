@@ -9,7 +9,7 @@ from ctypes import c_int, c_long, c_float, c_void_p, c_size_t, c_uint64, c_int64
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SEGSDE_LIB") or os.path.join(_HERE, "libsegsde_hip.so")   # override: kernel experiments
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 _LIB = None
 # Set only by the test-suite when it injects the host-interpreted build of the same kernel sources
@@ -46,6 +46,12 @@ _SIGS = {
     "segsde_conv2d_dgrad_upfold": (c_int, [POINTER(ConvDesc), P, c_int, P, P, P, P, P, P, c_int, c_int, P]),
     "segsde_conv2d_wgrad_upfold_workspace": (c_size_t, [POINTER(ConvDesc)]),
     "segsde_conv2d_wgrad_upfold": (c_int, [POINTER(ConvDesc), P, P, P, c_int, P, P, c_size_t, P]),
+    "segsde_stem_pack": (c_int, [P, c_int, c_int, c_int, P, P]),
+    "segsde_stem7x7_stats_rows": (c_long, [c_int, c_int, c_int, c_int, c_int]),
+    "segsde_stem7x7_forward": (c_int, [P, c_int, c_int, c_int, c_int, P, c_int, P, P, P]),
+    "segsde_stem7x7_wgrad_workspace": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
+    "segsde_stem7x7_wgrad": (c_int, [P, c_int, c_int, c_int, c_int, P, c_int, c_int, c_int, P, P, c_size_t, P]),
+    "segsde_nchw_to_nhwc_bordered": (c_int, [P, c_int, c_int, c_int, c_int, c_float, c_float, P, c_int, c_int, c_int, c_int, c_int, P]),
     "segsde_pack_weight": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "segsde_pack_weight_both": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P]),
     "segsde_pack_weight_both_multi": (c_int, [P, c_int, c_int, P]),

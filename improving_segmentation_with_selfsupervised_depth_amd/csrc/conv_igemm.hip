@@ -2555,6 +2555,111 @@ extern "C" int segsde_conv2d_wgrad_upfold(const segsde_conv_desc* d, const float
   return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Network stems (round 3): 7x7, stride 2, pad 3 on 3 / 6 input planes (resnet_encoder.py:40-52, :90-93)
+// ---------------------------------------------------------------------------------------------------
+// With 4 / 8 channels per pixel a 32-float reduction chunk is 8 / 4 neighbouring PIXELS of one input row, so a stem is not a
+// FAST-path shape (one tap per chunk) and ran on the generic float4 gather (71-87 TFLOP/s, ~40 VALU instructions of tap decode
+// per chunk and thread).  Here the layout kernel writes the normalised input with a zero border (3 rows above / below, 3
+// columns left, 5 right), and the convolution is described to the LDS-DMA kernel as a 7x1 convolution over VIRTUAL 32-channel
+// pixels with the real pixel pitch (4 / 8 floats): "channel" c of virtual pixel (h, w) is float c behind real pixel (h, w), i.e.
+// the 8 / 4 real pixels to its right.  4-channel input: one source, 8 pixels per tap row (the 7 taps of the row + one zero
+// weight).  8-channel input: two sources, the second one the same tensor 4 pixels (32 floats) further right.  No padding logic
+// is left (pad = 0 on the bordered tensor), the loop is the ordinary zero-VALU one; K = 7*32 / 7*64 instead of 49*4 / 49*8.
+namespace {
+__global__ __launch_bounds__(256) void stem_pack_kernel(const float* w, int Cout, int C, int cp, float* out) {
+  const int G = 8 * cp;
+  const long total = (long)Cout * 7 * G;
+  for (long e = blockIdx.x * 256L + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const int g = (int)(e % G); long t = e / G;
+    const int kh = (int)(t % 7), n = (int)(t / 7);
+    const int px = g / cp, ch = g - px * cp;
+    out[e] = (px < 7 && ch < C) ? w[(((long)n * C + ch) * 7 + kh) * 7 + px] : 0.f;
+  }
+}
+// dwp [Cout][8*cp][7] (what the weight-gradient reduce writes: n, virtual channel g = px*cp + ch, kh) -> OIHW [Cout][C][7][7]
+__global__ __launch_bounds__(256) void stem_unpack_kernel(const float* dwp, int Cout, int C, int cp, float* dw) {
+  const long total = (long)Cout * C * 49;
+  for (long e = blockIdx.x * 256L + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const int px = (int)(e % 7); long t = e / 7;
+    const int kh = (int)(t % 7); t /= 7;
+    const int ch = (int)(t % C), n = (int)(t / C);
+    dw[e] = dwp[((long)n * 8 * cp + px * cp + ch) * 7 + kh];
+  }
+}
+bool stem_desc(int B, int Hp, int Wp, int cp, int Cout, segsde_conv_desc& c) {
+  if (B <= 0 || Hp < 8 || Wp < 10 || (cp != 4 && cp != 8) || Cout <= 0 || Cout % 4) return false;
+  const int H = Hp - 6, W = Wp - 8;
+  memset(&c, 0, sizeof(c));
+  c.B = B; c.H = Hp; c.W = Wp; c.C0 = 32; c.C1 = cp == 8 ? 32 : 0; c.ld0 = cp; c.ld1 = cp; c.up0 = 0;
+  c.Ho = (H - 1) / 2 + 1; c.Wo = (W - 1) / 2 + 1; c.Cout = Cout; c.ldy = Cout;
+  c.KH = 7; c.KW = 1; c.stride = 2; c.dil = 1; c.pad = 0; c.pad_mode = SEGSDE_PAD_ZERO; c.in_div = 1;
+  return true;
+}
+}  // namespace
+
+extern "C" int segsde_stem_pack(const float* w_oihw, int Cout, int C, int cp, float* wstem, void* stream) {
+  if (!w_oihw || !wstem) return SEGSDE_ERR_NULL;
+  if (Cout <= 0 || C <= 0 || C > cp || (cp != 4 && cp != 8)) return SEGSDE_ERR_SHAPE;
+  hipLaunchKernelGGL(stem_pack_kernel, dim3(segsde_cdiv((long)Cout * 56 * cp, 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     w_oihw, Cout, C, cp, wstem);
+  SEGSDE_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" long segsde_stem7x7_stats_rows(int B, int Hp, int Wp, int cp, int Cout) {
+  segsde_conv_desc c;
+  if (!stem_desc(B, Hp, Wp, cp, Cout, c)) return 0;
+  float dummy[4];
+  const ConvP p = make_params(&c, dummy, dummy, dummy, nullptr, reinterpret_cast<float*>(16), nullptr);
+  return stats_rows(&c, p);
+}
+
+extern "C" int segsde_stem7x7_forward(const float* xpad, int B, int Hp, int Wp, int cp, const float* wstem, int Cout, float* y,
+                                      double* stats, void* stream) {
+  if (!xpad || !wstem || !y) return SEGSDE_ERR_NULL;
+  segsde_conv_desc c;
+  if (!stem_desc(B, Hp, Wp, cp, Cout, c)) return SEGSDE_ERR_SHAPE;
+  ConvP p = make_params(&c, xpad, cp == 8 ? xpad + 32 : nullptr, wstem, nullptr, y, nullptr);
+  if (!igemm_fast_ok(p) || !p.vecout) return SEGSDE_ERR_UNSUPPORTED;
+  if (stats) {
+    if (stats_rows(&c, p) == 0) return SEGSDE_ERR_UNSUPPORTED;
+    p.stats = stats;
+  }
+  return launch_by_n(p, static_cast<hipStream_t>(stream));
+}
+
+extern "C" size_t segsde_stem7x7_wgrad_workspace(int B, int Hp, int Wp, int cp, int Cout) {
+  segsde_conv_desc c;
+  if (!stem_desc(B, Hp, Wp, cp, Cout, c)) return 0;
+  int bkt, bn, splits, cps;
+  wgrad_plan(&c, bkt, bn, splits, cps);
+  return ((size_t)splits + 1) * 7 * 8 * cp * Cout * sizeof(float);      // split slabs + the [Cout][8 cp][7] gradient before unpacking
+}
+
+extern "C" int segsde_stem7x7_wgrad(const float* xpad, int B, int Hp, int Wp, int cp, const float* dy, int lddy, int Cout, int C,
+                                    float* dw_oihw, float* workspace, size_t workspace_bytes, void* stream) {
+  if (!xpad || !dy || !dw_oihw || !workspace) return SEGSDE_ERR_NULL;
+  segsde_conv_desc c;
+  if (!stem_desc(B, Hp, Wp, cp, Cout, c) || C <= 0 || C > cp) return SEGSDE_ERR_SHAPE;
+  if (workspace_bytes < segsde_stem7x7_wgrad_workspace(B, Hp, Wp, cp, Cout)) return SEGSDE_ERR_WORKSPACE;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  ConvP p = make_params(&c, xpad, cp == 8 ? xpad + 32 : nullptr, dy, nullptr, workspace, nullptr);
+  const int mode = wgrad_mode(p, dy, lddy);
+  if (mode != 2 && mode != 3) return SEGSDE_ERR_UNSUPPORTED;
+  int bkt, bn, splits, cps;
+  wgrad_plan(&c, bkt, bn, splits, cps);
+  if (int e = launch_wgrad_by_bn(bn, p, dy, lddy, workspace, splits, cps, s, WRed{})) return e;
+  float* dwp = workspace + (size_t)splits * p.Ktot * p.N;
+  const long total = (long)p.Ktot * p.N;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(segsde_cdiv(total, 32)), dim3(256), 1024, s, workspace, splits, p.Ktot, p.N, p.Ctot, 7,
+                     (mode == 2 && p.C1 > 0) ? p.C0 : 0, dwp, p.Ctot, 0);
+  SEGSDE_CHECK_LAUNCH();
+  hipLaunchKernelGGL(stem_unpack_kernel, dim3(segsde_cdiv((long)Cout * C * 49, 256)), dim3(256), 0, s, dwp, Cout, C, cp, dw_oihw);
+  SEGSDE_CHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" int segsde_pack_weight(const float* w_oihw, float* out, int O, int I, int KH, int KW, int for_dgrad,
                                   void* stream) {
   if (!w_oihw || !out) return SEGSDE_ERR_NULL;

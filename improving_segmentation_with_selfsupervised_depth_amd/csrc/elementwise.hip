@@ -101,7 +101,6 @@ __global__ __launch_bounds__(256) void colreduce_kernel(Op op, long M, int C, do
   if (!last) return;
   __threadfence();
   // pair_finalize_kernel's order: 16 partial-lanes (lane l takes rows l, l + 16, ...), then lanes 0..15 in sequence
-  constexpr int LPT = (16 * CW + 255) / 256;          // lane sums per thread
   for (int t = threadIdx.x; t < 16 * CW; t += 256) {
     const int l = t / CW, ch = t - l * CW, cg = blockIdx.y * CW + ch;
     double a = 0.0, b2 = 0.0;
@@ -109,7 +108,6 @@ __global__ __launch_bounds__(256) void colreduce_kernel(Op op, long M, int C, do
       for (int i = l; i < nb; i += 16) { a += part[((long)i * 2) * C + cg]; b2 += part[((long)i * 2 + 1) * C + cg]; }
     sh[l * CW + ch] = a; sh[(16 + l) * CW + ch] = b2;
   }
-  (void)LPT;
   __syncthreads();
   if (cc < CW && blockIdx.y * CW + cc < C) {
     double a = 0.0, b2 = 0.0;
@@ -758,6 +756,23 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* x, int B
     y[e] = c < C ? (x[(b * C + c) * HW + p] - mean) / sd : 0.f;
   }
 }
+// the same edge for the network stems (csrc/conv_igemm.hip, "Network stems"): 4 / 8 channels per pixel, written into the interior
+// of a [B][H + pt + pb][W + pl + pr][ldy] tensor whose border is zero (the normalised image's zero padding, materialised)
+__global__ __launch_bounds__(256) void nchw_to_nhwc_border_kernel(const float* x, int B, int C, int H, int W, float mean, float sd,
+                                                                  float* y, int ldy, int pt, int pl, int Hp, int Wp) {
+  const long npix = (long)B * Hp * Wp, HW = (long)H * W;
+  for (long m = blockIdx.x * 256L + threadIdx.x; m < npix; m += (long)gridDim.x * 256) {
+    const long b = m / ((long)Hp * Wp); const long r = m - b * Hp * Wp;
+    const int hp = (int)(r / Wp), wp = (int)(r - (long)hp * Wp), h = hp - pt, w = wp - pl;
+    const bool in = (unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W;
+    float v[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) v[c] = (in && c < C && c < ldy) ? (x[(b * C + c) * HW + (long)h * W + w] - mean) / sd : 0.f;
+    float4* q = reinterpret_cast<float4*>(y + m * ldy);
+    q[0] = make_float4(v[0], v[1], v[2], v[3]);
+    if (ldy == 8) q[1] = make_float4(v[4], v[5], v[6], v[7]);
+  }
+}
 __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* x, int ldx, int B, int C, int H, int W, float* y) {
   const long HW = (long)H * W, total = (long)B * HW * C;
   for (long e = blockIdx.x * 256L + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
@@ -1117,6 +1132,17 @@ extern "C" int segsde_nchw_to_nhwc(const float* x, int B, int C, int H, int W, f
   if (!x || !y) return SEGSDE_ERR_NULL;
   hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(ew_blocks((long)B * ldy * H * W)), dim3(256), 0, ST(stream), x, B, C, H, W,
                      mean, sd, y, ldy);
+  SEGSDE_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int segsde_nchw_to_nhwc_bordered(const float* x, int B, int C, int H, int W, float mean, float sd, float* y, int ldy,
+                                            int pad_top, int pad_left, int Hp, int Wp, void* stream) {
+  if (!x || !y) return SEGSDE_ERR_NULL;
+  if ((ldy != 4 && ldy != 8) || C > ldy || pad_top < 0 || pad_left < 0 || Hp < H + pad_top || Wp < W + pad_left ||
+      (reinterpret_cast<uintptr_t>(y) & 15))
+    return SEGSDE_ERR_SHAPE;
+  hipLaunchKernelGGL(nchw_to_nhwc_border_kernel, dim3(ew_blocks((long)B * Hp * Wp)), dim3(256), 0, ST(stream), x, B, C, H, W, mean, sd, y,
+                     ldy, pad_top, pad_left, Hp, Wp);
   SEGSDE_CHECK_LAUNCH();
   return 0;
 }

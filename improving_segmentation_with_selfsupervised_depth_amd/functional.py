@@ -88,6 +88,33 @@ def to_nchw_dense(x_nhwc):
     return _ToNCHWDense.apply(x_nhwc)
 
 
+class StemFn(Function):
+    """y = conv7x7/2((image - mean) / std, weight) for the network stems (models/resnet_encoder.py:90-93: the normalisation
+    followed by encoder.conv1).  The image is data: no gradient flows to it (callers route an image that requires one
+    through to_nhwc + ConvFn instead)."""
+
+    @staticmethod
+    def forward(ctx, image, weight, mean, std, stats_out=None, wstem=None):
+        xpad = H.stem_input(image, mean, std)
+        if wstem is None:
+            wstem = H.stem_pack(weight)
+        C = weight.shape[1]
+        if stats_out is not None:
+            y, part = H.stem_forward(xpad, wstem, C, want_stats=True)
+            stats_out.append(part)
+        else:
+            y = H.stem_forward(xpad, wstem, C)
+        ctx.C = C
+        ctx.save_for_backward(xpad)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (xpad,) = ctx.saved_tensors
+        dw = H.stem_wgrad(xpad, _c(dy), ctx.C) if ctx.needs_input_grad[1] else None
+        return None, dw, None, None, None, None
+
+
 class ConvFn(Function):
     """y = act(conv([up2x?(x0) | x1], weight) + bias); geometry in ``g`` (hipops.ConvGeom)."""
 

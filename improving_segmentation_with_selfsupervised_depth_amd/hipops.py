@@ -580,6 +580,76 @@ def nchw_to_nhwc(x, mean=0.0, std=1.0, pad_to=1):
     return y
 
 
+# ----------------------------------------------------------------------------------------------
+# network stems (7x7, stride 2, padding 3 on the normalised image): see csrc/conv_igemm.hip "Network stems"
+# ----------------------------------------------------------------------------------------------
+STEM = os.environ.get("SEGSDE_STEM", "1") != "0"
+STEM_TAKEN = {"fwd": 0, "wgrad": 0}
+
+
+def stem_ok(image, conv):
+    """conv: the module holding the stem's state (nn.Conv2d attributes).  The dedicated path needs the reference's stem geometry."""
+    return (STEM and image.dim() == 4 and conv.kernel_size == (7, 7) and conv.stride == (2, 2) and conv.padding == (3, 3)
+            and conv.dilation == (1, 1) and conv.bias is None and conv.groups == 1 and image.shape[1] == conv.in_channels
+            and conv.in_channels <= 8 and conv.out_channels % 4 == 0 and image.shape[2] >= 2 and image.shape[3] >= 2
+            and image.shape[0] * (image.shape[2] + 6) * (image.shape[3] + 8) * 8 < 2 ** 31)
+
+
+def stem_input(image, mean, std):
+    """(image - mean) / std as 4 / 8-channel pixels inside a zero border of 3 rows above / below, 3 columns left, 5 right."""
+    x = _f32(image).contiguous()
+    B, C, H, W = x.shape
+    cp = 4 if C <= 4 else 8
+    y = torch.empty((B, H + 6, W + 8, cp), dtype=torch.float32, device=x.device)   # the kernel writes the border too
+    check(_lib.lib().segsde_nchw_to_nhwc_bordered(_p(x), B, C, H, W, float(mean), float(std), _p(y), cp, 3, 3, H + 6, W + 8,
+                                                  _stream(x)), "nchw_to_nhwc_bordered")
+    return y
+
+
+def stem_pack(weight):
+    Cout, C = weight.shape[0], weight.shape[1]
+    cp = 4 if C <= 4 else 8
+    w = _f32(weight.detach()).contiguous()
+    out = torch.empty((Cout, 7, 8 * cp), dtype=torch.float32, device=w.device)
+    check(_lib.lib().segsde_stem_pack(_p(w), Cout, C, cp, _p(out), _stream(w)), "stem_pack")
+    return out
+
+
+def stem_forward(xpad, wstem, C, want_stats=False):
+    """xpad: stem_input(); wstem: stem_pack(); C: real input planes (FLOP accounting) -> y [B, Ho, Wo, Cout] (, partials)"""
+    B, Hp, Wp, cp = xpad.shape
+    Cout = wstem.shape[0]
+    H, W = Hp - 6, Wp - 8
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    y = torch.empty((B, Ho, Wo, Cout), dtype=torch.float32, device=xpad.device)
+    part = None
+    if want_stats:
+        rows = int(_lib.lib().segsde_stem7x7_stats_rows(B, Hp, Wp, cp, Cout))
+        if rows > 0:
+            part = torch.empty((rows, 2, Cout), dtype=torch.float64, device=xpad.device)
+    flops = 2.0 * B * Ho * Wo * Cout * C * 49
+    _timed("conv_fwd", flops, xpad, lambda: check(_lib.lib().segsde_stem7x7_forward(
+        _p(xpad), B, Hp, Wp, cp, _p(wstem), Cout, _p(y), _p(part), _stream(xpad)), "stem7x7_forward"),
+        "stem c%d k7 s2 %dx%d" % (C, H, W), executed=2.0 * B * Ho * Wo * Cout * 56 * cp)
+    STEM_TAKEN["fwd"] += 1
+    return (y, part) if want_stats else y
+
+
+def stem_wgrad(xpad, dy, C):
+    B, Hp, Wp, cp = xpad.shape
+    _, Ho, Wo, Cout = dy.shape
+    dy = _f32(dy)
+    dw = torch.empty((Cout, C, 7, 7), dtype=torch.float32, device=dy.device)
+    nbytes = int(_lib.lib().segsde_stem7x7_wgrad_workspace(B, Hp, Wp, cp, Cout))
+    ws = _ws(nbytes, dy)
+    flops = 2.0 * B * Ho * Wo * Cout * C * 49
+    _timed("conv_wgrad", flops, dy, lambda: check(_lib.lib().segsde_stem7x7_wgrad(
+        _p(xpad), B, Hp, Wp, cp, _p(dy), nhwc_ld(dy), Cout, C, _p(dw), _p(ws), nbytes, _stream(dy)), "stem7x7_wgrad"),
+        "stem c%d k7 s2 %dx%d" % (C, Hp - 6, Wp - 8), executed=2.0 * B * Ho * Wo * Cout * 56 * cp)
+    STEM_TAKEN["wgrad"] += 1
+    return dw
+
+
 def nhwc_to_nchw(x):
     B, H, W, C = x.shape
     y = torch.empty((B, C, H, W), dtype=torch.float32, device=x.device)

@@ -86,6 +86,28 @@ class Conv2d(nn.Conv2d):
             self._packs, self._pack_key = H.pack_weight_both(weight), key
         return self._packs
 
+    def forward_image(self, image, mean, std):
+        """Network stem: self((image - mean) / std) for an NCHW image, as one layout pass + the dedicated 7x7 / stride-2
+        kernel (Fn.StemFn); None when this module / image is not that case (the caller then takes to_nhwc + forward)."""
+        if not H.stem_ok(image, self) or (torch.is_grad_enabled() and image.requires_grad):
+            return None
+        wstem = None
+        if _PACK_SCOPE[0]:
+            key = (_PACK_SCOPE[0], self.weight._version, self.weight.data_ptr(), self.weight.device)
+            if key != getattr(self, "_stem_key", None):
+                self._stem_pack, self._stem_key = H.stem_pack(self.weight), key
+            wstem = self._stem_pack
+        if self.training and not _NO_FUSED_STATS and self._stats_wanted is not False:
+            if self._stats_wanted is None and self._stats_offered:
+                self._stats_wanted = False
+                return Fn.StemFn.apply(image, self.weight, mean, std, None, wstem)
+            self._stats_offered = True
+            holder = []
+            y = Fn.StemFn.apply(image, self.weight, mean, std, holder, wstem)
+            y._bn_partials = (holder[0], y._version, self) if holder and holder[0] is not None else None
+            return y
+        return Fn.StemFn.apply(image, self.weight, mean, std, None, wstem)
+
     def forward(self, x, skip=None, up=False, act="none", grad_box=None):
         c0 = x.shape[3]
         c1 = 0 if skip is None else skip.shape[3]

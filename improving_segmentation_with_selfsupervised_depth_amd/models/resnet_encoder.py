@@ -136,8 +136,12 @@ class ResnetEncoder(nn.Module):
         e = self.encoder
         # (x - 0.45) / 0.225 fused with the layout change; channels padded 3 -> 4 / 6 -> 8 with zeros so that the stem's
         # tile loads are 16-byte gathers (K = 49*4 instead of 49*3, but 2.5x faster than the scalar gather)
-        x = Fn.to_nhwc(input_image, 0.45, 0.225, pad_to=4)
-        f0 = e.bn1(e.conv1(x), act="relu")
+        # -- or, for the reference's own stem geometry, written with the zero border of the 7x7 window around it and
+        # convolved by the dedicated stem kernel (Conv2d.forward_image)
+        y0 = e.conv1.forward_image(input_image, 0.45, 0.225)
+        if y0 is None:
+            y0 = e.conv1(Fn.to_nhwc(input_image, 0.45, 0.225, pad_to=4))
+        f0 = e.bn1(y0, act="relu")
         feats = [f0]
         x = Fn.MaxPoolFn.apply(f0)
         for layer in (e.layer1, e.layer2, e.layer3, e.layer4):

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SEGSDE_ABI_VERSION 8
+#define SEGSDE_ABI_VERSION 9
 
 enum { SEGSDE_ERR_NULL = -1, SEGSDE_ERR_SHAPE = -2, SEGSDE_ERR_WORKSPACE = -3, SEGSDE_ERR_UNSUPPORTED = -4 };
 enum { SEGSDE_ACT_NONE = 0, SEGSDE_ACT_RELU = 1, SEGSDE_ACT_ELU = 2, SEGSDE_ACT_SIGMOID = 3 };
@@ -111,6 +111,21 @@ int segsde_conv2d_dgrad_upfold(const segsde_conv_desc* d, const float* dy, int l
 size_t segsde_conv2d_wgrad_upfold_workspace(const segsde_conv_desc* d);
 int segsde_conv2d_wgrad_upfold(const segsde_conv_desc* d, const float* x0, const float* x1, const float* dy, int lddy,
                                float* dw_oihw, float* workspace, size_t workspace_bytes, void* stream);
+
+/* Network stems: nn.Conv2d(3 * n, 64, 7, stride 2, padding 3, bias=False) of torchvision's ResNet / ResNetMultiImageInput
+ * (models/resnet_encoder.py:40-52, 90-93) on the LDS-DMA path.  xpad: the bordered input of segsde_nchw_to_nhwc_bordered with
+ * pad_top = 3, pad_left = 3, Hp = H + 6, Wp = W + 8 and cp = 4 (3 planes) or 8 (6 planes) channels per pixel; a 32-float
+ * reduction chunk is 8 / 4 neighbouring pixels of one input row ("virtual" 32-channel pixels with the real pixel pitch).
+ *   pack     : w_oihw [Cout][C][7][7] -> wstem [Cout][7][8 * cp]  (8 pixels x cp channels per tap row; pixel 7 and channels >= C zero)
+ *   forward  : y [B][Ho][Wo][Cout], Ho = (H-1)/2+1; stats (nullable): BatchNorm statistics partials, rows = segsde_stem7x7_stats_rows
+ *   wgrad    : dw_oihw [Cout][C][7][7], deterministic; no data-gradient (the input is the image) */
+int segsde_stem_pack(const float* w_oihw, int Cout, int C, int cp, float* wstem, void* stream);
+long segsde_stem7x7_stats_rows(int B, int Hp, int Wp, int cp, int Cout);
+int segsde_stem7x7_forward(const float* xpad, int B, int Hp, int Wp, int cp, const float* wstem, int Cout, float* y, double* stats,
+                           void* stream);
+size_t segsde_stem7x7_wgrad_workspace(int B, int Hp, int Wp, int cp, int Cout);
+int segsde_stem7x7_wgrad(const float* xpad, int B, int Hp, int Wp, int cp, const float* dy, int lddy, int Cout, int C,
+                         float* dw_oihw, float* workspace, size_t workspace_bytes, void* stream);
 
 /* OIHW -> [O][KH][KW][I] (for_dgrad=0) or [I][KH][KW][O] spatially flipped (for_dgrad=1). */
 int segsde_pack_weight(const float* w_oihw, float* out, int O, int I, int KH, int KW, int for_dgrad, void* stream);
@@ -208,6 +223,11 @@ int segsde_scale_channels(const float* x, int ldx, int B, long HW, int C, const 
  * mean = 0, std = 1 gives a plain layout change.  All ldy channels of every pixel are written: channels C..ldy-1 become
  * zero (the 3 / 6-channel network input padded to 4 / 8).  nhwc_to_nchw is the inverse layout change. */
 int segsde_nchw_to_nhwc(const float* x, int B, int C, int H, int W, float mean, float std, float* y, int ldy, void* stream);
+/* The network-input edge for the stems: (x - mean) / sd of NCHW planes written as 4 / 8-channel pixels (ldy) into the interior of a
+ * zero-bordered [B][Hp][Wp][ldy] tensor (interior at (pad_top, pad_left)): the stem's zero padding, materialised, so that
+ * segsde_stem7x7_forward needs no padding logic (models/resnet_encoder.py:90-93: normalisation, then conv1 with padding 3). */
+int segsde_nchw_to_nhwc_bordered(const float* x, int B, int C, int H, int W, float mean, float sd, float* y, int ldy, int pad_top,
+                                 int pad_left, int Hp, int Wp, void* stream);
 int segsde_nhwc_to_nchw(const float* x, int ldx, int B, int C, int H, int W, float* y, void* stream);
 
 /* ------------------------------------------------------------------------------------------------ *

@@ -632,6 +632,59 @@ def run_mix_use_gt_cases(device, golden):
         assert torch.equal(per[i], H.depthcomp_mask(d, 0.03, float(ft[i]))[i])
 
 
+def run_stem_cases(device, cases=None):
+    """Network stems (resnet_encoder.py:40-52, :90-93): (image - 0.45) / 0.225 -> Conv2d(3n, 64, 7, 2, 3, bias=False), forward
+    (+ BatchNorm statistics partials) and weight gradient of the dedicated path against torch's fp64 conv2d and its autograd, the
+    generic route of this package (to_nhwc + ConvFn) as a second witness."""
+    import torch.nn.functional as F
+    from improving_segmentation_with_selfsupervised_depth_amd import functional as Fn
+    from improving_segmentation_with_selfsupervised_depth_amd.models.layers import Conv2d
+    if cases is None:   # B, C, H, W, Cout
+        cases = [(2, 3, 16, 64, 64), (1, 6, 16, 64, 64), (1, 3, 15, 37, 64), (2, 6, 9, 21, 32), (1, 3, 2, 2, 64)]
+    assert H.STEM
+    taken0 = dict(H.STEM_TAKEN)
+    for (B, C, Hh, W, Cout) in cases:
+        gen = torch.Generator().manual_seed(Hh * 100 + W + C)
+        img = torch.rand(B, C, Hh, W, generator=gen)
+        conv = Conv2d(C, Cout, 7, 2, 3, bias=False)
+        with torch.no_grad():
+            conv.weight.copy_(torch.randn(Cout, C, 7, 7, generator=gen) * 0.1)
+        conv = conv.to(device).train()
+        Ho, Wo = (Hh - 1) // 2 + 1, (W - 1) // 2 + 1
+        dy = torch.randn(B, Ho, Wo, Cout, generator=gen)
+        what = "stem B%d %dx%d c%d->%d" % (B, Hh, W, C, Cout)
+        wq = conv.weight.detach().cpu().double().requires_grad_(True)
+        yt = F.conv2d((img.double() - 0.45) / 0.225, wq, None, 2, 3)
+        yt.backward(dy.double().permute(0, 3, 1, 2))
+        y = conv.forward_image(img.to(device), 0.45, 0.225)
+        assert y is not None, what + ": not taken"
+        assert_close(y, yt.permute(0, 2, 3, 1), rtol=1e-4, atol=2e-5, what=what + " forward")
+        part = getattr(y, "_bn_partials", None)
+        if part is not None and part[0] is not None:
+            st = part[0].sum(0).cpu()
+            flat = yt.permute(0, 2, 3, 1).reshape(-1, Cout)
+            assert_close(st[0], flat.sum(0), rtol=1e-5, atol=1e-4, what=what + " statistics: sum")
+            assert_close(st[1], (flat * flat).sum(0), rtol=1e-5, atol=1e-4, what=what + " statistics: sum of squares")
+        y.backward(dy.to(device))
+        assert_close(conv.weight.grad, wq.grad, rtol=1e-4, atol=2e-5 * max(1.0, float(wq.grad.abs().max())), what=what + " dW")
+        g1 = conv.weight.grad.clone()
+        conv.weight.grad = None
+        y2 = conv.forward_image(img.to(device), 0.45, 0.225)
+        y2.backward(dy.to(device))
+        assert torch.equal(y, y2) and torch.equal(conv.weight.grad, g1), what + " deterministic"
+        # the generic route on the same inputs
+        conv.weight.grad = None
+        y9 = conv(Fn.to_nhwc(img.to(device), 0.45, 0.225, pad_to=4))
+        assert_close(y, y9, rtol=1e-4, atol=2e-5, what=what + " forward vs generic route")
+        # an image that needs a gradient is not this path's business
+        assert conv.forward_image(img.to(device).requires_grad_(True), 0.45, 0.225) is None
+    took = {k: H.STEM_TAKEN[k] - taken0[k] for k in taken0}
+    assert took["fwd"] == 2 * len(cases) and took["wgrad"] == 2 * len(cases), took
+    # other geometries are declined
+    assert Conv2d(3, 64, 3, 2, 1, bias=False).forward_image(torch.rand(1, 3, 8, 8), 0.45, 0.225) is None
+    assert Conv2d(3, 64, 7, 2, 3, bias=True).forward_image(torch.rand(1, 3, 8, 8), 0.45, 0.225) is None
+
+
 def run_upfold_cases(device, cases=None):
     """Upsample-folded route of Conv3x3 on [upsample(x0) | x1] (depth_decoder.py:93-101): forward (+ bias + ELU), both data-
     gradients (+ fused activation backward) and the weight gradient against torch's fp64 interpolate -> ReflectionPad2d -> conv2d

@@ -52,6 +52,10 @@ def test_mix_use_gt_vs_reference(golden):
     KC.run_mix_use_gt_cases("cpu", golden)
 
 
+def test_network_stems():
+    KC.run_stem_cases("cpu")
+
+
 def test_upsample_folded_convolutions():
     KC.run_upfold_cases("cpu")
 

@@ -103,6 +103,10 @@ def test_mix_use_gt_vs_reference(golden):
     KC.run_mix_use_gt_cases("cuda", golden)
 
 
+def test_network_stems():
+    KC.run_stem_cases("cuda")
+
+
 def test_upsample_folded_convolutions():
     KC.run_upfold_cases("cuda")
 
