@@ -2563,9 +2563,9 @@ extern "C" int segsde_conv2d_wgrad_upfold(const segsde_conv_desc* d, const float
 // per chunk and thread).  Here the layout kernel writes the normalised input with a zero border (3 rows above / below, 3
 // columns left, 5 right), and the convolution is described to the LDS-DMA kernel as a 7x1 convolution over VIRTUAL 32-channel
 // pixels with the real pixel pitch (4 / 8 floats): "channel" c of virtual pixel (h, w) is float c behind real pixel (h, w), i.e.
-// the 8 / 4 real pixels to its right.  4-channel input: one source, 8 pixels per tap row (the 7 taps of the row + one zero
-// weight).  8-channel input: two sources, the second one the same tensor 4 pixels (32 floats) further right.  No padding logic
-// is left (pad = 0 on the bordered tensor), the loop is the ordinary zero-VALU one; K = 7*32 / 7*64 instead of 49*4 / 49*8.
+// the 8 real pixels from it to the right (the 7 taps of the row + one zero weight) are the 32 / 64 channels of one tap.  No
+// padding logic is left (pad = 0 on the bordered tensor), the loop is the ordinary zero-VALU one; K = 7*32 / 7*64 instead of
+// 49*4 / 49*8.
 namespace {
 __global__ __launch_bounds__(256) void stem_pack_kernel(const float* w, int Cout, int C, int cp, float* out) {
   const int G = 8 * cp;
@@ -2591,7 +2591,7 @@ bool stem_desc(int B, int Hp, int Wp, int cp, int Cout, segsde_conv_desc& c) {
   if (B <= 0 || Hp < 8 || Wp < 10 || (cp != 4 && cp != 8) || Cout <= 0 || Cout % 4) return false;
   const int H = Hp - 6, W = Wp - 8;
   memset(&c, 0, sizeof(c));
-  c.B = B; c.H = Hp; c.W = Wp; c.C0 = 32; c.C1 = cp == 8 ? 32 : 0; c.ld0 = cp; c.ld1 = cp; c.up0 = 0;
+  c.B = B; c.H = Hp; c.W = Wp; c.C0 = 8 * cp; c.C1 = 0; c.ld0 = cp; c.ld1 = 0; c.up0 = 0;
   c.Ho = (H - 1) / 2 + 1; c.Wo = (W - 1) / 2 + 1; c.Cout = Cout; c.ldy = Cout;
   c.KH = 7; c.KW = 1; c.stride = 2; c.dil = 1; c.pad = 0; c.pad_mode = SEGSDE_PAD_ZERO; c.in_div = 1;
   return true;
@@ -2620,7 +2620,7 @@ extern "C" int segsde_stem7x7_forward(const float* xpad, int B, int Hp, int Wp, 
   if (!xpad || !wstem || !y) return SEGSDE_ERR_NULL;
   segsde_conv_desc c;
   if (!stem_desc(B, Hp, Wp, cp, Cout, c)) return SEGSDE_ERR_SHAPE;
-  ConvP p = make_params(&c, xpad, cp == 8 ? xpad + 32 : nullptr, wstem, nullptr, y, nullptr);
+  ConvP p = make_params(&c, xpad, nullptr, wstem, nullptr, y, nullptr);
   if (!igemm_fast_ok(p) || !p.vecout) return SEGSDE_ERR_UNSUPPORTED;
   if (stats) {
     if (stats_rows(&c, p) == 0) return SEGSDE_ERR_UNSUPPORTED;
@@ -2644,7 +2644,7 @@ extern "C" int segsde_stem7x7_wgrad(const float* xpad, int B, int Hp, int Wp, in
   if (!stem_desc(B, Hp, Wp, cp, Cout, c) || C <= 0 || C > cp) return SEGSDE_ERR_SHAPE;
   if (workspace_bytes < segsde_stem7x7_wgrad_workspace(B, Hp, Wp, cp, Cout)) return SEGSDE_ERR_WORKSPACE;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  ConvP p = make_params(&c, xpad, cp == 8 ? xpad + 32 : nullptr, dy, nullptr, workspace, nullptr);
+  ConvP p = make_params(&c, xpad, nullptr, dy, nullptr, workspace, nullptr);
   const int mode = wgrad_mode(p, dy, lddy);
   if (mode != 2 && mode != 3) return SEGSDE_ERR_UNSUPPORTED;
   int bkt, bn, splits, cps;
