@@ -67,6 +67,11 @@ struct ConvP {
   // low-resolution grid); osfast = a strided sub-grid store (os > 1) whose tiles lie inside one sub-grid row.
   int padw, wtap, osfast;
   int submap;   // output rows are not rows m of the destination: out_row() maps them (strided sub-grids, single border rows / columns)
+  // Dilated windows with zero padding (ASPP, rates 6 / 12 / 18 on a 32-row map; layer4 of a dilated ResNet): a tap ROW whose
+  // source rows lie outside the image for every pixel of a tile is an all-zero operand -- the tile's K loop runs over its
+  // live tap rows only (tile-uniform: a tile is a run of consecutive pixels, its rows an interval).  Weight gradient: a
+  // pixel chunk whose rows are dead for the workgroup's tap row is skipped.
+  int tapskip;
 };
 constexpr int SEGSDE_PAD_CLAMP_ = 3;   // internal (never crosses the ABI)
 
@@ -292,7 +297,27 @@ __global__ __launch_bounds__(256, VAR == 6 ? 3 : 2) void conv_igemm_kernel(ConvP
 #pragma unroll
     for (int i = 0; i < AR; ++i) decode_m(p, m0 + r0 + RP * i, rb[i], rh[i], rw[i], rok[i]);
   }
-  ChunkState cs; cs.c0 = 0; cs.kh = 0; cs.kw = 0;
+  int nchunks = (p.Ktot + BK - 1) / BK;
+  int kh_first = 0;
+  if constexpr (FAST && MODE != 3) {
+    if (p.tapskip) {
+      // source row of tap row kh for a pixel with base row hb: hb + kh*dil - pad; the tile's base rows are [hA, hB] of ONE image
+      int bA, hA, wA, bB, hB, wB; bool okA, okB;
+      decode_m(p, m0, bA, hA, wA, okA);
+      decode_m(p, (m0 + BM < p.M ? m0 + BM : p.M) - 1, bB, hB, wB, okB);
+      if (bA == bB) {
+        const int lo = p.pad - hB, hi = p.H - 1 + p.pad - hA;          // live: lo <= kh*dil <= hi
+        const int khA = lo > 0 ? (lo + p.dil - 1) / p.dil : 0;
+        int khB = hi / p.dil;
+        khB = khB > p.KH - 1 ? p.KH - 1 : khB;
+        if (khA <= khB && hi >= 0) {
+          kh_first = __builtin_amdgcn_readfirstlane(khA);
+          nchunks = __builtin_amdgcn_readfirstlane((khB - khA + 1) * p.KW * (p.Ctot / BK));
+        }
+      }
+    }
+  }
+  ChunkState cs; cs.c0 = 0; cs.kh = kh_first; cs.kw = 0;
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -303,7 +328,6 @@ __global__ __launch_bounds__(256, VAR == 6 ? 3 : 2) void conv_igemm_kernel(ConvP
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   float4 ra[AR], rbv[BR], rex[AR];
-  const int nchunks = (p.Ktot + BK - 1) / BK;
 
   auto gload = [&](int kc) {   // generic gather (MODE 0/1)
     // chunks past the end are loaded from clamped (valid) addresses and discarded: the K loop stays branch-free
@@ -617,7 +641,7 @@ __global__ __launch_bounds__(256, VAR == 6 ? 3 : 2) void conv_igemm_kernel(ConvP
         constexpr unsigned PASS = RP * LDT * 4, BOFF = BM * LDT * 4, STG = STAGE * 4;
         // weight-row byte offset of the chunk being fetched: consecutive chunks are consecutive 128-byte pieces of the
         // packed row except across a tap change of a parity-class sub-problem, where it is recomputed from the tap
-        unsigned wbyte = (unsigned)((p.kh0 * p.KWf + p.kw0) * p.wtap) * 4u;
+        unsigned wbyte = (unsigned)(((p.kh0 + p.khs * kh_first) * p.KWf + p.kw0) * p.wtap) * 4u;
         auto dma_begin = [&]() {
           const bool in0 = cs.c0 < p.C0;
           rsa = segsde_make_rsrc(in0 ? base0 : base1);
@@ -1400,7 +1424,35 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(ConvP p, const float
     const unsigned lds0 = segsde_lds_addr(smem);
     const int wv = __builtin_amdgcn_readfirstlane(wave);
     constexpr unsigned STG = STAGE * 4;
-    auto issue = [&](int c, unsigned stage) {     // all tile loads of chunk c into stage (byte offset)
+    // Dead rows (ConvP::tapskip): with zero padding and a dilated window the tap rows [khl, khh] this workgroup's reduction
+    // columns belong to read source rows h*stride + kh*dil - pad; an output row h for which that lies outside the image for
+    // all of them contributes nothing to this tile -- its chunks (A side AND dY side) are never loaded.  Live rows are the
+    // interval [hlo, hhi] of every image; the chunk walk jumps from the end of row hhi to row hlo of the next image.
+    const int cpr = p.Wo / BP;                    // chunks per output row (SIMPLE: Wo % BP == 0)
+    int hlo = 0, hhi = p.Ho - 1;
+    if (p.tapskip && p.C1 == 0) {
+      const int kper = p.KW * p.Ctot;
+      const int khl = k0 / kper, khh = ((k0 + BKT < p.Ktot ? k0 + BKT : p.Ktot) - 1) / kper;
+      const int lo = p.pad - khh * p.dil, hi = p.H - 1 + p.pad - khl * p.dil;     // live: lo <= h*stride <= hi
+      hlo = lo > 0 ? (lo + p.stride - 1) / p.stride : 0;
+      hhi = hi < 0 ? -1 : (hi / p.stride < p.Ho - 1 ? hi / p.stride : p.Ho - 1);
+      hlo = __builtin_amdgcn_readfirstlane(hlo); hhi = __builtin_amdgcn_readfirstlane(hhi);
+    }
+    const int nlr = hhi - hlo + 1;                // live rows per image (<= 0: none)
+    auto live_before = [&](int c) {               // live chunks among the raw chunks [0, c)
+      const int per = p.Ho * cpr, q = c / per, r = c - q * per;
+      int t = r - hlo * cpr;
+      t = t < 0 ? 0 : (t > nlr * cpr ? nlr * cpr : t);
+      return q * nlr * cpr + t;
+    };
+    const int nlive = nlr <= 0 ? 0 : (nlr == p.Ho ? c_end - c_begin : live_before(c_end) - live_before(c_begin));
+    int cn = c_begin;                             // raw index of the next chunk to load, = chunk (cb, chh, cw)
+    if (nlive > 0) {                              // settle on the first live chunk at or after c_begin
+      if (chh < hlo) { cn += (hlo - chh) * cpr - cw / BP; chh = hlo; cw = 0; }
+      else if (chh > hhi) { cn += (p.Ho - chh + hlo) * cpr - cw / BP; chh = hlo; cw = 0; ++cb; }
+    }
+    auto issue = [&](unsigned stage) {            // all tile loads of chunk cn into stage (byte offset); advances to the next live chunk
+      const int c = cn;
       const bool live = c < nchunks_total;
       if (wave_src != 2) {
         const segsde_rsrc rr = segsde_make_rsrc(wave_src == 0 ? p.x0 + (size_t)cb * tbs0 : p.x1 + (size_t)cb * tbs1, live ? TAB_MARK : 0u);
@@ -1420,11 +1472,16 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(ConvP p, const float
 #pragma unroll
       for (int i = 0; i < DI; ++i)
         segsde_buffer_load4_lds(rd_, voffD[i], 0u, lds0 + stage + (unsigned)((BP * BKT + ((256 / DQ) * i + (64 / DQ) * wv) * BN) * 4));
-      cw += BP;
-      if (cw == p.Wo) { cw = 0; if (++chh == p.Ho) { chh = 0; ++cb; } }
+      cw += BP; ++cn;
+      if (cw == p.Wo) {
+        cw = 0;
+        if (++chh > hhi) { cn += (p.Ho - 1 - hhi + hlo) * cpr; chh = hlo; ++cb; }
+      }
     };
-    tload();
-    issue(c_begin, 0u);
+    if (nlive > 0) {
+      tload();
+      issue(0u);
+    }
     segsde_wait_vmcnt0();
     __syncthreads();
     float fa[2][4][TM], fd[2][4][TN];
@@ -1444,7 +1501,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(ConvP p, const float
       }
     };
     // unrolled by two so that the stage index is a compile-time constant (immediate LDS offsets, no address VALU)
-    auto chunk = [&](int c, auto buf_c) {
+    auto chunk = [&](auto buf_c) {
       constexpr int buf = decltype(buf_c)::value;
       fread(buf, 0, 0);
       tload();
@@ -1457,15 +1514,15 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(ConvP p, const float
 #pragma unroll
           for (int j = 0; j < TN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[g & 1][st][i], fd[g & 1][st][j], acc[i][j], 0, 0, 0);
-        if (u == 1) issue(c + 1, (unsigned)(buf ^ 1) * STG);
+        if (u == 1) issue((unsigned)(buf ^ 1) * STG);
         __builtin_amdgcn_sched_barrier(0);
       }
       segsde_wait_vmcnt0();
       __syncthreads();
     };
-    for (int c = c_begin; c < c_end; c += 2) {
-      chunk(c, std::integral_constant<int, 0>{});
-      if (c + 1 < c_end) chunk(c + 1, std::integral_constant<int, 1>{});
+    for (int i = 0; i < nlive; i += 2) {
+      chunk(std::integral_constant<int, 0>{});
+      if (i + 1 < nlive) chunk(std::integral_constant<int, 1>{});
     }
   } else {
   gload(c_begin);
@@ -1678,7 +1735,7 @@ __global__ __launch_bounds__(256) void reflect_dgrad_fix_kernel(const float* dy,
 // experiment knob (environment SEGSDE_TUNE="bk64=1"), read once.  Measured on MI355X (profiles/ab_conv_r01.log):
 // BK=64 (139 KB LDS => 1 workgroup/CU, half the barriers) loses 15-25 % on the large layers against BK=32 with two
 // co-resident workgroups per CU, and start-up staggering of co-resident workgroups changes nothing.
-struct Tune { int bk64 = 0; int adjfix = 0; int wplan = 0; int wovh = 4; int nos2 = 0; int dma = 1; int var = 0; int wdma = 1; int adjlds = 1; int wred = 0; int adjb = 1; };
+struct Tune { int bk64 = 0; int adjfix = 0; int wplan = 0; int wovh = 4; int nos2 = 0; int dma = 1; int var = 0; int wdma = 1; int adjlds = 1; int wred = 0; int adjb = 1; int tskip = 1; };
 const Tune& tune() {
   static Tune t = [] {
     Tune r;
@@ -1693,6 +1750,7 @@ const Tune& tune() {
       if (const char* q = strstr(e, "adjl=")) r.adjlds = atoi(q + 5);     // 0: reflection-adjoint loop register-staged in every wave
       if (const char* q = strstr(e, "wlds=")) r.wdma = atoi(q + 5);       // 0: register-staged weight-gradient tile loads
       if (const char* q = strstr(e, "adjb=")) r.adjb = atoi(q + 5);       // 0: reflection adjoint always inside the kernel (MODE 3); 1: zero-pad + border launches on the largest maps; 2: everywhere
+      if (const char* q = strstr(e, "tskip=")) r.tskip = atoi(q + 6);     // 0: dilated zero-padded windows run their dead tap rows too
       if (const char* q = strstr(e, "wred=")) r.wred = atoi(q + 5);       // 1: split partials reduced inside the kernel (measured: slower)
     }
     return r;
@@ -1754,6 +1812,8 @@ ConvP make_params(const segsde_conv_desc* d, const float* x0, const float* x1, c
   p.lin = d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && d->in_div <= 1 && !d->up0 && !d->sum2x2 && d->C1 == 0 &&
           d->H == d->Ho && d->W == d->Wo;
   p.padw = p.pad; p.wtap = p.Ctot; p.osfast = 0; p.submap = 0;
+  p.tapskip = (tune().tskip && d->pad_mode == SEGSDE_PAD_ZERO && d->dil > 1 && d->KH > 1 && d->in_div <= 1 && !d->up0 && !d->sum2x2 &&
+               d->stride == 1) ? 1 : 0;
   return p;
 }
 

@@ -70,6 +70,29 @@ def _fold_frac(g):
     return (4.0 * g.C0 + 9.0 * g.C1) / (9.0 * (g.C0 + g.C1))
 
 
+def _live_tap_frac(g, H, W, wgrad=False):
+    """Executed share of a dilated, zero-padded window (csrc/conv_igemm.hip, ConvP::tapskip): tap rows that only see padding
+    for a whole 128-pixel tile (forward / data-gradient) or a whole output row (weight gradient, 128-column reduction tiles
+    inside one tap row) are not multiplied.  Mirrors the kernels' tile-uniform rule for the reported 'executed' FLOPs; 1.0
+    where the rule does not apply."""
+    if g.reflect or g.dil <= 1 or g.k <= 1 or g.stride != 1 or g.up0 or os.environ.get("SEGSDE_TUNE", "").find("tskip=0") >= 0:
+        return 1.0
+    if wgrad:
+        if g.C1 or g.C0 % 128 or W % 32:
+            return 1.0
+        live = sum(max(0, min(H - 1, H - 1 + g.pad - kh * g.dil) - max(0, g.pad - kh * g.dil) + 1) for kh in range(g.k))
+        return live / float(g.k * H)
+    if (H * W) % 128 or (128 % W and W % 128):
+        return 1.0
+    rows = max(1, 128 // W)
+    live = total = 0
+    for r0 in range(0, H, rows):
+        r1 = r0 + rows - 1
+        live += sum(1 for kh in range(g.k) if r1 + kh * g.dil - g.pad >= 0 and r0 + kh * g.dil - g.pad <= H - 1)
+        total += g.k
+    return live / float(total)
+
+
 def _tag(g, H, W):
     return "%d+%d->%d k%d s%d d%d %dx%d%s%s" % (g.C0, g.C1, g.Cout, g.k, g.stride, g.dil, H, W, " up" if g.up0 else "",
                                                 " refl" if g.reflect else "")
@@ -212,7 +235,7 @@ def conv_forward(g, x0, x1, wpack, bias, act="none", want_stats=False, wfold=Non
                  stride=g.stride, dil=g.dil, pad=g.pad, pad_mode=PAD_REFLECT if g.reflect else PAD_ZERO, in_div=1,
                  act=ACT[act], sum2x2=0)
     flops = 2.0 * B * Ho * Wo * g.Cout * g.CinAlg * g.k * g.k
-    flops_x = flops * g.Cin / g.CinAlg      # executed: zero pad channels of a stem are multiplied too
+    flops_x = flops * g.Cin / g.CinAlg * _live_tap_frac(g, H, W)   # executed: zero pad channels of a stem are multiplied too, dead tap rows are not
     if wfold is not None and not want_stats:
         rc = _timed("conv_fwd", flops, x0, lambda: _lib.lib().segsde_conv2d_forward_upfold(
             ctypes.byref(d), _p(_f32(x0)), _p(x1), _p(wpack), _p(wfold), _p(bias), _p(y), _stream(x0)), _tag(g, H, W) + " fold",
@@ -276,7 +299,8 @@ def conv_dgrad(g, dy, wdpack, w_oihw, in_hw, need0=True, need1=True, accumulate_
         if g.up0 or g.C1 or tuple(acc.shape) != (B, H, W, g.C0) or not acc.is_contiguous():
             return None, None
         d = desc(0, 1)
-        rc = _timed("conv_dgrad", flops, dy, lambda: launch(d, acc, None, actgrad is not None), _tag(g, H, W))
+        rc = _timed("conv_dgrad", flops, dy, lambda: launch(d, acc, None, actgrad is not None), _tag(g, H, W),
+                    executed=flops * _live_tap_frac(g, H, W))
         if rc == -4:
             return None, None
         check(rc, "conv2d dgrad (accumulate)")
@@ -316,7 +340,7 @@ def conv_dgrad(g, dy, wdpack, w_oihw, in_hw, need0=True, need1=True, accumulate_
     full0 = torch.empty((B, H, W, g.C0), dtype=torch.float32, device=dy.device)
     d = desc(0)
     fused = actgrad is not None and not g.up0
-    rc = _timed("conv_dgrad", flops, dy, lambda: launch(d, full0, dx1, fused), _tag(g, H, W))
+    rc = _timed("conv_dgrad", flops, dy, lambda: launch(d, full0, dx1, fused), _tag(g, H, W), executed=flops * _live_tap_frac(g, H, W))
     if rc == -4 and fused:
         fused = False
         rc = launch(d, full0, dx1, False)
@@ -341,7 +365,7 @@ def conv_wgrad(g, x0, x1, dy):
     L = _lib.lib()
     dw = torch.empty((Cout, g.Cin, g.k, g.k), dtype=torch.float32, device=dy.device)
     flops = 2.0 * B * Ho * Wo * Cout * g.CinAlg * g.k * g.k
-    flops_x = flops * g.Cin / g.CinAlg
+    flops_x = flops * g.Cin / g.CinAlg * _live_tap_frac(g, H, W, wgrad=True)
     if upfold_ok(g, B * Ho * Wo):
         nbytes = L.segsde_conv2d_wgrad_upfold_workspace(ctypes.byref(d))
         if nbytes:

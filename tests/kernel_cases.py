@@ -77,6 +77,15 @@ CONV_CASES = [
     ("head_c64_19", 2, 5, 7, 64, 0, False, 19, 1, 1, 1, 0, False, True, "none"),
     ("head_c128_22", 1, 4, 6, 128, 0, False, 22, 1, 1, 1, 0, False, True, "none"),
     ("head_c256_3", 1, 3, 5, 256, 0, False, 3, 1, 1, 1, 0, False, False, "none"),
+    # dilated, zero-padded windows (ASPP rates, dilated layer4): tap rows that are dead for a whole tile / pixel chunk are skipped
+    # -- dilation below / at / above the map height (only the centre tap row survives), 128-pixel tiles inside one image, tiles
+    # that span images (no skipping there), reduction tiles inside one tap row (C = 128) and across tap rows (C = 32)
+    ("aspp_d6_h16", 2, 16, 64, 128, 0, False, 64, 3, 1, 6, 6, False, False, "none"),
+    ("aspp_d18_h16", 1, 16, 64, 128, 0, False, 64, 3, 1, 18, 18, False, False, "none"),
+    ("aspp_d12_h20_w32", 2, 20, 32, 64, 0, False, 128, 3, 1, 12, 12, False, True, "relu"),
+    ("aspp_d3_h5_c32", 3, 5, 32, 32, 0, False, 32, 3, 1, 3, 3, False, False, "none"),
+    ("aspp_d4_h4_multi", 5, 4, 32, 32, 0, False, 32, 3, 1, 4, 4, False, False, "none"),
+    ("aspp_d2_h9_odd", 2, 9, 37, 64, 0, False, 32, 3, 1, 2, 2, False, True, "none"),
     # widths that are multiples of 8 take the strip (sliding-window) stencil kernels
     ("disp_strip_c64", 2, 6, 24, 64, 0, False, 1, 3, 1, 1, 1, True, True, "sigmoid"),
     ("disp_strip_c128_zero", 1, 5, 16, 128, 0, False, 1, 3, 1, 1, 1, False, True, "none"),
@@ -630,6 +639,40 @@ def run_mix_use_gt_cases(device, golden):
     per = H.depthcomp_mask(d, 0.03, ft)
     for i in range(2):
         assert torch.equal(per[i], H.depthcomp_mask(d, 0.03, float(ft[i]))[i])
+
+
+def run_dead_tap_rows_case(device):
+    """ASPP-style dilated 3x3 with zero padding and a dilation beyond the map height (model_parts.py:5-32 at rate 18 on a 16-row
+    map): tap rows 0 and 2 only ever see padding.  The kernels skip such rows per tile, which this test PROVES rather than
+    assumes: their weights are set to +inf (0 * inf = nan would poison every output of a kernel that multiplies them) and the
+    result must equal the convolution with those weights zeroed."""
+    gen = torch.Generator().manual_seed(5)
+    B, Hh, W, C, Cout, dil = 2, 16, 64, 128, 64, 18
+    g = H.ConvGeom(C, Cout, 3, 1, dil, dil, False, 0, False)
+    x = torch.randn(B, Hh, W, C, generator=gen)
+    w = torch.randn(Cout, C, 3, 3, generator=gen) * 0.1
+    w0 = w.clone()
+    w0[:, :, 0, :] = 0
+    w0[:, :, 2, :] = 0
+    winf = w.clone()
+    winf[:, :, 0, :] = float("inf")
+    winf[:, :, 2, :] = float("inf")
+    ref = F.conv2d(nchw(x), w0, None, 1, dil, dil)
+    y = H.conv_forward(g, x.to(device), None, H.pack_weight(winf.to(device), False), None, "none")
+    assert bool(torch.isfinite(y).all()), "a dead tap row was multiplied"
+    assert_close(nchw(y), ref, what="dead tap rows fwd")
+    dy = torch.randn(B, Hh, W, Cout, generator=gen)
+    xr = nchw(x).clone().requires_grad_(True)
+    F.conv2d(xr, w0, None, 1, dil, dil).backward(nchw(dy))
+    dx, _ = H.conv_dgrad(g, dy.to(device), H.pack_weight(winf.to(device), True), winf.to(device), (Hh, W))
+    assert bool(torch.isfinite(dx).all()), "a dead tap row was multiplied (data gradient)"
+    assert_close(nchw(dx), xr.grad, what="dead tap rows dgrad")
+    # weight gradient: the dead rows' gradient is exactly zero, the live row's the reference's
+    wr = w.clone().requires_grad_(True)
+    F.conv2d(nchw(x), wr, None, 1, dil, dil).backward(nchw(dy))
+    dw = H.conv_wgrad(g, x.to(device), None, dy.to(device))
+    assert float(dw[:, :, 0, :].abs().max()) == 0.0 and float(dw[:, :, 2, :].abs().max()) == 0.0
+    assert_close(dw, wr.grad, rtol=1e-3, what="dead tap rows wgrad")
 
 
 def run_stem_cases(device, cases=None):

@@ -52,6 +52,10 @@ def test_mix_use_gt_vs_reference(golden):
     KC.run_mix_use_gt_cases("cpu", golden)
 
 
+def test_dead_tap_rows_are_skipped():
+    KC.run_dead_tap_rows_case("cpu")
+
+
 def test_network_stems():
     KC.run_stem_cases("cpu")
 

@@ -103,6 +103,10 @@ def test_mix_use_gt_vs_reference(golden):
     KC.run_mix_use_gt_cases("cuda", golden)
 
 
+def test_dead_tap_rows_are_skipped():
+    KC.run_dead_tap_rows_case("cuda")
+
+
 def test_network_stems():
     KC.run_stem_cases("cuda")
 
