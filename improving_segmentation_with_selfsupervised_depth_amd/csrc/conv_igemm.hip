@@ -1735,7 +1735,7 @@ __global__ __launch_bounds__(256) void reflect_dgrad_fix_kernel(const float* dy,
 // experiment knob (environment SEGSDE_TUNE="bk64=1"), read once.  Measured on MI355X (profiles/ab_conv_r01.log):
 // BK=64 (139 KB LDS => 1 workgroup/CU, half the barriers) loses 15-25 % on the large layers against BK=32 with two
 // co-resident workgroups per CU, and start-up staggering of co-resident workgroups changes nothing.
-struct Tune { int bk64 = 0; int adjfix = 0; int wplan = 0; int wovh = 4; int nos2 = 0; int dma = 1; int var = 0; int wdma = 1; int adjlds = 1; int wred = 0; int adjb = 1; int tskip = 1; };
+struct Tune { int bk64 = 0; int adjfix = 0; int wplan = 0; int wovh = 4; int nos2 = 0; int dma = 1; int var = 0; int wdma = 1; int adjlds = 1; int wred = 0; int adjb = 1; int tskip = 1; int tsbn = 0; };
 const Tune& tune() {
   static Tune t = [] {
     Tune r;
@@ -1750,6 +1750,7 @@ const Tune& tune() {
       if (const char* q = strstr(e, "adjl=")) r.adjlds = atoi(q + 5);     // 0: reflection-adjoint loop register-staged in every wave
       if (const char* q = strstr(e, "wlds=")) r.wdma = atoi(q + 5);       // 0: register-staged weight-gradient tile loads
       if (const char* q = strstr(e, "adjb=")) r.adjb = atoi(q + 5);       // 0: reflection adjoint always inside the kernel (MODE 3); 1: zero-pad + border launches on the largest maps; 2: everywhere
+      if (const char* q = strstr(e, "tsbn=")) r.tsbn = atoi(q + 5);       // 1: 128x64 tiles for one-round grids with dead tap rows
       if (const char* q = strstr(e, "tskip=")) r.tskip = atoi(q + 6);     // 0: dilated zero-padded windows run their dead tap rows too
       if (const char* q = strstr(e, "wred=")) r.wred = atoi(q + 5);       // 1: split partials reduced inside the kernel (measured: slower)
     }
@@ -1905,10 +1906,17 @@ int launch_reflect_fix(const float* dy, int lddy, const float* wd, float* dx, in
 namespace {
 // rows of statistics partials a forward launch of this shape writes (0: the shape does not take the staged epilogue
 // with a single tile shape, the statistics then have to come from segsde_bn_stats)
+// Dead tap rows make the tiles' K loops unequal (1/3 .. 3/3 of the taps): a grid that fits the chip in ONE round (two
+// workgroups per CU) takes as long as its longest tile whatever the others skip.  Narrower tiles = twice the workgroups, the
+// second half is handed out as the first ones finish.  (ONE predicate for the launch and for the statistics rows it writes.)
+bool narrow_for_tapskip(const ConvP& q) {
+  return q.tapskip && tune().tsbn && q.N > 64 && (q.ne - q.nb) % 64 == 0 &&
+         (long)segsde_cdiv(q.M, 128) * segsde_cdiv(q.ne - q.nb, 128) <= 512;
+}
 long stats_rows(const segsde_conv_desc* d, const ConvP& p) {
   if (!p.vecout || d->sum2x2 || d->in_div > 1 || p.y2 != p.y || p.bias || d->act != 0) return 0;
   if (d->Cout == 1 || (d->Cout % 128 > 0 && d->Cout % 128 <= 64 && d->Cout > 64)) return 0;
-  const int bn = d->Cout <= 32 ? 32 : (d->Cout <= 64 ? 64 : 128);
+  const int bn = d->Cout <= 32 ? 32 : ((d->Cout <= 64 || narrow_for_tapskip(p)) ? 64 : 128);
   return (long)segsde_cdiv(p.M, 128) * (256 / bn);
 }
 }  // namespace
@@ -1917,6 +1925,7 @@ namespace {
 int launch_by_n(const ConvP& q, hipStream_t s) {
   if (q.N <= 32) return launch_igemm<128, 32, 4, 1>(q, s);
   if (q.N <= 64) return launch_igemm<128, 64, 2, 2>(q, s);
+  if (narrow_for_tapskip(q)) return launch_igemm<128, 64, 2, 2>(q, s);
   if (q.N % 128 > 0 && q.N % 128 <= 64) {
     ConvP a = q, b = q;
     a.ne = q.N - q.N % 128; b.nb = a.ne;
@@ -2111,17 +2120,9 @@ extern "C" int segsde_conv2d_dgrad_actgrad(const segsde_conv_desc* d, const floa
     const int e = launch_adjoint_by_borders(p, s);
     if (e != SEGSDE_ERR_UNSUPPORTED) return e;
   }
-  int e;
-  if (p.N <= 32) e = launch_igemm<128, 32, 4, 1>(p, s);
-  else if (p.N <= 64) e = launch_igemm<128, 64, 2, 2>(p, s);   // (a 256x64 tile measured 3 % slower)
-  else if (p.N % 128 > 0 && p.N % 128 <= 64) {
-    // e.g. the 192-channel concat data-gradient: 128-wide tiles for the bulk, 64-wide tiles for the 64-channel tail
-    ConvP a = p, b = p;
-    a.ne = p.N - p.N % 128; b.nb = a.ne;
-    e = launch_igemm<128, 128, 2, 2>(a, s);
-    if (!e) e = (b.ne - b.nb <= 32) ? launch_igemm<128, 32, 4, 1>(b, s) : launch_igemm<128, 64, 2, 2>(b, s);
-  } else e = launch_igemm<128, 128, 2, 2>(p, s);
-  if (e) return e;
+  // tile width by N: 32 / 64 for narrow outputs (a 256x64 tile measured 3 % slower), 128-wide tiles for the bulk and 64-wide
+  // ones for a 64-channel tail (e.g. the 192-channel concat data-gradient)
+  if (int e = launch_by_n(p, s)) return e;
   if (d->pad_mode == SEGSDE_PAD_REFLECT_ADJOINT && (!igemm_fast_ok(p) || (tune().adjfix && !p.sum2x2)))
     // the generic gathers treat the padding as zeros; add the mirrored-padding contributions on the border pixels
     return launch_reflect_fix(x0, p.ld0, wpack, y, p.ldy, y2, p.ldy2, p.nsplit, p.B, p.H, p.W, p.N, p.C0, s);

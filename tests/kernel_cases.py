@@ -82,6 +82,7 @@ CONV_CASES = [
     # that span images (no skipping there), reduction tiles inside one tap row (C = 128) and across tap rows (C = 32)
     ("aspp_d6_h16", 2, 16, 64, 128, 0, False, 64, 3, 1, 6, 6, False, False, "none"),
     ("aspp_d18_h16", 1, 16, 64, 128, 0, False, 64, 3, 1, 18, 18, False, False, "none"),
+    ("aspp_d6_h16_n128", 1, 16, 64, 64, 0, False, 128, 3, 1, 6, 6, False, False, "none"),
     ("aspp_d12_h20_w32", 2, 20, 32, 64, 0, False, 128, 3, 1, 12, 12, False, True, "relu"),
     ("aspp_d3_h5_c32", 3, 5, 32, 32, 0, False, 32, 3, 1, 3, 3, False, False, "none"),
     ("aspp_d4_h4_multi", 5, 4, 32, 32, 0, False, 32, 3, 1, 4, 4, False, False, "none"),
