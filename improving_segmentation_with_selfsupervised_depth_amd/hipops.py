@@ -26,9 +26,9 @@ def _timed(kind, flops, like, launch, tag="", executed=None):
     if PROFILE is None or not like.is_cuda:
         return launch()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    s.record()
+    s.record(LAUNCH_STREAM)          # None = the current stream
     r = launch()
-    e.record()
+    e.record(LAUNCH_STREAM)
     PROFILE.append((kind, flops, s, e, tag, flops if executed is None else executed))
     return r
 
@@ -99,8 +99,16 @@ def _tag(g, H, W):
 PAD_ZERO, PAD_REFLECT, PAD_REFLECT_ADJOINT = 0, 1, 2
 
 
+# Launch-stream override (models/model_parts.py, ASPP forward on side streams): kernels launched while it is set go to that
+# stream instead of torch's current one.  Only for launches whose outputs stay alive until the caller has joined the streams --
+# allocations still come from the current stream's pool.
+LAUNCH_STREAM = None
+
+
 def _stream(t):
     if t.is_cuda:
+        if LAUNCH_STREAM is not None:
+            return ctypes.c_void_p(LAUNCH_STREAM.cuda_stream)
         return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
     if not _lib.HOST_POINTERS_OK:
         raise RuntimeError("segsde HIP kernels need tensors on a ROCm device (got %s); there is no CPU path" % t.device)
