@@ -214,6 +214,9 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--kernel-timing-period", type=int, default=0,
+                    help="bracket launch q of step i with HIP events iff (q + i) %% P == 0 (1: every launch of every step; "
+                         "default: min(steps, 8) -- every launch site once per P steps, 1/P of the event overhead per step)")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-baseline-timeout", type=float, default=150.0)
     args = ap.parse_args()
@@ -372,12 +375,15 @@ def main():
     Fn.fusion_report(reset=True)
     prof = None if args.no_kernel_timing else []
     H.PROFILE = prof
+    period = args.kernel_timing_period if args.kernel_timing_period > 0 else max(1, min(args.steps, 8))
+    H.PROFILE_PERIOD = period
     # per-step times without a host synchronisation inside the timed region: one HIP event per step boundary on the
     # launch stream (the device executes the steps back to back; the host runs ahead)
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
     marks[0].record()
     for i in range(args.steps):
+        H.profile_step(i)
         last = step()
         marks[i + 1].record()
     barrier()
@@ -425,8 +431,27 @@ def main():
             agg = {}
             layers = {}
             hbm = {}
+            # sampled timing (hipops.PROFILE_PERIOD): a launch that was not bracketed takes the mean duration of the bracketed
+            # launches of its own (kind, geometry) -- every launch site is bracketed in one step out of `period`
+            tsum = {}
             for kind, flops, s, e, tag, executed in prof:
-                t = s.elapsed_time(e) * 1e-3
+                if s is not None:
+                    a = tsum.setdefault((kind, tag), [0.0, 0])
+                    a[0] += s.elapsed_time(e) * 1e-3
+                    a[1] += 1
+            n_timed = sum(a[1] for a in tsum.values())
+            n_unsampled = sum(1 for r in prof if r[2] is None and (r[0], r[4]) not in tsum)
+            res["kernel_timing"] = {"period": period, "launches": len(prof), "bracketed_launches": n_timed,
+                                    "launches_without_a_sample": n_unsampled,
+                                    "rule": "launch q of step i is bracketed by HIP events iff (q + i) % period == 0; the others take the "
+                                            "mean of the bracketed launches of the same kind and geometry"}
+            for kind, flops, s, e, tag, executed in prof:
+                if s is not None:
+                    t = s.elapsed_time(e) * 1e-3
+                elif (kind, tag) in tsum:
+                    t = tsum[(kind, tag)][0] / tsum[(kind, tag)][1]
+                else:
+                    continue
                 if kind.startswith("hbm_"):       # `flops` holds the launch's algorithmic BYTES (operands once each)
                     a = hbm.setdefault(kind[4:], [0.0, 0.0, 0])
                     a[0] += flops

@@ -20,15 +20,33 @@ ACT = {"none": 0, "relu": 1, "elu": 2, "sigmoid": 3}
 PROFILE = None
 
 
+# Sampled timing: a HIP event pair around a launch drains the stream on both sides (the next kernel's launch latency is
+# no longer hidden behind the previous kernel: ~5 us per event, ~2 000 events = 9 ms of a 320 ms cfg3 step when EVERY launch
+# is bracketed).  With PROFILE_PERIOD = P the launch with sequence number q of step i is bracketed iff (q + i) % P == 0:
+# every launch site is timed in one step out of P, every step carries 1/P of the events; the launches that are not
+# bracketed are still recorded (events = None) so that the consumer knows the population.  bench.py sets these.
+PROFILE_PERIOD = 1
+_profile_state = [0, 0]      # [sequence number inside the step, step index]
+
+
+def profile_step(i):
+    _profile_state[0], _profile_state[1] = 0, int(i)
+
+
 def _timed(kind, flops, like, launch, tag="", executed=None):
     """executed: the multiply-add work the launch really issues when that is less than the algorithmic figure (the
     upsample-folded convolutions); defaults to ``flops``"""
     if PROFILE is None or not like.is_cuda:
         return launch()
+    q = _profile_state[0]
+    _profile_state[0] = q + 1
+    if PROFILE_PERIOD > 1 and (q + _profile_state[1]) % PROFILE_PERIOD:
+        PROFILE.append((kind, flops, None, None, tag, flops if executed is None else executed))
+        return launch()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    s.record(LAUNCH_STREAM)          # None = the current stream
+    s.record()
     r = launch()
-    e.record(LAUNCH_STREAM)
+    e.record()
     PROFILE.append((kind, flops, s, e, tag, flops if executed is None else executed))
     return r
 
@@ -99,16 +117,8 @@ def _tag(g, H, W):
 PAD_ZERO, PAD_REFLECT, PAD_REFLECT_ADJOINT = 0, 1, 2
 
 
-# Launch-stream override (models/model_parts.py, ASPP forward on side streams): kernels launched while it is set go to that
-# stream instead of torch's current one.  Only for launches whose outputs stay alive until the caller has joined the streams --
-# allocations still come from the current stream's pool.
-LAUNCH_STREAM = None
-
-
 def _stream(t):
     if t.is_cuda:
-        if LAUNCH_STREAM is not None:
-            return ctypes.c_void_p(LAUNCH_STREAM.cuda_stream)
         return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
     if not _lib.HOST_POINTERS_OK:
         raise RuntimeError("segsde HIP kernels need tensors on a ROCm device (got %s); there is no CPU path" % t.device)

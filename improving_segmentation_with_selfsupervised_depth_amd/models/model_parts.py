@@ -4,14 +4,8 @@ the state_dict keys (convs.K.0.weight, convs.K.1.*, convs.4.1.weight, convs.4.2.
 import torch
 from torch import nn
 
-import os
-
 from .. import functional as Fn
-from .. import hipops as H
 from .layers import Conv2d, BatchNorm2d
-
-_ASPP_STREAMS = os.environ.get("SEGSDE_ASPP_STREAMS", "0") == "1"
-_SIDE_STREAMS = {}
 
 
 class ASPPConv(nn.Sequential):
@@ -59,46 +53,13 @@ class ASPP(nn.Module):
             xs = Fn.FanoutFn.apply(x, box, len(branches))
         else:
             box, xs = None, [x] * len(branches)
-        if _ASPP_STREAMS and x.is_cuda:
-            res = self._branches_on_side_streams(branches, xs, box)
-        else:
-            res = [self.convs[0][1](self.convs[0][0](xs[0], grad_box=box), act="relu")]
-            for conv, xi in zip(branches[1:], xs[1:]):
-                res.append(conv(xi, grad_box=box) if isinstance(conv, ASPPConv) else conv(xi))
+        res = [self.convs[0][1](self.convs[0][0](xs[0], grad_box=box), act="relu")]
+        for conv, xi in zip(branches[1:], xs[1:]):
+            res.append(conv(xi, grad_box=box) if isinstance(conv, ASPPConv) else conv(xi))
         cat = Fn.ConcatFn.apply(*res)
         drop = self.project[3]
         p = drop.p if (drop.training and self.training) else 0.0
         return self.project[1](self.project[0](cat), act="relu", drop_p=p)
-
-
-    def _branches_on_side_streams(self, branches, xs, box):
-        """EXPERIMENT (SEGSDE_ASPP_STREAMS=1): the branch convolutions' FORWARD launches go to one side stream each.  A dilated
-        branch is 512 workgroups = one round of the chip whose tiles skip different numbers of dead tap rows (conv_igemm.hip,
-        ConvP::tapskip): alone it takes as long as its longest tile pair; next to the other branches the CUs that finish early
-        pick up their workgroups.  Only the convolution kernels move (their outputs are kept by autograd, nothing is freed
-        before the join); BatchNorm / ReLU and the whole backward stay on the current stream."""
-        dev = xs[0].device
-        main = torch.cuda.current_stream(dev)
-        side = _SIDE_STREAMS.setdefault(dev.index, [])
-        while len(side) < len(branches):
-            side.append(torch.cuda.Stream(dev))
-        fork = torch.cuda.Event()
-        fork.record(main)
-        raw = []
-        for i, (br, xi) in enumerate(zip(branches, xs)):
-            if isinstance(br, ASPPPooling):
-                raw.append(None)
-                continue
-            side[i].wait_event(fork)
-            H.LAUNCH_STREAM = side[i]
-            try:
-                raw.append(br[0](xi, grad_box=box))
-            finally:
-                H.LAUNCH_STREAM = None
-        for i, r in enumerate(raw):
-            if r is not None:
-                main.wait_stream(side[i])
-        return [br(xi) if r is None else br[1](r, act="relu") for br, xi, r in zip(branches, xs, raw)]
 
 
 class SelfAttention(nn.Module):
