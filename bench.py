@@ -408,7 +408,7 @@ def main():
                      else "train images/sec (%s)" % args.workload),
                "value": value, "unit": "img/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": ms, "ms_per_step_mean": ms_mean, "value_from_mean": B * world * args.steps / dt,
-               "ms_per_step_min": min(step_ms), "ms_per_step_max": max(step_ms), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+               "ms_per_step_min": min(step_ms), "ms_per_step_max": max(step_ms), "ms_per_step_all": [round(t, 2) for t in step_ms], "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
                "data": "synthetic", "config": {"workload": desc, "per_gpu_batch": B, "global_batch": B * world,
                                                "height": Hh, "width": W,
                                                "optimizer": opt_name + (" (torch fused)" if getattr(optimizer, "defaults", {}).get("fused") else ""),
