@@ -353,9 +353,18 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    # the last warm-up step runs with the launch bracketing on (results discarded): on a fresh box the first use of the timed-event
+    # path (hipEventCreate with timing, the record packets) pages cold library code in -- a ~60 ms host stall that otherwise lands
+    # in the first TIMED step (measured: 372 vs 311 ms, only in the first bench process of a box)
+    for w in range(args.warmup):
+        if w == args.warmup - 1 and not args.no_kernel_timing:
+            H.PROFILE, H.PROFILE_PERIOD = [], max(1, min(args.steps, 8) if args.kernel_timing_period <= 0 else args.kernel_timing_period)
+            H.profile_step(0)
         step()
     barrier()
+    if H.PROFILE:
+        _ = [s_.elapsed_time(e_) for _, _, s_, e_, _, _ in H.PROFILE if s_ is not None][:4]
+    H.PROFILE = None
     if os.environ.get("SEGSDE_BENCH_ATEN_OPS") and rank == 0:
         # diagnosis: which ATen operators (with shapes) still run inside a step -- everything on the hot path should be a
         # kernel of this package
