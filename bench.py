@@ -522,10 +522,17 @@ def main():
                         roof["traffic_source"] = "%s refused: collected from other kernel sources (csrc_sha256 %s != %s); re-run tools/gpu_pmc.sh" % (
                             rel, str(tj.get("csrc_sha256"))[:12], sha[:12])
                     else:
+                        # per LAUNCH of the C ABI, like `achieved` (one call = 1.27 kernels on average: class / border
+                        # launches of the folded routes): the counters' bytes per step / this run's calls per step
                         kk = [k for k in tj["kernels"] if k.startswith("conv_igemm_kernel")][0]
-                        roof["traffic"] = tj["kernels"][kk]["bytes_per_launch"]
+                        sp = float(tj.get("steps_profiled", 3))
+                        per_step = lambda e: e["bytes_per_launch"] * e["launches"] / sp
+                        roof["traffic"] = per_step(tj["kernels"][kk]) / (nl / args.steps)
+                        roof["traffic_per_kernel_launch"] = tj["kernels"][kk]["bytes_per_launch"]
+                        roof["traffic_over_algorithmic"] = roof["traffic"] / (abytes / nl)
+                        roof["traffic_gbs"] = per_step(tj["kernels"][kk]) / (tt / args.steps) / 1e9
                         roof["traffic_source"] = rel + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py)"
-                        wg_traffic = tj["kernels"]["conv_wgrad_kernel"]["bytes_per_launch"]
+                        wg_traffic = per_step(tj["kernels"]["conv_wgrad_kernel"]) / (agg["conv_wgrad"][2] / args.steps) if "conv_wgrad" in agg else None
                         res["pmc_traffic_bytes_per_launch"] = {k: v["bytes_per_launch"] for k, v in tj["kernels"].items()}
                 except Exception as ex:
                     roof["traffic_source"] = "%s unreadable: %r" % (rel, ex)
