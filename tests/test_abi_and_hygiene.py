@@ -85,3 +85,38 @@ def test_cpu_tensor_rejected(monkeypatch):
     monkeypatch.setattr(_lib, "HOST_POINTERS_OK", False)
     with pytest.raises(RuntimeError, match="no CPU path"):
         H.colsum(torch.zeros(4, 4))
+
+
+def test_launch_bracketing_samples_every_site_once(monkeypatch):
+    """bench.py's kernel timing (hipops._timed, PROFILE_PERIOD): launch q of step i is bracketed iff (q + i) % P == 0 -- over P
+    steps every launch site is timed exactly once, every launch is recorded (population), and the executed-FLOP figure of the
+    dilated windows follows the kernels' tile-uniform dead-row rule"""
+    import torch
+    from improving_segmentation_with_selfsupervised_depth_amd import hipops as H
+
+    class Ev:
+        def __init__(self, enable_timing=True):
+            pass
+
+        def record(self, stream=None):
+            pass
+
+    class Like:
+        is_cuda = True
+
+    monkeypatch.setattr(torch.cuda, "Event", Ev)
+    monkeypatch.setattr(H, "PROFILE", [])
+    monkeypatch.setattr(H, "PROFILE_PERIOD", 5)
+    ran = []
+    for i in range(5):
+        H.profile_step(i)
+        for q in range(7):
+            H._timed("conv_fwd", 1.0, Like(), lambda: ran.append(1), "site%d" % q)
+    assert len(ran) == 35 and len(H.PROFILE) == 35
+    timed = sorted(r[4] for r in H.PROFILE if r[2] is not None)
+    assert timed == ["site%d" % q for q in range(7)]
+    # live share of the ASPP windows on the 32 x 64 bottleneck map (DESIGN 3.2c)
+    for dil, want in ((6, 0.875), (12, 0.75), (18, 0.625)):
+        g = H.ConvGeom(2048, 256, 3, 1, dil, dil, False, 0, False)
+        assert abs(H._live_tap_frac(g, 32, 64) - want) < 1e-9 and abs(H._live_tap_frac(g, 32, 64, wgrad=True) - want) < 1e-9
+    assert H._live_tap_frac(H.ConvGeom(256, 256, 3, 1, 1, 1, False, 0, False), 32, 64) == 1.0
