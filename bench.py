@@ -101,13 +101,15 @@ def loss_cfg(B, H, W):
         test_max_depth=80, disparity_smoothness=1e-3, no_ssim=False, avg_reprojection=False, disable_automasking=False)}}
 
 
-def param_groups(model, opt):
+def param_groups(model, opt, capturable=False):
     """train.py:67-101 with experiments.py:32-48: backbone lr 1e-3, everything else 1e-2 (sgd); adam 1e-4"""
     # the stock torch optimisers; on the GPU their fused single-kernel implementation (same update rule, one pass over
     # parameter / gradient / momentum instead of ~5 multi-tensor passes: ~0.7 ms of a cfg3 step).  SEGSDE_BENCH_FUSED_OPT=0: foreach
     dev_ok = next(model.parameters()).is_cuda and os.environ.get("SEGSDE_BENCH_FUSED_OPT", "1") != "0"
     extra = {"fused": True} if dev_ok else {}
     if opt == "adam":
+        if capturable:
+            extra = dict(extra, capturable=True)      # step counters on the device: the update can be captured in a hipGraph
         return torch.optim.Adam(model.parameters(), lr=1e-4, **extra)
     enc = list(model.models["encoder"].parameters())
     ids = {id(p) for p in enc}
@@ -217,6 +219,10 @@ def main():
     ap.add_argument("--kernel-timing-period", type=int, default=0,
                     help="bracket launch q of step i with HIP events iff (q + i) %% P == 0 (1: every launch of every step; "
                          "default: min(steps, 8) -- every launch site once per P steps, 1/P of the event overhead per step)")
+    ap.add_argument("--hip-graph", action="store_true",
+                    help="capture one whole training step (forward, loss, backward, clip, optimiser) as a hipGraph after the warm-up and "
+                         "replay it for the timed steps: the launch-bound regime (cfg1: ~1 500 launches of 5-20 us per step through "
+                         "Python / ctypes).  Single GPU, labeled step only; implies --no-kernel-timing")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-baseline-timeout", type=float, default=150.0)
     args = ap.parse_args()
@@ -225,6 +231,10 @@ def main():
         print(json.dumps(cpu_baseline(args.workload, Hh, W, args.cpu_baseline_timeout - 25.0)))
         return
 
+    if args.hip_graph:
+        if args.gpus != 1 or args.workload == "cfg5":
+            raise SystemExit("--hip-graph: single GPU, labeled step only")
+        args.no_kernel_timing = True
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N`: become the launcher -- N ranks of this very script over RCCL on 127.0.0.1
         import socket
@@ -277,7 +287,7 @@ def main():
     torch.manual_seed(42)
     cfg = model_cfg(args.workload, Hh, W)
     model = get_model(cfg, 19).to(dev).train()
-    optimizer = param_groups(model, opt_name)
+    optimizer = param_groups(model, opt_name, capturable=args.hip_graph)
     loss_obj = get_monodepth_loss(loss_cfg(B, Hh, W), is_train=True)
     reducer = GradAllReducer(model, always=force_reducer) if (world > 1 or force_reducer) else None
     # identical initial parameters (seed 42 above + the reducer's broadcast), then INDEPENDENT dropout / tie-break
@@ -379,6 +389,30 @@ def main():
             for e in sorted((e for e in ka if e.key.startswith("aten::")), key=lambda e: -e.device_time_total):
                 if e.device_time_total > 0:
                     f.write("%-28s %10.1f %6d  %s\n" % (e.key, e.device_time_total, e.count, str(e.input_shapes)[:150]))
+    graph = None
+    if args.hip_graph:
+        # whole-step capture (torch.cuda.graphs drives hipStreamBeginCapture / hipGraphInstantiate; the package's kernels are
+        # launched on torch's current stream, i.e. the capturing one; every allocation comes from the graph's private pool)
+        from improving_segmentation_with_selfsupervised_depth_amd.models import layers as L_
+        L_.GRAPH_SAFE_DROPOUT[0] = True
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            step()                      # once more on the side stream, with the graph-safe dropout route
+        torch.cuda.current_stream(dev).wait_stream(side)
+        barrier()
+        graph = torch.cuda.CUDAGraph()
+        optimizer.zero_grad(set_to_none=True)
+        with torch.cuda.graph(graph):
+            graph_loss = step()
+        barrier()
+
+        def step():
+            graph.replay()
+            return graph_loss
+        for _ in range(2):
+            step()
+        barrier()
     torch.cuda.reset_peak_memory_stats(dev)
     from improving_segmentation_with_selfsupervised_depth_amd import functional as Fn
     Fn.fusion_report(reset=True)
@@ -421,7 +455,7 @@ def main():
                "data": "synthetic", "config": {"workload": desc, "per_gpu_batch": B, "global_batch": B * world,
                                                "height": Hh, "width": W,
                                                "optimizer": opt_name + (" (torch fused)" if getattr(optimizer, "defaults", {}).get("fused") else ""),
-                                               "parallelism": "dp%d" % world, "final_loss": loss_val,
+                                               "parallelism": "dp%d" % world, "final_loss": loss_val, "hip_graph": bool(args.hip_graph),
                                                "ranks": dist.get_world_size() if dist.is_initialized() else 1,
                                                "backend": (dist.get_backend() + (" (RCCL)" if dist.get_backend() == "nccl" else "")) if dist.is_initialized() else None,
                                                "allreduce_launches": reducer.collectives if reducer is not None else 0,

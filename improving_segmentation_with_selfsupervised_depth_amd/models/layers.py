@@ -19,6 +19,7 @@ def _seed():
 _NO_FUSED_STATS = bool(int(os.environ.get("SEGSDE_NO_FUSED_STATS", "0")))   # debugging: BatchNorm statistics as a separate pass
 
 
+GRAPH_SAFE_DROPOUT = [False]   # see BatchNorm2d.forward
 _PACK_SCOPE = [0, 0]      # [id of the active weight-pack scope (0: none), last id handed out]
 
 
@@ -168,6 +169,13 @@ class BatchNorm2d(nn.BatchNorm2d):
             momentum = 1.0 / float(int(self.num_batches_tracked) + 1) if nbt is not None else 0.0
         else:
             momentum = self.momentum
+        if drop_p > 0 and GRAPH_SAFE_DROPOUT[0]:
+            # hipGraph capture (bench.py --hip-graph): the fused dropout's seed is a host integer, i.e. a constant of the captured
+            # launch -- every replay would draw the same mask.  Under capture the mask comes from torch's device generator instead
+            # (Philox offsets advance per replay): BatchNorm (+ residual, activation) fused as always, dropout as one more
+            # elementwise pass over the (small: ASPP projection / class head) tensor
+            y = self.forward(x, residual, act, 0.0, grad_box)
+            return torch.nn.functional.dropout(y, drop_p, True)
         seed = _seed() if drop_p > 0 else 0
         partials = getattr(x, "_bn_partials", None) if training else None
         if partials is not None:

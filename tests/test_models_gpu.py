@@ -386,3 +386,71 @@ def test_real_model_two_ranks_one_gpu():
 
 def test_fusion_handoffs_are_counted():
     MC.run_fusion_diagnostics("cuda")
+
+
+def test_hip_graph_replay_matches_eager_steps():
+    """bench.py --hip-graph: one whole training step (forward, monodepth loss, backward, clip, optimiser) captured as a hipGraph and
+    replayed must leave exactly the parameters the eager steps leave (same kernels, same order; dropout in eval mode and a
+    fixed tie-break noise so that both runs are deterministic)."""
+    import copy
+    import bench
+    from improving_segmentation_with_selfsupervised_depth_amd.models import get_model
+    from improving_segmentation_with_selfsupervised_depth_amd.models import layers as L_
+    from improving_segmentation_with_selfsupervised_depth_amd.models.layers import weight_pack_scope
+    from improving_segmentation_with_selfsupervised_depth_amd.loss import get_monodepth_loss
+    B, Hh, W = 2, 64, 128
+    dev = torch.device("cuda")
+    torch.manual_seed(3)
+    cfg = bench.model_cfg("cfg1", Hh, W)
+    base = get_model(cfg, 19).to(dev).train()
+    MC.dropout_eval(base)
+    inputs = bench.synthetic_inputs(B, Hh, W, dev, 5, with_labels=False)
+    gen = torch.Generator().manual_seed(9)
+    noise = {s: torch.randn(B, 2, Hh, W, generator=gen).to(dev) for s in range(4)}
+
+    def make():
+        model = copy.deepcopy(base)
+        opt = torch.optim.SGD(model.parameters(), lr=1e-2, momentum=0.9, fused=True)
+        loss_obj = get_monodepth_loss(bench.loss_cfg(B, Hh, W), is_train=True)
+        loss_obj.tiebreak_noise = noise
+
+        def step():
+            with weight_pack_scope(model):
+                opt.zero_grad(set_to_none=True)
+                out = model(inputs)
+                loss_obj.generate_images_pred(inputs, out)
+                total = loss_obj.compute_losses(inputs, out)["loss"]
+                total.backward()
+                torch.nn.utils.clip_grad_norm_(model.parameters(), 10.0)
+                opt.step()
+                return total
+        return model, step
+
+    m_e, step_e = make()
+    for _ in range(4):
+        loss_e = step_e()
+    m_g, step_g = make()
+    L_.GRAPH_SAFE_DROPOUT[0] = True
+    try:
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            step_g()
+            step_g()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            loss_g = step_g()
+        graph.replay()
+        graph.replay()
+        torch.cuda.synchronize()
+    finally:
+        L_.GRAPH_SAFE_DROPOUT[0] = False
+    assert torch.isfinite(loss_g).all()
+    assert_close(loss_g, loss_e, rtol=1e-6, atol=0, what="loss of the 4th step")
+    worst = 0.0
+    for (k, pe), (_, pg) in zip(m_e.named_parameters(), m_g.named_parameters()):
+        d = float((pe - pg).abs().max())
+        worst = max(worst, d / (float(pe.abs().max()) + 1e-30))
+    assert worst <= 1e-6, worst
