@@ -366,11 +366,21 @@ def main():
     # the last warm-up step runs with the launch bracketing on (results discarded): on a fresh box the first use of the timed-event
     # path (hipEventCreate with timing, the record packets) pages cold library code in -- a ~60 ms host stall that otherwise lands
     # in the first TIMED step (measured: 372 vs 311 ms, only in the first bench process of a box)
-    for w in range(args.warmup):
-        if w == args.warmup - 1 and not args.no_kernel_timing:
-            H.PROFILE, H.PROFILE_PERIOD = [], max(1, min(args.steps, 8) if args.kernel_timing_period <= 0 else args.kernel_timing_period)
-            H.profile_step(0)
-        step()
+    import contextlib
+    # --hip-graph: the warm-up runs on a side stream, like the capture -- autograd's AccumulateGrad nodes remember the stream of the
+    # first backward; nodes born on the default stream make the captured backward wait on it, which invalidates the capture
+    # (hipStreamEndCapture then crashed the process)
+    warm_stream = torch.cuda.Stream(dev) if args.hip_graph else None
+    if warm_stream is not None:
+        warm_stream.wait_stream(torch.cuda.current_stream(dev))
+    with (torch.cuda.stream(warm_stream) if warm_stream is not None else contextlib.nullcontext()):
+        for w in range(args.warmup):
+            if w == args.warmup - 1 and not args.no_kernel_timing:
+                H.PROFILE, H.PROFILE_PERIOD = [], max(1, min(args.steps, 8) if args.kernel_timing_period <= 0 else args.kernel_timing_period)
+                H.profile_step(0)
+            step()
+    if warm_stream is not None:
+        torch.cuda.current_stream(dev).wait_stream(warm_stream)
     barrier()
     if H.PROFILE:
         _ = [s_.elapsed_time(e_) for _, _, s_, e_, _, _ in H.PROFILE if s_ is not None][:4]
