@@ -1,7 +1,9 @@
 """How sensitive is the whole-model gradient-norm criterion of tests/model_cases.py::run_full_model to rounding noise?
 The product (stem path on / off) on the golden inputs with the stem weights perturbed by +-1..2 ulp; error of the
-per-parameter gradient norms against the fp64 oracle.  (GPU: python tools/diag/gradient_norm_sensitivity.py r18_mono)"""
-import sys; sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/tests')
+per-parameter gradient norms against the fp64 oracle.  (GPU: python tests/diag/gradient_norm_sensitivity.py r18_mono)"""
+import os, sys
+_ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, _ROOT); sys.path.insert(0, os.path.join(_ROOT, 'tests'))
 import numpy as np, torch
 DEV = "cuda"
 from conftest import load_golden

@@ -1,10 +1,11 @@
 """Which ingredient of a captured training step breaks hipGraph instantiation on this stack?  One variant per process:
-python tools/diag/graph_capture_bisect.py <variant>   with variant in base | randn | dropout | adam | big | all"""
+python tests/diag/graph_capture_bisect.py <variant>   with variant in base | randn | dropout | adam | big | all"""
 import copy
 import sys
 import os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests"))
+_ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, _ROOT)
+sys.path.insert(0, os.path.join(_ROOT, "tests"))
 import torch
 import bench
 import model_cases as MC

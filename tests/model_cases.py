@@ -290,7 +290,7 @@ def run_full_model(device, golden, name):
     # assumed: the fp32 oracle (the reference's arithmetic) is re-evaluated with the stem weights scaled by 1 +- 1..2 ulp -- a
     # change of 1e-7 in the truth, but enough to flip the handful of auto-mask ties.  Its worst median / maximum error over
     # that small ensemble is the yardstick (measured on r18_mono: medians 5.1e-4 .. 1.6e-3, the recorded evaluation at the
-    # bottom of the range; the product's own medians over the same perturbations: 4.7e-4 .. 2.9e-3, tools/diag/
+    # bottom of the range; the product's own medians over the same perturbations: 4.7e-4 .. 2.9e-3, tests/diag/
     # gradient_norm_sensitivity.py).
     def fp32_reference_errors(scale):
         c32 = lambda v: v.float() if v.is_floating_point() else v
