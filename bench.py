@@ -210,8 +210,8 @@ def _flush_c_stdio():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=3)   # the allocator settles in step 3 (a 377 ms step with 2)
+    ap.add_argument("--steps", type=int, default=20)    # median over >= 20 timed steps after >= 5 warm-up steps
+    ap.add_argument("--warmup", type=int, default=5)    # (~8 s of device time for cfg3; the allocator settles in step 3)
     ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
