@@ -23,7 +23,12 @@ Design notes
     handed over (one copy per step in either mode; round 2 had two);
   * which parameters are live is agreed on ACROSS ranks (one small MAX all-reduce of a bitmap per step): ranks whose
     losses touched different parameters (a data-dependent branch, a skipped batch) still issue identical collectives
-    instead of hanging;
+    instead of hanging.  When that agreement says "rebuild" in a step in which some rank still holds old buckets back
+    (a gradient that never arrived there), every rank first issues the old buckets it has not started, in index order, so
+    that the old layout's collectives pair up on all ranks before the new layout's are issued;
+  * a bucket member that NO rank produced a gradient for in this step keeps ``p.grad = None`` (as in the single-GPU
+    run: momentum / weight-decay optimizers skip it), everything else receives the average.  ``p.grad`` aliases the
+    bucket until the next step's ``pack``: a gradient kept past the next backward must be cloned by the caller;
   * BatchNorm statistics stay per replica, exactly like N independent runs of the single-GPU reference.
 """
 import contextlib
@@ -89,7 +94,13 @@ class _Bucket:
 
 
 class GradAllReducer:
-    def __init__(self, module, bucket_mb=32.0, process_group=None, overlap=True, always=False):
+    def __init__(self, module, bucket_mb=32.0, process_group=None, overlap=True, always=False, control_group=None):
+        """control_group: a gloo group over the same ranks as ``process_group`` for the per-step agreement.  None creates
+        one with ``dist.new_group`` -- a collective over the DEFAULT group, so every rank of the job must then construct
+        its reducer (or pass a pre-created group when only a sub-group trains); False runs the agreement on
+        ``process_group`` itself with a device tensor (one small device synchronisation per step) -- the agreement then
+        shares a communicator with the bucket all-reduces, so nothing may start from the hooks (ranks that launch a
+        different number of buckets before ``finish()`` would pair a bucket with the bitmap): overlap is switched off."""
         self.module = module
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
@@ -110,13 +121,17 @@ class GradAllReducer:
         # so no device synchronisation, and its collective cannot interleave differently with the bucket all-reduces on
         # different ranks because it lives on another communicator)
         self._ctl = None
-        if self.world > 1:
+        if self.world > 1 and control_group is not None and control_group is not False:
+            self._ctl = control_group
+        elif self.world > 1 and control_group is None:
             ranks = dist.get_process_group_ranks(process_group) if process_group is not None else None
             try:
                 self._ctl = dist.new_group(ranks=ranks, backend="gloo")
-            except Exception as ex:      # no usable TCP interface for gloo: keep going on local decisions (the pre-round-3 behaviour)
-                warnings.warn("GradAllReducer: no gloo control group (%r); ranks that see different parameter sets are not "
-                              "reconciled" % (ex,))
+            except Exception as ex:      # no usable TCP interface for gloo: the agreement then runs on the main group
+                warnings.warn("GradAllReducer: no gloo control group (%r); the per-step agreement runs on the main group "
+                              "(one small device synchronisation per step)" % (ex,))
+        if self.world > 1 and self._ctl is None:
+            self.overlap = False
         self.broadcast_parameters()
 
     @property
@@ -200,31 +215,49 @@ class GradAllReducer:
         rebuild = self.buckets is None or any(p not in self._where for p in live)
         nb = len(self.buckets) if self.buckets is not None else 0
         dirty = [1 if b.dirty else 0 for b in self.buckets] if nb else []
-        if self.world > 1 and self._ctl is not None:
+        touched = [1 if p.grad is not None else 0 for p in cand]      # has a gradient THIS step (on this rank)
+        if self.world > 1:
             # the decision, the parameter set and the dirty buckets must be the same on every rank, or the collectives
-            # diverge and the job hangs: one MAX all-reduce of [rebuild?, has-gradient bitmap, dirty bitmap] per step on the
-            # control channel (CPU tensor, < 1 KB).  Unconditional: a rank cannot know that ANOTHER rank saw a new parameter.
-            flags = torch.tensor([1 if rebuild else 0] + [1 if (p.grad is not None or p in self._where) else 0 for p in cand]
-                                 + dirty, dtype=torch.int32)
-            dist.all_reduce(flags, op=dist.ReduceOp.MAX, group=self._ctl)
+            # diverge and the job hangs: one MAX all-reduce of [rebuild?, ever-had-a-gradient bitmap, has-one-this-step bitmap,
+            # dirty bitmap] per step on the control channel (CPU tensor, a few KB).  Unconditional: a rank cannot know that
+            # ANOTHER rank saw a new parameter.
+            flags = torch.tensor([1 if rebuild else 0] + [1 if (t or p in self._where) else 0 for t, p in zip(touched, cand)]
+                                 + touched + dirty, dtype=torch.int32)
+            if self._ctl is not None:
+                dist.all_reduce(flags, op=dist.ReduceOp.MAX, group=self._ctl)
+            else:                        # no host-side channel: the main group carries it (device tensor for RCCL)
+                dflags = flags.to(cand[0].device) if cand and self.backend == "nccl" else flags
+                dist.all_reduce(dflags, op=dist.ReduceOp.MAX, group=self.group)
+                flags = dflags.cpu()
             self.live_syncs += 1
             fl = flags.tolist()
-            pbits = fl[1:1 + len(cand)]
+            n = len(cand)
+            pbits = fl[1:1 + n]
+            touched = fl[1 + n:1 + 2 * n]
             rebuild = bool(fl[0]) or any(f and p not in self._where for f, p in zip(pbits, cand))
             union = [p for f, p in zip(pbits, cand) if f]
-            dirty = fl[1 + len(cand):]
+            dirty = fl[1 + 2 * n:]
         else:
             union = [p for p in cand if p.grad is not None or p in self._where]
         if not union:
             return                       # nothing has a gradient yet on any rank (e.g. a skipped batch on the first step)
+        touched_ids = {id(p) for t, p in zip(touched, cand) if t}
         if rebuild:
             # first step, or a parameter received its first gradient (on any rank): (re)build the buckets over everything
             # that has ever had a gradient, and reduce this step without overlap
             if self.buckets is not None:
+                # the old layout's collectives must pair up on every rank before the new layout's start: a rank that held
+                # buckets back (a gradient that did not arrive there) issues them now, in index order, like every other
+                # rank did from its hooks; their results are dropped (the local gradients still sit in p.grad)
                 for b in self.buckets:
-                    if b.work is not None:
-                        b.work.wait()
-                        b.work = None
+                    if b.work is None:
+                        for i in range(len(b.params)):
+                            if not b.ready[i]:
+                                b.pack(i)
+                        self._launch(b)
+                for b in self.buckets:
+                    b.work.wait()
+                    b.work = None
             self._build(union)
         # pass 1, index order like the hooks: whatever has not started yet (incomplete because a gradient did not show up in
         # the last backward, held back behind an incomplete one, overlap off, or fresh after a rebuild)
@@ -254,10 +287,12 @@ class GradAllReducer:
             b.work = None
             if inv != 1.0:
                 b.flat.mul_(inv)
-            # every bucket member receives the averaged gradient on every rank (a parameter that had none locally this step
-            # still gets the other ranks' average: replicas stay identical).  No copy back: p.grad is re-pointed at its
-            # slice of the bucket; the optimizer reads the bucket.
+            # every bucket member that had a gradient on SOME rank receives the average on every rank (a parameter that had
+            # none locally still gets the other ranks' average: replicas stay identical); one that no rank touched keeps
+            # grad = None, as in the single-GPU run.  No copy back: p.grad is re-pointed at its slice of the bucket (valid
+            # until the next step packs into it); the optimizer reads the bucket.
             for i, p in enumerate(b.params):
-                p.grad = b.slot(i).view_as(p)
+                if id(p) in touched_ids:
+                    p.grad = b.slot(i).view_as(p)
             b.reset()
         self._next = 0
