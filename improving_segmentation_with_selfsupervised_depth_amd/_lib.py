@@ -9,7 +9,7 @@ from ctypes import c_int, c_long, c_float, c_void_p, c_size_t, c_uint64, c_int64
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SEGSDE_LIB") or os.path.join(_HERE, "libsegsde_hip.so")   # override: kernel experiments
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 _LIB = None
 # Set only by the test-suite when it injects the host-interpreted build of the same kernel sources
@@ -69,6 +69,7 @@ _SIGS = {
     "segsde_maxpool3x3s2_forward": (c_int, [P, c_int, c_int, c_int, c_int, P, P, P]),
     "segsde_maxpool3x3s2_backward": (c_int, [P, P, c_int, c_int, c_int, c_int, P, P]),
     "segsde_upsample2x_backward": (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, c_int, P]),
+    "segsde_upsample2x_forward": (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, c_int, P]),
     "segsde_resize_bilinear_forward": (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, c_int, c_int, c_int, c_int, P]),
     "segsde_resize_bilinear_backward": (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, c_int, c_int, c_int, c_int, P]),
     "segsde_global_avgpool_workspace": (c_size_t, [c_int, c_long, c_int]),
@@ -102,6 +103,13 @@ _SIGS = {
     "segsde_smoothness_workspace": (c_size_t, [c_int, c_int, c_int]),
     "segsde_smoothness_forward": (c_int, [P, P, c_int, c_int, c_int, P, P, P, c_size_t, P]),
     "segsde_smoothness_backward": (c_int, [P, P, P, c_int, c_int, c_int, c_float, P, P, c_size_t, P]),
+    "segsde_smooth_loss_workspace": (c_size_t, [c_int, c_int, c_int]),
+    "segsde_smooth_loss_forward": (c_int, [P, P, c_int, c_int, c_int, P, P, c_size_t, P]),
+    "segsde_smooth_loss_backward": (c_int, [P, P, c_int, c_int, c_int, c_float, P, P, c_size_t, P]),
+    "segsde_ssim_map_forward": (c_int, [P, P, c_int, c_int, c_int, c_int, P, P]),
+    "segsde_ssim_map_backward": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P, P, P]),
+    "segsde_backproject_depth": (c_int, [P, P, c_int, c_int, c_int, P, P]),
+    "segsde_project3d": (c_int, [P, P, P, c_int, c_int, c_int, c_float, P, P]),
     "segsde_cross_entropy_workspace": (c_size_t, [c_long]),
     "segsde_cross_entropy_forward": (c_int, [P, c_int, c_long, c_int, P, c_int64, P, P, P, P, c_size_t, P]),
     "segsde_cross_entropy_backward": (c_int, [P, c_int, c_long, c_int, P, c_int64, P, P, P, P, c_int, P]),

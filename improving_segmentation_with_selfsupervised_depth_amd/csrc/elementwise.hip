@@ -524,6 +524,18 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const float* dy, in
   }
 }
 
+// nearest x2 upsample itself (monodepth_layers.py:202-205 as a stand-alone call; the decoders never materialise it)
+__global__ __launch_bounds__(256) void upsample2x_fwd_kernel(const float* x, int ldx, int B, int h, int w, int C, float* y,
+                                                             int ldy) {
+  const long total = (long)B * 2 * h * 2 * w * C;
+  for (long e = blockIdx.x * 256L + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const int c = (int)(e % C); long t = e / C;
+    const int X = (int)(t % (2 * w)); t /= 2 * w;
+    const int Y = (int)(t % (2 * h)); const int b = (int)(t / (2 * h));
+    y[((long)(b * 2 * h + Y) * 2 * w + X) * ldy + c] = x[((long)(b * h + (Y >> 1)) * w + (X >> 1)) * ldx + c];
+  }
+}
+
 // ------------------------------------------------------------------ bilinear resize (ATen upsample_bilinear2d semantics)
 struct Lerp { int i0, i1; float l0, l1; };
 __device__ __forceinline__ Lerp lerp_src(int dst, int in, int out, int align_corners) {
@@ -1012,6 +1024,13 @@ extern "C" int segsde_upsample2x_backward(const float* dy, int lddy, int B, int 
   if (!dy || !dx) return SEGSDE_ERR_NULL;
   hipLaunchKernelGGL(upsample2x_bwd_kernel, dim3(ew_blocks((long)B * h * w * C)), dim3(256), 0, ST(stream), dy, lddy, B, h,
                      w, C, dx, lddx);
+  SEGSDE_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int segsde_upsample2x_forward(const float* x, int ldx, int B, int h, int w, int C, float* y, int ldy, void* stream) {
+  if (!x || !y) return SEGSDE_ERR_NULL;
+  hipLaunchKernelGGL(upsample2x_fwd_kernel, dim3(ew_blocks((long)B * 4 * h * w * C)), dim3(256), 0, ST(stream), x, ldx, B, h, w, C,
+                     y, ldy);
   SEGSDE_CHECK_LAUNCH();
   return 0;
 }

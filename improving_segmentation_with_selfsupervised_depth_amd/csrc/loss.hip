@@ -1038,6 +1038,60 @@ extern "C" int segsde_smoothness_backward(const float* disp, const float* img, c
   return 0;
 }
 
+// get_smooth_loss(disp, img) by itself (models/monodepth_layers.py:208-221), i.e. WITHOUT the mean normalisation
+// MonodepthLoss puts in front of it: the same kernels with a "mean" m for which (m + 1e-7f) is exactly 1.0f.
+constexpr float SMOOTH_UNIT_MEAN = 0.99999988f;
+static_assert(SMOOTH_UNIT_MEAN + 1e-7f == 1.0f, "the un-normalised smoothness relies on (m + 1e-7f) == 1.0f");
+__global__ __launch_bounds__(64) void fill_kernel(float* p, int n, float v) {
+  if ((int)threadIdx.x < n) p[threadIdx.x] = v;
+}
+__global__ __launch_bounds__(256) void smooth_bwd_plain_kernel(const float* tmp, long HW, float* gdisp) {
+  const int b = blockIdx.y;
+  for (long p = blockIdx.x * 256L + threadIdx.x; p < HW; p += (long)gridDim.x * 256) gdisp[b * HW + p] += tmp[b * HW + p];
+}
+
+extern "C" size_t segsde_smooth_loss_workspace(int B, int h, int w) { return segsde_smoothness_workspace(B, h, w) + 256; }
+
+extern "C" int segsde_smooth_loss_forward(const float* disp, const float* img, int B, int h, int w, float* out, void* ws_,
+                                          size_t ws_bytes, void* stream) {
+  if (!disp || !img || !out || !ws_) return SEGSDE_ERR_NULL;
+  if (B <= 0 || B > 64 || h < 2 || w < 2) return SEGSDE_ERR_SHAPE;
+  if (ws_bytes < segsde_smooth_loss_workspace(B, h, w)) return SEGSDE_ERR_WORKSPACE;
+  const long HW = (long)h * w;
+  const int nb = plane_blocks(HW);
+  float* unit = (float*)ws_;
+  double* part = (double*)((char*)ws_ + 256);
+  hipLaunchKernelGGL(fill_kernel, dim3(1), dim3(64), 0, ST(stream), unit, B, SMOOTH_UNIT_MEAN);
+  SEGSDE_CHECK_LAUNCH();
+  hipLaunchKernelGGL(smooth_fwd_kernel, dim3(nb, B), dim3(256), 64, ST(stream), disp, img, (const float*)unit, h, w, part);
+  SEGSDE_CHECK_LAUNCH();
+  hipLaunchKernelGGL(smooth_finalize_kernel, dim3(1), dim3(256), 512 * sizeof(double), ST(stream), (const double*)part, B * nb,
+                     1.0 / ((double)B * h * (w - 1)), 1.0 / ((double)B * (h - 1) * w), out);
+  SEGSDE_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int segsde_smooth_loss_backward(const float* disp, const float* img, int B, int h, int w, float scale, float* gdisp,
+                                           void* ws_, size_t ws_bytes, void* stream) {
+  if (!disp || !img || !gdisp || !ws_) return SEGSDE_ERR_NULL;
+  if (B <= 0 || B > 64 || h < 2 || w < 2) return SEGSDE_ERR_SHAPE;
+  if (ws_bytes < segsde_smooth_loss_workspace(B, h, w)) return SEGSDE_ERR_WORKSPACE;
+  const long HW = (long)h * w;
+  const int nb = plane_blocks(HW);
+  float* unit = (float*)ws_;
+  double* part = (double*)((char*)ws_ + 256);
+  float* tmp = (float*)((char*)part + (((size_t)B * nb * 2 * sizeof(double) + 63) / 64) * 64);
+  const float sx = scale / ((float)B * h * (w - 1)), sy = scale / ((float)B * (h - 1) * w);
+  hipLaunchKernelGGL(fill_kernel, dim3(1), dim3(64), 0, ST(stream), unit, B, SMOOTH_UNIT_MEAN);
+  SEGSDE_CHECK_LAUNCH();
+  hipLaunchKernelGGL(smooth_bwd_a_kernel, dim3(nb, B), dim3(256), 64, ST(stream), disp, img, (const float*)unit, h, w, sx, sy, tmp,
+                     part);
+  SEGSDE_CHECK_LAUNCH();
+  hipLaunchKernelGGL(smooth_bwd_plain_kernel, dim3(nb, B), dim3(256), 0, ST(stream), (const float*)tmp, HW, gdisp);
+  SEGSDE_CHECK_LAUNCH();
+  return 0;
+}
+
 // ------------------------------------------------------------------------------------------ fused photometric entry points
 // a block walks `tiles` horizontally adjacent tiles so that its (double precision, 24-value) reduction is paid once per
 // strip; strips shrink while the launch would otherwise fall below ~8 blocks per CU

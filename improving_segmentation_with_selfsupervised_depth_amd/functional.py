@@ -119,7 +119,8 @@ class ConvFn(Function):
     """y = act(conv([up2x?(x0) | x1], weight) + bias); geometry in ``g`` (hipops.ConvGeom)."""
 
     @staticmethod
-    def forward(ctx, x0, x1, weight, bias, g, act, stats_out=None, grad_box=None, packs=None, x0_act=None, act_box=None):
+    def forward(ctx, x0, x1, weight, bias, g, act, stats_out=None, grad_box=None, packs=None, x0_act=None, act_box=None,
+                fold_cache=None):
         """stats_out: optional list; receives the BatchNorm statistics partials of y (or None) -- see Conv2d.forward.
         grad_box: optional dict shared with the BNActFn that adds this conv's input as a residual (see SplitFn): when its
         backward has already left the residual-path gradient there, this conv's data-gradient is accumulated onto it.
@@ -146,7 +147,13 @@ class ConvFn(Function):
         else:
             if H.upfold_ok(g, 4 * x0.shape[0] * x0.shape[1] * x0.shape[2]) and x0.is_contiguous() and (x1 is None or x1.is_contiguous()):
                 # decoder Conv3x3 on [upsample(x0) | x1]: the upsample-folded route (4 taps instead of 9 on the upsampled channels)
-                ctx.fold = H.upfold_pack(weight, g.C0)
+                # (the owning module caches the folded packs next to the plain ones for the active weight_pack_scope)
+                if fold_cache is not None and fold_cache.get("key") is not None and fold_cache.get("key") == fold_cache.get("want"):
+                    ctx.fold = fold_cache["fold"]
+                else:
+                    ctx.fold = H.upfold_pack(weight, g.C0)
+                    if fold_cache is not None and fold_cache.get("want") is not None:
+                        fold_cache["fold"], fold_cache["key"] = ctx.fold, fold_cache["want"]
             y = H.conv_forward(g, x0, x1, wp, bias, act, wfold=None if ctx.fold is None else ctx.fold[0])
         ctx.g, ctx.act = g, act
         ctx.in_hw = (x0.shape[1] * (2 if g.up0 else 1), x0.shape[2] * (2 if g.up0 else 1))
@@ -169,8 +176,6 @@ class ConvFn(Function):
             dbias = stash[2] if same else H.colsum(dz)
             fusion("bias_grad_from_activation_pass", bool(same))
         actgrad = (x0, ctx.x0_act) if ctx.x0_act is not None else None
-        if actgrad is not None and ctx.needs_input_grad[0]:
-            fusion("activation_backward_in_dgrad_epilogue", True)
         dx0 = dx1 = dw = None
         if ctx.needs_input_grad[0] or (x1 is not None and ctx.needs_input_grad[1]):
             wd = ctx.wd if ctx.wd is not None else H.pack_weight(weight, True)
@@ -190,13 +195,16 @@ class ConvFn(Function):
                         and dx0.is_contiguous():
                     box["g"] = dx0           # FanoutFn: the next consumer's data-gradient is accumulated onto this tensor
                     box["fused"] = True
+            if actgrad is not None and ctx.needs_input_grad[0]:
+                # counted from what the kernel did: a shape whose epilogue cannot take the derivative ran it as a separate pass
+                fusion("activation_backward_in_dgrad_epilogue", bool(H.ACTGRAD_FUSED[0]))
             if not ctx.needs_input_grad[0]:
                 dx0 = None
             if x1 is None or not ctx.needs_input_grad[1]:
                 dx1 = None
         if ctx.needs_input_grad[2]:
             dw = H.conv_wgrad(g, x0, x1, dz)
-        return dx0, dx1, dw, dbias, None, None, None, None, None, None, None
+        return dx0, dx1, dw, dbias, None, None, None, None, None, None, None, None
 
 
 class ActGradFn(Function):

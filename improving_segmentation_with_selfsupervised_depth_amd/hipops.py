@@ -274,6 +274,9 @@ def conv_forward(g, x0, x1, wpack, bias, act="none", want_stats=False, wfold=Non
     return (y, part) if want_stats else y
 
 
+ACTGRAD_FUSED = [False]      # did the last conv_dgrad(actgrad=...) apply the derivative in its epilogue (functional.py counts from this)
+
+
 def conv_dgrad(g, dy, wdpack, w_oihw, in_hw, need0=True, need1=True, accumulate_into=None, actgrad=None, fold=None):
     """Data gradient(s) of conv_forward w.r.t. (x0, x1).  dy: [B,Ho,Wo,Cout]; in_hw = (H, W) of the virtual input.
     Returns (dx0, dx1); dx0 is at the *stored* resolution of x0 (2x2-summed when g.up0).
@@ -286,6 +289,7 @@ def conv_dgrad(g, dy, wdpack, w_oihw, in_hw, need0=True, need1=True, accumulate_
     B, Ho, Wo, Cout = dy.shape
     H, W = in_hw
     assert Cout == g.Cout
+    ACTGRAD_FUSED[0] = False
     dx1 = torch.empty((B, H, W, g.C1), dtype=torch.float32, device=dy.device) if g.C1 else None
     L = _lib.lib()
     flops = 2.0 * B * Ho * Wo * Cout * g.CinAlg * g.k * g.k
@@ -322,6 +326,7 @@ def conv_dgrad(g, dy, wdpack, w_oihw, in_hw, need0=True, need1=True, accumulate_
         if rc == -4:
             return None, None
         check(rc, "conv2d dgrad (accumulate)")
+        ACTGRAD_FUSED[0] = actgrad is not None
         return acc, None
     if g.up0 and fold is not None and accumulate_into is None:
         # upsample-folded route: low-resolution gradient as a 4x4 stride-2 convolution of dy (+ clamp adjoint on the border),
@@ -339,6 +344,7 @@ def conv_dgrad(g, dy, wdpack, w_oihw, in_hw, need0=True, need1=True, accumulate_
             _p(ag_y) if dx0 is not None else None, ag_ld, ag_kind, _stream(dy)), _tag(g, H, W) + " fold", executed=flops * fr)
         if rc == 0:
             UPFOLD_TAKEN["dgrad"] += 1
+            ACTGRAD_FUSED[0] = actgrad is not None and dx0 is not None
             return dx0, dx1f
         if rc != -4:
             check(rc, "conv2d_dgrad_upfold")
@@ -348,6 +354,7 @@ def conv_dgrad(g, dy, wdpack, w_oihw, in_hw, need0=True, need1=True, accumulate_
         d = desc(1)
         rc = _timed("conv_dgrad", flops, dy, lambda: launch(d, dx0, dx1, actgrad is not None), _tag(g, H, W))
         if rc == 0:
+            ACTGRAD_FUSED[0] = actgrad is not None
             return dx0, dx1
         if rc == -4 and actgrad is not None:
             rc = launch(d, dx0, dx1, False)
@@ -369,6 +376,7 @@ def conv_dgrad(g, dy, wdpack, w_oihw, in_hw, need0=True, need1=True, accumulate_
               "upsample2x_backward")
     else:
         dx0 = full0
+    ACTGRAD_FUSED[0] = fused
     return (dx0 if fused else finish_unfused(dx0)), dx1
 
 
@@ -856,6 +864,67 @@ def smoothness_backward(disp, img, mean, scale, gdisp):
     ws_ = _ws(nb, disp)
     _timed('hbm_smooth_bwd', 24.0 * B * h * w, disp, lambda: check(L.segsde_smoothness_backward(_p(disp.contiguous()), _p(img.contiguous()), _p(mean), B, h, w, float(scale),
                                        _p(gdisp), _p(ws_), nb, _stream(disp)), "smooth_bwd"))
+
+
+def smooth_loss_forward(disp, img):
+    """get_smooth_loss(disp, img) without the mean normalisation (models/monodepth_layers.py:208-221) -> [1]"""
+    B, _, h, w = disp.shape
+    L = _lib.lib()
+    out = torch.empty(1, dtype=torch.float32, device=disp.device)
+    nb = L.segsde_smooth_loss_workspace(B, h, w)
+    ws_ = _ws(nb, disp)
+    check(L.segsde_smooth_loss_forward(_p(_f32(disp.contiguous())), _p(_f32(img.contiguous())), B, h, w, _p(out), _p(ws_), nb,
+                                       _stream(disp)), "smooth_loss_fwd")
+    return out
+
+
+def smooth_loss_backward(disp, img, scale):
+    B, _, h, w = disp.shape
+    L = _lib.lib()
+    g = torch.zeros((B, 1, h, w), dtype=torch.float32, device=disp.device)
+    nb = L.segsde_smooth_loss_workspace(B, h, w)
+    ws_ = _ws(nb, disp)
+    check(L.segsde_smooth_loss_backward(_p(disp.contiguous()), _p(img.contiguous()), B, h, w, float(scale), _p(g), _p(ws_), nb,
+                                        _stream(disp)), "smooth_loss_bwd")
+    return g
+
+
+def ssim_map(x, y):
+    """SSIM.forward (models/monodepth_layers.py:240-254): per-channel clamp((1 - SSIM) / 2, 0, 1) of two [B,C,H,W] images"""
+    B, C, Hh, W = x.shape
+    assert tuple(y.shape) == tuple(x.shape)
+    out = torch.empty((B, C, Hh, W), dtype=torch.float32, device=x.device)
+    check(_lib.lib().segsde_ssim_map_forward(_p(_f32(x.contiguous())), _p(_f32(y.contiguous())), B, C, Hh, W, _p(out),
+                                             _stream(x)), "ssim_map_fwd")
+    return out
+
+
+def ssim_map_backward(x, y, gout, need_x=True, need_y=True):
+    B, C, Hh, W = x.shape
+    gx = torch.empty((B, C, Hh, W), dtype=torch.float32, device=x.device) if need_x else None
+    gy = torch.empty((B, C, Hh, W), dtype=torch.float32, device=x.device) if need_y else None
+    check(_lib.lib().segsde_ssim_map_backward(_p(x.contiguous()), _p(y.contiguous()), _p(_f32(gout.contiguous())), B, C, Hh, W,
+                                              _p(gx), _p(gy), _stream(x)), "ssim_map_bwd")
+    return gx, gy
+
+
+def backproject_depth(depth, inv_K):
+    """BackprojectDepth.forward (models/monodepth_layers.py:169-174): depth [B,1,H,W], inv_K [B,4,4] -> cam_points [B,4,H*W]"""
+    B, _, Hh, W = depth.shape
+    out = torch.empty((B, 4, Hh * W), dtype=torch.float32, device=depth.device)
+    check(_lib.lib().segsde_backproject_depth(_p(_f32(depth.contiguous())), _p(_f32(inv_K.contiguous())), B, Hh, W, _p(out),
+                                              _stream(depth)), "backproject_depth")
+    return out
+
+
+def project3d(points, K, T, Hh, W, eps=1e-7):
+    """Project3D.forward (models/monodepth_layers.py:188-199): points [B,4,H*W] -> sampling grid [B,H,W,2]"""
+    B = points.shape[0]
+    assert tuple(points.shape) == (B, 4, Hh * W)
+    out = torch.empty((B, Hh, W, 2), dtype=torch.float32, device=points.device)
+    check(_lib.lib().segsde_project3d(_p(_f32(points.contiguous())), _p(_f32(K.contiguous())), _p(_f32(T.contiguous())), B, Hh, W,
+                                      float(eps), _p(out), _stream(points)), "project3d")
+    return out
 
 
 # ----------------------------------------------------------------------------------------------

@@ -70,6 +70,32 @@ class LazyOutputs(dict):
         for key, v in dict(*a, **k).items():
             self[key] = v
 
+    def pop(self, key, *default):
+        if key in self._lazy:
+            self.__missing__(key)
+        return dict.pop(self, key, *default)
+
+    def setdefault(self, key, default=None):
+        if key in self:
+            return self[key]
+        self[key] = default
+        return default
+
+    def copy(self):
+        """a plain dict of everything (the lazy entries are computed)"""
+        return dict(dict.items(self.materialize()))
+
+    def __eq__(self, other):
+        return dict.__eq__(self.materialize(), other.materialize() if isinstance(other, LazyOutputs) else other)
+
+    def __ne__(self, other):
+        return not self.__eq__(other)
+
+    __hash__ = None
+
+    def __reduce__(self):
+        return (dict, (self.copy(),))               # pickles as the plain dict it stands for
+
 
 def _one(dev):
     if dev not in _ONES:
@@ -192,8 +218,11 @@ class MonodepthLoss:
                                                     inputs[("color", f, 0)], self.min_depth, self.max_depth,
                                                     want_grid=not lazy, want_depth=(i == 0 and not lazy))
                 if lazy:
-                    def fill(disp=disp, T=T, f=f, s=s, i=i):
-                        _, g_, d_ = H.warp_forward(disp, inputs[("inv_K", 0)], inputs[("K", 0)], T, inputs[("color", f, 0)],
+                    # the thunk holds the very tensors this launch read (not the `inputs` dict: a caller that re-fills the
+                    # dict for the next batch must not change what a later access computes); they stay alive with `outputs`
+                    def fill(disp=disp, T=T, f=f, s=s, i=i, invK=inputs[("inv_K", 0)], K=inputs[("K", 0)],
+                             src=inputs[("color", f, 0)]):
+                        _, g_, d_ = H.warp_forward(disp, invK, K, T, src,
                                                    self.min_depth, self.max_depth, want_grid=True, want_depth=(i == 0))
                         dict.__setitem__(outputs, ("sample", f, s), g_)
                         outputs._lazy.pop(("sample", f, s), None)

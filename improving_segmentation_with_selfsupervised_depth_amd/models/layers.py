@@ -71,6 +71,7 @@ class Conv2d(nn.Conv2d):
         super().__init__(int(in_channels), int(out_channels), kernel_size, stride, padding, dilation, bias=bias)
         self.reflect = reflect
         self._pack_key, self._packs = None, None   # weight packs of the current weight version (see _weight_packs)
+        self._fold_cache = {}         # upsample-folded packs of the same weight version (filled by ConvFn inside a pack scope)
         self._stats_wanted = None     # None: unknown yet, True: a BatchNorm consumed the fused statistics, False: nobody did
         self._stats_offered = False
         k = self.kernel_size[0]
@@ -146,7 +147,9 @@ class Conv2d(nn.Conv2d):
         if act == "none":
             return Fn.ConvFn.apply(x, skip, weight, self.bias, g, act, None, grad_box, packs, x0_act)
         box = {"need_dbias": self.bias is not None and self.bias.requires_grad}
-        yz = Fn.ConvFn.apply(x, skip, weight, self.bias, g, act, None, grad_box, packs, x0_act, box)
+        fc = self._fold_cache
+        fc["want"] = (_PACK_SCOPE[0], weight._version, weight.data_ptr(), weight.device, c0) if (_PACK_SCOPE[0] and up) else None
+        yz = Fn.ConvFn.apply(x, skip, weight, self.bias, g, act, None, grad_box, packs, x0_act, box, fc)
         if not (torch.is_grad_enabled() and yz.requires_grad):
             return yz
         y = Fn.ActGradFn.apply(yz, act, box)

@@ -8,6 +8,7 @@ import torch
 from torch import nn
 
 from .. import functional as Fn
+from .. import hipops as H
 from .layers import Conv2d, BatchNorm2d
 
 
@@ -66,3 +67,112 @@ class ConvBlock(nn.Module):
             keep = torch.bernoulli(torch.full((B, C), 1.0 - drop.p, device=y.device))
             y = Fn.ChannelDropFn.apply(y, keep / (1.0 - drop.p) if drop.p < 1 else keep)
         return y
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# The remaining public names of the reference module (monodepth_layers.py:48-105, 145-254).  Only the reference's own
+# loss/monodepth_loss.py imports them; this package's MonodepthLoss runs the same arithmetic inside its fused kernels.  They are
+# kept as thin callables on device kernels so that a user script importing them by name still works (NCHW tensors in and
+# out, like the reference).  SSIM and get_smooth_loss are differentiable; BackprojectDepth / Project3D return detached
+# tensors (gradients through the warp are what MonodepthLoss.compute_losses provides).
+# ----------------------------------------------------------------------------------------------------------------------
+def get_translation_matrix(translation_vector):
+    """reference :50-63: [B,1,1,3] / [B,3] translation -> [B,4,4]"""
+    t = translation_vector.contiguous().view(-1, 1, 1, 3)
+    return Fn.PoseMatrixFn.apply(torch.zeros_like(t), t, False)
+
+
+def rot_from_axisangle(vec):
+    """reference :66-105: axis-angle [B,1,3] -> [B,4,4] rotation"""
+    v = vec.contiguous().view(-1, 1, 1, 3)
+    return Fn.PoseMatrixFn.apply(v, torch.zeros_like(v), False)
+
+
+class BackprojectDepth(nn.Module):
+    """reference :145-174: depth image -> homogeneous camera points [B,4,H*W]"""
+
+    def __init__(self, batch_size, height, width):
+        super().__init__()
+        self.batch_size, self.height, self.width = batch_size, height, width
+
+    def forward(self, depth, inv_K):
+        return H.backproject_depth(depth.detach().reshape(self.batch_size, 1, self.height, self.width), inv_K.detach())
+
+
+class Project3D(nn.Module):
+    """reference :177-199: camera points -> normalised sampling grid [B,H,W,2] for intrinsics K at pose T"""
+
+    def __init__(self, batch_size, height, width, eps=1e-7):
+        super().__init__()
+        self.batch_size, self.height, self.width, self.eps = batch_size, height, width, eps
+
+    def forward(self, points, K, T):
+        return H.project3d(points.detach(), K.detach(), T.detach(), self.height, self.width, self.eps)
+
+
+class _UpsampleFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        from .. import _lib
+        B, Hh, W, C = x.shape
+        y = torch.empty((B, 2 * Hh, 2 * W, C), dtype=torch.float32, device=x.device)
+        H.check(_lib.lib().segsde_upsample2x_forward(H._p(H._f32(x)), H.nhwc_ld(x), B, Hh, W, C, H._p(y), C, H._stream(x)),
+                "upsample2x_forward")
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        g = Fn._c(g)
+        B, H2, W2, C = g.shape
+        dx = torch.empty((B, H2 // 2, W2 // 2, C), dtype=torch.float32, device=g.device)
+        from .. import _lib
+        H.check(_lib.lib().segsde_upsample2x_backward(H._p(g), H.nhwc_ld(g), B, H2 // 2, W2 // 2, C, H._p(dx), C, H._stream(g)),
+                "upsample2x_backward")
+        return dx
+
+
+def upsample(x):
+    """reference :202-205: nearest x2 of an NCHW-logical tensor.  (Inside the decoders the upsampling never materialises: the
+    convolution's tile loader reads the low-resolution tensor, models/depth_decoder.py.)"""
+    return Fn.to_nchw(_UpsampleFn.apply(Fn._c(Fn.to_nhwc(x))))
+
+
+class _SmoothFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, disp, img):
+        ctx.save_for_backward(disp, img)
+        return H.smooth_loss_forward(disp, img).reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        disp, img = ctx.saved_tensors
+        return H.smooth_loss_backward(disp, img, 1.0) * g, None
+
+
+def get_smooth_loss(disp, img):
+    """reference :208-221: edge-aware smoothness of ``disp`` [B,1,h,w] under ``img`` [B,3,h,w] (no gradient to ``img``:
+    the reference's callers pass the input frame)"""
+    return _SmoothFn.apply(disp.float().contiguous(), img.detach().float().contiguous())
+
+
+class _SSIMFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, y):
+        ctx.save_for_backward(x, y)
+        return H.ssim_map(x, y)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, y = ctx.saved_tensors
+        return H.ssim_map_backward(x, y, g, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+
+
+class SSIM(nn.Module):
+    """reference :224-254: per-channel SSIM loss map of two images (3x3 mean windows over the reflection-padded planes)"""
+
+    def __init__(self):
+        super().__init__()
+        self.C1, self.C2 = 0.01 ** 2, 0.03 ** 2
+
+    def forward(self, x, y):
+        return _SSIMFn.apply(x.float().contiguous(), y.float().contiguous())

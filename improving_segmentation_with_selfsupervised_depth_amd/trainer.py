@@ -14,7 +14,8 @@ from . import hipops as H
 from .loss.loss import cross_entropy2d
 
 __all__ = ["extract_ema_params", "EmaUpdater", "update_ema_variables", "calc_pseudo_label_loss", "teacher_softmax",
-           "normalize_online_depth", "generate_mix_mask", "train_step_segmentation_unlabeled"]
+           "normalize_online_depth", "generate_mix_mask", "train_step_segmentation_unlabeled", "create_ema_model", "extract_param_dict",
+           "get_params", "get_train_params", "train_step"]
 
 
 def extract_ema_params(model, ema_model, model_names):
@@ -240,3 +241,156 @@ def train_step_segmentation_unlabeled(model, ema_model, monodepth_loss_calculato
     train_step_segmentation_unlabeled.last = {"MixMask": MixMask, "depths": depths, "pseudo_label": pseudo_label,
                                               "softmax_u_w": softmax_u_w, "inputs_u_s": inputs_u_s}   # debug images :726-744
     return L_2 + L_1, mono_loss
+
+
+# ----------------------------------------------------------------------------------------------
+# the labeled step around it (train.py:39-101, 442-549)
+# ----------------------------------------------------------------------------------------------
+def extract_param_dict(model):
+    """train.py:42-53: sub-model name -> parameters; a PAD decoder stands for both "segmentation" and "depth" """
+    from .models.joint_segmentation_depth_decoder import PAD
+    out, pad = {}, False
+    for name, sub in model.models.items():
+        if isinstance(sub, PAD):
+            out["segmentation"], out["depth"], pad = sub.segmentation_params(), sub.depth_params(), True
+        elif not (pad and name in ("depth", "segmentation")):
+            out[name] = sub.parameters()
+    return out
+
+
+def create_ema_model(model, cfg, n_classes):
+    """``Trainer.create_ema_model`` (train.py:328-344): a second model without pose networks whose (selected) parameters
+    start as detached copies of the student's"""
+    from copy import deepcopy
+    from .models import get_model
+    ema_cfg = deepcopy(cfg["model"])
+    ema_cfg["disable_pose"] = True
+    ema_model = get_model(ema_cfg, n_classes)
+    mp, mcp = _select(model, ema_model, cfg["training"]["save_monodepth_ema"], cfg["model"]["segmentation_name"],
+                      cfg["model"]["freeze_backbone"])
+    mp, mcp = list(mp), list(mcp)
+    assert len(mp) == len(mcp), f"len(mp)={len(mp)}; len(mcp)={len(mcp)}"
+    with torch.no_grad():
+        for src, dst in zip(mp, mcp):
+            dst.detach_()
+            dst.data = src.detach().to(dst.device).clone()
+    return ema_model
+
+
+def get_params(model, submodules):
+    """train.py:56-64"""
+    table = extract_param_dict(model)
+    for sm in submodules:
+        assert sm in table, f"{sm} not in {table.keys()}"
+    return [p for name, ps in table.items() if name in submodules for p in ps]
+
+
+def get_train_params(model, cfg):
+    """train.py:67-101: optimizer parameter groups from ``backbone_lr`` / ``pose_lr`` / ``depth_lr`` / ``segmentation_lr``"""
+    opt, rest, groups = cfg["training"]["optimizer"], extract_param_dict(model), []
+    if "backbone_lr" in opt:
+        groups.append({"params": rest.pop("encoder"), "lr": opt["backbone_lr"]})
+    if "pose_lr" in opt and "pose_encoder" in model.models:
+        groups.append({"params": [*rest.pop("pose_encoder"), *rest.pop("pose")], "lr": opt["pose_lr"]})
+    for key, name in (("depth_lr", "depth"), ("segmentation_lr", "segmentation")):
+        if key in opt:
+            groups.append({"params": rest.pop(name), "lr": opt[key]})
+    if not groups:
+        return model.parameters()
+    groups.append({"params": [p for ps in rest.values() for p in ps]})
+    return groups
+
+
+def train_step(model, optimizer, inputs, step, cfg, loss_fn, monodepth_loss_calculator, ema_model=None, scheduler=None,
+               unlabeled_inputs=None, reducer=None, mIoU=0):
+    """``Trainer.train_step`` (train.py:442-549) as a free function over the objects the method reads from ``self``
+    (``cfg`` is the same nested dict; ``unlabeled_inputs`` the batch the method draws from its unlabeled loader when
+    ``cfg["training"]["unlabeled_segmentation"]`` is set).  Same order of forward / ``backward()`` calls, gradient clipping,
+    optimizer / scheduler step and EMA update; returns the same dict of detached losses.  fp32 only (``amp: False``, as in
+    every shipped non-dec6 config).  ``reducer`` (ddp.GradAllReducer): every backward but the step's last runs under
+    ``no_sync()`` and ``finish()`` is called before the clipping."""
+    import contextlib
+    from .loss.loss import berhu
+    tr = cfg["training"]
+    if tr.get("amp", False):
+        raise NotImplementedError("amp: True is the reference's separate mixed-precision mode; this path computes in fp32")
+    unl = tr.get("unlabeled_segmentation", None)
+    dev = next(model.parameters()).device
+    model.train()
+    if ema_model is not None:
+        ema_model.train()
+    for k, v in inputs.items():
+        if torch.is_tensor(v):
+            inputs[k] = v.to(dev, non_blocking=True)
+    if unl is not None:
+        for k in unlabeled_inputs.keys():
+            if torch.is_tensor(unlabeled_inputs[k]):
+                unlabeled_inputs[k] = unlabeled_inputs[k].to(dev, non_blocking=True)
+    optimizer.zero_grad()
+    zero = torch.tensor(0)
+    segmentation_loss = segmentation_total = mono_loss = feat_dist_loss = mono_total = pseudo_depth_loss = zero
+    if cfg["model"].get("freeze_backbone_bn", False):
+        for m in model.models["encoder"].modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.train(False)
+    do_mono, do_seg = tr["monodepth_lambda"] > 0, tr["segmentation_lambda"] > 0
+    do_pd = tr.get("pseudo_depth_lambda", 0) > 0
+
+    def hold(last):           # all but the last backward() of the step keep the gradient all-reduce back
+        return reducer.no_sync() if (reducer is not None and not last) else contextlib.nullcontext()
+
+    outputs = model(inputs)
+    if do_mono:
+        monodepth_loss_calculator.generate_images_pred(inputs, outputs)
+        mono_loss = tr["monodepth_lambda"] * monodepth_loss_calculator.compute_losses(inputs, outputs)["loss"]
+        if tr["feat_dist_lambda"] > 0:
+            feat_dist_loss = tr["feat_dist_lambda"] * torch.dist(outputs["encoder_features"], outputs["imnet_features"], p=2)
+        mono_total = mono_loss + feat_dist_loss
+        with hold(not (do_pd or do_seg)):
+            mono_total.backward(retain_graph=True)
+    if do_pd:
+        with torch.no_grad():      # the bottom tenth of the frame (the ego vehicle) does not count, train.py:491-494
+            keep = torch.ones(outputs["disp", 0].shape, device=dev)
+            keep[:, :, int(outputs["disp", 0].shape[2] * 0.9):, :] = 0
+        pseudo_depth_loss = berhu(outputs["disp", 0], inputs["pseudo_depth"], keep) * tr["pseudo_depth_lambda"]
+        with hold(not do_seg):
+            pseudo_depth_loss.backward(retain_graph=True)
+    if do_seg:
+        segmentation_loss = loss_fn(input=outputs["semantics"], target=inputs["lbl"])
+        if "intermediate_semantics" in outputs:
+            segmentation_loss = (segmentation_loss + loss_fn(input=outputs["intermediate_semantics"], target=inputs["lbl"])) / 2
+        segmentation_loss = segmentation_loss * tr["segmentation_lambda"]
+        segmentation_total = segmentation_loss
+        with hold(unl is None):
+            segmentation_total.backward()
+        if unl is not None:
+            u_loss, u_mono = train_step_segmentation_unlabeled(
+                model, ema_model, monodepth_loss_calculator, unlabeled_inputs, mix_mask=unl.get("mix_mask", None),
+                depthmix_online_depth=unl.get("depthmix_online_depth", False), monodepth_lambda=tr["monodepth_lambda"],
+                consistency_weight=unl["consistency_weight"], backward_first_pseudo_label=unl["backward_first_pseudo_label"],
+                depthcomp_margin=unl["depthcomp_margin"], depthcomp_foreground_threshold=unl["depthcomp_foreground_threshold"],
+                color_jitter=unl.get("color_jitter"), blur=unl.get("blur"), reducer=reducer,
+                mix_use_gt=unl.get("mix_use_gt", False))
+            segmentation_total = segmentation_total + u_loss
+            mono_total = mono_total + u_mono
+    if reducer is not None:
+        reducer.finish()
+    if tr.get("clip_grad_norm") is not None:
+        clipped = get_params(model, ["encoder", "segmentation"]) if tr.get("disable_depth_grad_clip", False) \
+            else model.parameters()
+        torch.nn.utils.clip_grad_norm_(clipped, tr["clip_grad_norm"])
+    optimizer.step()
+    if scheduler is not None:
+        if isinstance(scheduler, torch.optim.lr_scheduler.ReduceLROnPlateau):
+            scheduler.step(metrics=mIoU)
+        else:
+            scheduler.step()
+    if ema_model is not None:
+        update_ema_variables(ema_model, model, 0.99, step, save_monodepth_ema=tr["save_monodepth_ema"],
+                             segmentation_name=cfg["model"]["segmentation_name"],
+                             freeze_backbone=cfg["model"]["freeze_backbone"])
+    total = segmentation_total + mono_total + pseudo_depth_loss
+    return {"segmentation_loss": segmentation_loss.detach(), "mono_loss": mono_loss.detach(),
+            "pseudo_depth_loss": pseudo_depth_loss.detach(), "feat_dist_loss": feat_dist_loss.detach(),
+            "segmentation_total_loss": segmentation_total.detach(), "mono_total_loss": mono_total.detach(),
+            "total_loss": total.detach()}

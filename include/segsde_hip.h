@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SEGSDE_ABI_VERSION 9
+#define SEGSDE_ABI_VERSION 10
 
 enum { SEGSDE_ERR_NULL = -1, SEGSDE_ERR_SHAPE = -2, SEGSDE_ERR_WORKSPACE = -3, SEGSDE_ERR_UNSUPPORTED = -4 };
 enum { SEGSDE_ACT_NONE = 0, SEGSDE_ACT_RELU = 1, SEGSDE_ACT_ELU = 2, SEGSDE_ACT_SIGMOID = 3 };
@@ -196,6 +196,8 @@ int segsde_maxpool3x3s2_forward(const float* x, int B, int H, int W, int C, floa
 int segsde_maxpool3x3s2_backward(const float* dy, const uint8_t* idx, int B, int H, int W, int C, float* dx, void* stream);
 /* adjoint of the nearest x2 upsample (models/monodepth_layers.py:202-205): dx[h,w] = sum of the 2x2 block of dy */
 int segsde_upsample2x_backward(const float* dy, int lddy, int B, int h, int w, int C, float* dx, int lddx, void* stream);
+/* upsample(x) of models/monodepth_layers.py:202-205 as a stand-alone call: x [B,h,w,C] -> y [B,2h,2w,C] */
+int segsde_upsample2x_forward(const float* x, int ldx, int B, int h, int w, int C, float* y, int ldy, void* stream);
 /* F.interpolate(mode="bilinear") and its adjoint, NHWC (joint_segmentation_depth_decoder.py:64-65,72-73,173-180;
  * torchvision ASPPPooling; loss/loss.py:22-23 with align_corners=1; loss/monodepth_loss.py:72-73 with C=1). */
 int segsde_resize_bilinear_forward(const float* x, int ldx, int B, int Hi, int Wi, int C, float* y, int ldy, int Ho, int Wo,
@@ -277,6 +279,23 @@ int segsde_smoothness_forward(const float* disp, const float* img, int B, int h,
                               void* workspace, size_t workspace_bytes, void* stream);
 int segsde_smoothness_backward(const float* disp, const float* img, const float* mean_disp, int B, int h, int w,
                                float scale, float* gdisp, void* workspace, size_t workspace_bytes, void* stream);
+
+/* The same layers by themselves, for callers outside the training path (a script that imports them by name from
+ * models/monodepth_layers.py): get_smooth_loss WITHOUT the mean normalisation (monodepth_layers.py:208-221; gdisp is
+ * accumulated into), SSIM.forward -> the per-channel loss map clamp((1 - SSIM) / 2, 0, 1) and its adjoint w.r.t. both
+ * images (:224-254; gx / gy may be NULL), BackprojectDepth.forward -> cam_points [B,4,H*W] (:169-174) and
+ * Project3D.forward -> pix_coords [B,H,W,2] in [-1, 1] (:188-199). */
+size_t segsde_smooth_loss_workspace(int B, int h, int w);
+int segsde_smooth_loss_forward(const float* disp, const float* img, int B, int h, int w, float* out, void* workspace,
+                               size_t workspace_bytes, void* stream);
+int segsde_smooth_loss_backward(const float* disp, const float* img, int B, int h, int w, float scale, float* gdisp,
+                                void* workspace, size_t workspace_bytes, void* stream);
+int segsde_ssim_map_forward(const float* x, const float* y, int B, int C, int H, int W, float* out, void* stream);
+int segsde_ssim_map_backward(const float* x, const float* y, const float* gout, int B, int C, int H, int W, float* gx,
+                             float* gy, void* stream);
+int segsde_backproject_depth(const float* depth, const float* inv_K, int B, int H, int W, float* cam_points, void* stream);
+int segsde_project3d(const float* points, const float* K, const float* T, int B, int H, int W, float eps, float* pix_coords,
+                     void* stream);
 
 /* ------------------------------------------------------------------------------------------------ *
  * Segmentation loss and DepthMix / ClassMix (loss/loss.py:17-37, loader/transformsgpu.py:33-47,     *

@@ -1,4 +1,4 @@
-// TEST INFRASTRUCTURE ONLY -- a tiny single-threaded *interpreter* for HIP kernels.
+// TEST INFRASTRUCTURE ONLY -- a tiny *interpreter* for HIP kernels (blocks of a launch are spread over a few host threads).
 //
 // The build container has no GPU.  To check index math, LDS staging, barriers
 // and MFMA/shuffle lane layouts of the real kernel sources (csrc/*.hip) BEFORE
@@ -20,6 +20,10 @@
 #include <functional>
 #include <vector>
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 
 #define __global__
 #define __device__
@@ -45,7 +49,7 @@ inline hipError_t hipMemset(void* p, int v, size_t n) { memset(p, v, n); return 
 inline hipError_t hipMalloc(void** p, size_t n) { *p = malloc(n); return *p ? 0 : 2; }
 inline hipError_t hipGetDevice(int* d) { *d = 0; return 0; }
 inline hipError_t hipDeviceSynchronize() { return 0; }
-inline void __threadfence() {}
+inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 enum hipMemcpyKind { hipMemcpyDeviceToDevice = 3 };
 inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memmove(d, s, n); return 0; }
 
@@ -70,8 +74,19 @@ struct State {
   Barrier block_bar; std::vector<Barrier> wave_bar; std::function<void()> body;
   // rendezvous scratch per wave
   std::vector<float> xa, xb; std::vector<double> xd; std::vector<long long> xi;
+  unsigned char* lds = nullptr;     // this host thread's 160 KB of "LDS" (one block runs per host thread at a time)
 };
-inline State& S() { static State s; return s; }
+// one interpreter state per host thread (the blocks of a launch are dealt out to a small pool, see launch()); the TLS slot
+// holds a plain pointer, so an access is a load + a predictable branch
+inline State*& tls_state() { static thread_local State* p = nullptr; return p; }
+inline State& S() {
+  State* p = tls_state();
+  if (__builtin_expect(!p, 0)) {
+    p = new State; p->lds = static_cast<unsigned char*>(aligned_alloc(64, 160 * 1024)); memset(p->lds, 0, 160 * 1024);
+    tls_state() = p;
+  }
+  return *p;
+}
 static const size_t STACK = 256 * 1024;
 inline void yield() { State& s = S(); swapcontext(&s.cur->ctx, &s.sched); }
 inline void barrier_wait(Barrier* b) {
@@ -114,15 +129,53 @@ inline void run_block(int nthreads) {
     if (progressed) idle_rounds = 0;
   }
 }
+// Host-thread pool: the blocks of one launch are independent (what they share goes through integer atomics, fences or the
+// next launch), so they are dealt out block by block to SEGSDE_EMU_THREADS host threads (default: the cores, at most 8;
+// 1 = the old single-threaded behaviour).  A launch returns when all its blocks are done, like a synchronous stream.
+struct Pool {
+  std::mutex m; std::condition_variable cv_job, cv_done; std::vector<std::thread> th;
+  std::function<void()> body; dim3 grid, block; std::atomic<unsigned> next{0}; unsigned total = 0; int pending = 0;
+  unsigned long gen = 0; int nthreads = 0;
+  static void work(Pool* p) {
+    State& s = S(); s.gdim = p->grid; s.bdim = p->block; s.body = p->body;
+    const unsigned gx = p->grid.x, gy = p->grid.y;
+    for (unsigned i; (i = p->next.fetch_add(1)) < p->total;) {
+      s.bid = dim3(i % gx, (i / gx) % gy, i / (gx * gy)); run_block(p->nthreads);
+    }
+    s.body = nullptr;
+  }
+  static void loop(Pool* p) {
+    unsigned long seen = 0;
+    for (;;) {
+      { std::unique_lock<std::mutex> l(p->m); p->cv_job.wait(l, [&] { return p->gen != seen; }); seen = p->gen; }
+      work(p);
+      { std::lock_guard<std::mutex> l(p->m); if (--p->pending == 0) p->cv_done.notify_one(); }
+    }
+  }
+};
+inline Pool& pool() {
+  static Pool* p = [] {
+    Pool* q = new Pool;                      // never destroyed: the workers live until the process exits
+    const char* e = getenv("SEGSDE_EMU_THREADS");
+    int n = e ? atoi(e) : (int)std::min(8u, std::max(1u, std::thread::hardware_concurrency()));
+    for (int i = 1; i < n; ++i) { q->th.emplace_back(Pool::loop, q); q->th.back().detach(); }
+    return q;
+  }();
+  return *p;
+}
 template <class K, class... A>
 inline void launch(K kernel, dim3 grid, dim3 block, size_t smem, hipStream_t, A... args) {
-  State& s = S(); s.gdim = grid; s.bdim = block;
   if (smem > 160 * 1024) { fprintf(stderr, "hipemu: %zu B of LDS requested\n", smem); abort(); }
-  int nthreads = block.x * block.y * block.z;
-  s.body = [=]() { kernel(args...); };
-  for (unsigned z = 0; z < grid.z; ++z) for (unsigned y = 0; y < grid.y; ++y) for (unsigned x = 0; x < grid.x; ++x) {
-    s.bid = dim3(x, y, z); run_block(nthreads);
-  }
+  Pool& p = pool();
+  p.grid = grid; p.block = block; p.nthreads = block.x * block.y * block.z;
+  p.total = grid.x * grid.y * grid.z; p.next = 0;
+  p.body = [=]() { kernel(args...); };
+  const bool fan = !p.th.empty() && p.total > 1;
+  if (fan) { std::lock_guard<std::mutex> l(p.m); p.pending = (int)p.th.size(); ++p.gen; }
+  if (fan) p.cv_job.notify_all();
+  Pool::work(&p);
+  if (fan) { std::unique_lock<std::mutex> l(p.m); p.cv_done.wait(l, [&] { return p.pending == 0; }); }
+  p.body = nullptr;
 }
 inline int lane() { return S().cur->lin & 63; }
 inline int wave() { return S().cur->lin >> 6; }
@@ -145,8 +198,7 @@ template <class T, class U> inline T shfl_idx(T v, U srcf) {
 #define gridDim (emu::S().gdim)
 #define hipLaunchKernelGGL(kernel, grid, block, smem, stream, ...) emu::launch(kernel, dim3(grid), dim3(block), smem, stream, ##__VA_ARGS__)
 
-alignas(16) inline unsigned char emu_lds[160 * 1024];
-#define SEGSDE_SMEM unsigned char* const segsde_smem = ::emu_lds
+#define SEGSDE_SMEM unsigned char* const segsde_smem = ::emu::S().lds
 // raw buffer loads: range-checked against num_records on the per-lane offset, zeros when out of range
 #define SEGSDE_BUFFER_OPS 1
 #define SEGSDE_OPAQUE(x) ((void)(x))
@@ -167,10 +219,10 @@ inline void segsde_buffer_store4(segsde_rsrc r, unsigned voff, unsigned soff, fl
 
 // LDS-DMA flavour: lane l's 16 bytes land at lds_wave_base + 16*l (executed synchronously here: the interpreter cannot
 // model a missing wait, only wrong addresses / wrong buffer hand-over order)
-inline unsigned segsde_lds_addr(const void* p) { return (unsigned)(static_cast<const unsigned char*>(p) - ::emu_lds); }
+inline unsigned segsde_lds_addr(const void* p) { return (unsigned)(static_cast<const unsigned char*>(p) - ::emu::S().lds); }
 inline void segsde_buffer_load4_lds(segsde_rsrc r, unsigned voff, unsigned soff, unsigned lds_wave_addr) {
   const float4 v = segsde_buffer_load4(r, voff, soff);
-  memcpy(::emu_lds + lds_wave_addr + 16 * emu::lane(), &v, sizeof(v));
+  memcpy(::emu::S().lds + lds_wave_addr + 16 * emu::lane(), &v, sizeof(v));
 }
 inline void segsde_wait_vmcnt0() {}
 template <int N> inline void segsde_wait_vmcnt() {}
@@ -193,9 +245,9 @@ inline int __all(int pred) {
 inline int __any(int pred) { return !__all(!pred); }
 inline float atomicAdd(float* p, float v) { float o = *p; *p = o + v; return o; }
 inline double atomicAdd(double* p, double v) { double o = *p; *p = o + v; return o; }
-inline int atomicAdd(int* p, int v) { int o = *p; *p = o + v; return o; }
-inline unsigned atomicAdd(unsigned* p, unsigned v) { unsigned o = *p; *p = o + v; return o; }
-inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) { unsigned long long o = *p; *p = o + v; return o; }
+inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
+inline unsigned atomicAdd(unsigned* p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
+inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
 inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
 inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
 inline float __expf(float x) { return expf(x); }

@@ -120,3 +120,46 @@ def test_launch_bracketing_samples_every_site_once(monkeypatch):
         g = H.ConvGeom(2048, 256, 3, 1, dil, dil, False, 0, False)
         assert abs(H._live_tap_frac(g, 32, 64) - want) < 1e-9 and abs(H._live_tap_frac(g, 32, 64, wgrad=True) - want) < 1e-9
     assert H._live_tap_frac(H.ConvGeom(256, 256, 3, 1, 1, 1, False, 0, False), 32, 64) == 1.0
+
+
+def test_signatures_match_reference():
+    """tests/golden/signatures.json = ``inspect.signature`` of every constructor / function / method of the drop-in boundary as
+    the reference defines it (tests/golden/make_signatures.py imports /root/reference).  The package's object must take the
+    same parameters, in the same order, with the same defaults; it may add trailing parameters only if they have defaults
+    (``skip`` / ``up`` of the decoder blocks, test hooks of the augmentations) -- every reference call site keeps working."""
+    import importlib
+    import inspect
+    import json
+    from conftest import GOLDEN
+    ref = json.load(open(os.path.join(GOLDEN, "signatures.json")))
+    assert len(ref) >= 50
+    extras, bad = {}, []
+    for key, want in sorted(ref.items()):
+        mod, name = key.split(":")
+        obj = importlib.import_module("improving_segmentation_with_selfsupervised_depth_amd." + mod)
+        try:
+            for part in name.split("."):
+                obj = getattr(obj, part)
+        except AttributeError:
+            bad.append((key, "missing"))
+            continue
+        got = inspect.signature(obj)
+        if str(got) == want:
+            continue
+        # same leading parameters (name, kind, default), extras defaulted
+        wp = want.strip()[1:-1]
+        gp = list(got.parameters.values())
+        n_ref = len(inspect.signature(eval("lambda " + wp.replace("self", "self_") + ": 0")).parameters) if wp else 0
+        lead = str(inspect.Signature(gp[:n_ref]))
+        rest = gp[n_ref:]
+        if lead.replace("self_", "self") != want or any(p.default is inspect.Parameter.empty and p.kind not in
+                                                           (p.VAR_KEYWORD, p.VAR_POSITIONAL) for p in rest):
+            bad.append((key, want, str(got)))
+        else:
+            extras[key] = [p.name for p in rest]
+    assert not bad, bad
+    print("wider than the reference:", extras)
+    # the only places where the package's signature is wider than the reference's
+    assert set(extras) <= {"models.monodepth_layers:ConvBlock.forward", "models.monodepth_layers:Conv3x3.forward",
+                           "loader.transformsgpu:color_jitter", "loader.transformsgpu:gaussian_blur",
+                           "models.model_parts:ASPP.forward", "models.model_parts:SelfAttention.forward"}, extras

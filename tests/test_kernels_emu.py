@@ -98,3 +98,7 @@ def test_residual_gradient_fusion():
 
 def test_loss_kernels(golden):
     KC.run_loss_kernel_cases("cpu", golden)
+
+
+def test_monodepth_layer_callables(golden):
+    KC.run_monodepth_layer_callables("cpu", golden)

@@ -155,3 +155,7 @@ def test_cpu_tensor_is_rejected():
     from improving_segmentation_with_selfsupervised_depth_amd import hipops as H
     with pytest.raises(RuntimeError):
         H.colsum(torch.zeros(4, 4))
+
+
+def test_monodepth_layer_callables(golden):
+    KC.run_monodepth_layer_callables("cuda", golden)

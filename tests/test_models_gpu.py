@@ -454,3 +454,46 @@ def test_hip_graph_replay_matches_eager_steps():
         d = float((pe - pg).abs().max())
         worst = max(worst, d / (float(pe.abs().max()) + 1e-30))
     assert worst <= 1e-6, worst
+
+
+@pytest.mark.parametrize("scenario", ["joint", "depthmix"])
+def test_train_step_replay_vs_reference_caller(scenario):
+    """VERDICT r3 item 5a.  tests/golden/trainstep.npz holds what the reference's OWN ``Trainer.train_step`` (imported from
+    /root/reference/train.py by tests/golden/make_trainstep.py, reference modules underneath) left after each of two
+    iterations: the returned losses, per-parameter gradient / update norms, parameter, BatchNorm and EMA checksums.  The same
+    script runs the same train.py over this package's modules on the kernel interpreter (log:
+    tests/golden/trainstep_package_run.json).  Here the package's mirror of the call sequence (``trainer.train_step``:
+    five ``backward()`` calls, ``freeze_backbone_bn``, parameter groups over ``model.models``, clipping, EMA) replays it
+    on the GPU."""
+    import numpy as np
+    import trainstep_case as TC
+    from improving_segmentation_with_selfsupervised_depth_amd import trainer as T
+    from improving_segmentation_with_selfsupervised_depth_amd.loss import get_monodepth_loss, get_segmentation_loss_function
+    from improving_segmentation_with_selfsupervised_depth_amd.models import get_model
+    from conftest import GOLDEN
+    import os
+    ref = dict(np.load(os.path.join(GOLDEN, "trainstep.npz"), allow_pickle=False))
+    cfg = TC.full_cfg(scenario)
+    model = get_model(cfg["model"], TC.NCLS)
+    model.load_state_dict(TC.state_dict(scenario), strict=True)
+    TC.no_dropout(model)
+    model.cuda()
+    ema = None
+    if cfg["training"]["unlabeled_segmentation"] is not None:
+        ema = T.create_ema_model(model, cfg, TC.NCLS).cuda()
+        TC.no_dropout(ema)
+    groups = T.get_train_params(model, cfg)
+    assert [len(list(g["params"])) for g in groups] == list(ref[scenario + "_param_group_sizes"])
+    o = cfg["training"]["optimizer"]
+    opt = torch.optim.SGD(T.get_train_params(model, cfg), lr=o["lr"], weight_decay=o["weight_decay"], momentum=o["momentum"])
+    assert [g["lr"] for g in opt.param_groups] == list(ref[scenario + "_param_group_lrs"])
+    loss_fn = get_segmentation_loss_function(cfg)
+    mono = get_monodepth_loss(cfg, is_train=True)
+    mono.tiebreak_noise = {s: n.cuda() for s, n in TC.noise().items()}
+    out = {}
+    for it in range(TC.ITERS):
+        before = {k: p.detach().cpu().clone() for k, p in model.named_parameters()}
+        unl = TC.batch(200 + it, labeled=False, onehot=True) if ema is not None else None
+        losses = T.train_step(model, opt, TC.batch(100 + it), it, cfg, loss_fn, mono, ema_model=ema, unlabeled_inputs=unl)
+        TC.record(out, scenario, it, losses, model, ema, before)
+    TC.compare(out, ref, scenario)

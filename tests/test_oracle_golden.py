@@ -473,3 +473,38 @@ def test_mix_use_gt_vs_reference(golden):
     torch.testing.assert_close(L, g["L_2"], rtol=1e-6, atol=0)
     L.backward()
     torch.testing.assert_close(w.grad, g["grad_weight"], rtol=1e-5, atol=1e-8)
+
+
+def test_trainstep_fixture_and_param_groups():
+    """tests/golden/trainstep.npz (the reference's own ``Trainer.train_step``, tests/golden/make_trainstep.py): the fixture is
+    complete, and the package's ``get_train_params`` (train.py:67-101) forms the same parameter groups over ``model.models``
+    as the reference did (sizes and learning rates; no kernel runs here).  When the package run of the same script has been
+    made (kernel interpreter, ~40 min), its log must say it passed."""
+    import json
+    import os
+    import trainstep_case as TC
+    from conftest import GOLDEN
+    from improving_segmentation_with_selfsupervised_depth_amd import trainer as T
+    from improving_segmentation_with_selfsupervised_depth_amd.models import get_model
+    ref = dict(np.load(os.path.join(GOLDEN, "trainstep.npz"), allow_pickle=False))
+    for sc in TC.SCENARIOS:
+        cfg = TC.full_cfg(sc)
+        model = get_model(cfg["model"], TC.NCLS)
+        assert [k for k, _ in model.named_parameters()] == [str(n) for n in ref[sc + "_param_names"]]
+        groups = T.get_train_params(model, cfg)
+        assert [len(list(g["params"])) for g in groups] == list(ref[sc + "_param_group_sizes"])
+        assert [g.get("lr", cfg["training"]["optimizer"]["lr"]) for g in groups] == list(ref[sc + "_param_group_lrs"])
+        for it in range(TC.ITERS):
+            for k in ("segmentation_loss", "mono_loss", "total_loss"):
+                assert np.isfinite(ref["%s_it%d_%s" % (sc, it, k)])
+            assert (ref["%s_it%d_update_norms" % (sc, it)] >= 0).all()
+        if sc == "depthmix":
+            assert "depthmix_it1_ema_param_sums" in ref
+            ema = T.create_ema_model(model, cfg, TC.NCLS)
+            assert len(list(ema.parameters())) == len(ref["depthmix_it1_ema_param_sums"])
+    log = os.path.join(GOLDEN, "trainstep_package_run.json")
+    if os.path.exists(log):
+        run = json.load(open(log))
+        assert set(run["scenarios"]) == set(TC.SCENARIOS)
+        for sc in TC.SCENARIOS:
+            assert run["scenarios"][sc]["loss"] < 1e-3

@@ -1,0 +1,147 @@
+"""Shared set-up of the drop-in check under the reference's own caller: the configuration dict the
+reference's ``Trainer`` reads, seeded weights / inputs / tie-break noise, and what is recorded after every iteration.
+
+Used by  tests/golden/make_trainstep.py  (build container: imports /root/reference/train.py and runs ``Trainer.train_step``
+against the reference's modules -> tests/golden/trainstep.npz, and against this package's modules on the kernel interpreter)
+and by the ``-m gpu`` replay (tests/test_models_gpu.py::test_train_step_replay_vs_reference_caller), which runs the
+package's own mirror of the call sequence (``trainer.train_step``) on the GPU against the recorded numbers."""
+import copy
+
+import numpy as np
+import torch
+
+B, HH, WW, NCLS = 2, 32, 64, 19
+ITERS = 2
+SCENARIOS = ("joint", "depthmix")
+
+
+def model_cfg(scenario="joint"):
+    """ResNet-18 joint seg+depth (the r18_jsd entry of tests/golden/state_dict_contract.json, at this test's frame size);
+    "depthmix": the same encoder with the PAD decoder (``mtl_pad``, the r101_pad entry's segmentation arguments) -- the only
+    decoder whose EMA teacher works next to a pose network (train.py:328-333 ``extract_pad_ema_params``)"""
+    import model_cases as MC
+    cfgs = MC.contract_cfgs()["cfgs"]
+    cfg = copy.deepcopy(cfgs["r18_jsd"])
+    if scenario == "depthmix":
+        cfg["segmentation_name"] = "mtl_pad"
+        cfg["segmentation_args"] = copy.deepcopy(cfgs["r101_pad"]["segmentation_args"])
+    cfg["height"], cfg["width"] = HH, WW
+    cfg["freeze_backbone_bn"] = scenario == "depthmix"       # train.py:461-462: encoder BatchNorm in eval mode inside the step
+    return cfg
+
+
+def full_cfg(scenario):
+    """the keys ``Trainer.train_step`` / ``train_step_segmentation_unlabeled`` / ``get_train_params`` read
+    (train.py:67-101, 442-570; values follow configs/cityscapes_joint.yml and the exp-212 block of experiments.py)"""
+    unl = None
+    if scenario == "depthmix":
+        unl = {"consistency_weight": 1.0, "mix_mask": "depthcomp", "depthmix_online_depth": True,
+               "backward_first_pseudo_label": False, "color_jitter": False, "blur": False, "only_unlabeled": False,
+               "mix_use_gt": True, "depthcomp_margin": 0.03, "depthcomp_foreground_threshold": 0, "debug_image": False}
+    return {
+        "seed": 42,
+        "model": model_cfg(scenario),
+        "training": {
+            "batch_size": B, "amp": False, "print_interval": 10 ** 6, "log_path": "/tmp/segsde_trainstep",
+            "optimizer": {"name": "sgd", "lr": 1.0e-2, "weight_decay": 0.0005, "momentum": 0.9, "backbone_lr": 1.0e-3,
+                          "pose_lr": 1.0e-4},
+            "lr_schedule": None, "segmentation_loss": {"name": "cross_entropy"},
+            "monodepth_lambda": 1.0, "pseudo_depth_lambda": 0.0, "feat_dist_lambda": 0.0, "segmentation_lambda": 1.0,
+            "clip_grad_norm": 10.0, "unlabeled_segmentation": unl, "save_monodepth_ema": False,
+            "monodepth_loss": dict(num_scales=4, frame_ids=[0, -1, 1], height=HH, width=WW, min_depth=0.1, max_depth=100,
+                                   test_min_depth=1e-3, test_max_depth=80, disparity_smoothness=1e-3, no_ssim=False,
+                                   avg_reprojection=False, disable_automasking=False),
+        },
+    }
+
+
+def state_dict(scenario="joint", seed=31):
+    from oracle import nets as N
+    return N.build_state_dict(model_cfg(scenario), NCLS, seed=seed, randomize_bn=True, zero_attention=False)
+
+
+def batch(seed, labeled=True, onehot=False):
+    """one loader batch (CPU tensors): frames, intrinsics scaled to this frame size, labels; ``onehot``: the unlabeled
+    loader's extras with mix_use_gt (sequence_segmentation_loader.py:237-246)"""
+    import model_cases as MC
+    inp, _ = MC._bench_inputs(B, HH, WW, seed, "cpu", with_labels=labeled)
+    if onehot:
+        g = torch.Generator().manual_seed(seed + 1)
+        lbl = torch.randint(0, NCLS, (B, HH, WW), generator=g)
+        lbl[torch.rand(B, HH, WW, generator=g) < 0.05] = NCLS
+        inp["onehot_lbl"] = torch.nn.functional.one_hot(lbl, NCLS + 2)[..., :NCLS].permute(0, 3, 1, 2).contiguous()
+        inp["is_labeled"] = torch.tensor([True, False])
+        inp["filename"] = ["a", "b"]
+    return inp
+
+
+def noise():
+    g = torch.Generator().manual_seed(77)
+    return {s: torch.randn(B, 2, HH, WW, generator=g) for s in range(4)}
+
+
+def no_dropout(model):
+    """``Trainer.train_step`` puts the whole model in train mode (train.py:443): dropout is taken out by p = 0 instead
+    of eval(), identically for the reference's and the package's modules"""
+    for m in model.modules():
+        if isinstance(m, (torch.nn.Dropout, torch.nn.Dropout2d)):
+            m.p = 0.0
+
+
+def record(d, tag, it, losses, model, ema_model, before):
+    """losses of the returned dict, per-parameter gradient norms (after clipping, as left in p.grad), per-parameter update
+    norms |p - p_before| and double-precision checksums of parameters / BatchNorm running statistics / EMA parameters"""
+    for k, v in losses.items():
+        d["%s_it%d_%s" % (tag, it, k)] = np.float64(float(v))
+    names, gn, un, cs = [], [], [], []
+    for k, p in model.named_parameters():
+        names.append(k)
+        gn.append(-1.0 if p.grad is None else float(p.grad.detach().double().norm()))
+        un.append(float((p.detach().double().cpu() - before[k].double()).norm()))
+        cs.append(float(p.detach().double().sum()))
+    d[tag + "_param_names"] = np.array(names)
+    d["%s_it%d_grad_norms" % (tag, it)] = np.array(gn)
+    d["%s_it%d_update_norms" % (tag, it)] = np.array(un)
+    d["%s_it%d_param_sums" % (tag, it)] = np.array(cs)
+    bn = [(k, float(v.detach().double().sum())) for k, v in model.state_dict().items() if k.endswith("running_mean")]
+    d[tag + "_bn_names"] = np.array([k for k, _ in bn])
+    d["%s_it%d_bn_running_mean_sums" % (tag, it)] = np.array([v for _, v in bn])
+    if ema_model is not None:
+        d["%s_it%d_ema_param_sums" % (tag, it)] = np.array([float(p.detach().double().sum()) for p in ema_model.parameters()])
+
+
+def compare(got, ref, tag, log=print):
+    """package run vs the reference run of the same caller.  Returns the worst figures; raises on a violation.
+    Tolerances: scalar losses 1e-3 relative (north_star); parameter updates (what the optimiser did with the clipped
+    gradients, momentum and weight decay) and gradient norms per parameter within 2 % of the parameter's own figure or
+    1e-3 of the largest figure of the iteration -- whole-model fp32 gradients of a ReLU / BatchNorm network differ by that
+    much between two correct fp32 implementations (tests/model_cases.py::gradients_vs_truth)."""
+    worst = {}
+    names = [str(n) for n in ref[tag + "_param_names"]]
+    assert [str(n) for n in got[tag + "_param_names"]] == names, "parameter names / order differ"
+    for it in range(ITERS):
+        for k in ref:
+            if k.startswith("%s_it%d_" % (tag, it)) and np.ndim(ref[k]) == 0:
+                r, g = float(ref[k]), float(got[k])
+                err = abs(g - r) / max(abs(r), 1e-6)
+                worst["loss"] = max(worst.get("loss", 0.0), err)
+                assert err < 1e-3, (k, g, r)
+        for what, rel in (("grad_norms", 2e-2), ("update_norms", 2e-2)):
+            r, g = np.asarray(ref["%s_it%d_%s" % (tag, it, what)]), np.asarray(got["%s_it%d_%s" % (tag, it, what)])
+            assert ((r < 0) == (g < 0)).all(), "different parameters received a gradient: %s" % \
+                [n for n, a, b in zip(names, r, g) if (a < 0) != (b < 0)][:5]
+            live = r >= 0
+            floor = 1e-3 * float(r[live].max())
+            err = np.abs(g - r)[live] / np.maximum(np.abs(r[live]), floor / rel)
+            j = int(err.argmax())
+            worst[what] = max(worst.get(what, 0.0), float(err[j]))
+            assert err[j] < rel, (what, it, np.array(names)[live][j], float(g[live][j]), float(r[live][j]))
+        for what in ("param_sums", "bn_running_mean_sums", "ema_param_sums"):
+            k = "%s_it%d_%s" % (tag, it, what)
+            if k in ref:
+                r, g = np.asarray(ref[k]), np.asarray(got[k])
+                err = float((np.abs(g - r) / np.maximum(np.abs(r), 1.0)).max())
+                worst[what] = max(worst.get(what, 0.0), err)
+                assert err < 1e-3, (what, it, err)
+    log("%s: worst relative deviations %s" % (tag, {k: float("%.3g" % v) for k, v in worst.items()}))
+    return worst
