@@ -198,6 +198,12 @@ def cpu_baseline(workload, H, W, budget_s):
                       % (workload_model, B, warm, len(times), med, min(times), cores, cpu_model_name(), torch.__version__)}
 
 
+def rccl_env():
+    """the documented way to steer RCCL here is its own environment (NCCL_MIN_NCHANNELS / NCCL_MAX_NCHANNELS for the number of
+    channels = CUs the collective kernels occupy next to the MFMA kernels, NCCL_ALGO, NCCL_PROTO, ...): the line records what was set"""
+    return {k: v for k, v in sorted(os.environ.items()) if k.startswith(("NCCL_", "RCCL_", "HSA_ENABLE_IPC", "TORCH_NCCL_"))}
+
+
 def _flush_c_stdio():
     try:
         import ctypes
@@ -223,6 +229,12 @@ def main():
                     help="capture one whole training step (forward, loss, backward, clip, optimiser) as a hipGraph after the warm-up and "
                          "replay it for the timed steps: the launch-bound regime (cfg1: ~1 500 launches of 5-20 us per step through "
                          "Python / ctypes).  Single GPU, labeled step only; implies --no-kernel-timing")
+    ap.add_argument("--bucket-mb", type=float, default=32.0, help="gradient all-reduce bucket size (N > 1)")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="N > 1: start every gradient all-reduce after the last backward instead of from the gradient hooks")
+    ap.add_argument("--allreduce-only", action="store_true",
+                    help="N > 1: after one training step (which builds the buckets) time the gradient payload's all-reduce alone, "
+                         "K = --steps times; prints its own JSON line")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-baseline-timeout", type=float, default=150.0)
     args = ap.parse_args()
@@ -289,7 +301,9 @@ def main():
     model = get_model(cfg, 19).to(dev).train()
     optimizer = param_groups(model, opt_name, capturable=args.hip_graph)
     loss_obj = get_monodepth_loss(loss_cfg(B, Hh, W), is_train=True)
-    reducer = GradAllReducer(model, always=force_reducer) if (world > 1 or force_reducer) else None
+    reducer = GradAllReducer(model, bucket_mb=args.bucket_mb, overlap=not args.no_overlap, always=force_reducer,
+                             timing=True) if (world > 1 or force_reducer) else None
+    use_reducer = [True]      # False: the same step with every backward under no_sync() and no finish() (exposed-communication probe)
     # identical initial parameters (seed 42 above + the reducer's broadcast), then INDEPENDENT dropout / tie-break
     # / augmentation streams per replica
     from improving_segmentation_with_selfsupervised_depth_amd.ddp import seed_per_rank
@@ -319,6 +333,10 @@ def main():
         import contextlib
         return reducer.no_sync() if reducer is not None else contextlib.nullcontext()
 
+    def last_backward():
+        import contextlib
+        return reducer.no_sync() if (reducer is not None and not use_reducer[0]) else contextlib.nullcontext()
+
     from improving_segmentation_with_selfsupervised_depth_amd.models.layers import weight_pack_scope
 
     def step():
@@ -341,14 +359,16 @@ def main():
             with nosync():
                 total.backward()
             del out
-            L_u, mono_u = T.train_step_segmentation_unlabeled(
-                model, ema_model, loss_obj, unlabeled_inputs, mix_mask="depthcomp", depthmix_online_depth=True,
-                monodepth_lambda=1.0, consistency_weight=1.0, backward_first_pseudo_label=False, depthcomp_margin=0.03,
-                depthcomp_foreground_threshold=0.0, color_jitter=True, blur=True, reducer=reducer, mix_use_gt=True)
+            with last_backward():
+                L_u, mono_u = T.train_step_segmentation_unlabeled(
+                    model, ema_model, loss_obj, unlabeled_inputs, mix_mask="depthcomp", depthmix_online_depth=True,
+                    monodepth_lambda=1.0, consistency_weight=1.0, backward_first_pseudo_label=False, depthcomp_margin=0.03,
+                    depthcomp_foreground_threshold=0.0, color_jitter=True, blur=True, reducer=reducer, mix_use_gt=True)
             total = total.detach() + L_u.detach() + mono_u.detach()
         else:
-            total.backward()
-        if reducer is not None:
+            with last_backward():
+                total.backward()
+        if reducer is not None and use_reducer[0]:
             reducer.finish()
         if clip is not None:
             torch.nn.utils.clip_grad_norm_(model.parameters(), clip)
@@ -423,9 +443,50 @@ def main():
         for _ in range(2):
             step()
         barrier()
+    if args.allreduce_only:
+        if reducer is None or reducer.buckets is None:
+            raise SystemExit("--allreduce-only needs --gpus N > 1 (or SEGSDE_FORCE_REDUCER=1) and at least one warm-up step")
+        # the gradient payload alone: every bucket launched back to back, then waited for -- what a step's communication costs
+        # when nothing overlaps it.  Bus bandwidth by the usual all-reduce convention 2 (n - 1) / n * bytes / time.
+        nbytes = sum(b.flat.numel() * 4 for b in reducer.buckets)
+        for _ in range(2):
+            for b in reducer.buckets:
+                reducer._launch(b)
+            for b in reducer.buckets:
+                reducer._wait(b)
+        barrier()
+        reducer.timing_ms()
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+        marks[0].record()
+        for i in range(args.steps):
+            for b in reducer.buckets:
+                reducer._launch(b)
+            for b in reducer.buckets:
+                reducer._wait(b)
+            marks[i + 1].record()
+        barrier()
+        ms_all = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
+        t = torch.tensor([float(np.median(ms_all))], device=dev, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        med = float(t[0])
+        busy, ncoll, _ = reducer.timing_ms()
+        if rank == 0:
+            print(json.dumps({"metric": "gradient all-reduce of one training step alone (%s)" % args.workload, "value": med,
+                              "unit": "ms", "higher_is_better": False, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                              "payload_mb": nbytes / 1e6, "buckets": len(reducer.buckets), "bucket_mb": args.bucket_mb,
+                              "bus_gbs": (2.0 * (world - 1) / world) * nbytes / (med * 1e-3) / 1e9 if world > 1 else None,
+                              "collective_stream_busy_ms": busy / args.steps, "ms_all": [round(x, 3) for x in ms_all],
+                              "backend": dist.get_backend() if dist.is_initialized() else None, "rccl_env": rccl_env()}), flush=True)
+        if world > 1 or force_reducer:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     torch.cuda.reset_peak_memory_stats(dev)
     from improving_segmentation_with_selfsupervised_depth_amd import functional as Fn
     Fn.fusion_report(reset=True)
+    if reducer is not None:
+        reducer.timing_ms()          # drop the warm-up steps' events
     prof = None if args.no_kernel_timing else []
     H.PROFILE = prof
     period = args.kernel_timing_period if args.kernel_timing_period > 0 else max(1, min(args.steps, 8))
@@ -444,10 +505,43 @@ def main():
     H.PROFILE = None
     step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
     med_ms = float(np.median(step_ms))
+    comm = None
+    if reducer is not None:
+        # why the N-GPU number is what it is, from the same run: how long the collectives occupied their stream per step
+        # (event pairs on the reducer's side stream), how much of that the step could NOT hide (this step minus the same step
+        # with every backward under no_sync() and no finish(): identical compute, no collective), and every rank's own median
+        busy_ms, ncoll, nbytes = reducer.timing_ms()
+        n2 = max(2, min(args.steps, 5))
+        use_reducer[0] = False
+        step()
+        marks2 = [torch.cuda.Event(enable_timing=True) for _ in range(n2 + 1)]
+        marks2[0].record()
+        for i in range(n2):
+            step()
+            marks2[i + 1].record()
+        barrier()
+        use_reducer[0] = True
+        quiet_ms = float(np.median([marks2[i].elapsed_time(marks2[i + 1]) for i in range(n2)]))
+        per_rank = torch.zeros(world, device=dev, dtype=torch.float64)
+        per_rank[rank] = med_ms
+        q = torch.tensor([quiet_ms, busy_ms / args.steps], device=dev, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(per_rank, op=dist.ReduceOp.SUM)
+            dist.all_reduce(q, op=dist.ReduceOp.MAX)
+        comm = {"allreduce_ms_per_step": float(q[1]), "allreduce_launches_per_step": ncoll / args.steps,
+                "allreduce_mb_per_step": nbytes / args.steps / 1e6, "buckets": len(reducer.buckets) if reducer.buckets else 0,
+                "bucket_mb": args.bucket_mb, "overlap": bool(reducer.overlap),
+                "ms_per_step_without_allreduce": float(q[0]), "per_rank_ms_per_step": [round(float(x), 3) for x in per_rank],
+                "rccl_env": rccl_env(),
+                "how": "allreduce_ms_per_step: union of the [start, end] event pairs of the buckets' collectives on the reducer's side "
+                       "stream (max over ranks); exposed_comm_ms = median step - median of %d steps of the same work with every backward "
+                       "under no_sync() and no finish() (max over ranks each)" % n2}
     if world > 1:
         t = torch.tensor([dt, med_ms], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt, med_ms = float(t[0]), float(t[1])
+    if comm is not None:
+        comm["exposed_comm_ms"] = med_ms - comm["ms_per_step_without_allreduce"]
     loss_val = float(last.detach())
 
     if rank == 0:
@@ -473,6 +567,8 @@ def main():
                                                "peak_memory_gb": torch.cuda.max_memory_allocated(dev) / 2 ** 30}}
         if unlabeled:
             res["config"]["images_per_step"] = {"labeled": B * world, "unlabeled": B * world}
+        if comm is not None:
+            res["comm"] = comm
         # fusion hand-offs of the timed steps, per step (functional.FUSIONS): a hand-off that stopped working shows up as "missed"
         res["fusions_per_step"] = {k: {kk: vv / args.steps for kk, vv in v.items()} for k, v in Fn.fusion_report().items()}
         res["fusions_per_step"]["upsample_folded_launches"] = {k: v / (args.steps + args.warmup) for k, v in H.UPFOLD_TAKEN.items()}

@@ -94,13 +94,21 @@ class _Bucket:
 
 
 class GradAllReducer:
-    def __init__(self, module, bucket_mb=32.0, process_group=None, overlap=True, always=False, control_group=None):
+    def __init__(self, module, bucket_mb=32.0, process_group=None, overlap=True, always=False, control_group=None,
+                 timing=False):
         """control_group: a gloo group over the same ranks as ``process_group`` for the per-step agreement.  None creates
         one with ``dist.new_group`` -- a collective over the DEFAULT group, so every rank of the job must then construct
         its reducer (or pass a pre-created group when only a sub-group trains); False runs the agreement on
         ``process_group`` itself with a device tensor (one small device synchronisation per step) -- the agreement then
         shares a communicator with the bucket all-reduces, so nothing may start from the hooks (ranks that launch a
         different number of buckets before ``finish()`` would pair a bucket with the bitmap): overlap is switched off."""
+        # timing=True (bench.py): every bucket's collective is issued from a side stream of its own that does nothing else --
+        # it waits for the launch stream (bucket packed), records an event, issues the all-reduce, and records a second event
+        # once the collective is done.  ``timing_ms()`` turns the pairs of the last step into the time the collectives
+        # occupied (their union: consecutive buckets queue behind each other on the communicator's stream).
+        self.timing = bool(timing)
+        self._comm_stream = None
+        self._events = []
         self.module = module
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
@@ -179,8 +187,53 @@ class GradAllReducer:
         self.rebuilds += 1
 
     def _launch(self, b):
-        b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        if self.timing and b.flat.is_cuda:
+            if self._comm_stream is None:
+                self._comm_stream = torch.cuda.Stream(b.flat.device)
+            cs = self._comm_stream
+            cs.wait_stream(torch.cuda.current_stream(b.flat.device))
+            b.t0 = torch.cuda.Event(enable_timing=True)
+            with torch.cuda.stream(cs):
+                b.t0.record(cs)
+                b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        else:
+            b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         self.collectives += 1
+
+    def _wait(self, b):
+        """the launch stream (and, for host-side backends, the host) waits for the bucket's collective"""
+        if self.timing and b.flat.is_cuda and getattr(b, "t0", None) is not None:
+            cs = self._comm_stream
+            with torch.cuda.stream(cs):
+                b.work.wait()
+                t1 = torch.cuda.Event(enable_timing=True)
+                t1.record(cs)
+            torch.cuda.current_stream(b.flat.device).wait_stream(cs)
+            self._events.append((b.t0, t1, b.flat.numel() * 4))
+            b.t0 = None
+        else:
+            b.work.wait()
+        b.work = None
+
+    def timing_ms(self, reset=True):
+        """(milliseconds the collectives recorded since the last reset occupied -- the union of their [start, end] intervals
+        on the device clock --, number of collectives, bytes); call after a device synchronisation"""
+        ev = self._events
+        if reset:
+            self._events = []
+        if not ev:
+            return 0.0, 0, 0
+        ref = ev[0][0]
+        spans = sorted((ref.elapsed_time(a), ref.elapsed_time(b)) for a, b, _ in ev)
+        total, cur_s, cur_e = 0.0, spans[0][0], spans[0][1]
+        for s_, e_ in spans[1:]:
+            if s_ > cur_e:
+                total += cur_e - cur_s
+                cur_s, cur_e = s_, e_
+            else:
+                cur_e = max(cur_e, e_)
+        total += cur_e - cur_s
+        return total, len(ev), sum(n for _, _, n in ev)
 
     def _launch_ready(self):
         """Collectives of one group must be issued in the same order on every rank.  Gradient-ready order is not that: a
@@ -256,8 +309,7 @@ class GradAllReducer:
                                 b.pack(i)
                         self._launch(b)
                 for b in self.buckets:
-                    b.work.wait()
-                    b.work = None
+                    self._wait(b)
             self._build(union)
         # pass 1, index order like the hooks: whatever has not started yet (incomplete because a gradient did not show up in
         # the last backward, held back behind an incomplete one, overlap off, or fresh after a rebuild)
@@ -276,15 +328,14 @@ class GradAllReducer:
                         warnings.warn("GradAllReducer: backward() ran more than once in this step outside no_sync(); the "
                                       "affected buckets are reduced again after the last backward (correct, not overlapped)")
                         self._warned = True
-                    b.work.wait()
+                    self._wait(b)
                     b.reset()
                     for i in range(len(b.params)):
                         b.pack(i)
                     self._launch(b)
         inv = 1.0 / self.world
         for b in self.buckets:
-            b.work.wait()
-            b.work = None
+            self._wait(b)
             if inv != 1.0:
                 b.flat.mul_(inv)
             # every bucket member that had a gradient on SOME rank receives the average on every rank (a parameter that had

@@ -1135,3 +1135,77 @@ def run_monodepth_layer_callables(device, golden):
     wgt = torch.randn(up.shape, generator=gen)
     (up * d(wgt)).sum().backward()
     assert_close(zu.grad, wgt.reshape(2, 5, 4, 2, 6, 2).sum((3, 5)), rtol=1e-6, atol=1e-6, what="upsample adjoint")
+
+
+def run_jitter_blur_properties(device):
+    """Properties that hold for ANY faithful implementation of kornia 0.4.0's ColorJitter / GaussianBlur2d (the restated
+    operators are parity-unpinned, DESIGN.md 4: these narrow what can be wrong without a kornia wheel): zero-strength identity,
+    hue periodicity in whole turns, grey pixels untouched by hue / saturation, brightness / contrast commute with clamping on
+    unsaturated pixels, blur taps normalised, separable passes == the 2-D outer-product kernel, blur commutes with flips."""
+    import math
+    from improving_segmentation_with_selfsupervised_depth_amd.loader import transformsgpu as TG
+    gen = torch.Generator().manual_seed(41)
+    B, Hh, W = 3, 40, 56
+    x = torch.rand(B, 3, Hh, W, generator=gen)
+    xd = x.to(device)
+    # s = 0: every factor is neutral whatever the draw, every order is the identity
+    p0, _ = TG.sample_color_jitter_params(B, 0.0, generator=gen)
+    assert torch.equal(p0, torch.tensor([1.0, 1.0, 1.0, 0.0]).expand(B, 4))
+    for order in ([0, 1, 2, 3], [3, 2, 1, 0], [2, 0, 3, 1]):
+        got, _ = TG.color_jitter(0.9, data=xd, params=p0, order=order)
+        assert_close(got, x, rtol=1e-5, atol=2e-6, what="zero-strength jitter, order %s" % (order,))
+    # hue: a whole turn (factor +-1 = 2 pi) is the identity; two half turns compose to the identity
+    for f in (1.0, -1.0, 2.0):
+        hp = torch.tensor([1.0, 1.0, 1.0, f]).expand(B, 4).contiguous()
+        got, _ = TG.color_jitter(0.9, data=xd, params=hp, order=[3, 0, 1, 2])
+        assert_close(got, x, rtol=1e-4, atol=1e-5, what="hue shift by %g turns" % f)
+    half = torch.tensor([1.0, 1.0, 1.0, 0.5]).expand(B, 4).contiguous()
+    once, _ = TG.color_jitter(0.9, data=xd, params=half, order=[3, 0, 1, 2])
+    twice, _ = TG.color_jitter(0.9, data=once, params=half, order=[3, 0, 1, 2])
+    assert_close(twice, x, rtol=1e-4, atol=2e-5, what="two half turns of hue")
+    assert float((once.cpu() - x).abs().max()) > 0.05                 # ... and half a turn is not the identity
+    # hue keeps max(r, g, b) (the V channel) and min (V (1 - S)) of every pixel
+    q = torch.tensor([1.0, 1.0, 1.0, 0.21]).expand(B, 4).contiguous()
+    hq, _ = TG.color_jitter(0.9, data=xd, params=q, order=[3, 0, 1, 2])
+    assert_close(hq.max(1)[0], x.max(1)[0], rtol=1e-5, atol=2e-6, what="hue keeps the value channel")
+    assert_close(hq.min(1)[0], x.min(1)[0], rtol=1e-4, atol=1e-5, what="hue keeps value * (1 - saturation)")
+    # grey pixels (r = g = b): hue and saturation leave them alone
+    grey = x[:, :1].repeat(1, 3, 1, 1)
+    gp = torch.tensor([1.0, 1.0, 1.37, -0.33]).expand(B, 4).contiguous()
+    gg, _ = TG.color_jitter(0.9, data=grey.to(device), params=gp, order=[2, 3, 0, 1])
+    assert_close(gg, grey, rtol=1e-5, atol=2e-6, what="grey under hue + saturation")
+    # saturation 0 -> grey at the value channel; brightness / contrast are exact affine maps before clamping
+    sp = torch.tensor([1.0, 1.0, 0.0, 0.0]).expand(B, 4).contiguous()
+    s0, _ = TG.color_jitter(0.9, data=xd, params=sp, order=[2, 0, 1, 3])
+    assert_close(s0, x.max(1, keepdim=True)[0].repeat(1, 3, 1, 1), rtol=1e-5, atol=2e-6, what="saturation factor 0")
+    bp = torch.tensor([1.2, 0.9, 1.0, 0.0]).expand(B, 4).contiguous()
+    bc, _ = TG.color_jitter(0.9, data=xd, params=bp, order=[0, 1, 2, 3])
+    assert_close(bc, torch.clamp(torch.clamp(x + 0.2, 0, 1) * 0.9, 0, 1), rtol=1e-5, atol=2e-6, what="brightness then contrast")
+    # ---- blur: taps are a normalised, symmetric, single-peaked Gaussian cut to its fp32 support
+    for k, sigma in ((5, 0.15), (5, 1.15), (51, 0.6), (103, 1.15), (205, 0.15)):
+        g = TG.gaussian_taps(k, sigma)
+        assert g.numel() % 2 == 1 and g.numel() <= k and abs(float(g.double().sum()) - 1.0) < 1e-6
+        assert torch.equal(g, g.flip(0)) and int(g.argmax()) == g.numel() // 2 and float(g.min()) > 0
+        full = torch.exp(-(torch.arange(k, dtype=torch.float32) - k // 2) ** 2 / float(2 * sigma ** 2))
+        full = full / full.sum()
+        r = g.numel() // 2
+        assert torch.equal(g, full[k // 2 - r:k // 2 + r + 1])
+        assert float(full[:k // 2 - r].abs().sum()) == 0.0 and float(full[k // 2 + r + 1:].abs().sum()) == 0.0   # only zeros are cut off
+    # separable passes == ONE 2-D correlation with the outer-product kernel on the reflect-padded image (kornia's filter2D)
+    sigma = 0.8
+    ky, kx = TG.blur_kernel_size(Hh), TG.blur_kernel_size(W)
+    got, _ = TG.gaussian_blur(0.9, data=xd, sigma=sigma)
+    gy = torch.exp(-(torch.arange(ky, dtype=torch.float64) - ky // 2) ** 2 / (2 * sigma ** 2))
+    gx = torch.exp(-(torch.arange(kx, dtype=torch.float64) - kx // 2) ** 2 / (2 * sigma ** 2))
+    k2 = torch.outer(gy / gy.sum(), gx / gx.sum())
+    xp = torch.nn.functional.pad(x.double(), (kx // 2, kx // 2, ky // 2, ky // 2), mode="reflect")
+    want = torch.nn.functional.conv2d(xp, k2[None, None].repeat(3, 1, 1, 1), groups=3)
+    assert_close(got, want.float(), rtol=1e-5, atol=2e-6, what="separable blur vs the 2-D kernel (float64)")
+    # mean-preserving up to the border handling; commutes with flips (symmetric taps, reflection border)
+    fl, _ = TG.gaussian_blur(0.9, data=xd.flip(2).flip(3).contiguous(), sigma=sigma)
+    assert_close(fl.flip(2).flip(3), got.cpu(), rtol=1e-6, atol=1e-6, what="blur commutes with flips")
+    assert float(got.min()) >= float(x.min()) - 1e-6 and float(got.max()) <= float(x.max()) + 1e-6   # a convex combination
+    # the kernel size rule of the reference (transformsgpu.py:26-27): odd, within one of 0.1 n
+    for n in (40, 56, 100, 512, 513, 1024, 2048):
+        k = TG.blur_kernel_size(n)
+        assert k % 2 == 1 and abs(k - 0.1 * n) <= 1.0 + 1e-9, (n, k)

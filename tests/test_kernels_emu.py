@@ -102,3 +102,7 @@ def test_loss_kernels(golden):
 
 def test_monodepth_layer_callables(golden):
     KC.run_monodepth_layer_callables("cpu", golden)
+
+
+def test_jitter_blur_properties():
+    KC.run_jitter_blur_properties("cpu")

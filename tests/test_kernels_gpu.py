@@ -159,3 +159,7 @@ def test_cpu_tensor_is_rejected():
 
 def test_monodepth_layer_callables(golden):
     KC.run_monodepth_layer_callables("cuda", golden)
+
+
+def test_jitter_blur_properties():
+    KC.run_jitter_blur_properties("cuda")

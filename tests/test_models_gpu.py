@@ -373,6 +373,22 @@ def test_bench_selfspawn_two_ranks_one_device():
     assert res["config"]["allreduce_launches"] > 0 and res["config"]["global_batch"] == 2 * res["config"]["per_gpu_batch"]
     assert res["value"] > 0 and res["steps"] == 2 and res["scaling"] == "weak"
     assert "hbm_kernels" in res and "roofline" in res
+    # the N > 1 line explains itself
+    c = res["comm"]
+    for k in ("allreduce_ms_per_step", "exposed_comm_ms", "ms_per_step_without_allreduce", "allreduce_launches_per_step",
+              "allreduce_mb_per_step", "buckets", "bucket_mb", "overlap", "per_rank_ms_per_step", "rccl_env"):
+        assert k in c, k
+    assert len(c["per_rank_ms_per_step"]) == 2 and all(x > 0 for x in c["per_rank_ms_per_step"])
+    assert c["buckets"] >= 1 and c["allreduce_launches_per_step"] >= c["buckets"] and c["allreduce_mb_per_step"] > 10
+    assert c["overlap"] is True and c["bucket_mb"] == 32.0
+    # knobs + the payload-only mode
+    cp = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--workload", "cfg1", "--steps", "2",
+                         "--warmup", "1", "--no-cpu-baseline", "--bucket-mb", "8", "--no-overlap", "--allreduce-only"],
+                        capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert cp.returncode == 0, cp.stderr[-3000:]
+    only = json.loads(cp.stdout.strip().splitlines()[-1])
+    assert only["unit"] == "ms" and only["value"] > 0 and only["n_gpus"] == 2 and only["bucket_mb"] == 8.0
+    assert only["buckets"] > c["buckets"] and abs(only["payload_mb"] - c["allreduce_mb_per_step"]) < 1.0
 
 
 def test_real_model_two_ranks_one_gpu():
