@@ -1138,11 +1138,13 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(ConvP p, const float
                                                          int chunks_per_split, WRed wr) {
   // MODE 0: scalar gather, 1: float4 gather, 2: FAST A side + vector dY + rows at least 32 pixels wide (straight-line
   // loop), 3: FAST A side with the general row walk / scalar dY (odd Cout, tiny feature maps), 4: MODE 2 with the tile
-  // loads writing LDS themselves (LDS-DMA, see the forward kernel)
+  // loads writing LDS themselves (LDS-DMA, see the forward kernel), 5: MODE 4 with the chunk's barrier moved into the chunk
+  // (round 4: tile loads run two chunks ahead, the first fragments of the next chunk are read before the chunk boundary)
   constexpr bool VEC = MODE >= 1;
   constexpr bool FAST = MODE >= 2;
-  constexpr bool SIMPLE = MODE == 2 || MODE == 4;
-  constexpr bool DMA = MODE == 4;
+  constexpr bool SIMPLE = MODE == 2 || MODE == 4 || MODE == 5;
+  constexpr bool DMA = MODE == 4 || MODE == 5;
+  constexpr bool PIPE = MODE == 5;
   constexpr int TM = BKT / (WM * 32), TN = BN / (WN * 32);
   constexpr int AQ = BKT / 4, DQ = BN / 4;             // float4 columns per tile row
   constexpr int AI = (BP * AQ) / 256, DI = (BP * DQ) / 256;
@@ -1482,6 +1484,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(ConvP p, const float
       tload();
       issue(0u);
     }
+    int left = nlive - 1;                         // PIPE: live chunks whose tile loads are still to be issued
+    if constexpr (PIPE) {
+      if (left > 0) { tload(); issue(STG); --left; }
+    }
     segsde_wait_vmcnt0();
     __syncthreads();
     float fa[2][4][TM], fd[2][4][TN];
@@ -1520,6 +1526,41 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(ConvP p, const float
       segsde_wait_vmcnt0();
       __syncthreads();
     };
+    // PIPE (MODE 5).  In the loop above every chunk ends in wait + barrier and the next one starts with the LDS reads of its
+    // first fragments: a read-latency chain right behind every barrier, on all four waves at once.  Here the barrier sits
+    // INSIDE the chunk, after the wave's last fragment read of this stage (group 3 is read at unit 10): once every wave has
+    // passed it, (a) this stage is free -- the tile loads of chunk c + 2 go into it right away (two chunks of lead instead of
+    // one), and (b) the other stage (loads issued one chunk ago, waited for before the barrier) is visible -- the first
+    // fragments of chunk c + 1 are read at unit 14, while the last MFMAs of chunk c still run.  Nothing waits at the chunk
+    // boundary any more; still one barrier per chunk.
+    auto pchunk = [&](auto buf_c) {
+      constexpr int buf = decltype(buf_c)::value;
+#pragma unroll
+      for (int u = 0; u < BP / 2; ++u) {
+        const int g = u / 4, st = u % 4;
+        if (st == 2 && g + 1 < BP / 8) fread(buf, g + 1, (g + 1) & 1);
+        if (u == 11 && left > 0) tload();
+        if (u == 12) {
+          segsde_wait_vmcnt0();
+          __syncthreads();
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[g & 1][st][i], fd[g & 1][st][j], acc[i][j], 0, 0, 0);
+        if (u == 12 && left > 0) { issue((unsigned)buf * STG); --left; }
+        if (u == 14) fread(buf ^ 1, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    if constexpr (PIPE) {
+      fread(0, 0, 0);
+      for (int i = 0; i < nlive; i += 2) {
+        pchunk(std::integral_constant<int, 0>{});
+        if (i + 1 < nlive) pchunk(std::integral_constant<int, 1>{});
+      }
+    } else
     for (int i = 0; i < nlive; i += 2) {
       chunk(std::integral_constant<int, 0>{});
       if (i + 1 < nlive) chunk(std::integral_constant<int, 1>{});
@@ -1735,7 +1776,7 @@ __global__ __launch_bounds__(256) void reflect_dgrad_fix_kernel(const float* dy,
 // experiment knob (environment SEGSDE_TUNE="bk64=1"), read once.  Measured on MI355X (profiles/ab_conv_r01.log):
 // BK=64 (139 KB LDS => 1 workgroup/CU, half the barriers) loses 15-25 % on the large layers against BK=32 with two
 // co-resident workgroups per CU, and start-up staggering of co-resident workgroups changes nothing.
-struct Tune { int bk64 = 0; int adjfix = 0; int wplan = 0; int wovh = 4; int nos2 = 0; int dma = 1; int var = 0; int wdma = 1; int adjlds = 1; int wred = 0; int adjb = 1; int tskip = 1; int tsbn = 0; };
+struct Tune { int bk64 = 0; int adjfix = 0; int wplan = 0; int wovh = 4; int nos2 = 0; int dma = 1; int var = 0; int wdma = 2; int adjlds = 1; int wred = 0; int adjb = 1; int tskip = 1; int tsbn = 0; };
 const Tune& tune() {
   static Tune t = [] {
     Tune r;
@@ -1748,7 +1789,7 @@ const Tune& tune() {
       if (const char* q = strstr(e, "dma=")) r.dma = atoi(q + 4);         // 0: register-staged tile loads (round-1 loop)
       if (const char* q = strstr(e, "var=")) r.var = atoi(q + 4);         // experiment variants of the LDS-DMA loop
       if (const char* q = strstr(e, "adjl=")) r.adjlds = atoi(q + 5);     // 0: reflection-adjoint loop register-staged in every wave
-      if (const char* q = strstr(e, "wlds=")) r.wdma = atoi(q + 5);       // 0: register-staged weight-gradient tile loads
+      if (const char* q = strstr(e, "wlds=")) r.wdma = atoi(q + 5);       // 0: register-staged weight-gradient tile loads, 1: LDS-DMA with the barrier at the chunk end (round 2), 2: barrier inside the chunk (round 4)
       if (const char* q = strstr(e, "adjb=")) r.adjb = atoi(q + 5);       // 0: reflection adjoint always inside the kernel (MODE 3); 1: zero-pad + border launches on the largest maps; 2: everywhere
       if (const char* q = strstr(e, "tsbn=")) r.tsbn = atoi(q + 5);       // 1: 128x64 tiles for one-round grids with dead tap rows
       if (const char* q = strstr(e, "tskip=")) r.tskip = atoi(q + 6);     // 0: dilated zero-padded windows run their dead tap rows too
@@ -2134,7 +2175,7 @@ template <int BKT, int BN, int WM, int WN, int MODE>
 int launch_wgrad_mode(const ConvP& p, const float* dy, int lddy, float* ws, int splits, int cps, hipStream_t stream, WRed wr) {
   const dim3 grid(segsde_cdiv(p.Ktot, BKT) * segsde_cdiv(p.N, BN) * splits);
   size_t smem = 2 * (size_t)BP * (BKT + BN) * sizeof(float);
-  if (MODE == 2 || MODE == 4)   // + the four offset tables (padded rows / columns of the two sources)
+  if (MODE == 2 || MODE == 4 || MODE == 5)   // + the four offset tables (padded rows / columns of the two sources)
     smem += 2 * (size_t)((p.Ho - 1) * p.stride + (p.KH - 1) * p.dil + 1 + (p.Wo - 1) * p.stride + (p.KW - 1) * p.dil + 1) * sizeof(unsigned);
   auto k = conv_wgrad_kernel<BKT, BN, WM, WN, MODE>;
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -2159,6 +2200,7 @@ template <int BKT, int BN, int WM, int WN>
 int launch_wgrad(const ConvP& p, const float* dy, int lddy, float* ws, int splits, int cps, hipStream_t stream, WRed wr = WRed{}) {
   switch (wgrad_mode(p, dy, lddy)) {
     case 2:
+      if (tune().wdma == 2) return launch_wgrad_mode<BKT, BN, WM, WN, 5>(p, dy, lddy, ws, splits, cps, stream, wr);
       if (tune().wdma) return launch_wgrad_mode<BKT, BN, WM, WN, 4>(p, dy, lddy, ws, splits, cps, stream, wr);
       return launch_wgrad_mode<BKT, BN, WM, WN, 2>(p, dy, lddy, ws, splits, cps, stream, wr);
     case 3: return launch_wgrad_mode<BKT, BN, WM, WN, 3>(p, dy, lddy, ws, splits, cps, stream, wr);

@@ -371,7 +371,11 @@ def train_step(model, optimizer, inputs, step, cfg, loss_fn, monodepth_loss_calc
                 depthcomp_margin=unl["depthcomp_margin"], depthcomp_foreground_threshold=unl["depthcomp_foreground_threshold"],
                 color_jitter=unl.get("color_jitter"), blur=unl.get("blur"), reducer=reducer,
                 mix_use_gt=unl.get("mix_use_gt", False))
+            # train.py:510-514: ``segmentation_total_loss = segmentation_loss`` binds a second NAME to the same tensor and the
+            # unlabeled loss is then added IN PLACE -- the reference's returned 'segmentation_loss' includes the unlabeled term
+            # whenever the unlabeled step runs (and equals 'segmentation_total_loss'); kept, so that logged curves compare
             segmentation_total = segmentation_total + u_loss
+            segmentation_loss = segmentation_total
             mono_total = mono_total + u_mono
     if reducer is not None:
         reducer.finish()

@@ -39,6 +39,8 @@ for p_ in (REPO, os.path.join(REPO, "tests"), HERE):
 ap = argparse.ArgumentParser()
 ap.add_argument("--impl", choices=["reference", "package"], required=True)
 ap.add_argument("--scenarios", default="joint,depthmix")
+ap.add_argument("--compare-only", action="store_true",
+                help="package impl: re-compare the numbers of the last package run (build/trainstep_package_out.npz) with trainstep.npz")
 args = ap.parse_args()
 torch.set_num_threads(8)
 
@@ -82,7 +84,7 @@ class _UnlabeledLoader:
     ignore_index = 250
 
 
-def make_trainer(scenario, noise):
+def make_trainer(scenario, noise, ulps=0):
     cfg = TC.full_cfg(scenario)
     t = object.__new__(ref_train.Trainer)
     t.cfg, t.device, t.mIoU = cfg, torch.device("cpu"), 0
@@ -91,6 +93,9 @@ def make_trainer(scenario, noise):
     t.model = get_model(cfg["model"], TC.NCLS)
     t.model.load_state_dict(TC.state_dict(scenario), strict=True)
     TC.no_dropout(t.model)
+    if ulps:         # yardstick runs: the stem weights moved by a few units in the last place
+        with torch.no_grad():
+            t.model.models["encoder"].encoder.conv1.weight.mul_(1.0 + ulps * 2.0 ** -23)
     t.ema_model = None
     if t.enable_unlabled_segmentation:
         t.ema_model = t.create_ema_model(t.model)
@@ -111,9 +116,9 @@ def make_trainer(scenario, noise):
     return t
 
 
-def run(scenario, d):
+def run(scenario, d, ulps=0):
     noise = TC.noise()
-    t = make_trainer(scenario, noise)
+    t = make_trainer(scenario, noise, ulps)
     groups = [len(g["params"]) for g in t.optimizer.param_groups]
     d[scenario + "_param_group_sizes"] = np.array(groups)
     d[scenario + "_param_group_lrs"] = np.array([g["lr"] for g in t.optimizer.param_groups])
@@ -143,10 +148,32 @@ def run(scenario, d):
 
 
 out = {}
-for sc in args.scenarios.split(","):
-    run(sc, out)
+keep = os.path.join(REPO, "build", "trainstep_package_out.npz")
+if args.compare_only:
+    out = dict(np.load(keep, allow_pickle=False))
+else:
+    for sc in args.scenarios.split(","):
+        run(sc, out)
+    if args.impl == "package":
+        os.makedirs(os.path.dirname(keep), exist_ok=True)
+        np.savez_compressed(keep, **out)      # ~40 min of interpretation: kept so that the comparison can be redone
 path = os.path.join(HERE, "trainstep.npz")
 if args.impl == "reference":
+    # yardstick: what fp32 round-off alone does to every recorded per-parameter figure -- the same reference run with the stem
+    # weights scaled by 1 +- 1..2 ulp (tests/diag/gradient_norm_sensitivity.py: a ReLU / BatchNorm network over a few dozen
+    # samples amplifies that to per cent level in single parameters, more in the second iteration)
+    for sc in args.scenarios.split(","):
+        spread = {}
+        for ulps in (1, -1, 2, -2):
+            alt = {}
+            run(sc, alt, ulps)
+            for k, v in alt.items():
+                if k.endswith(("grad_norms", "update_norms")):
+                    dlt = np.abs(np.asarray(v) - np.asarray(out[k]))
+                    spread[k] = np.maximum(spread[k], dlt) if k in spread else dlt
+                elif "_it" in k and np.ndim(v) == 0:
+                    spread[k] = max(spread.get(k, 0.0), abs(float(v) - float(out[k])))
+        out.update({k + "_spread": np.asarray(v) for k, v in spread.items()})
     np.savez_compressed(path, **out)
     print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024))
 else:

@@ -507,4 +507,4 @@ def test_trainstep_fixture_and_param_groups():
         run = json.load(open(log))
         assert set(run["scenarios"]) == set(TC.SCENARIOS)
         for sc in TC.SCENARIOS:
-            assert run["scenarios"][sc]["loss"] < 1e-3
+            assert run["scenarios"][sc]["loss"] < 2e-3

@@ -112,30 +112,37 @@ def record(d, tag, it, losses, model, ema_model, before):
 
 def compare(got, ref, tag, log=print):
     """package run vs the reference run of the same caller.  Returns the worst figures; raises on a violation.
-    Tolerances: scalar losses 1e-3 relative (north_star); parameter updates (what the optimiser did with the clipped
-    gradients, momentum and weight decay) and gradient norms per parameter within 2 % of the parameter's own figure or
-    1e-3 of the largest figure of the iteration -- whole-model fp32 gradients of a ReLU / BatchNorm network differ by that
-    much between two correct fp32 implementations (DESIGN.md 4, tests/model_cases.py::gradients_vs_truth)."""
+    Tolerances: scalar losses 1e-3 relative (north_star).  Per-parameter gradient norms (after clipping) and update norms
+    (what the optimiser did with them, momentum and weight decay): within 2 % of the parameter's own figure, or 1e-3 of the
+    largest figure of the iteration, or 3x the YARDSTICK -- how far the reference's own fp32 run moves that very figure when its
+    stem weights are scaled by 1 +- 1..2 ulp (``*_spread``, recorded by make_trainstep.py).  At this test's frame size the
+    deepest BatchNorms see 4 samples per channel and the second iteration of the DepthMix scenario is chaotic in single
+    parameters (the reference moves one gradient norm by 84 % under 2 ulp); the losses and the bulk of the parameters are not."""
     worst = {}
     names = [str(n) for n in ref[tag + "_param_names"]]
     assert [str(n) for n in got[tag + "_param_names"]] == names, "parameter names / order differ"
     for it in range(ITERS):
         for k in ref:
-            if k.startswith("%s_it%d_" % (tag, it)) and np.ndim(ref[k]) == 0:
+            if k.startswith("%s_it%d_" % (tag, it)) and np.ndim(ref[k]) == 0 and not k.endswith("_spread"):
                 r, g = float(ref[k]), float(got[k])
-                err = abs(g - r) / max(abs(r), 1e-6)
-                worst["loss"] = max(worst.get("loss", 0.0), err)
-                assert err < 1e-3, (k, g, r)
+                tol = max(1e-3 * max(abs(r), 1e-6), 3.0 * float(ref.get(k + "_spread", 0.0)))
+                worst["loss"] = max(worst.get("loss", 0.0), abs(g - r) / max(abs(r), 1e-6))
+                assert abs(g - r) <= tol, (k, g, r, tol)
         for what, rel in (("grad_norms", 2e-2), ("update_norms", 2e-2)):
-            r, g = np.asarray(ref["%s_it%d_%s" % (tag, it, what)]), np.asarray(got["%s_it%d_%s" % (tag, it, what)])
+            key = "%s_it%d_%s" % (tag, it, what)
+            r, g = np.asarray(ref[key]), np.asarray(got[key])
             assert ((r < 0) == (g < 0)).all(), "different parameters received a gradient: %s" % \
                 [n for n, a, b in zip(names, r, g) if (a < 0) != (b < 0)][:5]
             live = r >= 0
-            floor = 1e-3 * float(r[live].max())
-            err = np.abs(g - r)[live] / np.maximum(np.abs(r[live]), floor / rel)
-            j = int(err.argmax())
-            worst[what] = max(worst.get(what, 0.0), float(err[j]))
-            assert err[j] < rel, (what, it, np.array(names)[live][j], float(g[live][j]), float(r[live][j]))
+            spread = np.asarray(ref[key + "_spread"])[live] if key + "_spread" in ref else np.zeros(int(live.sum()))
+            tol = np.maximum(np.maximum(rel * np.abs(r[live]), 1e-3 * float(r[live].max())), 3.0 * spread)
+            excess = np.abs(g - r)[live] / tol
+            j = int(excess.argmax())
+            relerr = np.abs(g - r)[live] / np.maximum(np.abs(r[live]), 1e-3 * float(r[live].max()))
+            worst[what + " (median rel.)"] = max(worst.get(what + " (median rel.)", 0.0), float(np.median(relerr)))
+            worst[what + " (worst / tolerance)"] = max(worst.get(what + " (worst / tolerance)", 0.0), float(excess[j]))
+            assert excess[j] <= 1.0, (what, it, np.array(names)[live][j], float(g[live][j]), float(r[live][j]), float(tol[j]))
+            assert np.median(relerr) < 5e-3, (what, it, float(np.median(relerr)))       # the bulk agrees to a fraction of a per cent
         for what in ("param_sums", "bn_running_mean_sums", "ema_param_sums"):
             k = "%s_it%d_%s" % (tag, it, what)
             if k in ref:
@@ -143,5 +150,5 @@ def compare(got, ref, tag, log=print):
                 err = float((np.abs(g - r) / np.maximum(np.abs(r), 1.0)).max())
                 worst[what] = max(worst.get(what, 0.0), err)
                 assert err < 1e-3, (what, it, err)
-    log("%s: worst relative deviations %s" % (tag, {k: float("%.3g" % v) for k, v in worst.items()}))
+    log("%s: worst deviations %s" % (tag, {k: float("%.3g" % v) for k, v in worst.items()}))
     return worst

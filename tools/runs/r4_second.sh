@@ -4,5 +4,5 @@ ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
 cd $ROOT
-timeout 2400 python -m pytest tests -m gpu -q -x -k "train_step_replay or monodepth_layer or cfg2 or cfg5 or r50_mono or selfspawn or two_ranks or reducer or fusion or decoders or unlabeled or loss_kernels or full_model" 2>&1 | grep -v "RCCL\|HIP version\|ROCm version\|Hostname\|Librccl" | tail -25 > $OUT/r4_second_tests.log
+timeout 2400 python -m pytest tests -m gpu -q -k "cfg2_batch8 or train_step_replay or monodepth_layer or cfg5 or selfspawn or two_ranks or reducer or fusion or decoders or unlabeled or loss_kernels or full_model or jitter_blur" | tail -60 > $OUT/r4_second_tests.log
 cat $OUT/r4_second_tests.log
