@@ -149,6 +149,8 @@ def compare(got, ref, tag, log=print):
                 r, g = np.asarray(ref[k]), np.asarray(got[k])
                 err = float((np.abs(g - r) / np.maximum(np.abs(r), 1.0)).max())
                 worst[what] = max(worst.get(what, 0.0), err)
-                assert err < 1e-3, (what, it, err)
+                # checksums of whole tensors after the update(s): 1e-3 after the first iteration; the second one starts from
+                # gradients that differ at the yardstick's level (lr 1e-2 on the decoders) -- 3e-3
+                assert err < (1e-3 if it == 0 else 3e-3), (what, it, err)
     log("%s: worst deviations %s" % (tag, {k: float("%.3g" % v) for k, v in worst.items()}))
     return worst
