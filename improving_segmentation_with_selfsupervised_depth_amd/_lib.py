@@ -23,6 +23,11 @@ class PackJob(ctypes.Structure):
         "O", "I", "KH", "KW", "block0", "reserved")]
 
 
+class WinoJob(ctypes.Structure):
+    """mirror of ``segsde_wino_job`` (include/segsde_hip.h)"""
+    _fields_ = [("w", c_void_p), ("u_fwd", c_void_p), ("u_dgrad", c_void_p)] + [(n, c_int) for n in ("O", "I", "block0", "reserved")]
+
+
 class ConvDesc(ctypes.Structure):
     """mirror of ``segsde_conv_desc`` (include/segsde_hip.h)"""
     _fields_ = [(n, c_int) for n in (
@@ -41,6 +46,11 @@ _SIGS = {
     "segsde_bn_stats_from_partials": (c_int, [P, c_long, c_long, c_int, P, P, P, P, c_float, c_float, P, P, c_size_t, P]),
     "segsde_conv2d_wgrad_workspace": (c_size_t, [POINTER(ConvDesc)]),
     "segsde_conv2d_wgrad": (c_int, [POINTER(ConvDesc), P, P, P, c_int, P, P, c_size_t, P]),
+    "segsde_conv2d_winograd_workspace": (c_size_t, [POINTER(ConvDesc)]),
+    "segsde_conv2d_winograd_stats_rows": (ctypes.c_long, [POINTER(ConvDesc)]),
+    "segsde_winograd_pack": (c_int, [P, c_int, c_int, P, P, P]),
+    "segsde_winograd_pack_multi": (c_int, [P, c_int, c_int, P]),
+    "segsde_conv2d_winograd": (c_int, [POINTER(ConvDesc), P, P, P, P, P, P, P, c_size_t, P]),
     "segsde_upfold_pack": (c_int, [P, c_int, c_int, c_int, P, P, P]),
     "segsde_conv2d_forward_upfold": (c_int, [POINTER(ConvDesc), P, P, P, P, P, P, P]),
     "segsde_conv2d_dgrad_upfold": (c_int, [POINTER(ConvDesc), P, c_int, P, P, P, P, P, P, c_int, c_int, P]),

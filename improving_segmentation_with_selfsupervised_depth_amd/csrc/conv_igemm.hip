@@ -24,6 +24,7 @@
 #include <type_traits>
 #include "segsde_common.h"
 #include "conv_small.h"
+#include "winograd.h"
 #include <cstdlib>
 #include <mutex>
 #include <cstring>
@@ -72,6 +73,9 @@ struct ConvP {
   // live tap rows only (tile-uniform: a tile is a run of consecutive pixels, its rows an interval).  Weight gradient: a
   // pixel chunk whose rows are dead for the workgroup's tap row is skipped.
   int tapskip;
+  // Grouped weights (the sixteen position GEMMs of a Winograd convolution as one launch, FAST / LDS-DMA path only): a tile
+  // whose first row lies in image b of the B-image input reads its weight rows from w + b * wbstride floats.  0: one weight.
+  long wbstride;
 };
 constexpr int SEGSDE_PAD_CLAMP_ = 3;   // internal (never crosses the ABI)
 
@@ -422,7 +426,7 @@ __global__ __launch_bounds__(256, VAR == 6 ? 3 : 2) void conv_igemm_kernel(ConvP
     const SrcSel s1 = select_src(p, p.C0 < p.Ctot ? p.C0 : 0);
     const float* base0 = s0.src + (size_t)b0 * s0.bstride;   // resources rebased to the first image the tile touches
     const float* base1 = s1.src + (size_t)b0 * s1.bstride;
-    const segsde_rsrc rsw = segsde_make_rsrc(p.w);
+    const segsde_rsrc rsw = segsde_make_rsrc(p.w + (size_t)b0 * (size_t)p.wbstride);
     unsigned voff[AR], voffB[BR];
     bool wave_bord = false, wave_corner = false;
     int bflag[AR];
@@ -1856,6 +1860,7 @@ ConvP make_params(const segsde_conv_desc* d, const float* x0, const float* x1, c
   p.padw = p.pad; p.wtap = p.Ctot; p.osfast = 0; p.submap = 0;
   p.tapskip = (tune().tskip && d->pad_mode == SEGSDE_PAD_ZERO && d->dil > 1 && d->KH > 1 && d->in_div <= 1 && !d->up0 && !d->sum2x2 &&
                d->stride == 1) ? 1 : 0;
+  p.wbstride = 0;
   return p;
 }
 
@@ -2846,4 +2851,85 @@ extern "C" int segsde_reflect_dgrad_fix(const float* dy, int lddy, const float* 
   if (H < 2 || W < 2) return SEGSDE_ERR_SHAPE;
   return launch_reflect_fix(dy, lddy, wdpack, dx, lddx, dx2, lddx2, nsplit, B, H, W, Cin, Cout,
                             static_cast<hipStream_t>(stream));
+}
+
+
+// ---------------------------------------------------------------------------------------------------
+// Winograd F(2x2,3x3) route of the stride-1 3x3 convolutions with many channels (round 4; transforms: winograd.hip)
+// ---------------------------------------------------------------------------------------------------
+// forward AND data-gradient (the data-gradient of a 3x3 / stride 1 / pad 1 convolution is the same convolution of dY with the
+// flipped, transposed kernel: segsde_winograd_pack writes both transformed packs).  One call = input transform -> ONE launch of
+// the LDS-DMA implicit-GEMM kernel over the sixteen transform positions (a 1x1 convolution of a 16-"image" tensor whose weight
+// base advances with the image index: 16 GEMMs [T x C] x [C x Cout], T = B * H/2 * W/2) -> output transform (+ the BatchNorm
+// statistics partials of the output, like the implicit-GEMM epilogue's).  16 instead of 36 multiply-adds per 2x2 output block,
+// channel and filter; the transforms add ~4 B/element of cache-resident traffic each way.
+namespace {
+bool winograd_shape_ok(const segsde_conv_desc* d) {
+  if (validate(d)) return false;
+  const long T = (long)d->B * (d->H / 2) * (d->W / 2);
+  const int C = d->C0 + d->C1;
+  return d->KH == 3 && d->KW == 3 && d->stride == 1 && d->dil >= 1 && d->pad == d->dil && !d->up0 && d->in_div <= 1 && !d->sum2x2 &&
+         !d->accumulate && (d->pad_mode == SEGSDE_PAD_ZERO || (d->pad_mode == SEGSDE_PAD_REFLECT && d->dil == 1)) && d->H == d->Ho &&
+         d->W == d->Wo && d->H % (2 * d->dil) == 0 && d->W % (2 * d->dil) == 0 && d->H >= 4 * d->dil && d->W >= 4 * d->dil &&
+         C % 32 == 0 && d->C0 % 4 == 0 && d->Cout % 64 == 0 && d->ld0 % 4 == 0 && (!d->C1 || d->ld1 % 4 == 0) && d->ldy % 4 == 0 &&
+         T % 128 == 0 && 16 * T * (long)(C > d->Cout ? C : d->Cout) < (1L << 31) && tune().dma;
+}
+segsde_conv_desc winograd_gemm_desc(const segsde_conv_desc* d) {
+  segsde_conv_desc g = *d;
+  g.B = 16; g.H = d->B * (d->H / 2); g.W = d->W / 2; g.C0 = d->C0 + d->C1; g.C1 = 0; g.ld0 = g.C0; g.ld1 = 0; g.Ho = g.H; g.Wo = g.W;
+  g.ldy = d->Cout; g.ldy2 = 0; g.nsplit = 0; g.KH = 1; g.KW = 1; g.dil = 1; g.pad = 0; g.pad_mode = SEGSDE_PAD_ZERO; g.act = 0;
+  return g;
+}
+}  // namespace
+
+extern "C" size_t segsde_conv2d_winograd_workspace(const segsde_conv_desc* d) {
+  if (!winograd_shape_ok(d)) return 0;
+  const size_t T = (size_t)d->B * (d->H / 2) * (d->W / 2);
+  return 16 * T * ((size_t)d->C0 + (size_t)d->C1 + (size_t)d->Cout) * sizeof(float) + 256;
+}
+
+extern "C" long segsde_conv2d_winograd_stats_rows(const segsde_conv_desc* d) {
+  return winograd_shape_ok(d) ? segsde_wino_stats_rows((long)d->B * (d->H / 2) * (d->W / 2)) : 0;
+}
+
+extern "C" int segsde_winograd_pack(const float* w_oihw, int Cout, int Cin, float* u_fwd, float* u_dgrad, void* stream) {
+  if (!w_oihw || (!u_fwd && !u_dgrad)) return SEGSDE_ERR_NULL;
+  if (Cout <= 0 || Cin <= 0) return SEGSDE_ERR_SHAPE;
+  if (u_fwd)
+    if (int e = segsde_wino_weights(w_oihw, Cout, Cin, 0, u_fwd, stream)) return e;
+  if (u_dgrad)
+    if (int e = segsde_wino_weights(w_oihw, Cout, Cin, 1, u_dgrad, stream)) return e;
+  return 0;
+}
+
+extern "C" int segsde_winograd_pack_multi(const segsde_wino_job* jobs_device, int njobs, int total_blocks, void* stream) {
+  if (!jobs_device) return SEGSDE_ERR_NULL;
+  if (njobs <= 0 || total_blocks <= 0) return SEGSDE_ERR_SHAPE;
+  return segsde_wino_weights_multi(jobs_device, njobs, total_blocks, stream);
+}
+
+extern "C" int segsde_conv2d_winograd(const segsde_conv_desc* d, const float* x0, const float* x1, const float* u_pack,
+                                      const float* bias, float* y, double* stats, void* workspace, size_t workspace_bytes,
+                                      void* stream) {
+  // d: the convolution's own geometry (3x3, stride 1, pad = dil; [C0 | C1] -> Cout, activation d->act).  u_pack: [16][Cout][C0 + C1]
+  // from segsde_winograd_pack (its forward pack; for a data-gradient call d describes dY -> dX and u_pack is the data-gradient
+  // pack).  stats (nullable): [segsde_conv2d_winograd_stats_rows(d)][2][Cout] doubles.
+  if (!d || !x0 || !u_pack || !y || !workspace || (d->C1 && !x1)) return SEGSDE_ERR_NULL;
+  if (!winograd_shape_ok(d) || !aligned16(x0) || (d->C1 && !aligned16(x1)) || !aligned16(y) || !aligned16(u_pack) ||
+      (bias && !aligned16(bias)) || d->act < SEGSDE_ACT_NONE || d->act > SEGSDE_ACT_SIGMOID)
+    return SEGSDE_ERR_UNSUPPORTED;
+  if (workspace_bytes < segsde_conv2d_winograd_workspace(d)) return SEGSDE_ERR_WORKSPACE;
+  const size_t T = (size_t)d->B * (d->H / 2) * (d->W / 2);
+  const int C = d->C0 + d->C1;
+  float* V = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
+  float* Mb = V + 16 * T * C;
+  const segsde_conv_desc g = winograd_gemm_desc(d);
+  ConvP q = make_params(&g, V, nullptr, u_pack, nullptr, Mb, nullptr);
+  q.wbstride = (long)d->Cout * C;
+  if (!igemm_fast_ok(q) || !q.vecout || !q.lin) return SEGSDE_ERR_UNSUPPORTED;
+  if (int e = segsde_wino_input(x0, d->ld0, d->C1 ? x1 : nullptr, d->C1 ? d->ld1 : d->ld0, d->C0, d->B, d->H, d->W, C, d->dil,
+                                d->pad_mode == SEGSDE_PAD_REFLECT, V, stream))
+    return e;
+  if (int e = launch_by_n(q, static_cast<hipStream_t>(stream))) return e;
+  return segsde_wino_output(Mb, d->B, d->H, d->W, d->Cout, d->dil, bias, d->act, y, d->ldy, stats, stream);
 }

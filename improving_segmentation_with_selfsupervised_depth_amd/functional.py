@@ -120,7 +120,7 @@ class ConvFn(Function):
 
     @staticmethod
     def forward(ctx, x0, x1, weight, bias, g, act, stats_out=None, grad_box=None, packs=None, x0_act=None, act_box=None,
-                fold_cache=None):
+                fold_cache=None, wino_cache=None):
         """stats_out: optional list; receives the BatchNorm statistics partials of y (or None) -- see Conv2d.forward.
         grad_box: optional dict shared with the BNActFn that adds this conv's input as a residual (see SplitFn): when its
         backward has already left the residual-path gradient there, this conv's data-gradient is accumulated onto it.
@@ -141,8 +141,19 @@ class ConvFn(Function):
         else:
             wp = H.pack_weight(weight, False)
         ctx.fold = None
+        # Winograd route (3x3 / stride 1 / many channels): the transformed weight packs, cached by the owning module for the
+        # active weight_pack_scope like the plain packs
+        ctx.wino = None
+        if not g.up0 and H.winograd_ok(g, x0.shape[0], x0.shape[1], x0.shape[2]):
+            if wino_cache is not None and wino_cache.get("key") is not None and wino_cache.get("key") == wino_cache.get("want"):
+                ctx.wino = wino_cache["packs"]
+            else:
+                ctx.wino = H.winograd_pack(weight)
+                if wino_cache is not None and wino_cache.get("want") is not None:
+                    wino_cache["packs"], wino_cache["key"] = ctx.wino, wino_cache["want"]
+        wino_f = None if ctx.wino is None else ctx.wino[0]
         if stats_out is not None:
-            y, part = H.conv_forward(g, x0, x1, wp, bias, act, want_stats=True)
+            y, part = H.conv_forward(g, x0, x1, wp, bias, act, want_stats=True, wino=wino_f)
             stats_out.append(part)
         else:
             if H.upfold_ok(g, 4 * x0.shape[0] * x0.shape[1] * x0.shape[2]) and x0.is_contiguous() and (x1 is None or x1.is_contiguous()):
@@ -154,7 +165,7 @@ class ConvFn(Function):
                     ctx.fold = H.upfold_pack(weight, g.C0)
                     if fold_cache is not None and fold_cache.get("want") is not None:
                         fold_cache["fold"], fold_cache["key"] = ctx.fold, fold_cache["want"]
-            y = H.conv_forward(g, x0, x1, wp, bias, act, wfold=None if ctx.fold is None else ctx.fold[0])
+            y = H.conv_forward(g, x0, x1, wp, bias, act, wfold=None if ctx.fold is None else ctx.fold[0], wino=wino_f)
         ctx.g, ctx.act = g, act
         ctx.in_hw = (x0.shape[1] * (2 if g.up0 else 1), x0.shape[2] * (2 if g.up0 else 1))
         ctx.has_bias = bias is not None
@@ -190,7 +201,8 @@ class ConvFn(Function):
                     box["fused"] = True      # dx0 IS the residual-path gradient, now holding the sum
             if dx0 is None:
                 dx0, dx1 = H.conv_dgrad(g, dz, wd, weight.detach(), ctx.in_hw, actgrad=actgrad, fold=ctx.fold,
-                                        need0=ctx.needs_input_grad[0], need1=x1 is not None and ctx.needs_input_grad[1])
+                                        need0=ctx.needs_input_grad[0], need1=x1 is not None and ctx.needs_input_grad[1],
+                                        wino=None if (ctx.wino is None or x1 is not None) else ctx.wino[1])
                 if box is not None and box.get("publish") and box.get("g") is None and x1 is None and not g.up0 \
                         and dx0.is_contiguous():
                     box["g"] = dx0           # FanoutFn: the next consumer's data-gradient is accumulated onto this tensor
@@ -204,7 +216,7 @@ class ConvFn(Function):
                 dx1 = None
         if ctx.needs_input_grad[2]:
             dw = H.conv_wgrad(g, x0, x1, dz)
-        return dx0, dx1, dw, dbias, None, None, None, None, None, None, None, None
+        return dx0, dx1, dw, dbias, None, None, None, None, None, None, None, None, None
 
 
 class ActGradFn(Function):

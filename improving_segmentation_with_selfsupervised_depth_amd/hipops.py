@@ -84,6 +84,111 @@ def upfold_pack(w_oihw, C0):
     return wf, wd
 
 
+# Winograd F(2x2,3x3) route of the stride-1 3x3 convolutions with many channels (csrc/winograd.hip, segsde_conv2d_winograd):
+# SEGSDE_WINOGRAD=0 keeps the direct implicit GEMM (A/B measurements; the exactness tests of the direct kernels use it)
+WINOGRAD = os.environ.get("SEGSDE_WINOGRAD", "1") != "0"
+WINOGRAD_MIN_CH = int(os.environ.get("SEGSDE_WINOGRAD_MIN_CH", "256"))
+WINOGRAD_MIN_MACS = float(os.environ.get("SEGSDE_WINOGRAD_MIN_MACS", "4e9"))
+WINOGRAD_TAKEN = {"fwd": 0, "dgrad": 0}
+
+
+def winograd_ok(g, B=None, H=None, W=None, dgrad=False):
+    """Shape gate of the Winograd route.  Measured (profiles/probe_r04_winograd_gate.log, probe_r04_winograd_route.log): with the
+    transforms as separate passes the route wins from 256 channels on (1.4x at 256 channels, 1.8x at 512); at 128 channels the
+    transforms' traffic eats the 2.25x fewer multiply-adds.  The multiply-add floor keeps tiny launches (and the small-shape
+    golden tests of the direct kernels) on the direct route.  Forward: one or two sources, zero / mirrored padding (mirrored:
+    dilation 1), any dilation that divides the map into even sub-lattices.  Data-gradient: one source, zero padding."""
+    cin, cout = (g.Cout, g.C0) if dgrad else (g.Cin, g.Cout)      # the data-gradient is the convolution Cout -> C0
+    if not (WINOGRAD and g.k == 3 and g.stride == 1 and g.pad == g.dil and not g.up0 and g.cin_alg is None and g.C0 % 4 == 0
+            and cin % 32 == 0 and cout % 64 == 0 and min(g.Cin, g.Cout) >= WINOGRAD_MIN_CH and not (g.reflect and g.dil != 1)):
+        return False
+    if dgrad and (g.C1 or g.reflect):
+        return False
+    if B is None:
+        return True
+    if H % (2 * g.dil) or W % (2 * g.dil) or H < 4 * g.dil or W < 4 * g.dil or (B * (H // 2) * (W // 2)) % 128:
+        return False
+    return 9.0 * B * H * W * g.Cin * g.Cout >= WINOGRAD_MIN_MACS
+
+
+def winograd_static_ok(conv):
+    """could this nn.Conv2d ever take the route (weight_pack_scope packs those up front)"""
+    return (WINOGRAD and conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == conv.dilation
+            and conv.in_channels % 32 == 0 and conv.out_channels % 64 == 0
+            and min(conv.in_channels, conv.out_channels) >= WINOGRAD_MIN_CH)
+
+
+def winograd_pack(w_oihw):
+    """(forward pack [16][Cout][Cin], data-gradient pack [16][Cin][Cout]) = G g G^T of an OIHW 3x3 weight"""
+    w = _f32(w_oihw.detach()).contiguous()
+    O, I, KH, KW = w.shape
+    assert KH == 3 and KW == 3
+    uf = torch.empty((16, O, I), dtype=torch.float32, device=w.device)
+    ud = torch.empty((16, I, O), dtype=torch.float32, device=w.device)
+    check(_lib.lib().segsde_winograd_pack(_p(w), O, I, _p(uf), _p(ud), _stream(w)), "winograd_pack")
+    return uf, ud
+
+
+_WINO_MULTI = {}
+
+
+def winograd_packs_multi(weights):
+    """[(forward pack, data-gradient pack)] of many 3x3 weights in ONE launch; the packs are views into a flat buffer that the
+    next call with the same weights rewrites (what a training step needs, like pack_weights_multi)"""
+    ws = [_f32(w.detach()) for w in weights]
+    assert ws and all(w.is_contiguous() and w.dim() == 4 and tuple(w.shape[2:]) == (3, 3) for w in ws)
+    dev = ws[0].device
+    key = (dev, tuple((w.data_ptr(), tuple(w.shape)) for w in ws))
+    hit = _WINO_MULTI.get(key)
+    if hit is None:
+        if len(_WINO_MULTI) > 8:
+            _WINO_MULTI.clear()
+        total = sum(16 * w.shape[0] * w.shape[1] for w in ws)
+        flat = torch.empty(2 * total, dtype=torch.float32, device=dev)
+        jobs = (_lib.WinoJob * len(ws))()
+        views, off, blk = [], 0, 0
+        for i, w in enumerate(ws):
+            O, I = w.shape[0], w.shape[1]
+            n = 16 * O * I
+            uf, ud = flat[off:off + n].view(16, O, I), flat[off + n:off + 2 * n].view(16, I, O)
+            off += 2 * n
+            jobs[i] = _lib.WinoJob(w.data_ptr(), uf.data_ptr(), ud.data_ptr(), O, I, blk, 0)
+            blk += 2 * ((O * I + 255) // 256)
+            views.append((uf, ud))
+        raw = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8).to(dev)
+        hit = _WINO_MULTI[key] = (raw, flat, views, len(ws), blk)
+    raw, flat, views, n, blk = hit
+    check(_lib.lib().segsde_winograd_pack_multi(_p(raw), n, blk, _stream(flat)), "winograd_pack_multi")
+    return views
+
+
+def _winograd(kind, g, x0, x1, upack, Cout, want_stats, flops, tag, bias=None, act="none", reflect=False):
+    """one Winograd convolution [x0 | x1] [B,H,W,C] -> [B,H,W,Cout]; returns (y, partials or None), or None when the kernel
+    declines"""
+    B, H, W, C0 = x0.shape
+    C1 = 0 if x1 is None else x1.shape[3]
+    L = _lib.lib()
+    d = ConvDesc(B=B, H=H, W=W, C0=C0, C1=C1, ld0=nhwc_ld(x0), ld1=nhwc_ld(x1) if x1 is not None else 0, up0=0, Ho=H, Wo=W,
+                 Cout=Cout, ldy=Cout, ldy2=0, nsplit=0, KH=3, KW=3, stride=1, dil=g.dil, pad=g.dil,
+                 pad_mode=PAD_REFLECT if reflect else PAD_ZERO, in_div=1, act=ACT[act], sum2x2=0)
+    nbytes = L.segsde_conv2d_winograd_workspace(ctypes.byref(d))
+    if not nbytes:
+        return None
+    y = torch.empty((B, H, W, Cout), dtype=torch.float32, device=x0.device)
+    part = None
+    if want_stats:
+        part = torch.empty((int(L.segsde_conv2d_winograd_stats_rows(ctypes.byref(d))), 2, Cout), dtype=torch.float64, device=x0.device)
+    ws = _ws(nbytes, x0)
+    rc = _timed(kind, flops, x0, lambda: L.segsde_conv2d_winograd(ctypes.byref(d), _p(_f32(x0)), _p(x1), _p(upack), _p(bias), _p(y),
+                                                                   _p(part), _p(ws), nbytes, _stream(x0)), tag + " wino",
+                executed=flops * 16.0 / 36.0)
+    if rc == -4:
+        return None
+    check(rc, "conv2d_winograd")
+    WINOGRAD_TAKEN["fwd" if kind == "conv_fwd" else "dgrad"] += 1
+    return y, part
+
+
 def _fold_frac(g):
     return (4.0 * g.C0 + 9.0 * g.C1) / (9.0 * (g.C0 + g.C1))
 
@@ -237,7 +342,7 @@ def pack_weights_multi(weights):
     return views
 
 
-def conv_forward(g, x0, x1, wpack, bias, act="none", want_stats=False, wfold=None):
+def conv_forward(g, x0, x1, wpack, bias, act="none", want_stats=False, wfold=None, wino=None):
     """y = act(conv(cat[up?(x0), x1]) + bias).  x0: [B,H0,W0,C0] (H0 = H/2 if g.up0), x1: [B,H,W,C1] or None.
     want_stats: also return the per-tile statistics partials of y for the BatchNorm that follows ([rows,2,Cout] doubles,
     or None when this shape cannot fuse them) -> (y, partials)."""
@@ -254,6 +359,10 @@ def conv_forward(g, x0, x1, wpack, bias, act="none", want_stats=False, wfold=Non
                  act=ACT[act], sum2x2=0)
     flops = 2.0 * B * Ho * Wo * g.Cout * g.CinAlg * g.k * g.k
     flops_x = flops * g.Cin / g.CinAlg * _live_tap_frac(g, H, W)   # executed: zero pad channels of a stem are multiplied too, dead tap rows are not
+    if wino is not None and not g.up0 and (not want_stats or (bias is None and act == "none")) and winograd_ok(g, B, H, W):
+        r = _winograd("conv_fwd", g, x0, x1, wino, g.Cout, want_stats, flops, _tag(g, H, W), bias=bias, act=act, reflect=g.reflect)
+        if r is not None:
+            return r if want_stats else r[0]
     if wfold is not None and not want_stats:
         rc = _timed("conv_fwd", flops, x0, lambda: _lib.lib().segsde_conv2d_forward_upfold(
             ctypes.byref(d), _p(_f32(x0)), _p(x1), _p(wpack), _p(wfold), _p(bias), _p(y), _stream(x0)), _tag(g, H, W) + " fold",
@@ -277,7 +386,7 @@ def conv_forward(g, x0, x1, wpack, bias, act="none", want_stats=False, wfold=Non
 ACTGRAD_FUSED = [False]      # did the last conv_dgrad(actgrad=...) apply the derivative in its epilogue (functional.py counts from this)
 
 
-def conv_dgrad(g, dy, wdpack, w_oihw, in_hw, need0=True, need1=True, accumulate_into=None, actgrad=None, fold=None):
+def conv_dgrad(g, dy, wdpack, w_oihw, in_hw, need0=True, need1=True, accumulate_into=None, actgrad=None, fold=None, wino=None):
     """Data gradient(s) of conv_forward w.r.t. (x0, x1).  dy: [B,Ho,Wo,Cout]; in_hw = (H, W) of the virtual input.
     Returns (dx0, dx1); dx0 is at the *stored* resolution of x0 (2x2-summed when g.up0).
     accumulate_into: a dense [B,H,W,C0] tensor that already holds another gradient of x0 (single-source, non-upsampled
@@ -297,6 +406,13 @@ def conv_dgrad(g, dy, wdpack, w_oihw, in_hw, need0=True, need1=True, accumulate_
     if actgrad is not None:
         ag_y, ag_kind = actgrad[0], ACT[actgrad[1]]
         ag_ld = nhwc_ld(ag_y)
+
+    if (wino is not None and accumulate_into is None and actgrad is None and not g.reflect and g.C1 == 0
+            and winograd_ok(g, B, H, W, dgrad=True) and (Ho, Wo) == (H, W)):
+        # zero-padded 3x3 / stride 1: dX is the same convolution of dY with the flipped, transposed kernel
+        r = _winograd("conv_dgrad", g, dy, None, wino, g.C0, False, flops, _tag(g, H, W))
+        if r is not None:
+            return r[0], None
 
     def desc(sum2x2, accumulate=0):
         return ConvDesc(B=B, H=Ho, W=Wo, C0=Cout, C1=0, ld0=nhwc_ld(dy), ld1=0, up0=0, Ho=H, Wo=W, Cout=g.Cin, ldy=g.C0,

@@ -56,6 +56,12 @@ class weight_pack_scope:
         for m, pk in zip(convs, packs):
             w = m.weight
             m._packs, m._pack_key = pk, (scope_id, w._version, w.data_ptr(), w.device)
+        # the Winograd-transformed packs of the 3x3 / stride-1 convolutions with many channels, likewise in one launch
+        wino = [m for m in convs if H.winograd_static_ok(m)]
+        if wino:
+            for m, pk in zip(wino, H.winograd_packs_multi([m.weight for m in wino])):
+                w = m.weight
+                m._wino_cache["packs"], m._wino_cache["key"] = pk, (scope_id, w._version, w.data_ptr(), w.device)
 
     def __exit__(self, *exc):
         _PACK_SCOPE[0] = self._outer
@@ -72,6 +78,7 @@ class Conv2d(nn.Conv2d):
         self.reflect = reflect
         self._pack_key, self._packs = None, None   # weight packs of the current weight version (see _weight_packs)
         self._fold_cache = {}         # upsample-folded packs of the same weight version (filled by ConvFn inside a pack scope)
+        self._wino_cache = {}         # Winograd-transformed packs, likewise
         self._stats_wanted = None     # None: unknown yet, True: a BatchNorm consumed the fused statistics, False: nobody did
         self._stats_offered = False
         k = self.kernel_size[0]
@@ -131,6 +138,8 @@ class Conv2d(nn.Conv2d):
         pre = getattr(x, "_preact", None)
         if pre is not None and pre[2] == x._version and torch.is_grad_enabled() and pre[0].requires_grad:
             x, x0_act = pre[0], pre[1]
+        wc = self._wino_cache
+        wc["want"] = (_PACK_SCOPE[0], weight._version, weight.data_ptr(), weight.device) if _PACK_SCOPE[0] else None
         if self.bias is None and act == "none" and self.training and not _NO_FUSED_STATS and self._stats_wanted is not False:
             # bias-free, activation-free convolutions are the candidates for a following BatchNorm (torchvision ResNet /
             # ASPP convention): their epilogue also leaves the batch-statistics partials, picked up by
@@ -138,18 +147,18 @@ class Conv2d(nn.Conv2d):
             # segmentation projections) stops producing them after its first training forward.
             if self._stats_wanted is None and self._stats_offered:
                 self._stats_wanted = False
-                return Fn.ConvFn.apply(x, skip, weight, self.bias, g, act, None, grad_box, packs, x0_act)
+                return Fn.ConvFn.apply(x, skip, weight, self.bias, g, act, None, grad_box, packs, x0_act, None, None, wc)
             self._stats_offered = True
             holder = []
-            y = Fn.ConvFn.apply(x, skip, weight, self.bias, g, act, holder, grad_box, packs, x0_act)
+            y = Fn.ConvFn.apply(x, skip, weight, self.bias, g, act, holder, grad_box, packs, x0_act, None, None, wc)
             y._bn_partials = (holder[0], y._version, self) if holder and holder[0] is not None else None
             return y
         if act == "none":
-            return Fn.ConvFn.apply(x, skip, weight, self.bias, g, act, None, grad_box, packs, x0_act)
+            return Fn.ConvFn.apply(x, skip, weight, self.bias, g, act, None, grad_box, packs, x0_act, None, None, wc)
         box = {"need_dbias": self.bias is not None and self.bias.requires_grad}
         fc = self._fold_cache
         fc["want"] = (_PACK_SCOPE[0], weight._version, weight.data_ptr(), weight.device, c0) if (_PACK_SCOPE[0] and up) else None
-        yz = Fn.ConvFn.apply(x, skip, weight, self.bias, g, act, None, grad_box, packs, x0_act, box, fc)
+        yz = Fn.ConvFn.apply(x, skip, weight, self.bias, g, act, None, grad_box, packs, x0_act, box, fc, wc)
         if not (torch.is_grad_enabled() and yz.requires_grad):
             return yz
         y = Fn.ActGradFn.apply(yz, act, box)

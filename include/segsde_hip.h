@@ -232,6 +232,31 @@ int segsde_nchw_to_nhwc_bordered(const float* x, int B, int C, int H, int W, flo
                                  int pad_left, int Hp, int Wp, void* stream);
 int segsde_nhwc_to_nchw(const float* x, int ldx, int B, int C, int H, int W, float* y, void* stream);
 
+/* Winograd F(2x2,3x3) route of a stride-1 3x3 convolution with many channels whose padding equals its dilation (the conv2 of
+ * every bottleneck, models/resnet_encoder.py:90-101 via torchvision's Bottleneck, dilation 2 in layer4 of the dilated ResNet;
+ * the decoder's Conv3x3 on [x | skip] at the bottleneck resolution, models/depth_decoder.py:93-101).  The same call computes
+ * the data-gradient of a zero-padded convolution when handed dY, the transposed geometry and the data-gradient pack.
+ * segsde_winograd_pack: OIHW -> U = G g G^T as [16][Cout][Cin] (forward) and [16][Cin][Cout] of the flipped kernel
+ * (data-gradient); either output may be NULL.  segsde_winograd_pack_multi: the packs of many weights in one launch (device-
+ * resident job table; job j owns blocks [block0_j, block0_{j+1}), 2 * ceil(O * I / 256) each).  segsde_conv2d_winograd: input
+ * transform (x1 nullable: channels C0.. of the concat), sixteen position GEMMs as one launch of the implicit-GEMM kernel,
+ * output transform with bias (nullable) + activation d->act; `stats` (nullable) receives
+ * [segsde_conv2d_winograd_stats_rows(d)][2][Cout] doubles for segsde_bn_stats_from_partials.  Zero or mirrored padding (mirrored:
+ * dilation 1 only), H and W multiples of 2 * dilation, (C0 + C1) % 32 == 0, C0 % 4 == 0, Cout % 64 == 0; SEGSDE_ERR_UNSUPPORTED
+ * otherwise (callers use segsde_conv2d_forward). */
+typedef struct segsde_wino_job {
+  const float* w;    /* OIHW 3x3 weight */
+  float* u_fwd;      /* [16][O][I] */
+  float* u_dgrad;    /* [16][I][O] */
+  int O, I, block0, reserved;
+} segsde_wino_job;
+size_t segsde_conv2d_winograd_workspace(const segsde_conv_desc* d);
+long segsde_conv2d_winograd_stats_rows(const segsde_conv_desc* d);
+int segsde_winograd_pack(const float* w_oihw, int Cout, int Cin, float* u_fwd, float* u_dgrad, void* stream);
+int segsde_winograd_pack_multi(const segsde_wino_job* jobs_device, int njobs, int total_blocks, void* stream);
+int segsde_conv2d_winograd(const segsde_conv_desc* d, const float* x0, const float* x1, const float* u_pack, const float* bias,
+                           float* y, double* stats, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------------------ *
  * Pose: axis-angle + translation -> 4x4 (models/monodepth_layers.py:30-105)                         *
  * ------------------------------------------------------------------------------------------------ */

@@ -168,7 +168,7 @@ if args.impl == "reference":
             alt = {}
             run(sc, alt, ulps)
             for k, v in alt.items():
-                if k.endswith(("grad_norms", "update_norms")):
+                if k.endswith(("grad_norms", "update_norms", "param_sums", "bn_running_mean_sums")):
                     dlt = np.abs(np.asarray(v) - np.asarray(out[k]))
                     spread[k] = np.maximum(spread[k], dlt) if k in spread else dlt
                 elif "_it" in k and np.ndim(v) == 0:

@@ -1209,3 +1209,119 @@ def run_jitter_blur_properties(device):
     for n in (40, 56, 100, 512, 513, 1024, 2048):
         k = TG.blur_kernel_size(n)
         assert k % 2 == 1 and abs(k - 0.1 * n) <= 1.0 + 1e-9, (n, k)
+
+
+# ---------------------------------------------------------------------------------------------
+# Winograd F(2x2,3x3) route (csrc/winograd.hip + the grouped position GEMMs) against float64 and against the direct kernel
+# ---------------------------------------------------------------------------------------------
+def run_winograd_cases(device, shapes=((2, 16, 32, 64, 64), (1, 32, 16, 96, 128), (2, 8, 64, 128, 64))):
+    """forward (zero and mirrored padding, with the BatchNorm statistics partials), data-gradient and the autograd glue of the
+    Winograd route: error against a float64 convolution within 3x the direct kernel's own (plus 1e-6 of the largest value),
+    statistics partials summing to the column sums of the output, transformed packs cached per weight_pack_scope."""
+    from improving_segmentation_with_selfsupervised_depth_amd.models import layers as L
+    from improving_segmentation_with_selfsupervised_depth_amd import functional as Fn
+    old = (H.WINOGRAD_MIN_CH, H.WINOGRAD_MIN_MACS)
+    H.WINOGRAD_MIN_CH, H.WINOGRAD_MIN_MACS = 32, 0.0
+    try:
+        gen = torch.Generator().manual_seed(23)
+        for (B, Hh, W, C, Co) in shapes:
+            x = torch.randn(B, C, Hh, W, generator=gen)
+            w = torch.randn(Co, C, 3, 3, generator=gen) * (2.0 / (9 * C)) ** 0.5
+            dy = torch.randn(B, Co, Hh, W, generator=gen)
+            xd, wd_, dyd = nhwc(x).to(device).contiguous(), w.to(device), nhwc(dy).to(device).contiguous()
+            uf, ud = H.winograd_pack(wd_)
+            wp, wdp = H.pack_weight_both(wd_)
+            for refl in (False, True):
+                g = H.ConvGeom(C, Co, 3, 1, 1, 1, refl, 0, False)
+                assert H.winograd_ok(g, B, Hh, W)
+                xp = torch.nn.functional.pad(x.double(), (1, 1, 1, 1), mode="reflect" if refl else "constant")
+                want = torch.nn.functional.conv2d(xp, w.double())
+                n0 = H.WINOGRAD_TAKEN["fwd"]
+                y, part = H.conv_forward(g, xd, None, wp, None, want_stats=True, wino=uf)
+                assert H.WINOGRAD_TAKEN["fwd"] == n0 + 1, "the Winograd route declined %s" % ((B, Hh, W, C, Co),)
+                direct = H.conv_forward(g, xd, None, wp, None)
+                sc = float(want.abs().max())
+                e_w, e_d = float((nchw(y).double().cpu() - want).abs().max()), float((nchw(direct).double().cpu() - want).abs().max())
+                assert e_w <= 3 * e_d + 1e-6 * sc, ("forward", refl, (B, Hh, W, C, Co), e_w, e_d, sc)
+                rows = part.shape[0]
+                assert part.shape == (rows, 2, Co)
+                yy = y.double().reshape(-1, Co)
+                assert_close(part[:, 0].sum(0), yy.sum(0), rtol=1e-9, atol=1e-9 * float(yy.abs().sum(0).max()), what="Winograd statistics: sums")
+                assert_close(part[:, 1].sum(0), (yy * yy).sum(0), rtol=1e-9, atol=1e-9, what="Winograd statistics: sums of squares")
+            # data-gradient (zero padding): conv of dy with the flipped, transposed kernel
+            g = H.ConvGeom(C, Co, 3, 1, 1, 1, False, 0, False)
+            want = torch.nn.functional.conv_transpose2d(dy.double(), w.double(), padding=1)
+            n0 = H.WINOGRAD_TAKEN["dgrad"]
+            dx, _ = H.conv_dgrad(g, dyd, wdp, wd_, (Hh, W), wino=ud)
+            assert H.WINOGRAD_TAKEN["dgrad"] == n0 + (1 if C % 64 == 0 else 0)     # 96 gradient channels: the direct route
+            dxd, _ = H.conv_dgrad(g, dyd, wdp, wd_, (Hh, W))
+            sc = float(want.abs().max())
+            e_w, e_d = float((nchw(dx).double().cpu() - want).abs().max()), float((nchw(dxd).double().cpu() - want).abs().max())
+            assert e_w <= 3 * e_d + 1e-6 * sc, ("dgrad", (B, Hh, W, C, Co), e_w, e_d, sc)
+        # dilated window (layer4 of the dilated ResNet: dilation 2 = padding 2, four sub-lattices), forward and data-gradient
+        B, Hh, W, C, Co = 2, 16, 32, 64, 64
+        x = torch.randn(B, C, Hh, W, generator=gen)
+        w = torch.randn(Co, C, 3, 3, generator=gen) * (2.0 / (9 * C)) ** 0.5
+        dy = torch.randn(B, Co, Hh, W, generator=gen)
+        xd, wd_, dyd = nhwc(x).to(device).contiguous(), w.to(device), nhwc(dy).to(device).contiguous()
+        uf, ud = H.winograd_pack(wd_)
+        wp, wdp = H.pack_weight_both(wd_)
+        g = H.ConvGeom(C, Co, 3, 1, 2, 2, False, 0, False)
+        n0 = dict(H.WINOGRAD_TAKEN)
+        y, part = H.conv_forward(g, xd, None, wp, None, want_stats=True, wino=uf)
+        dx, _ = H.conv_dgrad(g, dyd, wdp, wd_, (Hh, W), wino=ud)
+        assert (H.WINOGRAD_TAKEN["fwd"], H.WINOGRAD_TAKEN["dgrad"]) == (n0["fwd"] + 1, n0["dgrad"] + 1)
+        want = torch.nn.functional.conv2d(x.double(), w.double(), padding=2, dilation=2)
+        assert_close(nchw(y), want.float(), rtol=1e-4, atol=2e-6 * float(want.abs().max()), what="Winograd, dilation 2: forward")
+        assert_close(part[:, 0].sum(0), y.double().reshape(-1, Co).sum(0), rtol=1e-9, atol=1e-9, what="Winograd, dilation 2: statistics")
+        want = torch.nn.functional.conv_transpose2d(dy.double(), w.double(), padding=2, dilation=2)
+        assert_close(nchw(dx), want.float(), rtol=1e-4, atol=2e-6 * float(want.abs().max()), what="Winograd, dilation 2: data-gradient")
+        # the decoder's Conv3x3 on [x | skip] at one resolution: two sources, mirrored padding, bias + ELU in the output transform
+        C0, C1 = 32, 96
+        x0, x1 = torch.randn(B, C0, Hh, W, generator=gen), torch.randn(B, C1, Hh, W, generator=gen)
+        w = torch.randn(Co, C0 + C1, 3, 3, generator=gen) * (2.0 / (9 * (C0 + C1))) ** 0.5
+        bias = torch.randn(Co, generator=gen) * 0.1
+        g = H.ConvGeom(C0, Co, 3, 1, 1, 1, True, C1, False)
+        uf, _ = H.winograd_pack(w.to(device))
+        wp = H.pack_weight(w.to(device))
+        n0 = H.WINOGRAD_TAKEN["fwd"]
+        y = H.conv_forward(g, nhwc(x0).to(device).contiguous(), nhwc(x1).to(device).contiguous(), wp, bias.to(device), act="elu", wino=uf)
+        assert H.WINOGRAD_TAKEN["fwd"] == n0 + 1
+        want = torch.nn.functional.elu(torch.nn.functional.conv2d(
+            torch.nn.functional.pad(torch.cat([x0, x1], 1).double(), (1, 1, 1, 1), mode="reflect"), w.double(), bias.double()))
+        assert_close(nchw(y), want.float(), rtol=1e-4, atol=2e-6 * float(want.abs().max()), what="Winograd: two sources + mirrored padding + bias + ELU")
+        # a weight_pack_scope(model) transforms every eligible weight in one launch; the packs equal the one-by-one ones
+        net = torch.nn.Sequential(L.Conv2d(64, 64, 3, padding=1, bias=False), L.Conv2d(64, 128, 3, padding=2, dilation=2, bias=True),
+                                  L.Conv2d(64, 64, 1), L.Conv2d(64, 64, 3, stride=2, padding=1)).to(device)
+        with L.weight_pack_scope(net):
+            assert net[0]._wino_cache.get("packs") is not None and net[1]._wino_cache.get("packs") is not None
+            assert not net[2]._wino_cache.get("packs") and not net[3]._wino_cache.get("packs")
+            for m in (net[0], net[1]):
+                uf1, ud1 = H.winograd_pack(m.weight)
+                assert torch.equal(m._wino_cache["packs"][0], uf1) and torch.equal(m._wino_cache["packs"][1], ud1)
+        # autograd glue: Conv2d -> BatchNorm2d through the Winograd route == the same modules on the direct route
+        B, Hh, W, C, Co = 2, 16, 32, 64, 64
+        torch.manual_seed(5)
+        conv, bn = L.Conv2d(C, Co, 3, padding=1, bias=False).to(device), L.BatchNorm2d(Co).to(device)
+        conv.train(); bn.train()
+        x = torch.randn(B, Hh, W, C, generator=gen).to(device)
+        res = []
+        for on in (True, False):
+            H.WINOGRAD = on
+            xi = x.clone().requires_grad_(True)
+            conv.zero_grad(); bn.zero_grad()
+            n0 = dict(H.WINOGRAD_TAKEN)
+            with L.weight_pack_scope():
+                y = bn(conv(xi), act="relu")
+                y2 = bn(conv(xi), act="relu")          # second forward in the scope: the transformed packs are reused
+                (y * y).sum().backward()
+            took = (H.WINOGRAD_TAKEN["fwd"] - n0["fwd"], H.WINOGRAD_TAKEN["dgrad"] - n0["dgrad"])
+            assert took == ((2, 1) if on else (0, 0)), took
+            assert torch.equal(y, y2)
+            res.append((y.detach(), xi.grad.detach(), conv.weight.grad.detach().clone(), bn.weight.grad.detach().clone()))
+        H.WINOGRAD = True
+        for a, b, what in zip(res[0], res[1], ("output", "input gradient", "weight gradient", "BatchNorm weight gradient")):
+            assert_close(a, b, rtol=1e-3, atol=1e-4 * float(b.abs().max()), what="Winograd vs direct through Conv2d + BatchNorm2d: " + what)
+    finally:
+        H.WINOGRAD_MIN_CH, H.WINOGRAD_MIN_MACS = old
+        H.WINOGRAD = True

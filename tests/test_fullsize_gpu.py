@@ -306,13 +306,14 @@ def test_headline_model_two_steps_vs_oracle(workload):
 
 def test_cfg2_batch8_replication_property():
     """BASELINE configs[1] at its own size AND batch: ResNet-50 monodepth, 512x1024, batch 8.  Size-independent property: a batch
-    made of four copies of a batch of two (frames, intrinsics and tie-break noise alike) has the same BatchNorm statistics, so the
-    mean losses of the batch-8 step equal those of the batch-2 step the oracle test above pins, and -- the loss being a batch
-    mean -- so does every parameter gradient IN EXACT ARITHMETIC.  In fp32 the re-associated reductions move the whole gradient
-    of this randomly initialised BatchNorm network at the per cent level (the CPU oracle in plain torch: median 0.9 % / worst
-    1.7 % between the two batches in fp32, 4e-10 in float64, measured at 128x256).  So the CPU oracle's own fp32 deviation
-    between its batch-2 and batch-8 evaluations at THIS size is the yardstick: the product may deviate 3x as much.  Checks the
-    step at 8 x 512 x 1024 (four times the rows: other tile counts / split plans in every kernel)."""
+    made of four copies of a batch of two (frames, intrinsics and tie-break noise alike) has the same BatchNorm statistics, so in
+    exact arithmetic the mean losses and -- the loss being a batch mean -- every parameter gradient of the batch-8 step equal
+    those of the batch-2 step.  The float64 evaluation of the CPU oracle at batch 2 is therefore the truth for BOTH steps.  The
+    product's gradients at batch 2 and at batch 8 (four times the rows: other tile counts / split plans in every kernel) are
+    judged against it with the vector criterion of DESIGN.md 4: as close to the truth as the oracle's own fp32 arithmetic is.
+    (Comparing two fp32 evaluations with each other says little here: this randomly initialised BatchNorm network moves its
+    whole gradient by 1-2 % when reductions are merely re-associated -- the oracle's own fp32 batch-2 and batch-8 evaluations
+    differ by a median 1.4 % per parameter at this size, 4e-10 in float64.)"""
     from improving_segmentation_with_selfsupervised_depth_amd.models import get_model
     from improving_segmentation_with_selfsupervised_depth_amd.loss import get_monodepth_loss
     from oracle import nets as N, photometric as P
@@ -339,50 +340,38 @@ def test_cfg2_batch8_replication_property():
         losses = lo.compute_losses(inp, out)
         losses["loss"].backward()
         res = {k: float(v.detach()) for k, v in losses.items()}
-        grads = {k: p.grad.detach().cpu().clone() for k, p in model.named_parameters() if p.grad is not None}
         bn = model.models["encoder"].encoder.bn1.running_mean.detach().cpu().clone()
         peak = torch.cuda.max_memory_allocated() / 2 ** 30
-        del model, out, losses
-        torch.cuda.empty_cache()
-        return res, grads, bn, peak
+        del out, losses
+        return res, model, bn, peak
 
-    def run_oracle(rep):
-        B = 2 * rep
-        sdo = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.clone()) for k, v in sd.items()}
-        inp = {k: v.repeat((rep,) + (1,) * (v.dim() - 1)) for k, v in inp2.items()}
-        lo = P.MonodepthLossOracle(**bench.loss_cfg(B, Hh, W)["training"]["monodepth_loss"], batch_size=B)
+    def run_oracle(dt):
+        cast = lambda v: v.to(dt) if torch.is_tensor(v) and v.is_floating_point() else v
+        sdo = {k: (cast(v.clone()).requires_grad_(True) if v.is_floating_point() and "running" not in k else cast(v.clone()))
+               for k, v in sd.items()}
+        inp = {k: cast(v) for k, v in inp2.items()}
+        lo = P.MonodepthLossOracle(**bench.loss_cfg(2, Hh, W)["training"]["monodepth_loss"], batch_size=2)
         out = N.model_forward(sdo, cfg, inp, train=True, dropout=False)
         lo.generate_images_pred(inp, out)
-        L = lo.compute_losses(inp, out, tiebreak_noise={s: n.repeat(rep, 1, 1, 1) for s, n in noise2.items()})["loss"]
+        L = lo.compute_losses(inp, out, tiebreak_noise={s: cast(n) for s, n in noise2.items()})["loss"]
         L.backward()
-        return float(L), {k: v.grad for k, v in sdo.items() if v.is_floating_point() and v.requires_grad and v.grad is not None}
-
-    def deviation(ga, gb):
-        top = max(float(g.norm()) for g in ga.values())
-        e = sorted(((float((gb[k] - ga[k]).norm()) / max(float(ga[k].norm()), 1e-3 * top), k) for k in ga), reverse=True)
-        return e[len(e) // 2][0], e[0][0], e[:4]
+        return float(L), {k: v.grad for k, v in sdo.items() if v.is_floating_point() and v.requires_grad}
 
     torch.set_num_threads(max(1, min(64, len(__import__("os").sched_getaffinity(0)))))
-    l2, g2, bn2, _ = run(1)
-    l8, g8, bn8, peak = run(4)
-    lo2, go2 = run_oracle(1)
-    lo8, go8 = run_oracle(4)
-    print("cfg2 losses at batch 2:", l2, "\n       at batch 8:", l8, "peak memory %.1f GB" % peak, "\n oracle:", lo2, lo8)
+    l32, g32 = run_oracle(torch.float32)
+    l64, g64 = run_oracle(torch.float64)
+    l2, m2, bn2, _ = run(1)
+    MC.gradients_vs_truth(list(m2.named_parameters()), g32, g64, "cfg2 at batch 2 (512x1024)")
+    del m2
+    torch.cuda.empty_cache()
+    l8, m8, bn8, peak = run(4)
+    print("cfg2 losses at batch 2:", l2, "\n       at batch 8:", l8, "peak memory %.1f GB" % peak, "\n oracle fp32 / fp64:", l32, l64)
     assert all(np.isfinite(v) for v in l8.values())
     for k in l2:
         assert abs(l8[k] - l2[k]) <= 1e-4 * abs(l2[k]), (k, l8[k], l2[k])
-    assert abs(l8["loss"] - lo8) <= 1e-3 * abs(lo8) and abs(l2["loss"] - lo2) <= 1e-3 * abs(lo2)     # the batch-8 step vs the CPU oracle
+    assert abs(l8["loss"] - l64) <= 1e-3 * abs(l64) and abs(l2["loss"] - l64) <= 1e-3 * abs(l64)
     assert_close(bn8, bn2, rtol=1e-5, atol=1e-7, what="stem BatchNorm running mean (same statistics)")
-    assert set(g2) == set(g8) == set(go2)
-    med_o, worst_o, _ = deviation(go2, go8)
-    med_p, worst_p, top_p = deviation(g2, g8)
-    med_x, worst_x, _ = deviation(go8, g8)
-    print("batch 8 (4 copies) vs batch 2, per-parameter relative gradient difference (median, worst): CPU oracle fp32 %.2e %.2e | "
-          "product %.2e %.2e | product vs oracle at batch 8: %.2e %.2e" % (med_o, worst_o, med_p, worst_p, med_x, worst_x))
-    for e in top_p:
-        print("   %.3e  %s" % e)
-    assert med_p <= 3 * med_o + 1e-3 and worst_p <= 3 * worst_o + 5e-3, (med_p, worst_p, med_o, worst_o)
-    assert med_x <= 3 * med_o + 1e-3 and worst_x <= 3 * worst_o + 5e-3, (med_x, worst_x, med_o, worst_o)
+    MC.gradients_vs_truth(list(m8.named_parameters()), g32, g64, "cfg2 at batch 8 = 4 copies of the batch of 2 (512x1024)")
     assert peak < 288.0
 
 

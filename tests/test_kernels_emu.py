@@ -106,3 +106,7 @@ def test_monodepth_layer_callables(golden):
 
 def test_jitter_blur_properties():
     KC.run_jitter_blur_properties("cpu")
+
+
+def test_winograd_route():
+    KC.run_winograd_cases("cpu")

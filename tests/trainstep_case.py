@@ -147,10 +147,13 @@ def compare(got, ref, tag, log=print):
             k = "%s_it%d_%s" % (tag, it, what)
             if k in ref:
                 r, g = np.asarray(ref[k]), np.asarray(got[k])
-                err = float((np.abs(g - r) / np.maximum(np.abs(r), 1.0)).max())
-                worst[what] = max(worst.get(what, 0.0), err)
-                # checksums of whole tensors after the update(s): 1e-3 after the first iteration; the second one starts from
-                # gradients that differ at the yardstick's level (lr 1e-2 on the decoders) -- 3e-3
-                assert err < (1e-3 if it == 0 else 3e-3), (what, it, err)
+                # checksums of whole tensors after the update(s): 1e-3 (of max(|sum|, 1)) after the first iteration, 3e-3 after
+                # the second, or 3x the yardstick (the ASPP image-pooling branch's BatchNorm sees B = 2 samples per channel:
+                # its running mean moves by per cent under 2 ulp of stem-weight noise)
+                base = (1e-3 if it == 0 else 3e-3) * np.maximum(np.abs(r), 1.0)
+                sp = np.asarray(ref[k + "_spread"]) if k + "_spread" in ref else np.zeros_like(r)
+                excess = float((np.abs(g - r) / np.maximum(base, 3.0 * sp)).max())
+                worst[what + " (worst / tolerance)"] = max(worst.get(what + " (worst / tolerance)", 0.0), excess)
+                assert excess <= 1.0, (what, it, excess)
     log("%s: worst deviations %s" % (tag, {k: float("%.3g" % v) for k, v in worst.items()}))
     return worst
