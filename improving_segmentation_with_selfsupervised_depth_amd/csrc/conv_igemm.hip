@@ -2933,3 +2933,61 @@ extern "C" int segsde_conv2d_winograd(const segsde_conv_desc* d, const float* x0
   if (int e = launch_by_n(q, static_cast<hipStream_t>(stream))) return e;
   return segsde_wino_output(Mb, d->B, d->H, d->W, d->Cout, d->dil, bias, d->act, y, d->ldy, stats, stream);
 }
+
+// Weight gradient on the same route: dU_p = sum over the tiles of V_p^T dM_p (V = the forward's transformed input, recomputed
+// here; dM = A dY A^T) is the weight-gradient kernel's own GEMM form, sixteen times: ONE launch of conv_wgrad_kernel over the
+// sixteen-"image" tensors with the split boundaries on the image boundaries (s splits per position), so that the slabs of a
+// position are exactly its partial sums; wino_wgrad_finish_kernel folds them in slab order and applies dW = G^T dU G.
+namespace {
+struct WinoWgradPlan { segsde_conv_desc g; int bn, s, cps; size_t off_dm, off_part, bytes; };
+bool winograd_wgrad_plan(const segsde_conv_desc* d, WinoWgradPlan& pl) {
+  if (!winograd_shape_ok(d)) return false;
+  const long T = (long)d->B * (d->H / 2) * (d->W / 2);
+  const int C = d->C0 + d->C1;
+  if (T % BP) return false;
+  pl.g = winograd_gemm_desc(d);
+  pl.g.H = (int)(T / 32); pl.g.W = 32; pl.g.Ho = pl.g.H; pl.g.Wo = 32;      // rows of 32 tiles: the table-driven loader's chunk
+  pl.bn = d->Cout <= 64 ? 64 : 128;
+  const long tiles = (long)segsde_cdiv(C, 128) * segsde_cdiv(d->Cout, pl.bn);
+  const long cp = T / BP;                          // chunks per position
+  int s = 1;
+  while (2 * s <= cp && cp % (2 * s) == 0 && cp / (2 * s) >= 8 && tiles * 16 * (2 * s) <= 1024) s *= 2;
+  pl.s = s; pl.cps = (int)(cp / s);
+  pl.off_dm = 16 * (size_t)T * C * sizeof(float);
+  pl.off_part = pl.off_dm + 16 * (size_t)T * d->Cout * sizeof(float);
+  pl.bytes = pl.off_part + (size_t)16 * s * C * d->Cout * sizeof(float) + 256;
+  return true;
+}
+}  // namespace
+
+extern "C" size_t segsde_conv2d_wgrad_winograd_workspace(const segsde_conv_desc* d) {
+  WinoWgradPlan pl;
+  return winograd_wgrad_plan(d, pl) ? pl.bytes : 0;
+}
+
+extern "C" int segsde_conv2d_wgrad_winograd(const segsde_conv_desc* d, const float* x0, const float* x1, const float* dy, int lddy,
+                                            float* dw_oihw, void* workspace, size_t workspace_bytes, void* stream) {
+  // d: the FORWARD geometry ([C0 | C1] -> Cout, 3x3, stride 1, pad = dil, zero or mirrored padding); dy [B,H,W,Cout] (pitch lddy)
+  if (!d || !x0 || !dy || !dw_oihw || !workspace || (d->C1 && !x1)) return SEGSDE_ERR_NULL;
+  WinoWgradPlan pl;
+  if (!winograd_wgrad_plan(d, pl) || !aligned16(x0) || (d->C1 && !aligned16(x1)) || !aligned16(dy) || lddy % 4 || lddy < d->Cout)
+    return SEGSDE_ERR_UNSUPPORTED;
+  if (workspace_bytes < pl.bytes) return SEGSDE_ERR_WORKSPACE;
+  const int C = d->C0 + d->C1;
+  char* base = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
+  float* V = reinterpret_cast<float*>(base);
+  float* dM = reinterpret_cast<float*>(base + pl.off_dm);
+  float* part = reinterpret_cast<float*>(base + pl.off_part);
+  ConvP p = make_params(&pl.g, V, nullptr, dM, nullptr, part, nullptr);
+  if (wgrad_mode(p, dM, d->Cout) != 2) return SEGSDE_ERR_UNSUPPORTED;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (int e = segsde_wino_input(x0, d->ld0, d->C1 ? x1 : nullptr, d->C1 ? d->ld1 : d->ld0, d->C0, d->B, d->H, d->W, C, d->dil,
+                                d->pad_mode == SEGSDE_PAD_REFLECT, V, stream))
+    return e;
+  if (int e = segsde_wino_grad(dy, lddy, d->B, d->H, d->W, d->Cout, d->dil, dM, stream)) return e;
+  int e;
+  if (pl.bn == 64) e = launch_wgrad<128, 64, 2, 2>(p, dM, d->Cout, part, 16 * pl.s, pl.cps, s);
+  else e = launch_wgrad<128, 128, 2, 2>(p, dM, d->Cout, part, 16 * pl.s, pl.cps, s);
+  if (e) return e;
+  return segsde_wino_wgrad_finish(part, pl.s, C, d->Cout, dw_oihw, stream);
+}

@@ -18,3 +18,7 @@ long segsde_wino_stats_rows(long T);
 int segsde_wino_weights(const float* w_oihw, int O, int I, int transpose_flip, float* U, void* stream);
 // many weights in one launch: device-resident job table (include/segsde_hip.h: segsde_wino_job), blocks [block0_j, block0_{j+1})
 int segsde_wino_weights_multi(const segsde_wino_job* jobs_device, int njobs, int total_blocks, void* stream);
+// weight gradient: dM [16][T][C] = A dY A^T of the output gradient dy [B,H,W,C]; part [16 * s][Cin][Co] (the split slabs of the
+// sixteen position GEMMs dU_p = V_p^T dM_p, s per position) -> dW [Co][Cin][3][3] = G^T dU G
+int segsde_wino_grad(const float* dy, int ld, int B, int H, int W, int C, int dil, float* dM, void* stream);
+int segsde_wino_wgrad_finish(const float* part, int s, int Cin, int Co, float* dw_oihw, void* stream);

@@ -153,6 +153,68 @@ __global__ __launch_bounds__(256) void wino_out_kernel(const float* M, int B, in
   }
 }
 
+// The output-side transform of the WEIGHT gradient: dM = A dY A^T, a 2x2 block of the output gradient -> its 4x4 plane
+// (A = [1 0; 1 1; 1 -1; 0 -1]); with it  dU_p = sum over tiles of V_p^T dM_p  (sixteen GEMMs over the tiles, the weight-gradient
+// kernel's own form) and dW = G^T dU G.  One thread: one tile x four channels, like the input transform.
+__global__ __launch_bounds__(256) void wino_grad_kernel(const float* dy, int ld, int B, int H, int W, int C, int d, float* dM) {
+  const int CQ = C >> 2, H2 = H / (2 * d), W2 = W / (2 * d);
+  const long T = (long)B * d * d * H2 * W2, total = T * CQ;
+  const long e = blockIdx.x * 256L + threadIdx.x;
+  if (e >= total) return;
+  const int cq = (int)(e % CQ);
+  const long t = e / CQ;
+  const TileAt q = tile_at(t, d, H2, W2);
+  const float* src = dy + ((long)(q.b * H + q.a + d * 2 * q.i) * W + q.c + d * 2 * q.j) * ld + 4 * cq;
+  const long dn = (long)d * ld, dw = (long)d * W * ld;
+  const F4 g00 = ld4(src), g01 = ld4(src + dn), g10 = ld4(src + dw), g11 = ld4(src + dw + dn);
+  const F4 z{0.f, 0.f, 0.f, 0.f};
+  F4 r[4][2];                            // A dY
+  r[0][0] = g00; r[0][1] = g01; r[1][0] = g00 + g10; r[1][1] = g01 + g11; r[2][0] = g00 - g10; r[2][1] = g01 - g11;
+  r[3][0] = z - g10; r[3][1] = z - g11;
+  float* out = dM + t * C + 4 * cq;
+  const long plane = T * C;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {          // (.) A^T
+    st4(out + (4 * k + 0) * plane, r[k][0]);
+    st4(out + (4 * k + 1) * plane, r[k][0] + r[k][1]);
+    st4(out + (4 * k + 2) * plane, r[k][0] - r[k][1]);
+    st4(out + (4 * k + 3) * plane, z - r[k][1]);
+  }
+}
+
+// part [16 * s][C][Co] (split slabs of the sixteen position GEMMs, s per position) -> dW [Co][C][3][3] = G^T dU G with
+// dU_p = the sum of position p's slabs in slab order (deterministic).  One thread per (c, co), co fastest (coalesced slab reads).
+__global__ __launch_bounds__(256) void wino_wgrad_finish_kernel(const float* part, int s, int C, int Co, float* dw) {
+  const long total = (long)C * Co;
+  const long e = blockIdx.x * 256L + threadIdx.x;
+  if (e >= total) return;
+  const int co = (int)(e % Co), c = (int)(e / Co);
+  float u[4][4];
+#pragma unroll
+  for (int p = 0; p < 16; ++p) {
+    const float* src = part + (long)p * s * total + e;
+    float a0 = 0.f, a1 = 0.f;
+    int z = 0;
+    for (; z + 1 < s; z += 2) { a0 += src[(long)z * total]; a1 += src[(long)(z + 1) * total]; }
+    if (z < s) a0 += src[(long)z * total];
+    u[p >> 2][p & 3] = a0 + a1;
+  }
+  float t[3][4];
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {          // G^T dU
+    t[0][v] = u[0][v] + 0.5f * (u[1][v] + u[2][v]);
+    t[1][v] = 0.5f * (u[1][v] - u[2][v]);
+    t[2][v] = 0.5f * (u[1][v] + u[2][v]) + u[3][v];
+  }
+  float* out = dw + ((long)co * C + c) * 9;
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {          // (.) G
+    out[3 * r + 0] = t[r][0] + 0.5f * (t[r][1] + t[r][2]);
+    out[3 * r + 1] = 0.5f * (t[r][1] - t[r][2]);
+    out[3 * r + 2] = 0.5f * (t[r][1] + t[r][2]) + t[r][3];
+  }
+}
+
 // thread (a, b), b fastest: forward a = o, b = i reads w[o][i][3][3] (36 contiguous bytes) and writes U[p][o][i]; the
 // data-gradient pack a = i, b = o reads the same nine values with the taps flipped and writes U'[p][i][o] -- coalesced writes
 // in both, the strided reads of the second variant hit L2 (the whole weight is 2.4 MB)
@@ -250,6 +312,20 @@ int segsde_wino_output(const float* M, int B, int H, int W, int Co, int dil, con
                        y, ldy, part);
   else
     hipLaunchKernelGGL(wino_out_kernel<false>, grid, dim3(256), 0, ST(stream), M, B, H, W, Co, dil, bias, act, y, ldy, part);
+  SEGSDE_CHECK_LAUNCH();
+  return 0;
+}
+
+int segsde_wino_grad(const float* dy, int ld, int B, int H, int W, int C, int dil, float* dM, void* stream) {
+  const long total = (long)B * (H / 2) * (W / 2) * (C / 4);
+  hipLaunchKernelGGL(wino_grad_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ST(stream), dy, ld, B, H, W, C, dil, dM);
+  SEGSDE_CHECK_LAUNCH();
+  return 0;
+}
+
+int segsde_wino_wgrad_finish(const float* part, int s, int C, int Co, float* dw_oihw, void* stream) {
+  const long total = (long)C * Co;
+  hipLaunchKernelGGL(wino_wgrad_finish_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ST(stream), part, s, C, Co, dw_oihw);
   SEGSDE_CHECK_LAUNCH();
   return 0;
 }

@@ -89,7 +89,7 @@ def upfold_pack(w_oihw, C0):
 WINOGRAD = os.environ.get("SEGSDE_WINOGRAD", "1") != "0"
 WINOGRAD_MIN_CH = int(os.environ.get("SEGSDE_WINOGRAD_MIN_CH", "256"))
 WINOGRAD_MIN_MACS = float(os.environ.get("SEGSDE_WINOGRAD_MIN_MACS", "4e9"))
-WINOGRAD_TAKEN = {"fwd": 0, "dgrad": 0}
+WINOGRAD_TAKEN = {"fwd": 0, "dgrad": 0, "wgrad": 0}
 
 
 def winograd_ok(g, B=None, H=None, W=None, dgrad=False):
@@ -508,6 +508,18 @@ def conv_wgrad(g, x0, x1, dy):
     dw = torch.empty((Cout, g.Cin, g.k, g.k), dtype=torch.float32, device=dy.device)
     flops = 2.0 * B * Ho * Wo * Cout * g.CinAlg * g.k * g.k
     flops_x = flops * g.Cin / g.CinAlg * _live_tap_frac(g, H, W, wgrad=True)
+    if not g.up0 and winograd_ok(g, B, H, W) and (Ho, Wo) == (H, W):
+        nbytes = L.segsde_conv2d_wgrad_winograd_workspace(ctypes.byref(d))
+        if nbytes:
+            ws = _ws(nbytes, dy)
+            rc = _timed("conv_wgrad", flops, dy, lambda: L.segsde_conv2d_wgrad_winograd(
+                ctypes.byref(d), _p(x0), _p(x1), _p(_f32(dy)), nhwc_ld(dy), _p(dw), _p(ws), nbytes, _stream(dy)),
+                _tag(g, H, W) + " wino", executed=flops * 16.0 / 36.0)
+            if rc == 0:
+                WINOGRAD_TAKEN["wgrad"] += 1
+                return dw
+            if rc != -4:
+                check(rc, "conv2d_wgrad_winograd")
     if upfold_ok(g, B * Ho * Wo):
         nbytes = L.segsde_conv2d_wgrad_upfold_workspace(ctypes.byref(d))
         if nbytes:

@@ -256,6 +256,11 @@ int segsde_winograd_pack(const float* w_oihw, int Cout, int Cin, float* u_fwd, f
 int segsde_winograd_pack_multi(const segsde_wino_job* jobs_device, int njobs, int total_blocks, void* stream);
 int segsde_conv2d_winograd(const segsde_conv_desc* d, const float* x0, const float* x1, const float* u_pack, const float* bias,
                            float* y, double* stats, void* workspace, size_t workspace_bytes, void* stream);
+/* the weight gradient on the same route: dU_p = V_p^T (A dY A^T)_p as sixteen position GEMMs in one launch of the
+ * weight-gradient kernel (split boundaries on the position boundaries), dW = G^T dU G written as OIHW.  d: the FORWARD geometry. */
+size_t segsde_conv2d_wgrad_winograd_workspace(const segsde_conv_desc* d);
+int segsde_conv2d_wgrad_winograd(const segsde_conv_desc* d, const float* x0, const float* x1, const float* dy, int lddy,
+                                 float* dw_oihw, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------ *
  * Pose: axis-angle + translation -> 4x4 (models/monodepth_layers.py:30-105)                         *

@@ -1258,6 +1258,20 @@ def run_winograd_cases(device, shapes=((2, 16, 32, 64, 64), (1, 32, 16, 96, 128)
             sc = float(want.abs().max())
             e_w, e_d = float((nchw(dx).double().cpu() - want).abs().max()), float((nchw(dxd).double().cpu() - want).abs().max())
             assert e_w <= 3 * e_d + 1e-6 * sc, ("dgrad", (B, Hh, W, C, Co), e_w, e_d, sc)
+            # weight gradient: sixteen position GEMMs over the tiles + G^T dU G (zero and mirrored padding)
+            for refl in (False, True):
+                g = H.ConvGeom(C, Co, 3, 1, 1, 1, refl, 0, False)
+                xp = torch.nn.functional.pad(x.double(), (1, 1, 1, 1), mode="reflect" if refl else "constant")
+                want = torch.nn.grad.conv2d_weight(xp, w.shape, dy.double())
+                n0 = H.WINOGRAD_TAKEN["wgrad"]
+                dw = H.conv_wgrad(g, xd, None, dyd)
+                assert H.WINOGRAD_TAKEN["wgrad"] == n0 + 1
+                H.WINOGRAD = False
+                dwd = H.conv_wgrad(g, xd, None, dyd)
+                H.WINOGRAD = True
+                sc = float(want.abs().max())
+                e_w, e_d = float((dw.double().cpu() - want).abs().max()), float((dwd.double().cpu() - want).abs().max())
+                assert e_w <= 3 * e_d + 2e-6 * sc, ("wgrad", refl, (B, Hh, W, C, Co), e_w, e_d, sc)
         # dilated window (layer4 of the dilated ResNet: dilation 2 = padding 2, four sub-lattices), forward and data-gradient
         B, Hh, W, C, Co = 2, 16, 32, 64, 64
         x = torch.randn(B, C, Hh, W, generator=gen)
@@ -1276,6 +1290,11 @@ def run_winograd_cases(device, shapes=((2, 16, 32, 64, 64), (1, 32, 16, 96, 128)
         assert_close(part[:, 0].sum(0), y.double().reshape(-1, Co).sum(0), rtol=1e-9, atol=1e-9, what="Winograd, dilation 2: statistics")
         want = torch.nn.functional.conv_transpose2d(dy.double(), w.double(), padding=2, dilation=2)
         assert_close(nchw(dx), want.float(), rtol=1e-4, atol=2e-6 * float(want.abs().max()), what="Winograd, dilation 2: data-gradient")
+        n0 = H.WINOGRAD_TAKEN["wgrad"]
+        dw = H.conv_wgrad(g, xd, None, dyd)
+        assert H.WINOGRAD_TAKEN["wgrad"] == n0 + 1
+        want = torch.nn.grad.conv2d_weight(x.double(), w.shape, dy.double(), padding=2, dilation=2)
+        assert_close(dw, want.float(), rtol=1e-4, atol=3e-6 * float(want.abs().max()), what="Winograd, dilation 2: weight gradient")
         # the decoder's Conv3x3 on [x | skip] at one resolution: two sources, mirrored padding, bias + ELU in the output transform
         C0, C1 = 32, 96
         x0, x1 = torch.randn(B, C0, Hh, W, generator=gen), torch.randn(B, C1, Hh, W, generator=gen)
@@ -1290,6 +1309,13 @@ def run_winograd_cases(device, shapes=((2, 16, 32, 64, 64), (1, 32, 16, 96, 128)
         want = torch.nn.functional.elu(torch.nn.functional.conv2d(
             torch.nn.functional.pad(torch.cat([x0, x1], 1).double(), (1, 1, 1, 1), mode="reflect"), w.double(), bias.double()))
         assert_close(nchw(y), want.float(), rtol=1e-4, atol=2e-6 * float(want.abs().max()), what="Winograd: two sources + mirrored padding + bias + ELU")
+        dyc = torch.randn(B, Co, Hh, W, generator=gen)
+        n0 = H.WINOGRAD_TAKEN["wgrad"]
+        dw = H.conv_wgrad(g, nhwc(x0).to(device).contiguous(), nhwc(x1).to(device).contiguous(), nhwc(dyc).to(device).contiguous())
+        assert H.WINOGRAD_TAKEN["wgrad"] == n0 + 1
+        want = torch.nn.grad.conv2d_weight(torch.nn.functional.pad(torch.cat([x0, x1], 1).double(), (1, 1, 1, 1), mode="reflect"),
+                                           w.shape, dyc.double())
+        assert_close(dw, want.float(), rtol=1e-4, atol=3e-6 * float(want.abs().max()), what="Winograd: two sources, weight gradient")
         # a weight_pack_scope(model) transforms every eligible weight in one launch; the packs equal the one-by-one ones
         net = torch.nn.Sequential(L.Conv2d(64, 64, 3, padding=1, bias=False), L.Conv2d(64, 128, 3, padding=2, dilation=2, bias=True),
                                   L.Conv2d(64, 64, 1), L.Conv2d(64, 64, 3, stride=2, padding=1)).to(device)

@@ -266,6 +266,20 @@ def test_headline_model_two_steps_vs_oracle(workload):
     (lo64.compute_losses(inp64, out64, tiebreak_noise={s_: n.double() for s_, n in noise.items()})["loss"]
      + seg_loss(out64, inp["lbl"], S.cross_entropy2d)).backward()
     gn64 = float(torch.sqrt(sum((v.grad.double() ** 2).sum() for v in sd64.values() if v.is_floating_point() and v.grad is not None)))
+    gn64_2 = None
+    if workload == "cfg2":
+        # the monodepth-only model's SECOND-step gradient norm is far more sensitive than the joint models' (no segmentation loss
+        # to dominate it; measured: two correct fp32 evaluations 9 % apart): its yardstick is the float64 second step as well
+        leaves64 = [(k, v) for k, v in sd64.items() if v.is_floating_point() and v.requires_grad]
+        opt64 = groups(leaves64)
+        torch.nn.utils.clip_grad_norm_([v for _, v in leaves64 if v.grad is not None], 10.0)
+        opt64.step()
+        opt64.zero_grad(set_to_none=True)
+        del out64
+        out64 = N.model_forward(sd64, cfg, inp64, train=True, dropout=False)
+        lo64.generate_images_pred(inp64, out64)
+        lo64.compute_losses(inp64, out64, tiebreak_noise={s_: n.double() for s_, n in noise.items()})["loss"].backward()
+        gn64_2 = float(torch.sqrt(sum((v.grad.double() ** 2).sum() for _, v in leaves64 if v.grad is not None)))
     del sd64, out64, lo64, inp64
     # ---- product (GPU)
     model = get_model(cfg, 19)
@@ -299,6 +313,11 @@ def test_headline_model_two_steps_vs_oracle(workload):
                 e_ref, e_prod = abs(ref[0][2] - gn64), abs(got[0][2] - gn64)
                 print("gradient norm step 0: float64 %.5f, fp32 oracle %.5f, product %.5f" % (gn64, ref[0][2], got[0][2]))
                 assert e_prod <= max(3 * e_ref, 1e-3 * gn64), (what, got[0][2], ref[0][2], gn64)
+                continue
+            if i == 2 and gn64_2 is not None:
+                e_ref, e_prod = abs(ref[1][2] - gn64_2), abs(got[1][2] - gn64_2)
+                print("gradient norm step 1: float64 %.5f, fp32 oracle %.5f, product %.5f" % (gn64_2, ref[1][2], got[1][2]))
+                assert e_prod <= max(3 * e_ref, 2e-2 * gn64_2), (what, got[1][2], ref[1][2], gn64_2)
                 continue
             tol = 1e-3 if i < 2 else 2e-2
             assert abs(got[step][i] - ref[step][i]) <= tol * abs(ref[step][i]) + 1e-12, (step, what, got[step][i], ref[step][i])
