@@ -643,7 +643,11 @@ def main():
             # nearest-upsampled channels, an exact regrouping of the same sums): the matrix pipe's own utilisation is
             # `executed_achieved` / `executed_frac`, which can never exceed 1.
             roof.update(executed_achieved=ex / tt / 1e12, executed_frac=ex / tt / 1e12 / PEAK_FP32_MATRIX_TFLOPS,
-                        executed_over_algorithmic=ex / fl)
+                        executed_over_algorithmic=ex / fl,
+                        frac_is="algorithmic: 2 * MAC of the convolutions as the reference defines them (SURVEY.md 8d) / time / peak; the "
+                                "upsample-folded, dead-tap-skipping and Winograd routes issue fewer multiply-adds than that, so single "
+                                "layers (and, with enough of them, the sum) can exceed 1 -- the matrix pipe's own utilisation is "
+                                "executed_frac")
             roof.update(achieved=fl / tt / 1e12, frac=fl / tt / 1e12 / PEAK_FP32_MATRIX_TFLOPS, launches=nl,
                         avg_launch_ms=tt / nl * 1e3, avg_launch_gflop=fl / nl / 1e9,
                         share_of_step=tt / dt, algorithmic_bytes_per_launch=abytes / nl)

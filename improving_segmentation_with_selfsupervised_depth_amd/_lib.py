@@ -55,7 +55,7 @@ _SIGS = {
     "segsde_conv2d_wgrad_winograd": (c_int, [POINTER(ConvDesc), P, P, P, c_int, P, P, c_size_t, P]),
     "segsde_upfold_pack": (c_int, [P, c_int, c_int, c_int, P, P, P]),
     "segsde_conv2d_forward_upfold": (c_int, [POINTER(ConvDesc), P, P, P, P, P, P, P]),
-    "segsde_conv2d_dgrad_upfold": (c_int, [POINTER(ConvDesc), P, c_int, P, P, P, P, P, P, c_int, c_int, P]),
+    "segsde_conv2d_dgrad_upfold": (c_int, [POINTER(ConvDesc), P, c_int, P, P, P, P, P, c_int, P, c_int, c_int, P]),
     "segsde_conv2d_wgrad_upfold_workspace": (c_size_t, [POINTER(ConvDesc)]),
     "segsde_conv2d_wgrad_upfold": (c_int, [POINTER(ConvDesc), P, P, P, c_int, P, P, c_size_t, P]),
     "segsde_stem_pack": (c_int, [P, c_int, c_int, c_int, P, P]),

@@ -2508,7 +2508,7 @@ extern "C" int segsde_conv2d_forward_upfold(const segsde_conv_desc* d, const flo
 }
 
 extern "C" int segsde_conv2d_dgrad_upfold(const segsde_conv_desc* d, const float* dy, int lddy, const float* wdpack,
-                                          const float* wfold, const float* wdfold, float* dx0, float* dx1,
+                                          const float* wfold, const float* wdfold, float* dx0, float* dx1, int accumulate_dx1,
                                           const float* act_out, int act_ld, int act_kind, void* stream) {
   // d: the FORWARD geometry (H x W virtual input, C0 upsampled + C1 skip channels, Cout).  dx0 [B,H/2,W/2,C0] dense (nullable),
   // dx1 [B,H,W,C1] dense (nullable); act_out: the saved activation output dx0 is differentiated through (nullable)
@@ -2532,6 +2532,7 @@ extern "C" int segsde_conv2d_dgrad_upfold(const segsde_conv_desc* d, const float
     segsde_conv_desc c = *d;            // reflection-adjoint data-gradient of the skip channels: rows C0.. of the dgrad pack
     c.C0 = d->Cout; c.C1 = 0; c.ld0 = lddy; c.ld1 = 0; c.up0 = 0; c.Cout = d->C1; c.ldy = d->C1; c.ldy2 = 0; c.nsplit = 0;
     c.pad_mode = SEGSDE_PAD_REFLECT_ADJOINT; c.act = 0;
+    c.accumulate = accumulate_dx1 ? 1 : 0;   // dx1 already holds another consumer's gradient of the skip tensor: add onto it
     if (int e = validate(&c)) return e;
     r = make_params(&c, dy, nullptr, wdpack + (long)d->C0 * 9 * d->Cout, nullptr, dx1, nullptr);
     if (!igemm_fast_ok(r) || !r.vecout) return SEGSDE_ERR_UNSUPPORTED;

@@ -4,6 +4,8 @@ All activations flowing between these Functions are NHWC fp32 tensors.  Module-l
 NCHW; ``to_nhwc`` / ``to_nchw`` convert at that edge for free when the tensor is already channels-last in memory
 (which is what every module of this package returns), and with a HIP layout kernel otherwise.
 """
+import weakref
+
 import torch
 from torch.autograd import Function
 
@@ -120,7 +122,7 @@ class ConvFn(Function):
 
     @staticmethod
     def forward(ctx, x0, x1, weight, bias, g, act, stats_out=None, grad_box=None, packs=None, x0_act=None, act_box=None,
-                fold_cache=None, wino_cache=None):
+                fold_cache=None, wino_cache=None, skip_box=None):
         """stats_out: optional list; receives the BatchNorm statistics partials of y (or None) -- see Conv2d.forward.
         grad_box: optional dict shared with the BNActFn that adds this conv's input as a residual (see SplitFn): when its
         backward has already left the residual-path gradient there, this conv's data-gradient is accumulated onto it.
@@ -129,6 +131,7 @@ class ConvFn(Function):
         NOTE for act != "none": the gradient arriving at this Function's output is taken to be w.r.t. the PRE-activation --
         consumers reach the output either through ActGradFn (which applies the derivative) or as a fused x0_act consumer."""
         ctx.grad_box = grad_box
+        ctx.skip_box = skip_box          # like grad_box, for the second source x1 (an encoder feature several decoders read)
         ctx.x0_act, ctx.act_box = x0_act, act_box
         x0 = _c(x0) if x0.stride(-1) != 1 else x0
         ctx.wd = None
@@ -200,9 +203,17 @@ class ConvFn(Function):
                 if dx0 is not None:
                     box["fused"] = True      # dx0 IS the residual-path gradient, now holding the sum
             if dx0 is None:
+                sbox = ctx.skip_box if (x1 is not None and ctx.needs_input_grad[1]) else None
                 dx0, dx1 = H.conv_dgrad(g, dz, wd, weight.detach(), ctx.in_hw, actgrad=actgrad, fold=ctx.fold,
                                         need0=ctx.needs_input_grad[0], need1=x1 is not None and ctx.needs_input_grad[1],
-                                        wino=None if (ctx.wino is None or x1 is not None) else ctx.wino[1])
+                                        wino=None if (ctx.wino is None or x1 is not None) else ctx.wino[1],
+                                        accumulate_skip_into=None if sbox is None else sbox.get("g"))
+                if sbox is not None and dx1 is not None:
+                    if H.SKIP_ACCUMULATED[0]:
+                        sbox["fused"] = True      # dx1 IS the shared tensor, now holding the sum
+                    elif sbox.get("publish") and sbox.get("g") is None and dx1.is_contiguous():
+                        sbox["g"] = dx1           # the next consumer's skip gradient is accumulated onto this tensor
+                        sbox["fused"] = True
                 if box is not None and box.get("publish") and box.get("g") is None and x1 is None and not g.up0 \
                         and dx0.is_contiguous():
                     box["g"] = dx0           # FanoutFn: the next consumer's data-gradient is accumulated onto this tensor
@@ -216,7 +227,7 @@ class ConvFn(Function):
                 dx1 = None
         if ctx.needs_input_grad[2]:
             dw = H.conv_wgrad(g, x0, x1, dz)
-        return dx0, dx1, dw, dbias, None, None, None, None, None, None, None, None, None
+        return dx0, dx1, dw, dbias, None, None, None, None, None, None, None, None, None, None
 
 
 class ActGradFn(Function):
@@ -348,6 +359,44 @@ class FanoutFn(Function):
                 fusion("fanout_grad_accumulate", False)
             total = gi if total is None else H.axpby(1.0, _c(total), 1.0, _c(gi))
         return total, None, None
+
+
+# Encoder features are read by the next encoder stage AND as the skip source of every decoder (models/depth_decoder.py:93-101):
+# plain autograd sums those gradients with one 12-byte-per-element pass per extra consumer (104 such adds per ResNet-101 joint
+# step, 3.4 ms).  ``fan_feature`` turns a feature into n views of a FanoutFn whose convolution consumers accumulate inside
+# their data-gradient epilogues; the views meant for the decoders wait in a registry keyed by the feature's storage, because
+# the feature crosses the module boundary as an NCHW-logical view (a new tensor object) -- ``take_fan_view`` hands a decoder
+# its own view plus the shared box, or the tensor it was given when there is nothing registered for it.
+_FANS = {}
+
+
+def fan_feature(x, n_spare, n_main=1):
+    """-> (the n_main views the producer's own module continues with, the shared box or None).  n_spare more views are parked for
+    ``take_fan_view``.  Without a gradient (or with nobody to share with) the views are x itself."""
+    if n_spare + n_main <= 1 or not (torch.is_grad_enabled() and x.requires_grad):
+        return (x,) * n_main, None
+    box = {}
+    views = FanoutFn.apply(x, box, n_main + n_spare)
+    if n_spare > 0:
+        base = views[0]._base if views[0]._base is not None else views[0]
+        _FANS[id(base)] = (weakref.ref(base), box, list(views[n_main:]))
+        if len(_FANS) > 64:
+            for k in [k for k, v in _FANS.items() if v[0]() is None]:
+                del _FANS[k]
+    return tuple(views[:n_main]), box
+
+
+def take_fan_view(t):
+    """t: an NHWC tensor as a consumer received it.  -> (the view to read instead, shared box) or (t, None)"""
+    base = t._base if t._base is not None else t
+    ent = _FANS.get(id(base))
+    if ent is None or ent[0]() is not base or not ent[2]:
+        return t, None
+    v = ent[2].pop()
+    if v.shape != t.shape or v.data_ptr() != t.data_ptr() or v.stride() != t.stride():
+        ent[2].append(v)
+        return t, None
+    return v, ent[1]
 
 
 class MaxPoolFn(Function):

@@ -386,7 +386,11 @@ def conv_forward(g, x0, x1, wpack, bias, act="none", want_stats=False, wfold=Non
 ACTGRAD_FUSED = [False]      # did the last conv_dgrad(actgrad=...) apply the derivative in its epilogue (functional.py counts from this)
 
 
-def conv_dgrad(g, dy, wdpack, w_oihw, in_hw, need0=True, need1=True, accumulate_into=None, actgrad=None, fold=None, wino=None):
+SKIP_ACCUMULATED = [False]   # did the last conv_dgrad(accumulate_skip_into=...) add its skip gradient onto that tensor
+
+
+def conv_dgrad(g, dy, wdpack, w_oihw, in_hw, need0=True, need1=True, accumulate_into=None, actgrad=None, fold=None, wino=None,
+               accumulate_skip_into=None):
     """Data gradient(s) of conv_forward w.r.t. (x0, x1).  dy: [B,Ho,Wo,Cout]; in_hw = (H, W) of the virtual input.
     Returns (dx0, dx1); dx0 is at the *stored* resolution of x0 (2x2-summed when g.up0).
     accumulate_into: a dense [B,H,W,C0] tensor that already holds another gradient of x0 (single-source, non-upsampled
@@ -399,6 +403,7 @@ def conv_dgrad(g, dy, wdpack, w_oihw, in_hw, need0=True, need1=True, accumulate_
     H, W = in_hw
     assert Cout == g.Cout
     ACTGRAD_FUSED[0] = False
+    SKIP_ACCUMULATED[0] = False
     dx1 = torch.empty((B, H, W, g.C1), dtype=torch.float32, device=dy.device) if g.C1 else None
     L = _lib.lib()
     flops = 2.0 * B * Ho * Wo * Cout * g.CinAlg * g.k * g.k
@@ -450,16 +455,25 @@ def conv_dgrad(g, dy, wdpack, w_oihw, in_hw, need0=True, need1=True, accumulate_
         wfold, wdfold = fold
         dx0 = torch.empty((B, H // 2, W // 2, g.C0), dtype=torch.float32, device=dy.device) if need0 else None
         dx1f = dx1 if need1 else None
+        # accumulate_skip_into: a dense [B,H,W,C1] tensor that already holds another consumer's gradient of the skip source (the
+        # encoder feature both decoders read): the skip launch adds onto it in its epilogue instead of producing a tensor that
+        # autograd would add with a 12-byte-per-element pass
+        acc1 = accumulate_skip_into
+        if dx1f is not None and acc1 is not None and tuple(acc1.shape) == (B, H, W, g.C1) and acc1.is_contiguous():
+            dx1f = acc1
+        else:
+            acc1 = None
         if dx0 is None and dx1f is None:
             return None, None
         df = ConvDesc(B=B, H=H, W=W, C0=g.C0, C1=g.C1, ld0=g.C0, ld1=g.C1, up0=1, Ho=Ho, Wo=Wo, Cout=Cout, ldy=Cout, ldy2=0,
                       nsplit=0, KH=3, KW=3, stride=1, dil=1, pad=1, pad_mode=PAD_REFLECT, in_div=1, act=0, sum2x2=0)
         fr = ((4.0 * g.C0 if need0 else 0.0) + (9.0 * g.C1 if need1 else 0.0)) / (9.0 * g.Cin)
         rc = _timed("conv_dgrad", flops, dy, lambda: L.segsde_conv2d_dgrad_upfold(
-            ctypes.byref(df), _p(_f32(dy)), nhwc_ld(dy), _p(wdpack), _p(wfold), _p(wdfold), _p(dx0), _p(dx1f),
+            ctypes.byref(df), _p(_f32(dy)), nhwc_ld(dy), _p(wdpack), _p(wfold), _p(wdfold), _p(dx0), _p(dx1f), 1 if acc1 is not None else 0,
             _p(ag_y) if dx0 is not None else None, ag_ld, ag_kind, _stream(dy)), _tag(g, H, W) + " fold", executed=flops * fr)
         if rc == 0:
             UPFOLD_TAKEN["dgrad"] += 1
+            SKIP_ACCUMULATED[0] = acc1 is not None
             ACTGRAD_FUSED[0] = actgrad is not None and dx0 is not None
             return dx0, dx1f
         if rc != -4:

@@ -66,10 +66,16 @@ class DepthDecoder(nn.Module):
                 continue
             x = self.convs[("upconv", i, 0)](x)
             up = x.shape[2] < feats[i - 1].shape[2] or i == 0
-            skip = None
+            skip, sbox = None, None
             if self.use_skips and i > 0:
-                skip = self.convs[("skip_proj", i)](feats[i - 1])
-            x = self.convs[("upconv", i, 1)](x, skip, up)
+                proj = self.convs[("skip_proj", i)]
+                if isinstance(proj, nn.Identity):
+                    # the encoder feature is read by several consumers: this decoder takes its own autograd view of it and the
+                    # box through which the consumers' data-gradients accumulate in their kernels (Fn.fan_feature)
+                    skip, sbox = Fn.take_fan_view(feats[i - 1])
+                else:
+                    skip = proj(feats[i - 1])
+            x = self.convs[("upconv", i, 1)](x, skip, up, skip_box=sbox)
             out[("upconv", i)] = x
             if i in self.scales and self.enable_disparity:
                 out[("disp", i)] = self.convs[("dispconv", i)](x, act="sigmoid")

@@ -17,6 +17,13 @@ class JointSegmentationMonodepth(nn.Module):
         self.provide_uncropped_for_pose = provide_uncropped_for_pose
         self.device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
         self.models = nn.ModuleDict(models)
+        # how many decoders read the encoder's features as skip sources: the encoder then hands every feature out as views of one
+        # gradient collector (resnet_encoder.ResnetEncoder.forward_nhwc, Fn.fan_feature)
+        from .depth_decoder import DepthDecoder
+        dec = [m for k, v in self.models.items() if k in ("depth", "segmentation", "mtl_decoder")
+               for m in v.modules() if isinstance(m, DepthDecoder) and m.use_skips]
+        if "encoder" in self.models:
+            self.models["encoder"].skip_consumers = len(dec)
 
     def predict_poses(self, inputs, features):
         """reference :20-70"""

@@ -117,7 +117,7 @@ class Conv2d(nn.Conv2d):
             return y
         return Fn.StemFn.apply(image, self.weight, mean, std, None, wstem)
 
-    def forward(self, x, skip=None, up=False, act="none", grad_box=None):
+    def forward(self, x, skip=None, up=False, act="none", grad_box=None, skip_box=None):
         c0 = x.shape[3]
         c1 = 0 if skip is None else skip.shape[3]
         weight = self.weight
@@ -158,7 +158,7 @@ class Conv2d(nn.Conv2d):
         box = {"need_dbias": self.bias is not None and self.bias.requires_grad}
         fc = self._fold_cache
         fc["want"] = (_PACK_SCOPE[0], weight._version, weight.data_ptr(), weight.device, c0) if (_PACK_SCOPE[0] and up) else None
-        yz = Fn.ConvFn.apply(x, skip, weight, self.bias, g, act, None, grad_box, packs, x0_act, box, fc, wc)
+        yz = Fn.ConvFn.apply(x, skip, weight, self.bias, g, act, None, grad_box, packs, x0_act, box, fc, wc, skip_box)
         if not (torch.is_grad_enabled() and yz.requires_grad):
             return yz
         y = Fn.ActGradFn.apply(yz, act, box)

@@ -36,8 +36,8 @@ class Conv3x3(nn.Module):
         self.pad = nn.ReflectionPad2d(1) if use_refl else nn.ZeroPad2d(1)   # kept for module-tree parity, no params
         self.conv = Conv2d(int(in_channels), int(out_channels), 3, padding=1, reflect=use_refl)
 
-    def forward(self, x, skip=None, up=False, act="none"):
-        return self.conv(x, skip, up, act)
+    def forward(self, x, skip=None, up=False, act="none", skip_box=None):
+        return self.conv(x, skip, up, act, skip_box=skip_box)
 
 
 class ConvBlock(nn.Module):
@@ -54,11 +54,11 @@ class ConvBlock(nn.Module):
         )
         self.bn = bn
 
-    def forward(self, x, skip=None, up=False):
+    def forward(self, x, skip=None, up=False, skip_box=None):
         if self.bn:
             y = self.block[1](self.block[0](x, skip, up), act="elu")
         else:
-            y = self.block[0](x, skip, up, act="elu")
+            y = self.block[0](x, skip, up, act="elu", skip_box=skip_box)
         drop = self.block[3]
         if isinstance(drop, nn.Dropout2d) and drop.training and self.training and drop.p > 0:
             # whole channel maps are zeroed with probability p and the survivors scaled by 1 / (1 - p); the Bernoulli draw

@@ -23,15 +23,20 @@ class BasicBlock(nn.Module):
         self.bn2 = BatchNorm2d(planes)
         self.downsample = downsample
 
-    def forward(self, x):
+    def forward(self, x, x_ds=None, box=None):
+        """x_ds / box: this block's input is a tensor several consumers read (an encoder feature: the skip source of the
+        decoders): x and x_ds are two of its Fn.FanoutFn views -- for conv1 and for the downsample convolution -- and ``box``
+        the box through which the consumers' data-gradients accumulate in their kernels"""
         if self.downsample is None and x.requires_grad:
             # identity skip: conv1's data-gradient lands on the skip-path gradient inside its kernel (Fn.SplitFn)
             box = {}
             xm, xs = Fn.SplitFn.apply(x, box)
             o = self.bn1(self.conv1(xm, grad_box=box), act="relu")
             return self.bn2(self.conv2(o), residual=xs, act="relu", grad_box=box)
-        idt = x if self.downsample is None else self.downsample[1](self.downsample[0](x))
-        o = self.bn1(self.conv1(x), act="relu")
+        if self.downsample is not None and x_ds is None and x.requires_grad:
+            (x, x_ds), box = Fn.fan_feature(x, 0, 2)       # conv1 and the downsample convolution read x: one summed gradient
+        idt = x if self.downsample is None else self.downsample[1](self.downsample[0](x if x_ds is None else x_ds, grad_box=box))
+        o = self.bn1(self.conv1(x, grad_box=box), act="relu")
         return self.bn2(self.conv2(o), residual=idt, act="relu")
 
 
@@ -49,15 +54,18 @@ class Bottleneck(nn.Module):
         self.relu = nn.ReLU(inplace=True)
         self.downsample = downsample
 
-    def forward(self, x):
+    def forward(self, x, x_ds=None, box=None):
+        """x_ds / box: see BasicBlock.forward"""
         if self.downsample is None and x.requires_grad:
             box = {}
             xm, xs = Fn.SplitFn.apply(x, box)
             o = self.bn1(self.conv1(xm, grad_box=box), act="relu")
             o = self.bn2(self.conv2(o), act="relu")
             return self.bn3(self.conv3(o), residual=xs, act="relu", grad_box=box)
-        idt = x if self.downsample is None else self.downsample[1](self.downsample[0](x))
-        o = self.bn1(self.conv1(x), act="relu")
+        if self.downsample is not None and x_ds is None and x.requires_grad:
+            (x, x_ds), box = Fn.fan_feature(x, 0, 2)
+        idt = x if self.downsample is None else self.downsample[1](self.downsample[0](x if x_ds is None else x_ds, grad_box=box))
+        o = self.bn1(self.conv1(x, grad_box=box), act="relu")
         o = self.bn2(self.conv2(o), act="relu")
         return self.bn3(self.conv3(o), residual=idt, act="relu")
 
@@ -143,11 +151,24 @@ class ResnetEncoder(nn.Module):
             y0 = e.conv1(Fn.to_nhwc(input_image, 0.45, 0.225, pad_to=4))
         f0 = e.bn1(y0, act="relu")
         feats = [f0]
-        x = Fn.MaxPoolFn.apply(f0)
-        for layer in (e.layer1, e.layer2, e.layer3, e.layer4):
-            for blk in layer:
-                x = blk(x)
+        # The features are read again as the skip sources of ``self.skip_consumers`` decoders (set by the model glue): every
+        # feature becomes a set of Fn.FanoutFn views -- the ones for the next stage are used here, the decoders fetch theirs with
+        # Fn.take_fan_view -- so that the consumers' data-gradients accumulate in their kernels instead of being
+        # summed by autograd with one full-tensor pass per extra consumer.
+        n = int(getattr(self, "skip_consumers", 0))
+        (x0,), _ = Fn.fan_feature(f0, n, 1)
+        x = Fn.MaxPoolFn.apply(x0)
+        layers = (e.layer1, e.layer2, e.layer3, e.layer4)
+        x_ds, box = None, None
+        for li, layer in enumerate(layers):
+            for bi, blk in enumerate(layer):
+                x = blk(x, x_ds, box) if (bi == 0 and x_ds is not None) else blk(x)
             feats.append(x)
+            x_ds, box = None, None
+            if li + 1 < len(layers) and n > 0 and layers[li + 1][0].downsample is not None:
+                (x, x_ds), box = Fn.fan_feature(x, n, 2)      # conv1 and the downsample convolution of the next stage + the decoders
+                if box is None:
+                    x_ds = None
         return feats
 
     def forward(self, input_image):

@@ -99,15 +99,16 @@ int segsde_conv2d_wgrad(const segsde_conv_desc* d, const float* x0, const float*
  *             wdfold [C0][4][4][Cout] (the 4x4 stride-2 kernel of the low-resolution data-gradient)
  *   forward : wpack = segsde_pack_weight(for_dgrad=0) of the same weight (its skip-channel slice is read in place)
  *   dgrad   : d = the FORWARD geometry; dy [B,H,W,Cout] pitch lddy; wdpack = segsde_pack_weight(for_dgrad=1); dx0
- *             [B,H/2,W/2,C0] dense (nullable), dx1 [B,H,W,C1] dense (nullable); act_out (nullable): saved activation output
+ *             [B,H/2,W/2,C0] dense (nullable), dx1 [B,H,W,C1] dense (nullable; accumulate_dx1 != 0: dx1 already holds
+ *             another consumer's gradient of the skip tensor and this one is ADDED to it); act_out (nullable): saved activation output
  *             (pitch act_ld, kind SEGSDE_ACT_*) whose derivative multiplies dx0, as in segsde_conv2d_dgrad_actgrad
  *   wgrad   : dw_oihw [Cout][Ctot][3][3], deterministic (fixed-order reduction of the split partials) */
 int segsde_upfold_pack(const float* w_oihw, int Cout, int C0, int Ctot, float* wfold, float* wdfold, void* stream);
 int segsde_conv2d_forward_upfold(const segsde_conv_desc* d, const float* x0, const float* x1, const float* wpack,
                                  const float* wfold, const float* bias, float* y, void* stream);
 int segsde_conv2d_dgrad_upfold(const segsde_conv_desc* d, const float* dy, int lddy, const float* wdpack, const float* wfold,
-                               const float* wdfold, float* dx0, float* dx1, const float* act_out, int act_ld, int act_kind,
-                               void* stream);
+                               const float* wdfold, float* dx0, float* dx1, int accumulate_dx1, const float* act_out, int act_ld,
+                               int act_kind, void* stream);
 size_t segsde_conv2d_wgrad_upfold_workspace(const segsde_conv_desc* d);
 int segsde_conv2d_wgrad_upfold(const segsde_conv_desc* d, const float* x0, const float* x1, const float* dy, int lddy,
                                float* dw_oihw, float* workspace, size_t workspace_bytes, void* stream);

@@ -721,3 +721,47 @@ def run_fusion_diagnostics(device):
     r2 = Fn.fusion_report(reset=True)
     assert r2["bn_stats_from_conv_epilogue"] == {"taken": 0, "missed": 1}, r2
     assert_close(y2, y1, rtol=1e-5, atol=1e-6, what="fallback statistics give the same normalisation")
+
+
+def run_skip_gradient_fanout(device):
+    """Encoder features read by the next encoder stage AND as skip sources of two decoders: with the gradient collector
+    (Fn.fan_feature / take_fan_view: the decoders' skip data-gradients and the next stage's first convolutions accumulate in
+    their kernels) the parameter and input gradients equal those of plain autograd summation, and the collector reports the
+    accumulations as taken."""
+    from improving_segmentation_with_selfsupervised_depth_amd import functional as Fn
+    from improving_segmentation_with_selfsupervised_depth_amd import hipops as Hh_
+    from improving_segmentation_with_selfsupervised_depth_amd.models.resnet_encoder import ResnetEncoder
+    from improving_segmentation_with_selfsupervised_depth_amd.models.depth_decoder import DepthDecoder
+    torch.manual_seed(11)
+    enc = ResnetEncoder(18, False).to(device).train()
+    kw = dict(num_ch_dec=[32, 32, 32, 64, 64], max_scale_size=[64, 64])
+    decs = [DepthDecoder(enc.num_ch_enc, range(4), **kw).to(device).train() for _ in range(2)]
+    img = torch.rand(1, 3, 64, 64).to(device)
+    old = Hh_.UPFOLD_MIN_SAVED_MACS
+    Hh_.UPFOLD_MIN_SAVED_MACS = 0.0            # the folded route (whose skip launch accumulates) also at this size
+    res = []
+    try:
+        for n in (2, 0):
+            enc.skip_consumers = n
+            for m in [enc] + decs:
+                m.zero_grad(set_to_none=True)
+            Fn.fusion_report(reset=True)
+            feats = enc(img)
+            loss = 0
+            for k, d in enumerate(decs):
+                out = d(feats)
+                loss = loss + sum((k + 1.0) * (out[("disp", s)] ** 2).mean() for s in range(4))
+            loss.backward()
+            rep = Fn.fusion_report(reset=True)
+            res.append(({k: p.grad.detach().clone() for m in [enc] + decs for k, p in m.named_parameters() if p.grad is not None},
+                        float(loss), rep.get("fanout_grad_accumulate", {"taken": 0, "missed": 0})))
+    finally:
+        Hh_.UPFOLD_MIN_SAVED_MACS = old
+        enc.skip_consumers = 0
+    (g1, l1, r1), (g0, l0, r0) = res
+    assert l1 == l0, (l1, l0)
+    assert r1["taken"] > r0["taken"], (r1, r0)          # skip gradients accumulated in the kernels
+    assert set(g1) == set(g0)
+    top = max(float(v.abs().max()) for v in g0.values())
+    for k in g0:
+        assert_close(g1[k], g0[k], rtol=2e-4, atol=1e-5 * top, what="gradient collector vs plain autograd: " + k)

@@ -68,3 +68,7 @@ def test_decoder_activation_backward_is_fused():
 
 def test_fusion_handoffs_are_counted():
     MC.run_fusion_diagnostics("cpu")
+
+
+def test_skip_gradient_fanout():
+    MC.run_skip_gradient_fanout("cpu")

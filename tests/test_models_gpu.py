@@ -513,3 +513,7 @@ def test_train_step_replay_vs_reference_caller(scenario):
         losses = T.train_step(model, opt, TC.batch(100 + it), it, cfg, loss_fn, mono, ema_model=ema, unlabeled_inputs=unl)
         TC.record(out, scenario, it, losses, model, ema, before)
     TC.compare(out, ref, scenario)
+
+
+def test_skip_gradient_fanout():
+    MC.run_skip_gradient_fanout("cuda")
