@@ -50,9 +50,9 @@ _SIGS = {
     "segsde_conv2d_winograd_stats_rows": (ctypes.c_long, [POINTER(ConvDesc)]),
     "segsde_winograd_pack": (c_int, [P, c_int, c_int, P, P, P]),
     "segsde_winograd_pack_multi": (c_int, [P, c_int, c_int, P]),
-    "segsde_conv2d_winograd": (c_int, [POINTER(ConvDesc), P, P, P, P, P, P, P, c_size_t, P]),
+    "segsde_conv2d_winograd": (c_int, [POINTER(ConvDesc), P, P, P, P, P, P, P, P, c_size_t, P]),
     "segsde_conv2d_wgrad_winograd_workspace": (c_size_t, [POINTER(ConvDesc)]),
-    "segsde_conv2d_wgrad_winograd": (c_int, [POINTER(ConvDesc), P, P, P, c_int, P, P, c_size_t, P]),
+    "segsde_conv2d_wgrad_winograd": (c_int, [POINTER(ConvDesc), P, P, P, c_int, P, P, P, c_size_t, P]),
     "segsde_upfold_pack": (c_int, [P, c_int, c_int, c_int, P, P, P]),
     "segsde_conv2d_forward_upfold": (c_int, [POINTER(ConvDesc), P, P, P, P, P, P, P]),
     "segsde_conv2d_dgrad_upfold": (c_int, [POINTER(ConvDesc), P, c_int, P, P, P, P, P, c_int, P, c_int, c_int, P]),
@@ -79,7 +79,7 @@ _SIGS = {
     "segsde_act_backward": (c_int, [P, c_int, P, c_int, c_long, c_int, c_int, P, c_int, P, P, c_size_t, P]),
     "segsde_colsum": (c_int, [P, c_int, c_long, c_int, P, P, c_size_t, P]),
     "segsde_maxpool3x3s2_forward": (c_int, [P, c_int, c_int, c_int, c_int, P, P, P]),
-    "segsde_maxpool3x3s2_backward": (c_int, [P, P, c_int, c_int, c_int, c_int, P, P]),
+    "segsde_maxpool3x3s2_backward": (c_int, [P, P, c_int, c_int, c_int, c_int, P, c_int, P]),
     "segsde_upsample2x_backward": (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, c_int, P]),
     "segsde_upsample2x_forward": (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, c_int, P]),
     "segsde_resize_bilinear_forward": (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, c_int, c_int, c_int, c_int, P]),

@@ -2084,9 +2084,13 @@ extern "C" int segsde_conv2d_dgrad_actgrad(const segsde_conv_desc* d, const floa
     if (stats_rows(d, p) == 0) return SEGSDE_ERR_UNSUPPORTED;
     p.stats = stats;
   }
+  // data-gradient of a stride-2 convolution as four parity classes (below): what an accumulating launch needs from it
+  const bool parity_split = d->in_div == 2 && d->stride == 1 && (d->dil & 1) && d->pad_mode == SEGSDE_PAD_ZERO && !d->sum2x2 &&
+                            d->C1 == 0 && !d->up0 && !bias && d->act == 0 && !y2 && !tune().nos2 && p.vecout;
   if (d->accumulate) {
     // only the plain staged-epilogue launches add in place: one destination, no activation / bias, no special route
-    if (y2 || bias || d->act != 0 || d->sum2x2 || d->in_div > 1 || !p.vecout || d->Cout == 1 || d->C0 % 4 != 0 ||
+    // (round 4: and the parity classes of a stride-2 data-gradient, whose sub-grid stores add just the same)
+    if (y2 || bias || d->act != 0 || d->sum2x2 || (d->in_div > 1 && !parity_split) || !p.vecout || d->Cout == 1 || d->C0 % 4 != 0 ||
         d->C0 == 1 || (d->pad_mode == SEGSDE_PAD_REFLECT_ADJOINT && !igemm_fast_ok(p)))
       return SEGSDE_ERR_UNSUPPORTED;
   }
@@ -2112,8 +2116,7 @@ extern "C" int segsde_conv2d_dgrad_actgrad(const segsde_conv_desc* d, const floa
   // the strided outputs.  Split the gradient image into its four (row parity, column parity) classes: each class is a
   // dense stride-1 problem over the taps of matching parity (1 / 2 / 2 / 4 of the 9 taps of a 3x3, 1 / 0 / 0 / 0 of a 1x1)
   // that reads dY without holes and stores into the strided sub-grid -- a quarter of the matrix work, no wasted MFMAs.
-  if (d->in_div == 2 && d->stride == 1 && (d->dil & 1) && d->pad_mode == SEGSDE_PAD_ZERO && !d->sum2x2 && d->C1 == 0 && !d->up0 &&
-      !bias && d->act == 0 && !y2 && !tune().nos2 && p.vecout) {
+  if (parity_split) {
     bool ok = true;
     ConvP sub[4]; int nsub = 0; bool empty = false;
     for (int ph = 0; ph < 2 && ok; ++ph)
@@ -2139,8 +2142,9 @@ extern "C" int segsde_conv2d_dgrad_actgrad(const segsde_conv_desc* d, const floa
         if (!igemm_fast_ok(q)) ok = false;
         sub[nsub++] = q;
       }
+    if (!ok && d->accumulate) return SEGSDE_ERR_UNSUPPORTED;
     if (ok) {
-      if (empty) {   // 1x1: only the (even, even) class receives anything
+      if (empty && !d->accumulate) {   // 1x1: only the (even, even) class receives anything (accumulating: the rest keeps what it holds)
         if (hipMemsetAsync(y, 0, (size_t)d->B * d->Ho * d->Wo * p.ldy * sizeof(float), s) != hipSuccess) return SEGSDE_ERR_SHAPE;
       }
       for (int i = 0; i < nsub; ++i) {
@@ -2910,8 +2914,8 @@ extern "C" int segsde_winograd_pack_multi(const segsde_wino_job* jobs_device, in
 }
 
 extern "C" int segsde_conv2d_winograd(const segsde_conv_desc* d, const float* x0, const float* x1, const float* u_pack,
-                                      const float* bias, float* y, double* stats, void* workspace, size_t workspace_bytes,
-                                      void* stream) {
+                                      const float* bias, float* y, double* stats, float* v_keep, void* workspace,
+                                      size_t workspace_bytes, void* stream) {
   // d: the convolution's own geometry (3x3, stride 1, pad = dil; [C0 | C1] -> Cout, activation d->act).  u_pack: [16][Cout][C0 + C1]
   // from segsde_winograd_pack (its forward pack; for a data-gradient call d describes dY -> dX and u_pack is the data-gradient
   // pack).  stats (nullable): [segsde_conv2d_winograd_stats_rows(d)][2][Cout] doubles.
@@ -2922,8 +2926,12 @@ extern "C" int segsde_conv2d_winograd(const segsde_conv_desc* d, const float* x0
   if (workspace_bytes < segsde_conv2d_winograd_workspace(d)) return SEGSDE_ERR_WORKSPACE;
   const size_t T = (size_t)d->B * (d->H / 2) * (d->W / 2);
   const int C = d->C0 + d->C1;
-  float* V = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
-  float* Mb = V + 16 * T * C;
+  // v_keep (nullable, 16 * T * (C0 + C1) floats, 16-byte aligned): the transformed input is written THERE instead of into the
+  // workspace -- a training forward keeps it for the weight gradient (segsde_conv2d_wgrad_winograd's v_saved)
+  float* W0 = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
+  float* V = v_keep ? v_keep : W0;
+  float* Mb = W0 + 16 * T * C;
+  if (!aligned16(V)) return SEGSDE_ERR_UNSUPPORTED;
   const segsde_conv_desc g = winograd_gemm_desc(d);
   ConvP q = make_params(&g, V, nullptr, u_pack, nullptr, Mb, nullptr);
   q.wbstride = (long)d->Cout * C;
@@ -2967,7 +2975,8 @@ extern "C" size_t segsde_conv2d_wgrad_winograd_workspace(const segsde_conv_desc*
 }
 
 extern "C" int segsde_conv2d_wgrad_winograd(const segsde_conv_desc* d, const float* x0, const float* x1, const float* dy, int lddy,
-                                            float* dw_oihw, void* workspace, size_t workspace_bytes, void* stream) {
+                                            const float* v_saved, float* dw_oihw, void* workspace, size_t workspace_bytes,
+                                            void* stream) {
   // d: the FORWARD geometry ([C0 | C1] -> Cout, 3x3, stride 1, pad = dil, zero or mirrored padding); dy [B,H,W,Cout] (pitch lddy)
   if (!d || !x0 || !dy || !dw_oihw || !workspace || (d->C1 && !x1)) return SEGSDE_ERR_NULL;
   WinoWgradPlan pl;
@@ -2976,15 +2985,18 @@ extern "C" int segsde_conv2d_wgrad_winograd(const segsde_conv_desc* d, const flo
   if (workspace_bytes < pl.bytes) return SEGSDE_ERR_WORKSPACE;
   const int C = d->C0 + d->C1;
   char* base = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
-  float* V = reinterpret_cast<float*>(base);
+  // v_saved (nullable): the transformed input a forward call of segsde_conv2d_winograd left in its v_keep -- no second input transform
+  float* V = v_saved ? const_cast<float*>(v_saved) : reinterpret_cast<float*>(base);
+  if (!aligned16(V)) return SEGSDE_ERR_UNSUPPORTED;
   float* dM = reinterpret_cast<float*>(base + pl.off_dm);
   float* part = reinterpret_cast<float*>(base + pl.off_part);
   ConvP p = make_params(&pl.g, V, nullptr, dM, nullptr, part, nullptr);
   if (wgrad_mode(p, dM, d->Cout) != 2) return SEGSDE_ERR_UNSUPPORTED;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (int e = segsde_wino_input(x0, d->ld0, d->C1 ? x1 : nullptr, d->C1 ? d->ld1 : d->ld0, d->C0, d->B, d->H, d->W, C, d->dil,
-                                d->pad_mode == SEGSDE_PAD_REFLECT, V, stream))
-    return e;
+  if (!v_saved)
+    if (int e = segsde_wino_input(x0, d->ld0, d->C1 ? x1 : nullptr, d->C1 ? d->ld1 : d->ld0, d->C0, d->B, d->H, d->W, C, d->dil,
+                                  d->pad_mode == SEGSDE_PAD_REFLECT, V, stream))
+      return e;
   if (int e = segsde_wino_grad(dy, lddy, d->B, d->H, d->W, d->Cout, d->dil, dM, stream)) return e;
   int e;
   if (pl.bn == 64) e = launch_wgrad<128, 64, 2, 2>(p, dM, d->Cout, part, 16 * pl.s, pl.cps, s);

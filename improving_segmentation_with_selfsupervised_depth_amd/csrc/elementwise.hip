@@ -427,7 +427,7 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* x, int B,
 }
 
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* dy, const uint8_t* idx, int B, int H, int W, int C,
-                                                          int Ho, int Wo, float* dx) {
+                                                          int Ho, int Wo, float* dx, int accumulate) {
   const long total = (long)B * H * W * C;
   for (long e = blockIdx.x * 256L + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
     const int c = (int)(e % C); long t = e / C;
@@ -447,7 +447,7 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* dy, const
         if (idx[o] == kh * 3 + kw) s += dy[o];
       }
     }
-    dx[e] = s;
+    dx[e] = accumulate ? dx[e] + s : s;
   }
 }
 
@@ -483,7 +483,7 @@ __global__ __launch_bounds__(256) void maxpool_fwd4_kernel(const float* x, int B
   }
 }
 __global__ __launch_bounds__(256) void maxpool_bwd4_kernel(const float* dy, const uint8_t* idx, int B, int H, int W, int C4,
-                                                           int Ho, int Wo, float* dx) {
+                                                           int Ho, int Wo, float* dx, int accumulate) {
   const int total = B * H * W * C4;       // host guarantees < 2^31
   for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
     const int c4 = e % C4; int t = e / C4;
@@ -504,6 +504,10 @@ __global__ __launch_bounds__(256) void maxpool_bwd4_kernel(const float* dy, cons
         const unsigned char tap = (unsigned char)(kh * 3 + kw);
         s.x += k.x == tap ? g.x : 0.f; s.y += k.y == tap ? g.y : 0.f; s.z += k.z == tap ? g.z : 0.f; s.w += k.w == tap ? g.w : 0.f;
       }
+    }
+    if (accumulate) {
+      const float4 o = reinterpret_cast<const float4*>(dx)[e];
+      s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
     }
     reinterpret_cast<float4*>(dx)[e] = s;
   }
@@ -1005,17 +1009,17 @@ extern "C" int segsde_maxpool3x3s2_forward(const float* x, int B, int H, int W, 
   return 0;
 }
 extern "C" int segsde_maxpool3x3s2_backward(const float* dy, const uint8_t* idx, int B, int H, int W, int C, float* dx,
-                                            void* stream) {
+                                            int accumulate, void* stream) {
   if (!dy || !idx || !dx) return SEGSDE_ERR_NULL;
   const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
   if (C % 4 == 0 && (long)B * H * W * (C / 4) < (1L << 31) && al16p(dy) && al16p(dx) && (reinterpret_cast<uintptr_t>(idx) & 3) == 0) {
     hipLaunchKernelGGL(maxpool_bwd4_kernel, dim3(ew_blocks((long)B * H * W * (C / 4))), dim3(256), 0, ST(stream), dy, idx, B, H, W,
-                       C / 4, Ho, Wo, dx);
+                       C / 4, Ho, Wo, dx, accumulate);
     SEGSDE_CHECK_LAUNCH();
     return 0;
   }
   hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(ew_blocks((long)B * H * W * C)), dim3(256), 0, ST(stream), dy, idx, B, H, W,
-                     C, Ho, Wo, dx);
+                     C, Ho, Wo, dx, accumulate);
   SEGSDE_CHECK_LAUNCH();
   return 0;
 }

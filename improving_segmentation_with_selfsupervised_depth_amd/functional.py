@@ -155,8 +155,10 @@ class ConvFn(Function):
                 if wino_cache is not None and wino_cache.get("want") is not None:
                     wino_cache["packs"], wino_cache["key"] = ctx.wino, wino_cache["want"]
         wino_f = None if ctx.wino is None else ctx.wino[0]
+        keep_v = wino_f is not None and ctx.needs_input_grad[2]     # the weight gradient reuses the forward's transformed input
+        H.WINO_V[0] = None
         if stats_out is not None:
-            y, part = H.conv_forward(g, x0, x1, wp, bias, act, want_stats=True, wino=wino_f)
+            y, part = H.conv_forward(g, x0, x1, wp, bias, act, want_stats=True, wino=wino_f, keep_v=keep_v)
             stats_out.append(part)
         else:
             if H.upfold_ok(g, 4 * x0.shape[0] * x0.shape[1] * x0.shape[2]) and x0.is_contiguous() and (x1 is None or x1.is_contiguous()):
@@ -168,7 +170,8 @@ class ConvFn(Function):
                     ctx.fold = H.upfold_pack(weight, g.C0)
                     if fold_cache is not None and fold_cache.get("want") is not None:
                         fold_cache["fold"], fold_cache["key"] = ctx.fold, fold_cache["want"]
-            y = H.conv_forward(g, x0, x1, wp, bias, act, wfold=None if ctx.fold is None else ctx.fold[0], wino=wino_f)
+            y = H.conv_forward(g, x0, x1, wp, bias, act, wfold=None if ctx.fold is None else ctx.fold[0], wino=wino_f, keep_v=keep_v)
+        ctx.wino_v, H.WINO_V[0] = H.WINO_V[0], None
         ctx.g, ctx.act = g, act
         ctx.in_hw = (x0.shape[1] * (2 if g.up0 else 1), x0.shape[2] * (2 if g.up0 else 1))
         ctx.has_bias = bias is not None
@@ -226,7 +229,8 @@ class ConvFn(Function):
             if x1 is None or not ctx.needs_input_grad[1]:
                 dx1 = None
         if ctx.needs_input_grad[2]:
-            dw = H.conv_wgrad(g, x0, x1, dz)
+            dw = H.conv_wgrad(g, x0, x1, dz, wino_v=ctx.wino_v)
+            ctx.wino_v = None
         return dx0, dx1, dw, dbias, None, None, None, None, None, None, None, None, None, None
 
 
@@ -400,17 +404,26 @@ def take_fan_view(t):
 
 
 class MaxPoolFn(Function):
+    """box: the shared box of the pooled tensor's gradient collector (Fn.fan_feature), if it has one: the pooling gradient is
+    added onto the gradient another consumer already left there"""
+
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, box=None):
         y, idx = H.maxpool_forward(_c(x))
         ctx.shape = tuple(x.shape)
+        ctx.box = box
         ctx.save_for_backward(idx)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         (idx,) = ctx.saved_tensors
-        return H.maxpool_backward(_c(dy), idx, ctx.shape)
+        box = ctx.box
+        acc = box.get("g") if (box is not None and box.get("fused")) else None
+        dx = H.maxpool_backward(_c(dy), idx, ctx.shape, accumulate_into=acc)
+        if box is not None and acc is None and box.get("publish") and box.get("g") is None:
+            box["g"], box["fused"] = dx, True
+        return dx, None
 
 
 class ResizeFn(Function):

@@ -162,7 +162,11 @@ def winograd_packs_multi(weights):
     return views
 
 
-def _winograd(kind, g, x0, x1, upack, Cout, want_stats, flops, tag, bias=None, act="none", reflect=False):
+WINOGRAD_KEEP_V = os.environ.get("SEGSDE_WINOGRAD_KEEP_V", "1") != "0"   # a training forward keeps its transformed input for the weight gradient
+WINO_V = [None]     # the transformed input of the last _winograd(..., keep_v=True) call (ConvFn picks it up)
+
+
+def _winograd(kind, g, x0, x1, upack, Cout, want_stats, flops, tag, bias=None, act="none", reflect=False, keep_v=False):
     """one Winograd convolution [x0 | x1] [B,H,W,C] -> [B,H,W,Cout]; returns (y, partials or None), or None when the kernel
     declines"""
     B, H, W, C0 = x0.shape
@@ -179,12 +183,14 @@ def _winograd(kind, g, x0, x1, upack, Cout, want_stats, flops, tag, bias=None, a
     if want_stats:
         part = torch.empty((int(L.segsde_conv2d_winograd_stats_rows(ctypes.byref(d))), 2, Cout), dtype=torch.float64, device=x0.device)
     ws = _ws(nbytes, x0)
+    vk = torch.empty((16, B * (H // 2) * (W // 2), C0 + C1), dtype=torch.float32, device=x0.device) if keep_v else None
     rc = _timed(kind, flops, x0, lambda: L.segsde_conv2d_winograd(ctypes.byref(d), _p(_f32(x0)), _p(x1), _p(upack), _p(bias), _p(y),
-                                                                   _p(part), _p(ws), nbytes, _stream(x0)), tag + " wino",
+                                                                   _p(part), _p(vk), _p(ws), nbytes, _stream(x0)), tag + " wino",
                 executed=flops * 16.0 / 36.0)
     if rc == -4:
         return None
     check(rc, "conv2d_winograd")
+    WINO_V[0] = vk
     WINOGRAD_TAKEN["fwd" if kind == "conv_fwd" else "dgrad"] += 1
     return y, part
 
@@ -342,7 +348,7 @@ def pack_weights_multi(weights):
     return views
 
 
-def conv_forward(g, x0, x1, wpack, bias, act="none", want_stats=False, wfold=None, wino=None):
+def conv_forward(g, x0, x1, wpack, bias, act="none", want_stats=False, wfold=None, wino=None, keep_v=False):
     """y = act(conv(cat[up?(x0), x1]) + bias).  x0: [B,H0,W0,C0] (H0 = H/2 if g.up0), x1: [B,H,W,C1] or None.
     want_stats: also return the per-tile statistics partials of y for the BatchNorm that follows ([rows,2,Cout] doubles,
     or None when this shape cannot fuse them) -> (y, partials)."""
@@ -360,7 +366,9 @@ def conv_forward(g, x0, x1, wpack, bias, act="none", want_stats=False, wfold=Non
     flops = 2.0 * B * Ho * Wo * g.Cout * g.CinAlg * g.k * g.k
     flops_x = flops * g.Cin / g.CinAlg * _live_tap_frac(g, H, W)   # executed: zero pad channels of a stem are multiplied too, dead tap rows are not
     if wino is not None and not g.up0 and (not want_stats or (bias is None and act == "none")) and winograd_ok(g, B, H, W):
-        r = _winograd("conv_fwd", g, x0, x1, wino, g.Cout, want_stats, flops, _tag(g, H, W), bias=bias, act=act, reflect=g.reflect)
+        WINO_V[0] = None
+        r = _winograd("conv_fwd", g, x0, x1, wino, g.Cout, want_stats, flops, _tag(g, H, W), bias=bias, act=act, reflect=g.reflect,
+                      keep_v=keep_v and WINOGRAD_KEEP_V)
         if r is not None:
             return r if want_stats else r[0]
     if wfold is not None and not want_stats:
@@ -510,8 +518,8 @@ def conv_dgrad(g, dy, wdpack, w_oihw, in_hw, need0=True, need1=True, accumulate_
     return (dx0 if fused else finish_unfused(dx0)), dx1
 
 
-def conv_wgrad(g, x0, x1, dy):
-    """dW in OIHW layout."""
+def conv_wgrad(g, x0, x1, dy, wino_v=None):
+    """dW in OIHW layout.  wino_v: the transformed input the forward's Winograd call kept (hipops.WINO_V), if any."""
     B, H0, W0, _ = x0.shape
     H, W = (2 * H0, 2 * W0) if g.up0 else (H0, W0)
     _, Ho, Wo, Cout = dy.shape
@@ -527,7 +535,7 @@ def conv_wgrad(g, x0, x1, dy):
         if nbytes:
             ws = _ws(nbytes, dy)
             rc = _timed("conv_wgrad", flops, dy, lambda: L.segsde_conv2d_wgrad_winograd(
-                ctypes.byref(d), _p(x0), _p(x1), _p(_f32(dy)), nhwc_ld(dy), _p(dw), _p(ws), nbytes, _stream(dy)),
+                ctypes.byref(d), _p(x0), _p(x1), _p(_f32(dy)), nhwc_ld(dy), _p(wino_v), _p(dw), _p(ws), nbytes, _stream(dy)),
                 _tag(g, H, W) + " wino", executed=flops * 16.0 / 36.0)
             if rc == 0:
                 WINOGRAD_TAKEN["wgrad"] += 1
@@ -665,11 +673,16 @@ def maxpool_forward(x):
     return y, idx
 
 
-def maxpool_backward(dy, idx, in_shape):
+def maxpool_backward(dy, idx, in_shape, accumulate_into=None):
+    """accumulate_into: a dense tensor of in_shape that already holds another consumer's gradient of the pooled tensor: the
+    result is added to it in the kernel and that tensor is returned"""
     B, H, W, C = in_shape
     dy = dy.contiguous()
-    dx = torch.empty(in_shape, dtype=torch.float32, device=dy.device)
-    check(_lib.lib().segsde_maxpool3x3s2_backward(_p(_f32(dy)), _p(idx), B, H, W, C, _p(dx), _stream(dy)), "maxpool_bwd")
+    acc = accumulate_into if (accumulate_into is not None and tuple(accumulate_into.shape) == tuple(in_shape)
+                              and accumulate_into.is_contiguous()) else None
+    dx = acc if acc is not None else torch.empty(in_shape, dtype=torch.float32, device=dy.device)
+    check(_lib.lib().segsde_maxpool3x3s2_backward(_p(_f32(dy)), _p(idx), B, H, W, C, _p(dx), 1 if acc is not None else 0,
+                                                  _stream(dy)), "maxpool_bwd")
     return dx
 
 

@@ -156,8 +156,8 @@ class ResnetEncoder(nn.Module):
         # Fn.take_fan_view -- so that the consumers' data-gradients accumulate in their kernels instead of being
         # summed by autograd with one full-tensor pass per extra consumer.
         n = int(getattr(self, "skip_consumers", 0))
-        (x0,), _ = Fn.fan_feature(f0, n, 1)
-        x = Fn.MaxPoolFn.apply(x0)
+        (x0,), box0 = Fn.fan_feature(f0, n, 1)
+        x = Fn.MaxPoolFn.apply(x0, box0)
         layers = (e.layer1, e.layer2, e.layer3, e.layer4)
         x_ds, box = None, None
         for li, layer in enumerate(layers):

@@ -194,7 +194,9 @@ int segsde_colsum(const float* x, int ldx, long M, int C, float* out, void* work
 
 /* nn.MaxPool2d(3, 2, 1) (models/resnet_encoder.py:96); idx keeps the winning tap (first max in scan order). */
 int segsde_maxpool3x3s2_forward(const float* x, int B, int H, int W, int C, float* y, uint8_t* idx, void* stream);
-int segsde_maxpool3x3s2_backward(const float* dy, const uint8_t* idx, int B, int H, int W, int C, float* dx, void* stream);
+/* accumulate != 0: dx already holds another consumer's gradient of the pooled tensor and this one is added to it */
+int segsde_maxpool3x3s2_backward(const float* dy, const uint8_t* idx, int B, int H, int W, int C, float* dx, int accumulate,
+                                 void* stream);
 /* adjoint of the nearest x2 upsample (models/monodepth_layers.py:202-205): dx[h,w] = sum of the 2x2 block of dy */
 int segsde_upsample2x_backward(const float* dy, int lddy, int B, int h, int w, int C, float* dx, int lddx, void* stream);
 /* upsample(x) of models/monodepth_layers.py:202-205 as a stand-alone call: x [B,h,w,C] -> y [B,2h,2w,C] */
@@ -256,12 +258,14 @@ long segsde_conv2d_winograd_stats_rows(const segsde_conv_desc* d);
 int segsde_winograd_pack(const float* w_oihw, int Cout, int Cin, float* u_fwd, float* u_dgrad, void* stream);
 int segsde_winograd_pack_multi(const segsde_wino_job* jobs_device, int njobs, int total_blocks, void* stream);
 int segsde_conv2d_winograd(const segsde_conv_desc* d, const float* x0, const float* x1, const float* u_pack, const float* bias,
-                           float* y, double* stats, void* workspace, size_t workspace_bytes, void* stream);
+                           float* y, double* stats, float* v_keep, void* workspace, size_t workspace_bytes, void* stream);
 /* the weight gradient on the same route: dU_p = V_p^T (A dY A^T)_p as sixteen position GEMMs in one launch of the
- * weight-gradient kernel (split boundaries on the position boundaries), dW = G^T dU G written as OIHW.  d: the FORWARD geometry. */
+ * weight-gradient kernel (split boundaries on the position boundaries), dW = G^T dU G written as OIHW.  d: the FORWARD geometry.
+ * v_keep of the forward call (nullable; 16 * B*H/2*W/2 * (C0+C1) floats) receives the transformed input; handed back as v_saved
+ * (nullable) the weight gradient skips its own input transform. */
 size_t segsde_conv2d_wgrad_winograd_workspace(const segsde_conv_desc* d);
 int segsde_conv2d_wgrad_winograd(const segsde_conv_desc* d, const float* x0, const float* x1, const float* dy, int lddy,
-                                 float* dw_oihw, void* workspace, size_t workspace_bytes, void* stream);
+                                 const float* v_saved, float* dw_oihw, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------ *
  * Pose: axis-angle + translation -> 4x4 (models/monodepth_layers.py:30-105)                         *

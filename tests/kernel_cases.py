@@ -312,6 +312,11 @@ def run_misc_cases(device):
     assert torch.equal(nchw(yo).cpu(), y.detach())
     dx = H.maxpool_backward(d(nhwc(gy)), idx, (2, 9, 11, 12))
     assert_close(nchw(dx), x.grad, what="maxpool bwd")
+    base = torch.randn(2, 9, 11, 12, generator=gen)
+    acc = d(base.clone())
+    out = H.maxpool_backward(d(nhwc(gy)), idx, (2, 9, 11, 12), accumulate_into=acc)
+    assert out.data_ptr() == acc.data_ptr()
+    assert_close(out, base + dx.cpu(), rtol=1e-6, atol=1e-6, what="maxpool bwd accumulated onto another consumer's gradient")
     x6 = F.relu(torch.randn(1, 6, 8, 7, generator=gen))          # channel count off the four-channel kernels
     yo6, idx6 = H.maxpool_forward(d(nhwc(x6)))
     assert torch.equal(nchw(yo6).cpu(), F.max_pool2d(x6, 3, 2, 1)), "maxpool, scalar kernel"
