@@ -648,6 +648,18 @@ def main():
                                 "upsample-folded, dead-tap-skipping and Winograd routes issue fewer multiply-adds than that, so single "
                                 "layers (and, with enough of them, the sum) can exceed 1 -- the matrix pipe's own utilisation is "
                                 "executed_frac")
+            # the same split by route: the direct implicit-GEMM launches (what the matrix pipe's utilisation figure is about) and
+            # the Winograd calls, whose time includes their HBM-side transforms while `executed` counts the position GEMMs only
+            wl = [v for (kind, tag), v in layers.items() if kind in ("conv_fwd", "conv_dgrad") and tag.endswith(" wino")]
+            if wl:
+                wf, wt, wn, wx = (sum(v[i] for v in wl) for i in range(4))
+                roof["winograd"] = {"launches": wn, "ms_per_step": wt / args.steps * 1e3, "achieved": wf / wt / 1e12,
+                                    "executed_achieved": wx / wt / 1e12, "share_of_step": wt / dt,
+                                    "note": "one launch = input transform + 16 position GEMMs + output transform; executed = the GEMMs' "
+                                            "multiply-adds (16/36 of the algorithmic ones) over the whole call's time"}
+                roof["direct"] = {"launches": nl - wn, "achieved": (fl - wf) / (tt - wt) / 1e12,
+                                  "executed_achieved": (ex - wx) / (tt - wt) / 1e12,
+                                  "executed_frac": (ex - wx) / (tt - wt) / 1e12 / PEAK_FP32_MATRIX_TFLOPS}
             roof.update(achieved=fl / tt / 1e12, frac=fl / tt / 1e12 / PEAK_FP32_MATRIX_TFLOPS, launches=nl,
                         avg_launch_ms=tt / nl * 1e3, avg_launch_gflop=fl / nl / 1e9,
                         share_of_step=tt / dt, algorithmic_bytes_per_launch=abytes / nl)

@@ -4,6 +4,7 @@ All activations flowing between these Functions are NHWC fp32 tensors.  Module-l
 NCHW; ``to_nhwc`` / ``to_nchw`` convert at that edge for free when the tensor is already channels-last in memory
 (which is what every module of this package returns), and with a HIP layout kernel otherwise.
 """
+import collections
 import weakref
 
 import torch
@@ -371,7 +372,8 @@ class FanoutFn(Function):
 # their data-gradient epilogues; the views meant for the decoders wait in a registry keyed by the feature's storage, because
 # the feature crosses the module boundary as an NCHW-logical view (a new tensor object) -- ``take_fan_view`` hands a decoder
 # its own view plus the shared box, or the tensor it was given when there is nothing registered for it.
-_FANS = {}
+_FANS = collections.OrderedDict()      # at most _FANS_MAX entries: parked views keep their feature alive, old ones are dropped
+_FANS_MAX = 16
 
 
 def fan_feature(x, n_spare, n_main=1):
@@ -383,10 +385,10 @@ def fan_feature(x, n_spare, n_main=1):
     views = FanoutFn.apply(x, box, n_main + n_spare)
     if n_spare > 0:
         base = views[0]._base if views[0]._base is not None else views[0]
+        _FANS.pop(id(base), None)
         _FANS[id(base)] = (weakref.ref(base), box, list(views[n_main:]))
-        if len(_FANS) > 64:
-            for k in [k for k, v in _FANS.items() if v[0]() is None]:
-                del _FANS[k]
+        while len(_FANS) > _FANS_MAX:          # a forward whose decoders never came for their views (or a dead feature)
+            _FANS.popitem(last=False)
     return tuple(views[:n_main]), box
 
 
@@ -400,6 +402,8 @@ def take_fan_view(t):
     if v.shape != t.shape or v.data_ptr() != t.data_ptr() or v.stride() != t.stride():
         ent[2].append(v)
         return t, None
+    if not ent[2]:
+        del _FANS[id(base)]                    # every parked view has been handed out
     return v, ent[1]
 
 

@@ -6,12 +6,13 @@ ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 -L > $OUT/r3_counters_list.txt 2>&1 || true
+TAG=${PMC_TAG:-r04}
+rocprofv3 -L > $OUT/${TAG}_counters_list.txt 2>&1 || true
 run() {  # name, counters...
   local name=$1; shift
-  rocprofv3 --kernel-trace --pmc "$@" -d $OUT/pmc_$name -o pmc -- python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing > $OUT/r3_pmc_$name.log 2>&1
+  rocprofv3 --kernel-trace --pmc "$@" -d $OUT/pmc_$name -o pmc -- python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing > $OUT/${TAG}_pmc_$name.log 2>&1
   local db=$(ls $OUT/pmc_$name/*.db 2>/dev/null | head -1)
-  [ -n "$db" ] && python $ROOT/tools/pmc_table.py $db $OUT/r3_pmc_$name.txt > /dev/null
+  [ -n "$db" ] && python $ROOT/tools/pmc_table.py $db $OUT/${TAG}_pmc_$name.txt > /dev/null
   rm -rf $OUT/pmc_$name      # the databases are tens of MB each: only the summaries travel back
 }
 run mfma SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE
@@ -19,4 +20,4 @@ run waits SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INST
 run fetch FETCH_SIZE
 run write WRITE_SIZE
 ls $OUT | head -40
-python $ROOT/tools/traffic_json.py $OUT/r3_pmc_fetch.txt $OUT/r3_pmc_write.txt $OUT/traffic_r03.json > /dev/null
+python $ROOT/tools/traffic_json.py $OUT/${TAG}_pmc_fetch.txt $OUT/${TAG}_pmc_write.txt $OUT/traffic_${TAG}.json > /dev/null
