@@ -2877,11 +2877,12 @@ bool winograd_shape_ok(const segsde_conv_desc* d) {
          !d->accumulate && (d->pad_mode == SEGSDE_PAD_ZERO || (d->pad_mode == SEGSDE_PAD_REFLECT && d->dil == 1)) && d->H == d->Ho &&
          d->W == d->Wo && d->H % (2 * d->dil) == 0 && d->W % (2 * d->dil) == 0 && d->H >= 4 * d->dil && d->W >= 4 * d->dil &&
          C % 32 == 0 && d->C0 % 4 == 0 && d->Cout % 64 == 0 && d->ld0 % 4 == 0 && (!d->C1 || d->ld1 % 4 == 0) && d->ldy % 4 == 0 &&
-         T % 128 == 0 && 16 * T * (long)(C > d->Cout ? C : d->Cout) < (1L << 31) && tune().dma;
+         16 * segsde_wino_rows(T) * (long)(C > d->Cout ? C : d->Cout) < (1L << 31) && tune().dma;
 }
 segsde_conv_desc winograd_gemm_desc(const segsde_conv_desc* d) {
   segsde_conv_desc g = *d;
-  g.B = 16; g.H = d->B * (d->H / 2); g.W = d->W / 2; g.C0 = d->C0 + d->C1; g.C1 = 0; g.ld0 = g.C0; g.ld1 = 0; g.Ho = g.H; g.Wo = g.W;
+  const long Tp = segsde_wino_rows((long)d->B * (d->H / 2) * (d->W / 2));     // rows per position, whole 128-row tiles
+  g.B = 16; g.H = (int)(Tp / 32); g.W = 32; g.C0 = d->C0 + d->C1; g.C1 = 0; g.ld0 = g.C0; g.ld1 = 0; g.Ho = g.H; g.Wo = g.W;
   g.ldy = d->Cout; g.ldy2 = 0; g.nsplit = 0; g.KH = 1; g.KW = 1; g.dil = 1; g.pad = 0; g.pad_mode = SEGSDE_PAD_ZERO; g.act = 0;
   return g;
 }
@@ -2889,7 +2890,7 @@ segsde_conv_desc winograd_gemm_desc(const segsde_conv_desc* d) {
 
 extern "C" size_t segsde_conv2d_winograd_workspace(const segsde_conv_desc* d) {
   if (!winograd_shape_ok(d)) return 0;
-  const size_t T = (size_t)d->B * (d->H / 2) * (d->W / 2);
+  const size_t T = (size_t)segsde_wino_rows((long)d->B * (d->H / 2) * (d->W / 2));
   return 16 * T * ((size_t)d->C0 + (size_t)d->C1 + (size_t)d->Cout) * sizeof(float) + 256;
 }
 
@@ -2924,7 +2925,7 @@ extern "C" int segsde_conv2d_winograd(const segsde_conv_desc* d, const float* x0
       (bias && !aligned16(bias)) || d->act < SEGSDE_ACT_NONE || d->act > SEGSDE_ACT_SIGMOID)
     return SEGSDE_ERR_UNSUPPORTED;
   if (workspace_bytes < segsde_conv2d_winograd_workspace(d)) return SEGSDE_ERR_WORKSPACE;
-  const size_t T = (size_t)d->B * (d->H / 2) * (d->W / 2);
+  const size_t T = (size_t)segsde_wino_rows((long)d->B * (d->H / 2) * (d->W / 2));
   const int C = d->C0 + d->C1;
   // v_keep (nullable, 16 * T * (C0 + C1) floats, 16-byte aligned): the transformed input is written THERE instead of into the
   // workspace -- a training forward keeps it for the weight gradient (segsde_conv2d_wgrad_winograd's v_saved)
@@ -2951,11 +2952,9 @@ namespace {
 struct WinoWgradPlan { segsde_conv_desc g; int bn, s, cps; size_t off_dm, off_part, bytes; };
 bool winograd_wgrad_plan(const segsde_conv_desc* d, WinoWgradPlan& pl) {
   if (!winograd_shape_ok(d)) return false;
-  const long T = (long)d->B * (d->H / 2) * (d->W / 2);
+  const long T = segsde_wino_rows((long)d->B * (d->H / 2) * (d->W / 2));
   const int C = d->C0 + d->C1;
-  if (T % BP) return false;
-  pl.g = winograd_gemm_desc(d);
-  pl.g.H = (int)(T / 32); pl.g.W = 32; pl.g.Ho = pl.g.H; pl.g.Wo = 32;      // rows of 32 tiles: the table-driven loader's chunk
+  pl.g = winograd_gemm_desc(d);              // rows of 32 tiles: the table-driven loader's chunk
   pl.bn = d->Cout <= 64 ? 64 : 128;
   const long tiles = (long)segsde_cdiv(C, 128) * segsde_cdiv(d->Cout, pl.bn);
   const long cp = T / BP;                          // chunks per position

@@ -13,6 +13,8 @@ int segsde_wino_input(const float* x0, int ld0, const float* x1, int ld1, int C0
 int segsde_wino_output(const float* M, int B, int H, int W, int Co, int dil, const float* bias, int act, float* y, int ldy,
                        double* part, void* stream);
 long segsde_wino_stats_rows(long T);
+// rows per position plane of V / M / dM: T rounded up to the GEMM's 128-row tiles (the transforms zero-fill / skip the rest)
+long segsde_wino_rows(long T);
 // OIHW 3x3 weight -> U [16][O][I] (transpose_flip = 0: forward) or U' [16][I][O] of the spatially flipped kernel (1: the
 // data-gradient's convolution), U = G g G^T
 int segsde_wino_weights(const float* w_oihw, int O, int I, int transpose_flip, float* U, void* stream);

@@ -40,13 +40,20 @@ __device__ __forceinline__ TileAt tile_at(long t, int d, int H2, int W2) {
 // stores, whole 64-byte-or-longer runs per pixel); the 4x4 patches of neighbouring tiles overlap by two pixels (L1 / L2).
 // Two sources: channels [0, C0) come from x0, [C0, C) from x1 (the decoder's concat, models/depth_decoder.py:93-101).
 __global__ __launch_bounds__(256) void wino_in_kernel(const float* x0, int ld0, const float* x1, int ld1, int C0, int B, int H, int W,
-                                                      int C, int d, int reflect, float* V) {
+                                                      int C, int d, int reflect, long Tp, float* V) {
+  // Tp >= T: rows per position plane, T rounded up to the GEMM's 128-row tiles (the rows past T are written as zeros)
   const int CQ = C >> 2, H2 = H / (2 * d), W2 = W / (2 * d), Hs = H / d, Ws = W / d;
-  const long T = (long)B * d * d * H2 * W2, total = T * CQ;
+  const long T = (long)B * d * d * H2 * W2, total = Tp * CQ;
   const long e = blockIdx.x * 256L + threadIdx.x;
   if (e >= total) return;
   const int cq = (int)(e % CQ);
   const long t = e / CQ;
+  if (t >= T) {
+    const F4 z{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 16; ++k) st4(V + k * Tp * C + t * C + 4 * cq, z);
+    return;
+  }
   const TileAt q = tile_at(t, d, H2, W2);
   const bool s0 = 4 * cq < C0;
   const float* src = s0 ? x0 + 4 * cq : x1 + (4 * cq - C0);
@@ -71,7 +78,7 @@ __global__ __launch_bounds__(256) void wino_in_kernel(const float* x0, int ld0, 
     u[0][c] = p[0][c] - p[2][c]; u[1][c] = p[1][c] + p[2][c]; u[2][c] = p[2][c] - p[1][c]; u[3][c] = p[1][c] - p[3][c];
   }
   float* out = V + t * C + 4 * cq;
-  const long plane = T * C;
+  const long plane = Tp * C;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {          // (.) B
     st4(out + (4 * r + 0) * plane, u[r][0] - u[r][2]);
@@ -97,11 +104,11 @@ __device__ __forceinline__ F4 act4(const F4& v, const F4& b, int act) {
 
 template <bool STATS>
 __global__ __launch_bounds__(256) void wino_out_kernel(const float* M, int B, int H, int W, int Co, int d, const float* bias, int act,
-                                                       float* y, int ldy, double* part) {
+                                                       long Tp, float* y, int ldy, double* part) {
   SEGSDE_SMEM;
   double* sh = reinterpret_cast<double*>(segsde_smem);     // [2][16][64]
   const int H2 = H / (2 * d), W2 = W / (2 * d);
-  const long T = (long)B * d * d * H2 * W2, plane = T * Co;
+  const long T = (long)B * d * d * H2 * W2, plane = Tp * Co;
   const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
   const int c = blockIdx.y * 64 + 4 * tx;
   const long per = (T + gridDim.x - 1) / gridDim.x;
@@ -156,13 +163,19 @@ __global__ __launch_bounds__(256) void wino_out_kernel(const float* M, int B, in
 // The output-side transform of the WEIGHT gradient: dM = A dY A^T, a 2x2 block of the output gradient -> its 4x4 plane
 // (A = [1 0; 1 1; 1 -1; 0 -1]); with it  dU_p = sum over tiles of V_p^T dM_p  (sixteen GEMMs over the tiles, the weight-gradient
 // kernel's own form) and dW = G^T dU G.  One thread: one tile x four channels, like the input transform.
-__global__ __launch_bounds__(256) void wino_grad_kernel(const float* dy, int ld, int B, int H, int W, int C, int d, float* dM) {
+__global__ __launch_bounds__(256) void wino_grad_kernel(const float* dy, int ld, int B, int H, int W, int C, int d, long Tp, float* dM) {
   const int CQ = C >> 2, H2 = H / (2 * d), W2 = W / (2 * d);
-  const long T = (long)B * d * d * H2 * W2, total = T * CQ;
+  const long T = (long)B * d * d * H2 * W2, total = Tp * CQ;
   const long e = blockIdx.x * 256L + threadIdx.x;
   if (e >= total) return;
   const int cq = (int)(e % CQ);
   const long t = e / CQ;
+  if (t >= T) {
+    const F4 z0{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 16; ++k) st4(dM + k * Tp * C + t * C + 4 * cq, z0);
+    return;
+  }
   const TileAt q = tile_at(t, d, H2, W2);
   const float* src = dy + ((long)(q.b * H + q.a + d * 2 * q.i) * W + q.c + d * 2 * q.j) * ld + 4 * cq;
   const long dn = (long)d * ld, dw = (long)d * W * ld;
@@ -172,7 +185,7 @@ __global__ __launch_bounds__(256) void wino_grad_kernel(const float* dy, int ld,
   r[0][0] = g00; r[0][1] = g01; r[1][0] = g00 + g10; r[1][1] = g01 + g11; r[2][0] = g00 - g10; r[2][1] = g01 - g11;
   r[3][0] = z - g10; r[3][1] = z - g11;
   float* out = dM + t * C + 4 * cq;
-  const long plane = T * C;
+  const long plane = Tp * C;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {          // (.) A^T
     st4(out + (4 * k + 0) * plane, r[k][0]);
@@ -294,31 +307,33 @@ __global__ __launch_bounds__(256) void wino_weight_multi_kernel(const segsde_win
 
 long segsde_wino_stats_rows(long T) { long nb = T / 64; return nb < 1 ? 1 : (nb > 512 ? 512 : nb); }
 
+long segsde_wino_rows(long T) { return (T + 127) / 128 * 128; }
+
 int segsde_wino_input(const float* x0, int ld0, const float* x1, int ld1, int C0, int B, int H, int W, int C, int dil, int reflect,
                       float* V, void* stream) {
-  const long total = (long)B * (H / 2) * (W / 2) * (C / 4);
+  const long Tp = segsde_wino_rows((long)B * (H / 2) * (W / 2)), total = Tp * (C / 4);
   hipLaunchKernelGGL(wino_in_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ST(stream), x0, ld0, x1 ? x1 : x0, ld1, C0, B,
-                     H, W, C, dil, reflect, V);
+                     H, W, C, dil, reflect, Tp, V);
   SEGSDE_CHECK_LAUNCH();
   return 0;
 }
 
 int segsde_wino_output(const float* M, int B, int H, int W, int Co, int dil, const float* bias, int act, float* y, int ldy,
                        double* part, void* stream) {
-  const long T = (long)B * (H / 2) * (W / 2);
+  const long T = (long)B * (H / 2) * (W / 2), Tp = segsde_wino_rows(T);
   const dim3 grid((unsigned)segsde_wino_stats_rows(T), (unsigned)((Co + 63) / 64));
   if (part)
     hipLaunchKernelGGL(wino_out_kernel<true>, grid, dim3(256), 2 * 16 * 64 * sizeof(double), ST(stream), M, B, H, W, Co, dil, bias, act,
-                       y, ldy, part);
+                       Tp, y, ldy, part);
   else
-    hipLaunchKernelGGL(wino_out_kernel<false>, grid, dim3(256), 0, ST(stream), M, B, H, W, Co, dil, bias, act, y, ldy, part);
+    hipLaunchKernelGGL(wino_out_kernel<false>, grid, dim3(256), 0, ST(stream), M, B, H, W, Co, dil, bias, act, Tp, y, ldy, part);
   SEGSDE_CHECK_LAUNCH();
   return 0;
 }
 
 int segsde_wino_grad(const float* dy, int ld, int B, int H, int W, int C, int dil, float* dM, void* stream) {
-  const long total = (long)B * (H / 2) * (W / 2) * (C / 4);
-  hipLaunchKernelGGL(wino_grad_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ST(stream), dy, ld, B, H, W, C, dil, dM);
+  const long Tp = segsde_wino_rows((long)B * (H / 2) * (W / 2)), total = Tp * (C / 4);
+  hipLaunchKernelGGL(wino_grad_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ST(stream), dy, ld, B, H, W, C, dil, Tp, dM);
   SEGSDE_CHECK_LAUNCH();
   return 0;
 }

@@ -88,7 +88,7 @@ def upfold_pack(w_oihw, C0):
 # SEGSDE_WINOGRAD=0 keeps the direct implicit GEMM (A/B measurements; the exactness tests of the direct kernels use it)
 WINOGRAD = os.environ.get("SEGSDE_WINOGRAD", "1") != "0"
 WINOGRAD_MIN_CH = int(os.environ.get("SEGSDE_WINOGRAD_MIN_CH", "256"))
-WINOGRAD_MIN_MACS = float(os.environ.get("SEGSDE_WINOGRAD_MIN_MACS", "4e9"))
+WINOGRAD_MIN_MACS = float(os.environ.get("SEGSDE_WINOGRAD_MIN_MACS", "1e8"))
 WINOGRAD_TAKEN = {"fwd": 0, "dgrad": 0, "wgrad": 0}
 
 
@@ -106,7 +106,7 @@ def winograd_ok(g, B=None, H=None, W=None, dgrad=False):
         return False
     if B is None:
         return True
-    if H % (2 * g.dil) or W % (2 * g.dil) or H < 4 * g.dil or W < 4 * g.dil or (B * (H // 2) * (W // 2)) % 128:
+    if H % (2 * g.dil) or W % (2 * g.dil) or H < 4 * g.dil or W < 4 * g.dil:
         return False
     return 9.0 * B * H * W * g.Cin * g.Cout >= WINOGRAD_MIN_MACS
 
@@ -183,7 +183,8 @@ def _winograd(kind, g, x0, x1, upack, Cout, want_stats, flops, tag, bias=None, a
     if want_stats:
         part = torch.empty((int(L.segsde_conv2d_winograd_stats_rows(ctypes.byref(d))), 2, Cout), dtype=torch.float64, device=x0.device)
     ws = _ws(nbytes, x0)
-    vk = torch.empty((16, B * (H // 2) * (W // 2), C0 + C1), dtype=torch.float32, device=x0.device) if keep_v else None
+    Tp = (B * (H // 2) * (W // 2) + 127) // 128 * 128          # rows per position plane: whole 128-row GEMM tiles
+    vk = torch.empty((16, Tp, C0 + C1), dtype=torch.float32, device=x0.device) if keep_v else None
     rc = _timed(kind, flops, x0, lambda: L.segsde_conv2d_winograd(ctypes.byref(d), _p(_f32(x0)), _p(x1), _p(upack), _p(bias), _p(y),
                                                                    _p(part), _p(vk), _p(ws), nbytes, _stream(x0)), tag + " wino",
                 executed=flops * 16.0 / 36.0)

@@ -261,7 +261,8 @@ int segsde_conv2d_winograd(const segsde_conv_desc* d, const float* x0, const flo
                            float* y, double* stats, float* v_keep, void* workspace, size_t workspace_bytes, void* stream);
 /* the weight gradient on the same route: dU_p = V_p^T (A dY A^T)_p as sixteen position GEMMs in one launch of the
  * weight-gradient kernel (split boundaries on the position boundaries), dW = G^T dU G written as OIHW.  d: the FORWARD geometry.
- * v_keep of the forward call (nullable; 16 * B*H/2*W/2 * (C0+C1) floats) receives the transformed input; handed back as v_saved
+ * v_keep of the forward call (nullable; 16 * Tp * (C0+C1) floats, Tp = B*H/2*W/2 rounded up to a multiple of 128) receives the
+ * transformed input; handed back as v_saved
  * (nullable) the weight gradient skips its own input transform. */
 size_t segsde_conv2d_wgrad_winograd_workspace(const segsde_conv_desc* d);
 int segsde_conv2d_wgrad_winograd(const segsde_conv_desc* d, const float* x0, const float* x1, const float* dy, int lddy,

@@ -1219,7 +1219,7 @@ def run_jitter_blur_properties(device):
 # ---------------------------------------------------------------------------------------------
 # Winograd F(2x2,3x3) route (csrc/winograd.hip + the grouped position GEMMs) against float64 and against the direct kernel
 # ---------------------------------------------------------------------------------------------
-def run_winograd_cases(device, shapes=((2, 16, 32, 64, 64), (1, 32, 16, 96, 128), (2, 8, 64, 128, 64))):
+def run_winograd_cases(device, shapes=((2, 16, 32, 64, 64), (1, 32, 16, 96, 128), (2, 8, 64, 128, 64), (1, 12, 20, 64, 64))):
     """forward (zero and mirrored padding, with the BatchNorm statistics partials), data-gradient and the autograd glue of the
     Winograd route: error against a float64 convolution within 3x the direct kernel's own (plus 1e-6 of the largest value),
     statistics partials summing to the column sums of the output, transformed packs cached per weight_pack_scope."""
