@@ -193,9 +193,17 @@ class GradAllReducer:
             cs = self._comm_stream
             cs.wait_stream(torch.cuda.current_stream(b.flat.device))
             b.t0 = torch.cuda.Event(enable_timing=True)
+            b.t1 = None
             with torch.cuda.stream(cs):
                 b.t0.record(cs)
                 b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                if self.backend == "nccl":
+                    # RCCL: wait() only makes the side stream wait for the communicator's stream (the host does not block), so
+                    # the end event can be queued right here and carries the collective's completion time.  (Queued in
+                    # finish() it would carry the time finish() was called: the whole backward, not the collective.)
+                    b.work.wait()
+                    b.t1 = torch.cuda.Event(enable_timing=True)
+                    b.t1.record(cs)
         else:
             b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         self.collectives += 1
@@ -204,13 +212,15 @@ class GradAllReducer:
         """the launch stream (and, for host-side backends, the host) waits for the bucket's collective"""
         if self.timing and b.flat.is_cuda and getattr(b, "t0", None) is not None:
             cs = self._comm_stream
-            with torch.cuda.stream(cs):
-                b.work.wait()
-                t1 = torch.cuda.Event(enable_timing=True)
-                t1.record(cs)
+            t1 = b.t1
+            if t1 is None:               # host-side backend (gloo): wait() blocks the host, so it happens here
+                with torch.cuda.stream(cs):
+                    b.work.wait()
+                    t1 = torch.cuda.Event(enable_timing=True)
+                    t1.record(cs)
             torch.cuda.current_stream(b.flat.device).wait_stream(cs)
             self._events.append((b.t0, t1, b.flat.numel() * 4))
-            b.t0 = None
+            b.t0 = b.t1 = None
         else:
             b.work.wait()
         b.work = None

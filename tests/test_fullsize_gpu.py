@@ -569,3 +569,56 @@ def test_cfg5_pieces_at_1024x2048():
     gn = torch.stack([p.grad.norm() for p in student.parameters() if p.grad is not None])
     assert torch.isfinite(gn).all().item() and float(gn.max()) > 0
     T.update_ema_variables(teacher, student, 0.99, 5)
+
+
+@pytest.mark.parametrize("geom", [("layer3 conv2 256->256 @32x64", 32, 64, 256, 0, 256, 1, False, False),
+                                  ("layer4 conv2 512->512 d2 @32x64", 32, 64, 512, 0, 512, 2, False, False),
+                                  ("decoder [256|1024]->256 refl + bias + ELU @32x64", 32, 64, 256, 1024, 256, 1, True, True),
+                                  ("pose layer4 512->512 @16x32", 16, 32, 512, 0, 512, 1, False, False)],
+                         ids=["r101_layer3", "layer4_dil2", "decoder_two_sources", "pose_layer4"])
+def test_winograd_fullsize_vs_direct(geom):
+    """The Winograd route at the benchmark's own batch (16) against the direct implicit GEMM -- itself checked against float64
+    on sampled entries at this size by test_conv_fullsize_sampled -- on the WHOLE tensor: forward (with the BatchNorm statistics
+    partials where the layer has them), data-gradient and weight gradient.  1e-5 of the largest value per tensor; the statistics'
+    column sums to 1e-9."""
+    name, Hh, W, C0, C1, Co, dil, refl, biasact = geom
+    dev = "cuda"
+    gen = torch.Generator().manual_seed(31)
+    g = H.ConvGeom(C0, Co, 3, 1, dil, dil, refl, C1, False)
+    x0 = torch.randn(B16, Hh, W, C0, generator=gen).to(dev)
+    x1 = torch.randn(B16, Hh, W, C1, generator=gen).to(dev) if C1 else None
+    w = (torch.randn(Co, C0 + C1, 3, 3, generator=gen) * (2.0 / (9 * (C0 + C1))) ** 0.5).to(dev)
+    bias = (torch.randn(Co, generator=gen) * 0.1).to(dev) if biasact else None
+    act = "elu" if biasact else "none"
+    dy = torch.randn(B16, Hh, W, Co, generator=gen).to(dev)
+    wp, wd = H.pack_weight_both(w)
+    uf, ud = H.winograd_pack(w)
+    assert H.winograd_ok(g, B16, Hh, W)
+    n0 = dict(H.WINOGRAD_TAKEN)
+    if biasact:
+        yw, pw = H.conv_forward(g, x0, x1, wp, bias, act, wino=uf), None
+        yd = H.conv_forward(g, x0, x1, wp, bias, act)
+    else:
+        yw, pw = H.conv_forward(g, x0, x1, wp, None, want_stats=True, wino=uf)
+        yd, pd = H.conv_forward(g, x0, x1, wp, None, want_stats=True)
+    assert H.WINOGRAD_TAKEN["fwd"] == n0["fwd"] + 1
+    sc = float(yd.abs().max())
+    assert float((yw - yd).abs().max()) <= 1e-5 * sc, (name, "forward", float((yw - yd).abs().max()), sc)
+    if pw is not None:
+        assert_close(pw[:, 0].sum(0), yw.double().reshape(-1, Co).sum(0), rtol=1e-9, atol=1e-6, what=name + ": statistics sums")
+        assert_close(pw[:, 1].sum(0), (yw.double() ** 2).reshape(-1, Co).sum(0), rtol=1e-9, atol=1e-6, what=name + ": statistics squares")
+    if not C1 and not refl:
+        dxw, _ = H.conv_dgrad(g, dy, wd, w, (Hh, W), wino=ud)
+        assert H.WINOGRAD_TAKEN["dgrad"] == n0["dgrad"] + 1
+        dxd, _ = H.conv_dgrad(g, dy, wd, w, (Hh, W))
+        sc = float(dxd.abs().max())
+        assert float((dxw - dxd).abs().max()) <= 1e-5 * sc, (name, "data-gradient", float((dxw - dxd).abs().max()), sc)
+    dww = H.conv_wgrad(g, x0, x1, dy)
+    assert H.WINOGRAD_TAKEN["wgrad"] == n0["wgrad"] + 1
+    H.WINOGRAD = False
+    try:
+        dwd = H.conv_wgrad(g, x0, x1, dy)
+    finally:
+        H.WINOGRAD = True
+    sc = float(dwd.abs().max())
+    assert float((dww - dwd).abs().max()) <= 3e-5 * sc, (name, "weight gradient", float((dww - dwd).abs().max()), sc)
