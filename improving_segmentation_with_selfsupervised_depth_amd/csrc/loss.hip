@@ -657,6 +657,135 @@ __global__ __launch_bounds__(256) void photometric_fwd_kernel(const float* pred0
   }
 }
 
+// ---- packed variants (round 4).  PMC (profiles/pmc_r0{3,4}_sq_waits.txt) shows these kernels bound by VALU issue, not by HBM:
+// 1 116 (forward) / 1 893 (backward) vector instructions per wave and tile = 0.88 / 0.71 of the issue slots of the launch.  The two
+// source frames of a pixel run the same arithmetic on different data against the SAME target window, so the packed kernels keep
+// (frame 0, frame 1) in the two halves of a 64-bit register pair -- v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 do both frames in
+// one issue slot -- and compute the target's window sums once instead of once per frame.  Same operations in the same order
+// per frame as the per-stage kernels (bit-identical errors, hence selections).
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 splat2(float v) { f2 r; r.x = v; r.y = v; return r; }
+// x / c for a constant c, correctly rounded like the IEEE division it replaces (Markstein: q = RN(x * RN(1/c)), the exact
+// residual x - c q through one fma, one fma to apply it) in 3 issue slots instead of the ~10 of v_div_scale / v_rcp /
+// v_div_fmas / v_div_fixup.  Checked against x / 9.f and x / 3.f for EVERY non-negative float, denormals included: identical.
+template <int C> __device__ __forceinline__ f2 div_by(f2 x) {
+  constexpr float c = (float)C, rc = 1.f / (float)C;
+  const f2 q = x * rc;
+  return __builtin_elementwise_fma(__builtin_elementwise_fma(splat2(-c), q, x), splat2(rc), q);
+}
+template <int C> __device__ __forceinline__ float div_by(float x) {
+  constexpr float c = (float)C, rc = 1.f / (float)C;
+  const float q = x * rc;
+  return __builtin_fmaf(__builtin_fmaf(-c, q, x), rc, q);
+}
+
+// staging for the packed kernels: target planes [3][per] floats, then the two frames interleaved [3][per] f2
+__device__ __forceinline__ void stage_tile2(float* smt, f2* smp, const StagePos& sp, int per, const float* target_b,
+                                            const float* pred0_b, const float* pred1_b, long HW, int w_left, int W) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    if (sp.e[i] < 0) continue;
+    const long off = sp.rowoff[i] + refl_clamp(w_left + sp.c[i], W);
+    float t[3]; f2 q[3];
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) { t[ch] = target_b[ch * HW + off]; q[ch].x = pred0_b[ch * HW + off]; q[ch].y = pred1_b[ch * HW + off]; }
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) { smt[ch * per + sp.e[i]] = t[ch]; smp[ch * per + sp.e[i]] = q[ch]; }
+  }
+}
+
+// (error of frame 0, error of frame 1) at tile position (r, c): tile_error for both frames at once
+__device__ __forceinline__ f2 tile_error2(const f2* px, const float* py, int cols, int per, int r, int c, int no_ssim) {
+  f2 l1 = splat2(0.f), ss = splat2(0.f);
+#pragma unroll
+  for (int ch = 0; ch < 3; ++ch) {
+    const f2* x = px + ch * per;
+    const float* y = py + ch * per;
+    l1 += __builtin_elementwise_abs(y[r * cols + c] - x[r * cols + c]);
+    if (!no_ssim) {
+      f2 sx = splat2(0.f), sxx = splat2(0.f), sxy = splat2(0.f);
+      float sy = 0.f, syy = 0.f;
+#pragma unroll
+      for (int dh = -1; dh <= 1; ++dh)
+#pragma unroll
+        for (int dw = -1; dw <= 1; ++dw) {
+          const f2 a = x[(r + dh) * cols + c + dw];
+          const float b = y[(r + dh) * cols + c + dw];
+          sx += a; sy += b; sxx += a * a; syy += b * b; sxy += a * b;
+        }
+      const f2 mx = div_by<9>(sx);
+      const float my = div_by<9>(sy);
+      const f2 sig_x = div_by<9>(sxx) - mx * mx, sig_xy = div_by<9>(sxy) - mx * my;
+      const float sig_y = div_by<9>(syy) - my * my;
+      const f2 n = (2.f * mx * my + C1) * (2.f * sig_xy + C2);
+      const f2 d = (mx * mx + my * my + C1) * (sig_x + sig_y + C2);
+      ss += __builtin_elementwise_min(__builtin_elementwise_max((1.f - n / d) / 2.f, splat2(0.f)), splat2(1.f));
+    }
+  }
+  l1 = div_by<3>(l1);
+  return no_ssim ? l1 : (0.85f * div_by<3>(ss) + 0.15f * l1);
+}
+
+template <bool IDENT>
+__global__ __launch_bounds__(256) void photometric_fwd2_kernel(const float* pred0, const float* pred1, const float* target,
+                                                               const float* ident, const float* noise, int H, int W,
+                                                               int no_ssim, int avg, int tiles_per_block, float* out_err,
+                                                               uint8_t* sel, float* isel, double* part) {
+  SEGSDE_SMEM;
+  const int per = PF_H * PF_W;                                   // even: the f2 planes stay 8-byte aligned
+  float* smt = reinterpret_cast<float*>(segsde_smem);            // [3][per] target
+  f2* smp = reinterpret_cast<f2*>(smt + 3 * per + ((3 * per) & 1));   // [3][per] (frame 0, frame 1)
+  double* sh = reinterpret_cast<double*>(reinterpret_cast<float*>(smp) + 6 * per);
+  const PhotoBlk pb = photo_block();
+  const int b = pb.bz, h0 = pb.by * PT_H;
+  const long HW = (long)H * W;
+  const float* tb = target + (long)b * 3 * HW;
+  const float* p0b = pred0 + (long)b * 3 * HW;
+  const float* p1b = pred1 + (long)b * 3 * HW;
+  const StagePos sp = stage_setup(PF_H, PF_W, h0 - 1, H, W);
+  const int r = threadIdx.x / PT_W, c = threadIdx.x - r * PT_W;
+  const int h = h0 + r;
+  const int ntx = (W + PT_W - 1) / PT_W;
+  double acc = 0.0;
+  for (int tx = pb.bx * tiles_per_block; tx < ntx && tx < (pb.bx + 1) * tiles_per_block; ++tx) {
+    const int w0 = tx * PT_W, w = w0 + c;
+    __syncthreads();                                           // the previous tile's window reads are done
+    stage_tile2(smt, smp, sp, per, tb, p0b, p1b, HW, w0 - 1, W);
+    __syncthreads();
+    if (h < H && w < W) {
+      const long p = (long)h * W + w;
+      const f2 e = tile_error2(smp, smt, PF_W, per, r + 1, c + 1, no_ssim);
+      const float e0 = e.x, e1 = e.y;
+      if (IDENT) {
+        out_err[((long)b * 2) * HW + p] = e0;
+        out_err[((long)b * 2 + 1) * HW + p] = e1;
+      } else {
+        float v[4]; int n = 0;
+        const int ni = ident ? (avg ? 1 : 2) : 0;
+        if (ident) {
+          const float i0 = ident[((long)b * 2) * HW + p], i1 = ident[((long)b * 2 + 1) * HW + p];
+          if (avg) { v[n] = (i0 + i1) / 2.f; if (noise) v[n] += noise[(long)b * HW + p] * 0.00001f; ++n; }
+          else {
+            v[n] = i0; if (noise) v[n] += noise[((long)b * 2) * HW + p] * 0.00001f; ++n;
+            v[n] = i1; if (noise) v[n] += noise[((long)b * 2 + 1) * HW + p] * 0.00001f; ++n;
+          }
+        }
+        if (avg) v[n++] = (e0 + e1) / 2.f;
+        else { v[n++] = e0; v[n++] = e1; }
+        float best = v[0]; int bi = 0;
+        for (int j = 1; j < n; ++j) if (v[j] < best) { best = v[j]; bi = j; }
+        sel[(long)b * HW + p] = (uint8_t)bi;
+        if (isel) isel[(long)b * HW + p] = bi > ni - 1 ? 1.f : 0.f;
+        acc += (double)best;
+      }
+    }
+  }
+  if (!IDENT) {
+    const double t = segsde_block_sum(acc, sh);
+    if (threadIdx.x == 0) part[((long)b * gridDim.y + pb.by) * gridDim.x + pb.bx] = t;
+  }
+}
+
 struct PhotoBwdP {
   const float* pred[2]; const float* target; const uint8_t* sel; const float* disp; const float* inv_K; const float* K;
   const float* T[2]; const float* src[2];
@@ -861,6 +990,247 @@ __global__ __launch_bounds__(256) void photometric_bwd_kernel(PhotoBwdP a) {
     }
 }
 
+// Packed backward: same phases as photometric_bwd_kernel with (frame 0, frame 1) in register pairs.
+//  * coefficient walkers: one thread per (column of tile + 1, channel) -- 102 instead of 204 -- the target's row sums once;
+//  * gather walkers: one thread per (tile column, channel), 96 instead of 192;
+//    the two walker phases of a tile run on opposite halves of the block and swap halves with the tile's parity, so that the
+//    four SIMDs of a CU see the same load over a strip;
+//  * warp adjoint: the geometry of a pixel is evaluated by the same scalar code as in the forward pass (identical sampling
+//    cells), everything behind it -- tap gradients, d/dP sums, d/d depth -- is packed; the taps of both frames are requested
+//    before either is used;
+//  * sel of tile + 1 is staged together with the pixels (one barrier less), the reciprocals of the gradient path are v_rcp_f32.
+__device__ __forceinline__ f2 rcp2(f2 v) { f2 r; r.x = __builtin_amdgcn_rcpf(v.x); r.y = __builtin_amdgcn_rcpf(v.y); return r; }
+
+// SPLIT: the walkers of a column are two threads, one per half of the rows (two warm-up rows each): all four waves walk, the
+// serial chain of a phase is 7 / 6 row steps instead of 12 / 10
+template <bool SPLIT>
+__global__ __launch_bounds__(256) void photometric_bwd2_kernel(PhotoBwdP a) {
+  SEGSDE_SMEM;
+  const int perp = PB_H * PB_W, perc = PC_H * PC_W, npt = PT_H * PT_W;
+  float* smt = reinterpret_cast<float*>(segsde_smem);     // [3][perp] target
+  f2* smp = reinterpret_cast<f2*>(smt + 3 * perp);        // [3][perp] (frame 0, frame 1); 3 * perp is even
+  f2* cf = smp + 3 * perp;                                // [3 channels][3 coefficients][perc]
+  f2* gpx = cf + 9 * perc;                                // [3][npt]: d err / d warped pixel
+  float* geo = reinterpret_cast<float*>(gpx + 3 * npt);   // P0[12] pad P1[12] pad iK[16], then the P's interleaved: f2[12]
+  f2* P2 = reinterpret_cast<f2*>(geo + 48);
+  double* sh = reinterpret_cast<double*>(geo + 72);
+  uint8_t* ssel = reinterpret_cast<uint8_t*>(sh + 4);     // [PC_H][PC_W]: selection of tile + 1 (255 outside the image)
+  const PhotoBlk pb = photo_block();
+  const int b = pb.bz, h0 = pb.by * PT_H;
+  const int H = a.H, W = a.W;
+  const long HW = (long)H * W;
+  {
+    const int t = threadIdx.x;
+    if (t < 24) {
+      const int f = t / 12, e = t - f * 12, r = e >> 2, c = e & 3;
+      float s = 0.f;
+      for (int k = 0; k < 4; ++k) s += a.K[b * 16 + r * 4 + k] * a.T[f][b * 16 + k * 4 + c];
+      geo[f * 16 + e] = s;
+      geo[48 + e * 2 + f] = s;
+    }
+    if (t >= 32 && t < 48) geo[t] = a.inv_K[b * 16 + t - 32];
+  }
+  const float* tb = a.target + (long)b * 3 * HW;
+  const float* p0b = a.pred[0] + (long)b * 3 * HW;
+  const float* p1b = a.pred[1] + (long)b * 3 * HW;
+  const float* s0b = a.src[0] + (long)b * 3 * HW;
+  const float* s1b = a.src[1] + (long)b * 3 * HW;
+  const float* disp_b = a.disp + (long)b * a.hs * a.ws;
+  const StagePos sp = stage_setup(PB_H, PB_W, h0 - 2, H, W);
+  const int r = threadIdx.x / PT_W, c = threadIdx.x - r * PT_W;
+  const int h = h0 + r;
+  const int ntx = (W + PT_W - 1) / PT_W;
+  const float up_one = a.avg ? 0.5f * a.scale : a.scale;
+  // a thread adds at most tiles_per_block (<= 16) values per entry in fp32; from the block reduction on the sums are double
+  f2 acc[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) acc[i] = splat2(0.f);
+  for (int tx = pb.bx * a.tiles_per_block; tx < ntx && tx < (pb.bx + 1) * a.tiles_per_block; ++tx) {
+  const int w0 = tx * PT_W, w = w0 + c;
+  __syncthreads();                                             // the previous tile's LDS reads are done (geo is visible)
+  stage_tile2(smt, smp, sp, perp, tb, p0b, p1b, HW, w0 - 2, W);
+  for (int e = threadIdx.x; e < perc; e += 256) {
+    const int qr = e / PC_W, qc = e - qr * PC_W;
+    const int qh = h0 - 1 + qr, qw = w0 - 1 + qc;
+    ssel[e] = (qh >= 0 && qh < H && qw >= 0 && qw < W) ? a.sel[(long)b * HW + (long)qh * W + qw] : (uint8_t)255;
+  }
+  __syncthreads();
+  const int half = (tx & 1) << 7;
+  // ---- per-window-centre coefficients for tile + 1 (see photometric_bwd_kernel): column walkers with rolling three-row sums
+  const int tb_ = SPLIT ? (int)threadIdx.x : (int)((threadIdx.x + half) & 255);
+  if (tb_ < PC_W * 3 * (SPLIT ? 2 : 1)) {
+    const int grp = tb_ / (PC_W * 3), tb1 = tb_ - grp * (PC_W * 3);
+    const int ch = tb1 / PC_W, qc = tb1 - ch * PC_W;
+    constexpr int NB = SPLIT ? PC_H / 2 + 2 : PC_H + 2;   // staged rows a walker visits
+    const int rb = grp * (PC_H / 2);                      // its first staged row = its first centre
+    f2* o = cf + (ch * 3) * perc + qc;
+    if (a.no_ssim) {
+      for (int qr = rb; qr < rb + NB - 2; ++qr) { o[qr * PC_W] = splat2(0.f); o[perc + qr * PC_W] = splat2(0.f); o[2 * perc + qr * PC_W] = splat2(0.f); }
+    } else {
+      const f2* x = smp + ch * perp + rb * PB_W + qc;
+      const float* y = smt + ch * perp + rb * PB_W + qc;
+      f2 rx[3], rxx[3], rxy[3];
+      float ry[3], ryy[3];
+#pragma unroll
+      for (int rr_ = 0; rr_ < NB; ++rr_) {                 // staged rows rb .. ; window of centre qr = staged rows qr .. qr+2
+        const f2 x0 = x[rr_ * PB_W], x1 = x[rr_ * PB_W + 1], x2 = x[rr_ * PB_W + 2];
+        const float y0 = y[rr_ * PB_W], y1 = y[rr_ * PB_W + 1], y2 = y[rr_ * PB_W + 2];
+        const int k = rr_ % 3;
+        rx[k] = x0 + x1 + x2; ry[k] = y0 + y1 + y2;
+        rxx[k] = x0 * x0 + x1 * x1 + x2 * x2; ryy[k] = y0 * y0 + y1 * y1 + y2 * y2; rxy[k] = x0 * y0 + x1 * y1 + x2 * y2;
+        if (rr_ < 2) continue;
+        const int qr = rb + rr_ - 2;
+        const int sl = ssel[qr * PC_W + qc];
+        f2 up = splat2(0.f);
+        if (a.avg) { if (sl == a.ni) up = splat2(up_one); }
+        else { if (sl == a.ni) up.x = up_one; if (sl == a.ni + 1) up.y = up_one; }
+        f2 c0 = splat2(0.f), c1 = splat2(0.f), c2 = splat2(0.f);
+        if (up.x != 0.f || up.y != 0.f) {
+          const f2 sx = rx[0] + rx[1] + rx[2], sxx = rxx[0] + rxx[1] + rxx[2], sxy = rxy[0] + rxy[1] + rxy[2];
+          const float sy = ry[0] + ry[1] + ry[2], syy = ryy[0] + ryy[1] + ryy[2];
+          constexpr float R9 = 1.f / 9.f;
+          const f2 gq = up * (0.85f / 3.f) * (-0.5f);
+          const f2 mx = sx * R9;
+          const float my = sy * R9;
+          const f2 sig_x = sxx * R9 - mx * mx, sig_xy = sxy * R9 - mx * my;
+          const float sig_y = syy * R9 - my * my;
+          const f2 A1 = 2.f * mx * my + C1, A2 = 2.f * sig_xy + C2;
+          const f2 B1 = mx * mx + my * my + C1, B2 = sig_x + sig_y + C2;
+          const f2 n = A1 * A2, d = B1 * B2, rd = rcp2(d), q = n * rd;
+          const f2 raw = (1.f - q) * 0.5f;
+          f2 m = gq * R9 * rd;                                   // clamp passes gradient on [0,1]
+          if (!(raw.x >= 0.f && raw.x <= 1.f)) m.x = 0.f;
+          if (!(raw.y >= 0.f && raw.y <= 1.f)) m.y = 0.f;
+          c0 = m * (2.f * my * A2 - 2.f * A1 * my - q * (2.f * mx * B2 - 2.f * B1 * mx));
+          c1 = m * (-q * 2.f * B1);
+          c2 = m * (2.f * A1);
+        }
+        o[qr * PC_W] = c0; o[perc + qr * PC_W] = c1; o[2 * perc + qr * PC_W] = c2;
+      }
+    }
+  }
+  __syncthreads();
+  // ---- d err / d warped pixel: 3x3 gather of the coefficient windows (reflection fold as multiplicities) + the L1 term
+  const int tc_ = SPLIT ? (int)threadIdx.x : (int)((threadIdx.x + 128 + half) & 255);
+  if (tc_ < PT_W * 3 * (SPLIT ? 2 : 1)) {
+    const int grp = tc_ / (PT_W * 3), tc1 = tc_ - grp * (PT_W * 3);
+    const int ch = tc1 / PT_W, c_ = tc1 - ch * PT_W;
+    constexpr int NC = SPLIT ? PT_H / 2 + 2 : PT_H + 2;   // coefficient rows a walker visits
+    const int rb = grp * (PT_H / 2);                      // its first coefficient row = its first pixel row
+    const int wq = w0 + c_;
+    const float mw0 = wq - 1 >= 0 ? (wq == 1 ? 2.f : 1.f) : 0.f, mw2 = wq + 1 <= W - 1 ? (wq == W - 2 ? 2.f : 1.f) : 0.f;
+    const f2* o = cf + (ch * 3) * perc + rb * PC_W + c_;   // coefficient column c_ .. c_+2 <-> dw = -1 .. +1
+    f2 ra[3], rbx[3], rby[3];
+#pragma unroll
+    for (int qr = 0; qr < NC; ++qr) {                    // coefficient rows rb .. <-> image rows h0-1+rb ..
+      const f2* q = o + qr * PC_W;
+      const int k = qr % 3;
+      ra[k] = mw0 * q[0] + q[1] + mw2 * q[2];
+      rbx[k] = mw0 * q[perc] + q[perc + 1] + mw2 * q[perc + 2];
+      rby[k] = mw0 * q[2 * perc] + q[2 * perc + 1] + mw2 * q[2 * perc + 2];
+      if (qr < 2) continue;
+      const int r_ = rb + qr - 2, hq = h0 + r_;          // pixel row; its window rows are coefficient rows r_ .. r_+2
+      const float mh0 = hq - 1 >= 0 ? (hq == 1 ? 2.f : 1.f) : 0.f, mh2 = hq + 1 <= H - 1 ? (hq == H - 2 ? 2.f : 1.f) : 0.f;
+      const int k0 = (qr - 2) % 3, k1 = (qr - 1) % 3, k2 = qr % 3;
+      const f2 sa = mh0 * ra[k0] + ra[k1] + mh2 * ra[k2];
+      const f2 sbx = mh0 * rbx[k0] + rbx[k1] + mh2 * rbx[k2];
+      const f2 sby = mh0 * rby[k0] + rby[k1] + mh2 * rby[k2];
+      const f2 xv = smp[ch * perp + (r_ + 2) * PB_W + c_ + 2];
+      const float yv = smt[ch * perp + (r_ + 2) * PB_W + c_ + 2];
+      const int sl = ssel[(r_ + 1) * PC_W + c_ + 1];
+      f2 upp = splat2(0.f);
+      if (a.avg) { if (sl == a.ni) upp = splat2(up_one); }
+      else { if (sl == a.ni) upp.x = up_one; if (sl == a.ni + 1) upp.y = up_one; }
+      const f2 gl1 = upp * (a.no_ssim ? (1.f / 3.f) : (0.15f / 3.f));
+      const f2 df = yv - xv;      // d|t - x|/dx = -sign(t - x)
+      f2 sg;
+      sg.x = df.x > 0.f ? -1.f : (df.x < 0.f ? 1.f : 0.f);
+      sg.y = df.y > 0.f ? -1.f : (df.y < 0.f ? 1.f : 0.f);
+      gpx[ch * npt + r_ * PT_W + c_] = sa + sbx * xv + sby * yv + gl1 * sg;
+    }
+  }
+  __syncthreads();
+  // ---- per pixel: warp adjoint of both frames
+  {
+    const bool live = h < H && w < W;
+    const long p = (long)h * W + w;
+    f2 gp[3];
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) gp[ch] = gpx[ch * npt + r * PT_W + c];
+    const bool any0 = live && (gp[0].x != 0.f || gp[1].x != 0.f || gp[2].x != 0.f);
+    const bool any1 = live && (gp[0].y != 0.f || gp[1].y != 0.f || gp[2].y != 0.f);
+    // a frame nobody in the wave needs (auto-mask regions select one frame, or the identity, over large areas) is not
+    // projected at all; the votes sit in converged code
+    const bool wave0 = __any(any0) != 0, wave1 = __any(any1) != 0;
+    float gdisp = 0.f;
+    if (any0 || any1) {     // otherwise masked out here and in every neighbouring window, for both frames
+      const float* iK = geo + 32;
+      Geo g0, g1;
+      if (wave0) g0 = geometry(disp_b, a.hs, a.ws, H, W, h, w, iK, geo, a.min_disp, a.max_disp);
+      if (wave1) g1 = geometry(disp_b, a.hs, a.ws, H, W, h, w, iK, geo + 16, a.min_disp, a.max_disp);
+      if (!wave0) g0 = g1;
+      if (!wave1) g1 = g0;
+      const int x00 = (int)floorf(g0.ix), y00 = (int)floorf(g0.iy), x01 = (int)floorf(g1.ix), y01 = (int)floorf(g1.iy);
+      const bool vx0 = x00 + 1 <= W - 1, vy0 = y00 + 1 <= H - 1, vx1 = x01 + 1 <= W - 1, vy1 = y01 + 1 <= H - 1;
+      // ATen grid_sampler_2d_backward; taps outside the image are never dereferenced (their weight is zero: border clamp)
+      const long o0 = (long)y00 * W + x00, o1 = (long)y01 * W + x01;
+      const long e0 = vx0 ? 1 : 0, s0 = vy0 ? W : 0, e1 = vx1 ? 1 : 0, s1 = vy1 ? W : 0;
+      f2 vnw[3], vne[3], vsw[3], vse[3];
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) {
+        const float* q0 = s0b + ch * HW + o0;
+        const float* q1 = s1b + ch * HW + o1;
+        vnw[ch].x = q0[0]; vne[ch].x = q0[e0]; vsw[ch].x = q0[s0]; vse[ch].x = q0[s0 + e0];
+        vnw[ch].y = q1[0]; vne[ch].y = q1[e1]; vsw[ch].y = q1[s1]; vse[ch].y = q1[s1 + e1];
+      }
+      f2 ix, iy, fx1, fy1, fx0, fy0, mE, mS;
+      ix.x = g0.ix; ix.y = g1.ix; iy.x = g0.iy; iy.y = g1.iy;
+      fx0.x = (float)x00; fx0.y = (float)x01; fy0.x = (float)y00; fy0.y = (float)y01;
+      fx1 = fx0 + 1.f; fy1 = fy0 + 1.f;
+      mE.x = vx0 ? 1.f : 0.f; mE.y = vx1 ? 1.f : 0.f; mS.x = vy0 ? 1.f : 0.f; mS.y = vy1 ? 1.f : 0.f;
+      const f2 wy0 = fy1 - iy, wy1 = iy - fy0, wx0 = fx1 - ix, wx1 = ix - fx0;
+      f2 gix = splat2(0.f), giy = splat2(0.f);
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) {
+        const f2 go = gp[ch];
+        const f2 ne = vne[ch] * mE, sw = vsw[ch] * mS, se = vse[ch] * (mE * mS);
+        gix -= vnw[ch] * wy0 * go; giy -= vnw[ch] * wx0 * go;
+        gix += ne * wy0 * go;      giy -= ne * wx1 * go;
+        gix -= sw * wy1 * go;      giy += sw * wx0 * go;
+        gix += se * wy1 * go;      giy += se * wx1 * go;
+      }
+      f2 g_x, g_y, den, px_, py_;
+      g_x.x = (g0.in_x && any0) ? gix.x : 0.f; g_x.y = (g1.in_x && any1) ? gix.y : 0.f;
+      g_y.x = (g0.in_y && any0) ? giy.x : 0.f; g_y.y = (g1.in_y && any1) ? giy.y : 0.f;
+      den.x = g0.p2 + 1e-7f; den.y = g1.p2 + 1e-7f;
+      px_.x = g0.x; px_.y = g1.x; py_.x = g0.y; py_.y = g1.y;
+      const f2 rden = rcp2(den);
+      f2 gp0 = g_x * rden, gp1 = g_y * rden, gp2 = -(g_x * px_ + g_y * py_) * rden;
+      if (!any0) { gp0.x = 0.f; gp1.x = 0.f; gp2.x = 0.f; }
+      if (!any1) { gp0.y = 0.f; gp1.y = 0.f; gp2.y = 0.f; }
+      const float cx = g0.depth * g0.xn, cy = g0.depth * g0.yn, cz = g0.depth * g0.zn;
+      acc[0] += gp0 * cx; acc[1] += gp0 * cy; acc[2] += gp0 * cz; acc[3] += gp0;
+      acc[4] += gp1 * cx; acc[5] += gp1 * cy; acc[6] += gp1 * cz; acc[7] += gp1;
+      acc[8] += gp2 * cx; acc[9] += gp2 * cy; acc[10] += gp2 * cz; acc[11] += gp2;
+      const f2 gcx = P2[0] * gp0 + P2[4] * gp1 + P2[8] * gp2;
+      const f2 gcy = P2[1] * gp0 + P2[5] * gp1 + P2[9] * gp2;
+      const f2 gcz = P2[2] * gp0 + P2[6] * gp1 + P2[10] * gp2;
+      const f2 gdepth = gcx * g0.xn + gcy * g0.yn + gcz * g0.zn;
+      const f2 gd = (-gdepth * g0.depth * g0.depth) * (a.max_disp - a.min_disp);
+      gdisp = gd.x + gd.y;
+    }
+    if (live) a.g_disp_up[(long)b * HW + p] = gdisp;
+  }
+  }   // tiles of the strip
+  const long blk = ((long)b * gridDim.y + pb.by) * gridDim.x + pb.bx;
+#pragma unroll
+  for (int i = 0; i < 12; ++i) {
+    const double t0 = segsde_block_sum((double)acc[i].x, sh);
+    const double t1 = segsde_block_sum((double)acc[i].y, sh);
+    if (threadIdx.x == 0) { a.gP_part[(blk * 2 + 0) * 12 + i] = t0; a.gP_part[(blk * 2 + 1) * 12 + i] = t1; }
+  }
+}
+
 // gT_f[b] += weight * K[b]^T (rows 0..2) * sum_blocks gP_f[b]      (both frames: grid (B, 2))
 __global__ __launch_bounds__(256) void photometric_bwd_finalize_kernel(const double* gP_part, int nblk, const float* K,
                                                                        const float* weight, float* gT0, float* gT1) {
@@ -899,7 +1269,11 @@ extern "C" int segsde_warp_forward(const float* disp, int hs, int ws, const floa
                                    float* grid, float* depth, void* stream) {
   if (!disp || !inv_K || !K || !T || !src || !color) return SEGSDE_ERR_NULL;
   if (B <= 0 || H < 2 || W < 2 || hs <= 0 || ws <= 0 || (long)H * W >= (1L << 31)) return SEGSDE_ERR_SHAPE;
-  hipLaunchKernelGGL(warp_fwd_kernel, dim3(plane_blocks((long)H * W), B), dim3(256), 512, ST(stream), disp, hs, ws, inv_K, K,
+  // one pixel per thread up to 2048 blocks per image: the kernel is a chain of dependent loads (disparity -> taps), more waves
+  // in flight hide it better than a grid-stride loop does (SEGSDE_WARP_BLOCKS=512: the cap of rounds 1-3)
+  static const int cap = [] { const char* e = getenv("SEGSDE_WARP_BLOCKS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 2048; }();
+  const long nbw = ((long)H * W + 255) / 256;
+  hipLaunchKernelGGL(warp_fwd_kernel, dim3((unsigned)(nbw < 1 ? 1 : (nbw > cap ? cap : nbw)), B), dim3(256), 512, ST(stream), disp, hs, ws, inv_K, K,
                      T, src, H, W, 1.f / max_depth, 1.f / min_depth, color, grid, depth);
   SEGSDE_CHECK_LAUNCH();
   return 0;
@@ -1110,6 +1484,15 @@ static inline dim3 photo_grid(int B, int H, int W) {
   return dim3((ntx + t - 1) / t, (H + PT_H - 1) / PT_H, B);
 }
 static inline long photo_blocks(int B, int H, int W) { const dim3 g = photo_grid(B, H, W); return (long)g.x * g.y * g.z; }
+// experiment knob: SEGSDE_PHOTO_PACKED=0 keeps the one-frame-per-lane kernels of round 3 (A/B in profiles/experiments_r04.md)
+static inline bool photo_packed() {
+  static const bool v = [] { const char* e = getenv("SEGSDE_PHOTO_PACKED"); return !(e && e[0] == '0'); }();
+  return v;
+}
+static inline bool photo_split() {   // SEGSDE_PHOTO_SPLIT=0: the packed backward with whole-column walkers on half of the block
+  static const bool v = [] { const char* e = getenv("SEGSDE_PHOTO_SPLIT"); return !(e && e[0] == '0'); }();
+  return v;
+}
 
 extern "C" size_t segsde_photometric_workspace(int B, int H, int W) {
   return (size_t)photo_blocks(B, H, W) * 24 * sizeof(double);
@@ -1119,10 +1502,10 @@ extern "C" int segsde_photometric_identity(const float* src0, const float* src1,
                                            int no_ssim, float* ident, void* stream) {
   if (!src0 || !src1 || !target || !ident) return SEGSDE_ERR_NULL;
   if (B <= 0 || H < 2 || W < 2 || (long)H * W >= (1L << 31)) return SEGSDE_ERR_SHAPE;
-  hipLaunchKernelGGL(photometric_fwd_kernel<true>, photo_grid(B, H, W), dim3(256), (9 * PF_H * PF_W + 1) * sizeof(float) + 64,
-                     ST(stream), src0, src1, target, (const float*)nullptr, (const float*)nullptr, H, W, no_ssim, 0,
-                     photo_tiles_per_block(B, H, W), ident,
-                     (uint8_t*)nullptr, (float*)nullptr, (double*)nullptr);
+  hipLaunchKernelGGL(photo_packed() ? photometric_fwd2_kernel<true> : photometric_fwd_kernel<true>, photo_grid(B, H, W), dim3(256),
+                     (9 * PF_H * PF_W + 1) * sizeof(float) + 64, ST(stream), src0, src1, target, (const float*)nullptr,
+                     (const float*)nullptr, H, W, no_ssim, 0, photo_tiles_per_block(B, H, W), ident, (uint8_t*)nullptr,
+                     (float*)nullptr, (double*)nullptr);
   SEGSDE_CHECK_LAUNCH();
   return 0;
 }
@@ -1134,7 +1517,7 @@ extern "C" int segsde_photometric_forward(const float* pred0, const float* pred1
   if (!pred0 || !pred1 || !target || !sel || !sum_out || !ws_) return SEGSDE_ERR_NULL;
   if (B <= 0 || H < 2 || W < 2 || (long)H * W >= (1L << 31)) return SEGSDE_ERR_SHAPE;
   if (ws_bytes < segsde_photometric_workspace(B, H, W)) return SEGSDE_ERR_WORKSPACE;
-  hipLaunchKernelGGL(photometric_fwd_kernel<false>, photo_grid(B, H, W), dim3(256),
+  hipLaunchKernelGGL(photo_packed() ? photometric_fwd2_kernel<false> : photometric_fwd_kernel<false>, photo_grid(B, H, W), dim3(256),
                      (9 * PF_H * PF_W + 1) * sizeof(float) + 64, ST(stream), pred0, pred1, target, ident, noise, H, W, no_ssim,
                      avg, photo_tiles_per_block(B, H, W), (float*)nullptr, sel, identity_selection, (double*)ws_);
   SEGSDE_CHECK_LAUNCH();
@@ -1163,7 +1546,11 @@ extern "C" int segsde_photometric_backward(const float* pred0, const float* pred
   a.scale = scale; a.min_disp = 1.f / max_depth; a.max_disp = 1.f / min_depth;
   a.g_disp_up = g_disp_up; a.gP_part = (double*)ws_;
   const size_t lds = (9 * PB_H * PB_W + 18 * PC_H * PC_W + 6 * PT_H * PT_W + 48) * sizeof(float) + 64 + ((PC_H * PC_W + 15) / 16) * 16;
-  hipLaunchKernelGGL(photometric_bwd_kernel, photo_grid(B, H, W), dim3(256), lds, ST(stream), a);
+  if (photo_packed())
+    hipLaunchKernelGGL(photo_split() ? photometric_bwd2_kernel<true> : photometric_bwd2_kernel<false>, photo_grid(B, H, W), dim3(256),
+                       lds + 24 * sizeof(float), ST(stream), a);
+  else
+    hipLaunchKernelGGL(photometric_bwd_kernel, photo_grid(B, H, W), dim3(256), lds, ST(stream), a);
   SEGSDE_CHECK_LAUNCH();
   const int nblk = (int)(photo_blocks(B, H, W) / B);
   hipLaunchKernelGGL(photometric_bwd_finalize_kernel, dim3(B, 2), dim3(256), 204 * sizeof(double), ST(stream),

@@ -291,4 +291,5 @@ inline void __builtin_amdgcn_sched_barrier(int) {}
 inline void __builtin_amdgcn_s_setprio(int) {}
 inline void __builtin_amdgcn_s_sleep(int) {}
 inline int __builtin_amdgcn_readfirstlane(int v) { return v; }   // only applied to wave-uniform values
+inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }   // v_rcp_f32 (1 ulp on the device)
 inline void __builtin_amdgcn_sched_group_barrier(int, int, int) {}
