@@ -727,6 +727,29 @@ def main():
                                       "frac_of_measured_hbm": v[0] / v[1] / (MEASURED_PEAKS["hbm_gbs"] * 1e9),
                                       "share_of_step": v[1] / dt}
                                   for k, v in sorted(hbm.items(), key=lambda kv: -kv[1][1])}
+            # The photometric family is bound by vector-instruction issue, not by HBM (DESIGN.md 3.3 "Round 4"): next to the HBM
+            # fractions, the share of the VALU issue slots its launches use -- SQ_INSTS_VALU of the committed PMC pass of this
+            # command x 4 cycles per wave64 instruction / (256 CUs x 4 SIMDs x 2.4 GHz x the live HIP-event time of the launch)
+            wpath = newest_profile("pmc_r*_sq_waits.txt")
+            if args.workload == "cfg3" and wpath:
+                lines = open(wpath).read().splitlines()
+                if any(l.startswith("# csrc_sha256 " + sha) for l in lines):
+                    hdr = next((l.split() for l in lines if l.startswith("kernel ")), None)
+                    fam = {"photometric_bwd": "photometric_bwd2_kernel<true>", "photometric_fwd": "photometric_fwd2_kernel<false>",
+                           "photometric_identity": "photometric_fwd2_kernel<true>", "warp_fwd": "warp_fwd_kernel"}
+                    for k, kname in fam.items():
+                        row = next((l.split() for l in lines if l.startswith(kname + " ")), None)
+                        if not (hdr and row and k in res["hbm_kernels"] and "SQ_INSTS_VALU" in hdr):
+                            continue
+                        ncol = len(hdr) - 1                       # numeric columns: launches + the counters
+                        nums = row[-ncol:]
+                        insts = float(nums[hdr.index("SQ_INSTS_VALU") - 1]) / float(nums[0])
+                        e = res["hbm_kernels"][k]
+                        sec = e["ms_per_step"] / e["launches_per_step"] * 1e-3
+                        e["bound"] = "valu"
+                        e["valu_wave_instructions_per_launch"] = insts
+                        e["valu_issue_frac"] = insts * 4.0 / (256 * 4 * 2.4e9 * sec)
+                        e["valu_source"] = os.path.relpath(wpath, ROOT)
         else:
             roof.update(achieved=res["step_tflops"], frac=res["step_tflops"] / PEAK_FP32_MATRIX_TFLOPS)
         res["roofline"] = roof

@@ -1795,7 +1795,7 @@ const Tune& tune() {
       if (const char* q = strstr(e, "adjl=")) r.adjlds = atoi(q + 5);     // 0: reflection-adjoint loop register-staged in every wave
       if (const char* q = strstr(e, "wlds=")) r.wdma = atoi(q + 5);       // 0: register-staged weight-gradient tile loads, 1: LDS-DMA with the barrier at the chunk end (round 2), 2: barrier inside the chunk (round 4)
       if (const char* q = strstr(e, "adjb=")) r.adjb = atoi(q + 5);       // 0: reflection adjoint always inside the kernel (MODE 3); 1: zero-pad + border launches on the largest maps; 2: everywhere
-      if (const char* q = strstr(e, "tsbn=")) r.tsbn = atoi(q + 5);       // 1: 128x64 tiles for one-round grids with dead tap rows
+      if (const char* q = strstr(e, "tsbn=")) r.tsbn = atoi(q + 5);       // 1: 128x64 tiles for every one-round grid with dead tap rows, -1: for none (default 0: where the imbalance exceeds a fifth)
       if (const char* q = strstr(e, "tskip=")) r.tskip = atoi(q + 6);     // 0: dilated zero-padded windows run their dead tap rows too
       if (const char* q = strstr(e, "wred=")) r.wred = atoi(q + 5);       // 1: split partials reduced inside the kernel (measured: slower)
     }
@@ -1955,9 +1955,21 @@ namespace {
 // Dead tap rows make the tiles' K loops unequal (1/3 .. 3/3 of the taps): a grid that fits the chip in ONE round (two
 // workgroups per CU) takes as long as its longest tile whatever the others skip.  Narrower tiles = twice the workgroups, the
 // second half is handed out as the first ones finish.  (ONE predicate for the launch and for the statistics rows it writes.)
+// Round 4: it pays where the one-round grid loses more than a fifth to the imbalance -- mean live tap rows per output row
+// below 0.8 of the maximum (rate 12 on the 32-row map: 8 rows with three live tap rows, 24 with two -> 0.75; measured 4.13 ->
+// 3.80 ms/step) -- and costs where it does not (rate 6: 0.875, rate 18: 0.94: the 128x64 tile's lower rate is all that is left;
+// 4.16 -> 4.54 and 2.78 -> 3.12 ms/step, profiles/experiments_r03.md).  tsbn=1 forces it, tsbn=-1 turns it off.
 bool narrow_for_tapskip(const ConvP& q) {
-  return q.tapskip && tune().tsbn && q.N > 64 && (q.ne - q.nb) % 64 == 0 &&
-         (long)segsde_cdiv(q.M, 128) * segsde_cdiv(q.ne - q.nb, 128) <= 512;
+  if (!q.tapskip || tune().tsbn < 0 || q.N <= 64 || (q.ne - q.nb) % 64 != 0 ||
+      (long)segsde_cdiv(q.M, 128) * segsde_cdiv(q.ne - q.nb, 128) > 512) return false;
+  if (tune().tsbn > 0) return true;
+  long live = 0; int most = 0;
+  for (int h = 0; h < q.Ho; ++h) {
+    int n = 0;
+    for (int kh = 0; kh < q.KH; ++kh) { const int hs = h * q.stride + kh * q.dil - q.pad; n += hs >= 0 && hs < q.H; }
+    live += n; most = n > most ? n : most;
+  }
+  return most > 0 && (double)live < 0.8 * (double)most * q.Ho;
 }
 long stats_rows(const segsde_conv_desc* d, const ConvP& p) {
   if (!p.vecout || d->sum2x2 || d->in_div > 1 || p.y2 != p.y || p.bias || d->act != 0) return 0;

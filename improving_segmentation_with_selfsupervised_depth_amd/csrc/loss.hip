@@ -1269,9 +1269,9 @@ extern "C" int segsde_warp_forward(const float* disp, int hs, int ws, const floa
                                    float* grid, float* depth, void* stream) {
   if (!disp || !inv_K || !K || !T || !src || !color) return SEGSDE_ERR_NULL;
   if (B <= 0 || H < 2 || W < 2 || hs <= 0 || ws <= 0 || (long)H * W >= (1L << 31)) return SEGSDE_ERR_SHAPE;
-  // one pixel per thread up to 2048 blocks per image: the kernel is a chain of dependent loads (disparity -> taps), more waves
-  // in flight hide it better than a grid-stride loop does (SEGSDE_WARP_BLOCKS=512: the cap of rounds 1-3)
-  static const int cap = [] { const char* e = getenv("SEGSDE_WARP_BLOCKS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 2048; }();
+  // up to 512 blocks per image, grid-stride: one pixel per thread (2048 blocks at 512x1024) measured 131 against 117 us in the
+  // step's kernel trace (SEGSDE_WARP_BLOCKS=2048, profiles/experiments_r04.md)
+  static const int cap = [] { const char* e = getenv("SEGSDE_WARP_BLOCKS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 512; }();
   const long nbw = ((long)H * W + 255) / 256;
   hipLaunchKernelGGL(warp_fwd_kernel, dim3((unsigned)(nbw < 1 ? 1 : (nbw > cap ? cap : nbw)), B), dim3(256), 512, ST(stream), disp, hs, ws, inv_K, K,
                      T, src, H, W, 1.f / max_depth, 1.f / min_depth, color, grid, depth);

@@ -196,36 +196,40 @@ __global__ __launch_bounds__(256) void wino_grad_kernel(const float* dy, int ld,
 }
 
 // part [16 * s][C][Co] (split slabs of the sixteen position GEMMs, s per position) -> dW [Co][C][3][3] = G^T dU G with
-// dU_p = the sum of position p's slabs in slab order (deterministic).  One thread per (c, co), co fastest (coalesced slab reads).
+// dU_p = the sum of position p's slabs in slab order (deterministic).  A block = 64 (c, co) pairs (co fastest: coalesced slab
+// reads) x the four rows of the 4x4 position grid: thread (q, pair) sums the slabs of positions 4q .. 4q+3, the rows meet in
+// LDS, threads q < 3 finish output row q.  (One thread per pair with all sixteen positions -- 16 s dependent-latency loads on
+// 4 waves per CU -- took 33 us per 256x256 weight for 34 MB; round 4.)
 __global__ __launch_bounds__(256) void wino_wgrad_finish_kernel(const float* part, int s, int C, int Co, float* dw) {
+  SEGSDE_SMEM;
+  float* sh = reinterpret_cast<float*>(segsde_smem);   // [4 q][4 v][64]
   const long total = (long)C * Co;
-  const long e = blockIdx.x * 256L + threadIdx.x;
-  if (e >= total) return;
+  const int el = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const long e = blockIdx.x * 64L + el;
+  if (e < total) {
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const float* src = part + (long)(4 * q + v) * s * total + e;
+      float a0 = 0.f, a1 = 0.f;
+      int z = 0;
+      for (; z + 1 < s; z += 2) { a0 += src[(long)z * total]; a1 += src[(long)(z + 1) * total]; }
+      if (z < s) a0 += src[(long)z * total];
+      sh[(q * 4 + v) * 64 + el] = a0 + a1;
+    }
+  }
+  __syncthreads();
+  if (e >= total || q == 3) return;
   const int co = (int)(e % Co), c = (int)(e / Co);
-  float u[4][4];
+  float t[4];
 #pragma unroll
-  for (int p = 0; p < 16; ++p) {
-    const float* src = part + (long)p * s * total + e;
-    float a0 = 0.f, a1 = 0.f;
-    int z = 0;
-    for (; z + 1 < s; z += 2) { a0 += src[(long)z * total]; a1 += src[(long)(z + 1) * total]; }
-    if (z < s) a0 += src[(long)z * total];
-    u[p >> 2][p & 3] = a0 + a1;
+  for (int v = 0; v < 4; ++v) {          // row q of G^T dU
+    const float u0 = sh[(0 * 4 + v) * 64 + el], u1 = sh[(1 * 4 + v) * 64 + el], u2 = sh[(2 * 4 + v) * 64 + el], u3 = sh[(3 * 4 + v) * 64 + el];
+    t[v] = q == 0 ? u0 + 0.5f * (u1 + u2) : (q == 1 ? 0.5f * (u1 - u2) : 0.5f * (u1 + u2) + u3);
   }
-  float t[3][4];
-#pragma unroll
-  for (int v = 0; v < 4; ++v) {          // G^T dU
-    t[0][v] = u[0][v] + 0.5f * (u[1][v] + u[2][v]);
-    t[1][v] = 0.5f * (u[1][v] - u[2][v]);
-    t[2][v] = 0.5f * (u[1][v] + u[2][v]) + u[3][v];
-  }
-  float* out = dw + ((long)co * C + c) * 9;
-#pragma unroll
-  for (int r = 0; r < 3; ++r) {          // (.) G
-    out[3 * r + 0] = t[r][0] + 0.5f * (t[r][1] + t[r][2]);
-    out[3 * r + 1] = 0.5f * (t[r][1] - t[r][2]);
-    out[3 * r + 2] = 0.5f * (t[r][1] + t[r][2]) + t[r][3];
-  }
+  float* out = dw + ((long)co * C + c) * 9 + 3 * q;   // (.) G
+  out[0] = t[0] + 0.5f * (t[1] + t[2]);
+  out[1] = 0.5f * (t[1] - t[2]);
+  out[2] = 0.5f * (t[1] + t[2]) + t[3];
 }
 
 // thread (a, b), b fastest: forward a = o, b = i reads w[o][i][3][3] (36 contiguous bytes) and writes U[p][o][i]; the
@@ -340,7 +344,7 @@ int segsde_wino_grad(const float* dy, int ld, int B, int H, int W, int C, int di
 
 int segsde_wino_wgrad_finish(const float* part, int s, int C, int Co, float* dw_oihw, void* stream) {
   const long total = (long)C * Co;
-  hipLaunchKernelGGL(wino_wgrad_finish_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ST(stream), part, s, C, Co, dw_oihw);
+  hipLaunchKernelGGL(wino_wgrad_finish_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 16 * 64 * sizeof(float), ST(stream), part, s, C, Co, dw_oihw);
   SEGSDE_CHECK_LAUNCH();
   return 0;
 }
