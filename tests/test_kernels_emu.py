@@ -84,6 +84,19 @@ def test_fused_photometric_vs_stage_kernels():
     KC.run_fused_photometric_vs_stage("cpu")
 
 
+@pytest.mark.parametrize("knobs", [{"SEGSDE_PHOTO_SPLIT": "0"}, {"SEGSDE_PHOTO_PACKED": "0"}], ids=["unsplit_walkers", "round3_kernels"])
+def test_fused_photometric_knob_variants(knobs):
+    """the A/B variants of the photometric kernels (knobs are read once per process: a child process each)"""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    code = "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import emu; emu.install(); import kernel_cases as KC; KC.run_fused_photometric_vs_stage(%r); print('VARIANT OK')" % (
+        os.path.dirname(here), here, "cpu")
+    cp = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **knobs), capture_output=True, text=True, timeout=900)
+    assert cp.returncode == 0 and "VARIANT OK" in cp.stdout, cp.stdout[-2000:] + cp.stderr[-2000:]
+
+
 def test_strong_transform_jitter_blur():
     KC.run_augment_cases("cpu")
 
