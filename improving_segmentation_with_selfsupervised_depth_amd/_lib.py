@@ -9,7 +9,7 @@ from ctypes import c_int, c_long, c_float, c_void_p, c_size_t, c_uint64, c_int64
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SEGSDE_LIB") or os.path.join(_HERE, "libsegsde_hip.so")   # override: kernel experiments
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 _LIB = None
 # Set only by the test-suite when it injects the host-interpreted build of the same kernel sources
@@ -53,6 +53,10 @@ _SIGS = {
     "segsde_conv2d_winograd": (c_int, [POINTER(ConvDesc), P, P, P, P, P, P, P, P, c_size_t, P]),
     "segsde_conv2d_wgrad_winograd_workspace": (c_size_t, [POINTER(ConvDesc)]),
     "segsde_conv2d_wgrad_winograd": (c_int, [POINTER(ConvDesc), P, P, P, c_int, P, P, P, c_size_t, P]),
+    "segsde_winograd_fused_ok": (c_int, [c_int, c_int, c_int, c_int, c_int]),
+    "segsde_winograd_fused_stats_rows": (ctypes.c_long, [c_int, c_int, c_int]),
+    "segsde_winograd_fused_pack": (c_int, [P, c_int, c_int, c_int, P, P]),
+    "segsde_conv2d_winograd_fused": (c_int, [P, c_int, c_int, c_int, c_int, c_int, c_int, P, c_int, P, c_int, P, c_int, P, P]),
     "segsde_upfold_pack": (c_int, [P, c_int, c_int, c_int, P, P, P]),
     "segsde_conv2d_forward_upfold": (c_int, [POINTER(ConvDesc), P, P, P, P, P, P, P]),
     "segsde_conv2d_dgrad_upfold": (c_int, [POINTER(ConvDesc), P, c_int, P, P, P, P, P, c_int, P, c_int, c_int, P]),

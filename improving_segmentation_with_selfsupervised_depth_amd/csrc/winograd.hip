@@ -277,9 +277,11 @@ __global__ __launch_bounds__(256) void wino_weight_multi_kernel(const segsde_win
   const int lb = (int)blockIdx.x - jb.block0, tf = lb >= nblk ? 1 : 0;
   const long e = (long)(lb - tf * nblk) * 256 + threadIdx.x;
   if (e >= per) return;
-  const int A = tf ? jb.I : jb.O, Bn = tf ? jb.O : jb.I;
+  // reserved & 1: the [16][K][N] layout of the one-kernel route (winograd_fused.hip): forward [16][I][O], data-gradient [16][O][I]
+  const int tr = tf ^ (jb.reserved & 1);
+  const int A = tr ? jb.I : jb.O, Bn = tr ? jb.O : jb.I;
   const int b = (int)(e % Bn), a = (int)(e / Bn);
-  const int o = tf ? b : a, i = tf ? a : b;
+  const int o = tr ? b : a, i = tr ? a : b;
   const float* g = jb.w + ((long)o * jb.I + i) * 9;
   float k[3][3];
 #pragma unroll

@@ -1,0 +1,262 @@
+// Winograd F(2x2,3x3) with the transforms INSIDE the GEMM kernel (round 4 experiment): the 3x3 / stride 1 / pad 1
+// convolutions with 64 or 128 channels (ResNet layer1 / layer2 conv2: models/resnet_encoder.py, torchvision Bottleneck.conv2), where
+// the route of winograd.hip -- transforms as passes through memory around sixteen grouped position GEMMs -- loses to the direct
+// implicit GEMM because V and M (4 x the activation each) cost more than the multiply-adds they save.
+//
+// One workgroup = 32 tiles (4 x 8: a 8 x 16 pixel block of the output) x 64 filters x ALL sixteen transform positions:
+//  * the raw 10 x 18 pixel patch of the block, 64 channels at a time, is staged ONCE in LDS, channel-major (plane pitch 181);
+//  * wave w owns the four positions of transform row w (p = 4 w + j): per pair of channels a lane (tile = lane & 31, channel =
+//    lane >> 5) reads the 2 x 4 raw pixels row w's combination needs, forms its four A operands with 8 additions -- V never
+//    exists in memory -- and takes its eight B operands (4 positions x 2 filter blocks of 32) straight from the transformed
+//    weights U[p][c][n] in L2 (n fastest: 128-byte runs per half-wave); 8 x v_mfma_f32_32x32x2_f32 per step, 128 accumulators;
+//  * epilogue: the sixteen 32 x 32 position blocks of a filter block meet in LDS (the patch is dead by then), every thread
+//    finishes four tiles of one filter: Y = A^T M A, bias / activation, the four output pixels, and -- STATS -- the
+//    double-precision column sums of what it stored (the following BatchNorm's batch statistics, same partial-row format as
+//    the implicit-GEMM epilogue's).
+// 16 instead of 36 multiply-adds per output, and no transform traffic: x is read once (+ halo), y written once.
+#include "segsde_common.h"
+#include "winograd.h"
+
+namespace {
+#define ST(s) static_cast<hipStream_t>(s)
+constexpr int FT_H = 4, FT_W = 8;                     // tiles of a block: 32 = the rows of the 32x32x2 MFMA
+constexpr int FP_H = 2 * FT_H + 2, FP_W = 2 * FT_W + 2;   // its 10 x 18 pixel patch
+constexpr int FPS = FP_H * FP_W + 1;                  // channel-plane pitch in LDS (odd: conflict-free staging writes)
+constexpr int FCH = 64;                               // channels per LDS fill
+constexpr int FZP = 65;                               // row pitch of the epilogue's half-transformed blocks Z[8][32][FZP]
+constexpr int F_FLOATS = 8 * 32 * FZP > FCH * FPS ? 8 * 32 * FZP : FCH * FPS;
+constexpr size_t F_LDS = (size_t)F_FLOATS * sizeof(float) + 2 * 4 * 64 * sizeof(double);
+
+template <bool STATS>
+__global__ __launch_bounds__(256, 2) void wino_fused_kernel(const float* x, int ldx, int B, int H, int W, int C, int reflect,
+                                                            const float* U, int Co, const float* bias, int act, float* y, int ldy,
+                                                            double* part) {
+  SEGSDE_SMEM;
+  float* lds = reinterpret_cast<float*>(segsde_smem);
+  double* sh = reinterpret_cast<double*>(lds + F_FLOATS);
+  const int H2 = H >> 1, W2 = W >> 1;
+  const int nbw = (W2 + FT_W - 1) / FT_W, nbh = (H2 + FT_H - 1) / FT_H;
+  int blk = segsde_xcd_remap(blockIdx.x, gridDim.x);
+  const int bw = blk % nbw; blk /= nbw;
+  const int bh = blk % nbh; const int b = blk / nbh;
+  const int co0 = blockIdx.y * 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int t = lane & 31, kk = lane >> 5, th = t >> 3, tw = t & 7;
+  const int h_top = 2 * bh * FT_H - 1, w_left = 2 * bw * FT_W - 1;   // image position of patch pixel (0, 0)
+  // rows of the patch that transform row `wave` combines: B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]
+  const int a1 = wave == 0 ? 0 : (wave == 2 ? 2 : 1);
+  const int a2 = wave == 0 ? 2 : (wave == 1 ? 2 : (wave == 2 ? 1 : 3));
+  const bool plus = wave == 1;
+  const float* pl = lds + kk * FPS + (2 * th) * FP_W + 2 * tw;
+  const int o1 = a1 * FP_W, o2 = a2 * FP_W;
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][nb][r] = 0.f;
+
+  for (int c0 = 0; c0 < C; c0 += FCH) {
+    __syncthreads();                                   // the previous fill's reads are done
+    {
+      // all requests of the fill first (12 independent 16-byte loads per thread), then the transposing LDS writes
+      constexpr int NL = (FP_H * FP_W * (FCH / 4) + 255) / 256;
+      float4 v[NL];
+#pragma unroll
+      for (int i = 0; i < NL; ++i) {
+        const int e = tid + 256 * i;
+        const int pix = e >> 4, cq = e & 15;
+        const int pr = pix / FP_W, pc = pix - pr * FP_W;
+        int hh = h_top + pr, ww = w_left + pc;
+        if (reflect) {       // ReflectionPad2d(1) (monodepth_layers.py:127-142); pixels of tiles past the image: any valid address
+          hh = hh < 0 ? -hh : (hh >= H ? 2 * H - 2 - hh : hh); ww = ww < 0 ? -ww : (ww >= W ? 2 * W - 2 - ww : ww);
+          hh = hh < 0 ? 0 : hh; ww = ww < 0 ? 0 : ww;
+        }
+        v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (e < FP_H * FP_W * (FCH / 4) && (unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W)
+          v[i] = *reinterpret_cast<const float4*>(x + ((long)(b * H + hh) * W + ww) * ldx + c0 + 4 * cq);
+      }
+#pragma unroll
+      for (int i = 0; i < NL; ++i) {
+        const int e = tid + 256 * i;
+        if (e < FP_H * FP_W * (FCH / 4)) {
+          float* d = lds + (4 * (e & 15)) * FPS + (e >> 4);
+          d[0] = v[i].x; d[FPS] = v[i].y; d[2 * FPS] = v[i].z; d[3 * FPS] = v[i].w;
+        }
+      }
+    }
+    __syncthreads();
+    // U[p][c][n]: this lane's column n = co0 + nb * 32 + t of channel c0 + 2 s + kk, positions 4 wave + j
+    const float* up = U + ((long)(4 * wave) * C + c0 + kk) * Co + co0 + t;
+    const long upos = (long)C * Co;
+    // B operands come straight from L2 (a few hundred ns): requested PD steps (PD x 512 MFMA cycles) ahead; the raw pixels
+    // (LDS) one step ahead
+    constexpr int PD = 4, NS = FCH / 2;
+    float bv[PD][8], rv[2][8];
+    auto fetch_b = [&](int s, int q) {
+      const float* us = up + (long)(2 * s) * Co;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { bv[q][2 * j] = us[j * upos]; bv[q][2 * j + 1] = us[j * upos + 32]; }
+    };
+    auto fetch_a = [&](int s, int q) {
+      const float* src = pl + (2 * s) * FPS;
+#pragma unroll
+      for (int bb = 0; bb < 4; ++bb) { rv[q][bb] = src[o1 + bb]; rv[q][4 + bb] = src[o2 + bb]; }
+    };
+#pragma unroll
+    for (int s = 0; s < PD - 1; ++s) fetch_b(s, s);
+    fetch_a(0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const int q = s & 1, qb = s % PD;
+      if (s + PD - 1 < NS) fetch_b(s + PD - 1, (s + PD - 1) % PD);
+      if (s + 1 < NS) fetch_a(s + 1, q ^ 1);
+      __builtin_amdgcn_sched_barrier(0);               // the scheduler otherwise sinks the requests to one step before their use
+      float ev[4];
+#pragma unroll
+      for (int bb = 0; bb < 4; ++bb) ev[bb] = plus ? rv[q][bb] + rv[q][4 + bb] : rv[q][bb] - rv[q][4 + bb];
+      const float A0 = ev[0] - ev[2], A1 = ev[1] + ev[2], A2 = ev[2] - ev[1], A3 = ev[1] - ev[3];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A0, bv[qb][0], acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A0, bv[qb][1], acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A1, bv[qb][2], acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A1, bv[qb][3], acc[1][1], 0, 0, 0);
+      acc[2][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A2, bv[qb][4], acc[2][0], 0, 0, 0);
+      acc[2][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A2, bv[qb][5], acc[2][1], 0, 0, 0);
+      acc[3][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A3, bv[qb][6], acc[3][0], 0, 0, 0);
+      acc[3][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A3, bv[qb][7], acc[3][1], 0, 0, 0);
+    }
+  }
+
+  // ---- epilogue.  Y = A^T M A with A^T = [1 1 1 0; 0 1 -1 -1]: wave w holds row w of the 4 x 4 position grid, so the column
+  // half (.) A runs on its accumulators (four values -> two); the rows meet in LDS as Z[w][column 0 / 1][tile][filter] (the
+  // patch is dead by then), one round for all 64 filters, and every thread finishes eight tiles of one filter
+  __syncthreads();                                     // the last fill's patch reads are done
+  {
+    float* zw = lds + ((2 * wave) * 32 + 4 * kk) * FZP + t;
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float m0 = acc[0][nb][r], m1 = acc[1][nb][r], m2 = acc[2][nb][r], m3 = acc[3][nb][r];
+        const int row = (r & 3) + 8 * (r >> 2);
+        zw[row * FZP + nb * 32] = (m0 + m1) + m2;
+        zw[(32 + row) * FZP + nb * 32] = (m1 - m2) - m3;
+      }
+  }
+  __syncthreads();
+  const int n = tid & 63, tg = tid >> 6;               // thread: filter n, tiles 8 tg .. 8 tg + 7 (tile row tg of the block)
+  const bool post = bias != nullptr || act != SEGSDE_ACT_NONE;
+  const int co = co0 + n;
+  const float bsv = bias ? bias[co] : 0.f;
+  double ssum = 0.0, ssq = 0.0;
+  const int ti = bh * FT_H + tg;
+#pragma unroll
+  for (int q = 0; q < FT_W; ++q) {
+    const int tl = tg * FT_W + q;
+    const float* zp = lds + tl * FZP + n;
+    float z0[4], z1[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { z0[i] = zp[(2 * i) * 32 * FZP]; z1[i] = zp[(2 * i + 1) * 32 * FZP]; }
+    float o[4];                                        // (0,0) (0,1) (1,0) (1,1)
+    o[0] = (z0[0] + z0[1]) + z0[2]; o[1] = (z1[0] + z1[1]) + z1[2];
+    o[2] = (z0[1] - z0[2]) - z0[3]; o[3] = (z1[1] - z1[2]) - z1[3];
+    if (post) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) o[k] = segsde_act(o[k] + bsv, act);
+    }
+    const int tj = bw * FT_W + q;
+    if (ti < H2 && tj < W2) {
+      float* yp = y + ((long)(b * H + 2 * ti) * W + 2 * tj) * ldy + co;
+      yp[0] = o[0]; yp[ldy] = o[1]; yp[(long)W * ldy] = o[2]; yp[(long)W * ldy + ldy] = o[3];
+      if (STATS) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const double v = (double)o[k]; ssum += v; ssq += v * v; }
+      }
+    }
+  }
+  if (STATS) {
+    sh[tg * 64 + n] = ssum; sh[256 + tg * 64 + n] = ssq;
+    __syncthreads();
+    if (tid < 64) {
+      double a = 0.0, c2 = 0.0;
+      for (int l = 0; l < 4; ++l) { a += sh[l * 64 + tid]; c2 += sh[256 + l * 64 + tid]; }
+      part[((long)blockIdx.x * 2 + 0) * Co + co0 + tid] = a;
+      part[((long)blockIdx.x * 2 + 1) * Co + co0 + tid] = c2;
+    }
+  }
+}
+
+// OIHW 3x3 weight -> U[16][K][N], N fastest: forward (flip = 0) K = I, N = O; data-gradient (flip = 1: the convolution of dY with
+// the spatially flipped kernel) K = O, N = I.  thread (k, n), n fastest: coalesced writes, the nine reads of a thread are contiguous.
+__global__ __launch_bounds__(256) void wino_weight_kn_kernel(const float* w, int O, int I, int flip, float* U) {
+  const int K = flip ? O : I, N = flip ? I : O;
+  const long e = blockIdx.x * 256L + threadIdx.x;
+  if (e >= (long)K * N) return;
+  const int nn = (int)(e % N), kq = (int)(e / N);
+  const int o = flip ? kq : nn, i = flip ? nn : kq;
+  const float* g = w + ((long)o * I + i) * 9;
+  float k[3][3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) k[r][c] = flip ? g[(2 - r) * 3 + (2 - c)] : g[r * 3 + c];
+  float tq[4][3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {          // G g (the expressions of wino_weight_kernel)
+    tq[0][c] = k[0][c];
+    tq[1][c] = 0.5f * ((k[0][c] + k[1][c]) + k[2][c]);
+    tq[2][c] = 0.5f * ((k[0][c] - k[1][c]) + k[2][c]);
+    tq[3][c] = k[2][c];
+  }
+  const long plane = (long)K * N;
+  float* out = U + e;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {          // (.) G^T
+    out[(4 * r + 0) * plane] = tq[r][0];
+    out[(4 * r + 1) * plane] = 0.5f * ((tq[r][0] + tq[r][1]) + tq[r][2]);
+    out[(4 * r + 2) * plane] = 0.5f * ((tq[r][0] - tq[r][1]) + tq[r][2]);
+    out[(4 * r + 3) * plane] = tq[r][2];
+  }
+}
+
+inline long fused_blocks(int B, int H, int W) {
+  return (long)B * (((H >> 1) + FT_H - 1) / FT_H) * (((W >> 1) + FT_W - 1) / FT_W);
+}
+}  // namespace
+
+extern "C" int segsde_winograd_fused_ok(int B, int H, int W, int C, int Cout) {
+  return B > 0 && H >= 4 && W >= 4 && H % 2 == 0 && W % 2 == 0 && C >= FCH && C % FCH == 0 && Cout >= 64 && Cout % 64 == 0 &&
+         fused_blocks(B, H, W) < (1L << 31) && (long)B * H * W * (C > Cout ? C : Cout) < (1L << 40);
+}
+
+extern "C" long segsde_winograd_fused_stats_rows(int B, int H, int W) { return fused_blocks(B, H, W); }
+
+extern "C" int segsde_winograd_fused_pack(const float* w_oihw, int O, int I, int flip, float* U, void* stream) {
+  if (!w_oihw || !U) return SEGSDE_ERR_NULL;
+  if (O <= 0 || I <= 0) return SEGSDE_ERR_SHAPE;
+  const long total = (long)O * I;
+  hipLaunchKernelGGL(wino_weight_kn_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ST(stream), w_oihw, O, I, flip, U);
+  SEGSDE_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int segsde_conv2d_winograd_fused(const float* x, int ldx, int B, int H, int W, int C, int reflect, const float* u_kn,
+                                            int Cout, const float* bias, int act, float* y, int ldy, double* stats, void* stream) {
+  if (!x || !u_kn || !y) return SEGSDE_ERR_NULL;
+  if (!segsde_winograd_fused_ok(B, H, W, C, Cout) || ldx < C || ldx % 4 != 0 || ldy < Cout) return SEGSDE_ERR_UNSUPPORTED;
+  const dim3 grid((unsigned)fused_blocks(B, H, W), (unsigned)(Cout / 64));
+  if (stats) {
+    auto k = wino_fused_kernel<true>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_LDS);
+    hipLaunchKernelGGL(k, grid, dim3(256), F_LDS, ST(stream), x, ldx, B, H, W, C, reflect, u_kn, Cout, bias, act, y, ldy, stats);
+  } else {
+    auto k = wino_fused_kernel<false>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_LDS);
+    hipLaunchKernelGGL(k, grid, dim3(256), F_LDS, ST(stream), x, ldx, B, H, W, C, reflect, u_kn, Cout, bias, act, y, ldy, (double*)nullptr);
+  }
+  SEGSDE_CHECK_LAUNCH();
+  return 0;
+}

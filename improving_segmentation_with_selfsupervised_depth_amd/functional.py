@@ -148,15 +148,19 @@ class ConvFn(Function):
         # Winograd route (3x3 / stride 1 / many channels): the transformed weight packs, cached by the owning module for the
         # active weight_pack_scope like the plain packs
         ctx.wino = None
-        if not g.up0 and H.winograd_ok(g, x0.shape[0], x0.shape[1], x0.shape[2]):
-            if wino_cache is not None and wino_cache.get("key") is not None and wino_cache.get("key") == wino_cache.get("want"):
+        # kn: the one-kernel Winograd route (64 .. 256 channels, one source) and its [16][K][N] packs; otherwise the grouped-GEMM
+        # route from 256 channels on (two sources, dilation, 512 channels)
+        kn = not g.up0 and x1 is None and H.winograd_fused_ok(g, x0.shape[0], x0.shape[1], x0.shape[2])
+        if kn or (not g.up0 and H.winograd_ok(g, x0.shape[0], x0.shape[1], x0.shape[2])):
+            if (wino_cache is not None and wino_cache.get("key") is not None and wino_cache.get("key") == wino_cache.get("want")
+                    and bool(wino_cache.get("kn")) == kn):
                 ctx.wino = wino_cache["packs"]
             else:
-                ctx.wino = H.winograd_pack(weight)
+                ctx.wino = H.winograd_pack(weight, kn=kn)
                 if wino_cache is not None and wino_cache.get("want") is not None:
-                    wino_cache["packs"], wino_cache["key"] = ctx.wino, wino_cache["want"]
+                    wino_cache["packs"], wino_cache["key"], wino_cache["kn"] = ctx.wino, wino_cache["want"], kn
         wino_f = None if ctx.wino is None else ctx.wino[0]
-        keep_v = wino_f is not None and ctx.needs_input_grad[2]     # the weight gradient reuses the forward's transformed input
+        keep_v = wino_f is not None and not kn and ctx.needs_input_grad[2]   # the weight gradient reuses the forward's transformed input
         H.WINO_V[0] = None
         if stats_out is not None:
             y, part = H.conv_forward(g, x0, x1, wp, bias, act, want_stats=True, wino=wino_f, keep_v=keep_v)

@@ -118,8 +118,11 @@ def winograd_static_ok(conv):
             and min(conv.in_channels, conv.out_channels) >= WINOGRAD_MIN_CH)
 
 
-def winograd_pack(w_oihw):
-    """(forward pack [16][Cout][Cin], data-gradient pack [16][Cin][Cout]) = G g G^T of an OIHW 3x3 weight"""
+def winograd_pack(w_oihw, kn=False):
+    """(forward pack [16][Cout][Cin], data-gradient pack [16][Cin][Cout]) = G g G^T of an OIHW 3x3 weight; kn: the [16][K][N]
+    packs of the one-kernel route instead ([16][Cin][Cout], [16][Cout][Cin])"""
+    if kn:
+        return winograd_fused_pack(w_oihw, False), winograd_fused_pack(w_oihw, True)
     w = _f32(w_oihw.detach()).contiguous()
     O, I, KH, KW = w.shape
     assert KH == 3 and KW == 3
@@ -132,13 +135,13 @@ def winograd_pack(w_oihw):
 _WINO_MULTI = {}
 
 
-def winograd_packs_multi(weights):
+def winograd_packs_multi(weights, kn=False):
     """[(forward pack, data-gradient pack)] of many 3x3 weights in ONE launch; the packs are views into a flat buffer that the
     next call with the same weights rewrites (what a training step needs, like pack_weights_multi)"""
     ws = [_f32(w.detach()) for w in weights]
     assert ws and all(w.is_contiguous() and w.dim() == 4 and tuple(w.shape[2:]) == (3, 3) for w in ws)
     dev = ws[0].device
-    key = (dev, tuple((w.data_ptr(), tuple(w.shape)) for w in ws))
+    key = (dev, bool(kn), tuple((w.data_ptr(), tuple(w.shape)) for w in ws))
     hit = _WINO_MULTI.get(key)
     if hit is None:
         if len(_WINO_MULTI) > 8:
@@ -150,9 +153,12 @@ def winograd_packs_multi(weights):
         for i, w in enumerate(ws):
             O, I = w.shape[0], w.shape[1]
             n = 16 * O * I
-            uf, ud = flat[off:off + n].view(16, O, I), flat[off + n:off + 2 * n].view(16, I, O)
+            if kn:
+                uf, ud = _kn(flat[off:off + n].view(16, I, O)), _kn(flat[off + n:off + 2 * n].view(16, O, I))
+            else:
+                uf, ud = flat[off:off + n].view(16, O, I), flat[off + n:off + 2 * n].view(16, I, O)
             off += 2 * n
-            jobs[i] = _lib.WinoJob(w.data_ptr(), uf.data_ptr(), ud.data_ptr(), O, I, blk, 0)
+            jobs[i] = _lib.WinoJob(w.data_ptr(), uf.data_ptr(), ud.data_ptr(), O, I, blk, 1 if kn else 0)
             blk += 2 * ((O * I + 255) // 256)
             views.append((uf, ud))
         raw = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8).to(dev)
@@ -193,6 +199,73 @@ def _winograd(kind, g, x0, x1, upack, Cout, want_stats, flops, tag, bias=None, a
     check(rc, "conv2d_winograd")
     WINO_V[0] = vk
     WINOGRAD_TAKEN["fwd" if kind == "conv_fwd" else "dgrad"] += 1
+    return y, part
+
+
+# ---- Winograd with the transforms inside the kernel (csrc/winograd_fused.hip): 3x3 / stride 1 / padding 1, one source,
+# 64 .. 256 channels.  Measured (profiles/probe_r04_winograd_fused.log, B = 16): 1.6-1.7x the direct kernel forward, 1.55x
+# data-gradient from 64 channels on, 1.3x the grouped-GEMM route of winograd.hip at 256 channels (168 against 217 us), equal to
+# it at 512 (where the grouped route also hands its transformed input to the weight gradient).  SEGSDE_WINO_FUSED=0: off.
+WINO_FUSED = os.environ.get("SEGSDE_WINO_FUSED", "1") != "0"
+WINO_FUSED_MAX_CH = int(os.environ.get("SEGSDE_WINO_FUSED_MAX_CH", "256"))
+WINO_FUSED_TAKEN = {"fwd": 0, "dgrad": 0}
+
+
+def winograd_fused_ok(g, B=None, H=None, W=None, dgrad=False):
+    """the shapes csrc/winograd_fused.hip takes: 3x3 / stride 1 / padding 1 / dilation 1, one source at output resolution, channel
+    counts multiples of 64 up to WINO_FUSED_MAX_CH; zero padding (forward and data-gradient) or mirrored padding (forward)"""
+    cin, cout = (g.Cout, g.C0) if dgrad else (g.Cin, g.Cout)
+    if not (WINOGRAD and WINO_FUSED and g.k == 3 and g.stride == 1 and g.dil == 1 and g.pad == 1 and not g.up0 and not g.C1
+            and g.cin_alg is None and cin % 64 == 0 and cout % 64 == 0 and max(cin, cout) <= WINO_FUSED_MAX_CH
+            and not (dgrad and g.reflect)):
+        return False
+    if B is None:
+        return True
+    return bool(_lib.lib().segsde_winograd_fused_ok(B, H, W, cin, cout)) and 9.0 * B * H * W * cin * cout >= WINOGRAD_MIN_MACS
+
+
+def winograd_fused_static_ok(conv):
+    """could this nn.Conv2d ever take the one-kernel route (weight_pack_scope packs those in the [16][K][N] layout up front)"""
+    return (WINOGRAD and WINO_FUSED and conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1)
+            and conv.dilation == (1, 1) and conv.in_channels % 64 == 0 and conv.out_channels % 64 == 0
+            and max(conv.in_channels, conv.out_channels) <= WINO_FUSED_MAX_CH)
+
+
+class _KnPack(torch.Tensor):
+    """a transformed weight pack in the [16][K][N] layout (a plain tensor with a type the dispatch can see)"""
+
+
+def _kn(t):
+    return t.as_subclass(_KnPack)
+
+
+def winograd_fused_pack(w_oihw, flip):
+    """OIHW 3x3 -> U[16][K][N] (N fastest): flip False = forward pack (K = Cin, N = Cout), True = data-gradient pack"""
+    O, I = w_oihw.shape[0], w_oihw.shape[1]
+    w = _f32(w_oihw.detach()).contiguous()
+    u = torch.empty((16, O, I) if flip else (16, I, O), dtype=torch.float32, device=w.device)
+    check(_lib.lib().segsde_winograd_fused_pack(_p(w), O, I, 1 if flip else 0, _p(u), _stream(w)), "winograd_fused_pack")
+    return _kn(u)
+
+
+def winograd_fused(kind, x, u_kn, bias=None, act="none", want_stats=False, tag=None, reflect=False):
+    """x [B,H,W,C] NHWC -> act(conv3x3(x) + bias) [B,H,W,N] with u_kn [16][C][N]; (y, statistics partials or None)"""
+    B, H, W, C = x.shape
+    N = u_kn.shape[2]
+    assert u_kn.shape[1] == C
+    L = _lib.lib()
+    y = torch.empty((B, H, W, N), dtype=torch.float32, device=x.device)
+    part = None
+    if want_stats:
+        part = torch.empty((int(L.segsde_winograd_fused_stats_rows(B, H, W)), 2, N), dtype=torch.float64, device=x.device)
+    flops = 2.0 * B * H * W * C * N * 9
+    rc = _timed(kind, flops, x, lambda: L.segsde_conv2d_winograd_fused(_p(_f32(x)), nhwc_ld(x), B, H, W, C, 1 if reflect else 0, _p(u_kn), N, _p(bias),
+                                                                       ACT[act], _p(y), N, _p(part), _stream(x)),
+                (tag or "%d+0->%d k3 s1 d1 %dx%d" % (C, N, H, W)) + " wino-fused", executed=flops * 16.0 / 36.0)
+    if rc == -4:
+        return None
+    check(rc, "conv2d_winograd_fused")
+    WINO_FUSED_TAKEN["fwd" if kind == "conv_fwd" else "dgrad"] += 1
     return y, part
 
 
@@ -366,7 +439,12 @@ def conv_forward(g, x0, x1, wpack, bias, act="none", want_stats=False, wfold=Non
                  act=ACT[act], sum2x2=0)
     flops = 2.0 * B * Ho * Wo * g.Cout * g.CinAlg * g.k * g.k
     flops_x = flops * g.Cin / g.CinAlg * _live_tap_frac(g, H, W)   # executed: zero pad channels of a stem are multiplied too, dead tap rows are not
-    if wino is not None and not g.up0 and (not want_stats or (bias is None and act == "none")) and winograd_ok(g, B, H, W):
+    if isinstance(wino, _KnPack):
+        if (not want_stats or (bias is None and act == "none")) and winograd_fused_ok(g, B, H, W) and x1 is None:
+            r = winograd_fused("conv_fwd", x0, wino, bias=bias, act=act, want_stats=want_stats, tag=_tag(g, H, W), reflect=g.reflect)
+            if r is not None:
+                return r if want_stats else r[0]
+    elif wino is not None and not g.up0 and (not want_stats or (bias is None and act == "none")) and winograd_ok(g, B, H, W):
         WINO_V[0] = None
         r = _winograd("conv_fwd", g, x0, x1, wino, g.Cout, want_stats, flops, _tag(g, H, W), bias=bias, act=act, reflect=g.reflect,
                       keep_v=keep_v and WINOGRAD_KEEP_V)
@@ -421,7 +499,12 @@ def conv_dgrad(g, dy, wdpack, w_oihw, in_hw, need0=True, need1=True, accumulate_
         ag_y, ag_kind = actgrad[0], ACT[actgrad[1]]
         ag_ld = nhwc_ld(ag_y)
 
-    if (wino is not None and accumulate_into is None and actgrad is None and not g.reflect and g.C1 == 0
+    if isinstance(wino, _KnPack):
+        if (accumulate_into is None and actgrad is None and winograd_fused_ok(g, B, H, W, dgrad=True) and (Ho, Wo) == (H, W)):
+            r = winograd_fused("conv_dgrad", dy, wino, tag=_tag(g, H, W))
+            if r is not None:
+                return r[0], None
+    elif (wino is not None and accumulate_into is None and actgrad is None and not g.reflect and g.C1 == 0
             and winograd_ok(g, B, H, W, dgrad=True) and (Ho, Wo) == (H, W)):
         # zero-padded 3x3 / stride 1: dX is the same convolution of dY with the flipped, transposed kernel
         r = _winograd("conv_dgrad", g, dy, None, wino, g.C0, False, flops, _tag(g, H, W))

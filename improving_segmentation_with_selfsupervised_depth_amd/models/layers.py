@@ -57,11 +57,15 @@ class weight_pack_scope:
             w = m.weight
             m._packs, m._pack_key = pk, (scope_id, w._version, w.data_ptr(), w.device)
         # the Winograd-transformed packs of the 3x3 / stride-1 convolutions with many channels, likewise in one launch
-        wino = [m for m in convs if H.winograd_static_ok(m)]
-        if wino:
-            for m, pk in zip(wino, H.winograd_packs_multi([m.weight for m in wino])):
-                w = m.weight
-                m._wino_cache["packs"], m._wino_cache["key"] = pk, (scope_id, w._version, w.data_ptr(), w.device)
+        # (the one-kernel route's packs have their own layout: two launches, one per layout)
+        for kn in (True, False):
+            wino = [m for m in convs if (H.winograd_fused_static_ok(m) if kn
+                                         else (H.winograd_static_ok(m) and not H.winograd_fused_static_ok(m)))]
+            if wino:
+                for m, pk in zip(wino, H.winograd_packs_multi([m.weight for m in wino], kn=kn)):
+                    w = m.weight
+                    m._wino_cache["packs"], m._wino_cache["key"] = pk, (scope_id, w._version, w.data_ptr(), w.device)
+                    m._wino_cache["kn"] = kn
 
     def __exit__(self, *exc):
         _PACK_SCOPE[0] = self._outer

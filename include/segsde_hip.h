@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SEGSDE_ABI_VERSION 10
+#define SEGSDE_ABI_VERSION 11
 
 enum { SEGSDE_ERR_NULL = -1, SEGSDE_ERR_SHAPE = -2, SEGSDE_ERR_WORKSPACE = -3, SEGSDE_ERR_UNSUPPORTED = -4 };
 enum { SEGSDE_ACT_NONE = 0, SEGSDE_ACT_RELU = 1, SEGSDE_ACT_ELU = 2, SEGSDE_ACT_SIGMOID = 3 };
@@ -249,8 +249,8 @@ int segsde_nhwc_to_nchw(const float* x, int ldx, int B, int C, int H, int W, flo
  * otherwise (callers use segsde_conv2d_forward). */
 typedef struct segsde_wino_job {
   const float* w;    /* OIHW 3x3 weight */
-  float* u_fwd;      /* [16][O][I] */
-  float* u_dgrad;    /* [16][I][O] */
+  float* u_fwd;      /* [16][O][I]  (reserved & 1: [16][I][O], the layout of segsde_conv2d_winograd_fused) */
+  float* u_dgrad;    /* [16][I][O]  (reserved & 1: [16][O][I]) */
   int O, I, block0, reserved;
 } segsde_wino_job;
 size_t segsde_conv2d_winograd_workspace(const segsde_conv_desc* d);
@@ -267,6 +267,19 @@ int segsde_conv2d_winograd(const segsde_conv_desc* d, const float* x0, const flo
 size_t segsde_conv2d_wgrad_winograd_workspace(const segsde_conv_desc* d);
 int segsde_conv2d_wgrad_winograd(const segsde_conv_desc* d, const float* x0, const float* x1, const float* dy, int lddy,
                                  const float* v_saved, float* dw_oihw, void* workspace, size_t workspace_bytes, void* stream);
+/* Winograd F(2x2,3x3) with both transforms inside ONE kernel (no V / M tensors): the 64- and 128-channel conv2 of layer1 / layer2
+ * (models/resnet_encoder.py:90-101 via torchvision's Bottleneck / BasicBlock) and the decoder's single-source Conv3x3
+ * (models/monodepth_layers.py:127-142, reflect = 1: mirrored padding, forward only) -- 3x3, stride 1, padding 1, one source, H and W
+ * even, C % 64 == 0, Cout % 64 == 0.  segsde_winograd_fused_pack: OIHW -> U[16][K][N] with N fastest; flip = 0: the forward pack
+ * (K = Cin, N = Cout), flip = 1: the data-gradient pack of the spatially flipped kernel (K = Cout, N = Cin; call the convolution
+ * with x = dY, C = Cout, Cout = Cin).  y = act(Y + bias) (bias nullable); stats (nullable):
+ * [segsde_winograd_fused_stats_rows(B, H, W)][2][Cout] doubles for segsde_bn_stats_from_partials.  SEGSDE_ERR_UNSUPPORTED outside
+ * these shapes (segsde_winograd_fused_ok tells beforehand). */
+int segsde_winograd_fused_ok(int B, int H, int W, int C, int Cout);
+long segsde_winograd_fused_stats_rows(int B, int H, int W);
+int segsde_winograd_fused_pack(const float* w_oihw, int Cout, int Cin, int flip, float* u_kn, void* stream);
+int segsde_conv2d_winograd_fused(const float* x, int ldx, int B, int H, int W, int C, int reflect, const float* u_kn, int Cout,
+                                 const float* bias, int act, float* y, int ldy, double* stats, void* stream);
 
 /* ------------------------------------------------------------------------------------------------ *
  * Pose: axis-angle + translation -> 4x4 (models/monodepth_layers.py:30-105)                         *

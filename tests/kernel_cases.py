@@ -1226,7 +1226,9 @@ def run_winograd_cases(device, shapes=((2, 16, 32, 64, 64), (1, 32, 16, 96, 128)
     from improving_segmentation_with_selfsupervised_depth_amd.models import layers as L
     from improving_segmentation_with_selfsupervised_depth_amd import functional as Fn
     old = (H.WINOGRAD_MIN_CH, H.WINOGRAD_MIN_MACS)
+    old_fused = H.WINO_FUSED
     H.WINOGRAD_MIN_CH, H.WINOGRAD_MIN_MACS = 32, 0.0
+    H.WINO_FUSED = False          # this case is about the grouped-GEMM route (run_winograd_fused_cases: the one-kernel route)
     try:
         gen = torch.Generator().manual_seed(23)
         for (B, Hh, W, C, Co) in shapes:
@@ -1356,3 +1358,88 @@ def run_winograd_cases(device, shapes=((2, 16, 32, 64, 64), (1, 32, 16, 96, 128)
     finally:
         H.WINOGRAD_MIN_CH, H.WINOGRAD_MIN_MACS = old
         H.WINOGRAD = True
+        H.WINO_FUSED = old_fused
+
+
+def run_winograd_fused_cases(device, shapes=((1, 8, 16, 64, 64), (2, 12, 20, 64, 128), (1, 16, 32, 128, 64), (1, 6, 4, 128, 128))):
+    """the one-kernel Winograd route (csrc/winograd_fused.hip) against a float64 convolution: error within 3x the direct kernel's
+    own, whole and partial 4x8-tile blocks, one and two channel fills, forward with bias + ELU, with the BatchNorm statistics
+    partials, and the data-gradient through the flipped pack"""
+    gen = torch.Generator().manual_seed(29)
+    for (B, Hh, W, C, Co) in shapes:
+        x = torch.randn(B, C, Hh, W, generator=gen)
+        w = torch.randn(Co, C, 3, 3, generator=gen) * (2.0 / (9 * C)) ** 0.5
+        bias = torch.randn(Co, generator=gen)
+        dy = torch.randn(B, Co, Hh, W, generator=gen)
+        xd, wd_, dyd, bd = nhwc(x).to(device).contiguous(), w.to(device), nhwc(dy).to(device).contiguous(), bias.to(device)
+        wp, wdp = H.pack_weight_both(wd_)
+        g = H.ConvGeom(C, Co, 3, 1, 1, 1, False, 0, False)
+        uf, ud = H.winograd_fused_pack(wd_, False), H.winograd_fused_pack(wd_, True)
+        assert uf.shape == (16, C, Co) and ud.shape == (16, Co, C)
+        want = torch.nn.functional.conv2d(x.double(), w.double(), padding=1)
+        sc = float(want.abs().max())
+        what = "fused Winograd %s" % ((B, Hh, W, C, Co),)
+        y, part = H.winograd_fused("conv_fwd", xd, uf, want_stats=True)
+        direct = H.conv_forward(g, xd, None, wp, None)
+        e_w, e_d = float((nchw(y).double().cpu() - want).abs().max()), float((nchw(direct).double().cpu() - want).abs().max())
+        assert e_w <= 3 * e_d + 1e-6 * sc, (what, "forward", e_w, e_d, sc)
+        yy = y.double().reshape(-1, Co)
+        assert part.shape[1:] == (2, Co)
+        assert_close(part[:, 0].sum(0), yy.sum(0), rtol=1e-9, atol=1e-9 * float(yy.abs().sum(0).max()), what=what + " statistics: sums")
+        assert_close(part[:, 1].sum(0), (yy * yy).sum(0), rtol=1e-9, atol=1e-9, what=what + " statistics: sums of squares")
+        y2, none = H.winograd_fused("conv_fwd", xd, uf, bias=bd, act="elu")
+        assert none is None
+        want2 = torch.nn.functional.elu(want + bias.double().view(1, -1, 1, 1))
+        assert_close(nchw(y2).cpu(), want2.float(), rtol=1e-4, atol=3 * e_d + 1e-5 * sc, what=what + " bias + ELU")
+        wantg = torch.nn.functional.conv_transpose2d(dy.double(), w.double(), padding=1)
+        dx, _ = H.winograd_fused("conv_dgrad", dyd, ud)
+        dxd, _ = H.conv_dgrad(g, dyd, wdp, wd_, (Hh, W))
+        scg = float(wantg.abs().max())
+        e_w, e_d = float((nchw(dx).double().cpu() - wantg).abs().max()), float((nchw(dxd).double().cpu() - wantg).abs().max())
+        assert e_w <= 3 * e_d + 1e-6 * scg, (what, "data-gradient", e_w, e_d, scg)
+    # mirrored padding (the decoder's single-source Conv3x3, forward)
+    B, Hh, W, C, Co = 2, 12, 24, 64, 64
+    x = torch.randn(B, C, Hh, W, generator=gen)
+    w = torch.randn(Co, C, 3, 3, generator=gen) * (2.0 / (9 * C)) ** 0.5
+    uf = H.winograd_fused_pack(w.to(device), False)
+    y, _ = H.winograd_fused("conv_fwd", nhwc(x).to(device).contiguous(), uf, reflect=True)
+    want = torch.nn.functional.conv2d(torch.nn.functional.pad(x.double(), (1, 1, 1, 1), mode="reflect"), w.double())
+    assert_close(nchw(y).cpu(), want.float(), rtol=1e-4, atol=3e-6 * float(want.abs().max()), what="fused Winograd, mirrored padding")
+    # autograd glue: Conv2d -> BatchNorm2d and a mirrored Conv2d + bias + ELU through the one-kernel route == the direct route;
+    # a weight_pack_scope(model) transforms the eligible weights in one launch, in the route's own layout
+    from improving_segmentation_with_selfsupervised_depth_amd.models import layers as L
+    old = (H.WINOGRAD_MIN_MACS, H.WINO_FUSED)
+    H.WINOGRAD_MIN_MACS = 0.0
+    try:
+        net = torch.nn.Sequential(L.Conv2d(64, 128, 3, padding=1, bias=False), L.Conv2d(512, 512, 3, padding=1, bias=False),
+                                  L.Conv2d(64, 64, 3, padding=2, dilation=2)).to(device)
+        with L.weight_pack_scope(net):
+            assert net[0]._wino_cache.get("kn") is True and net[1]._wino_cache.get("kn") is False
+            uf1, ud1 = H.winograd_pack(net[0].weight, kn=True)
+            assert torch.equal(net[0]._wino_cache["packs"][0], uf1) and torch.equal(net[0]._wino_cache["packs"][1], ud1)
+            assert not net[2]._wino_cache.get("packs")
+        torch.manual_seed(7)
+        conv, bn = L.Conv2d(C, Co, 3, padding=1, bias=False).to(device), L.BatchNorm2d(Co).to(device)
+        conv2 = L.Conv2d(Co, Co, 3, padding=1, bias=True, reflect=True).to(device)
+        for m in (conv, bn, conv2):
+            m.train()
+        xin = torch.randn(B, Hh, W, C, generator=gen).to(device)
+        res = []
+        for on in (True, False):
+            H.WINO_FUSED = on
+            xi = xin.clone().requires_grad_(True)
+            for m in (conv, bn, conv2):
+                m.zero_grad()
+            n0 = dict(H.WINO_FUSED_TAKEN)
+            with L.weight_pack_scope():
+                yv = conv2(bn(conv(xi), act="relu"), act="elu")
+                (yv * yv).sum().backward()
+            took = (H.WINO_FUSED_TAKEN["fwd"] - n0["fwd"], H.WINO_FUSED_TAKEN["dgrad"] - n0["dgrad"])
+            assert took == ((2, 1) if on else (0, 0)), took      # conv + mirrored conv2 forward, conv's data-gradient
+            res.append((yv.detach(), xi.grad.detach(), conv.weight.grad.detach().clone(), conv2.weight.grad.detach().clone(),
+                        conv2.bias.grad.detach().clone(), bn.weight.grad.detach().clone()))
+        for a, b, what in zip(res[0], res[1], ("output", "input gradient", "weight gradient", "mirrored conv weight gradient",
+                                               "bias gradient", "BatchNorm weight gradient")):
+            assert_close(a, b, rtol=1e-3, atol=1e-4 * float(b.abs().max()), what="fused Winograd vs direct through Conv2d + BatchNorm2d: " + what)
+    finally:
+        H.WINOGRAD_MIN_MACS, H.WINO_FUSED = old

@@ -123,3 +123,8 @@ def test_jitter_blur_properties():
 
 def test_winograd_route():
     KC.run_winograd_cases("cpu")
+
+
+def test_winograd_fused_kernel():
+    KC.run_winograd_fused_cases("cpu")
+

@@ -180,3 +180,8 @@ def test_jitter_blur_properties():
 
 def test_winograd_route():
     KC.run_winograd_cases("cuda")
+
+
+def test_winograd_fused_kernel():
+    KC.run_winograd_fused_cases("cuda")
+
