@@ -56,7 +56,7 @@ _SIGS = {
     "segsde_winograd_fused_ok": (c_int, [c_int, c_int, c_int, c_int, c_int]),
     "segsde_winograd_fused_stats_rows": (ctypes.c_long, [c_int, c_int, c_int]),
     "segsde_winograd_fused_pack": (c_int, [P, c_int, c_int, c_int, P, P]),
-    "segsde_conv2d_winograd_fused": (c_int, [P, c_int, c_int, c_int, c_int, c_int, c_int, P, c_int, P, c_int, P, c_int, P, P]),
+    "segsde_conv2d_winograd_fused": (c_int, [P, c_int, c_int, c_int, c_int, c_int, c_int, P, c_int, P, c_int, P, c_int, c_int, P, P]),
     "segsde_upfold_pack": (c_int, [P, c_int, c_int, c_int, P, P, P]),
     "segsde_conv2d_forward_upfold": (c_int, [POINTER(ConvDesc), P, P, P, P, P, P, P]),
     "segsde_conv2d_dgrad_upfold": (c_int, [POINTER(ConvDesc), P, c_int, P, P, P, P, P, c_int, P, c_int, c_int, P]),

@@ -30,7 +30,7 @@ constexpr size_t F_LDS = (size_t)F_FLOATS * sizeof(float) + 2 * 4 * 64 * sizeof(
 template <bool STATS>
 __global__ __launch_bounds__(256, 2) void wino_fused_kernel(const float* x, int ldx, int B, int H, int W, int C, int reflect,
                                                             const float* U, int Co, const float* bias, int act, float* y, int ldy,
-                                                            double* part) {
+                                                            double* part, int accumulate) {
   SEGSDE_SMEM;
   float* lds = reinterpret_cast<float*>(segsde_smem);
   double* sh = reinterpret_cast<double*>(lds + F_FLOATS);
@@ -170,6 +170,9 @@ __global__ __launch_bounds__(256, 2) void wino_fused_kernel(const float* x, int 
     const int tj = bw * FT_W + q;
     if (ti < H2 && tj < W2) {
       float* yp = y + ((long)(b * H + 2 * ti) * W + 2 * tj) * ldy + co;
+      if (accumulate) {     // a data-gradient added onto the gradient another consumer of the tensor left there
+        o[0] += yp[0]; o[1] += yp[ldy]; o[2] += yp[(long)W * ldy]; o[3] += yp[(long)W * ldy + ldy];
+      }
       yp[0] = o[0]; yp[ldy] = o[1]; yp[(long)W * ldy] = o[2]; yp[(long)W * ldy + ldy] = o[3];
       if (STATS) {
 #pragma unroll
@@ -244,18 +247,20 @@ extern "C" int segsde_winograd_fused_pack(const float* w_oihw, int O, int I, int
 }
 
 extern "C" int segsde_conv2d_winograd_fused(const float* x, int ldx, int B, int H, int W, int C, int reflect, const float* u_kn,
-                                            int Cout, const float* bias, int act, float* y, int ldy, double* stats, void* stream) {
+                                            int Cout, const float* bias, int act, float* y, int ldy, int accumulate, double* stats,
+                                            void* stream) {
   if (!x || !u_kn || !y) return SEGSDE_ERR_NULL;
-  if (!segsde_winograd_fused_ok(B, H, W, C, Cout) || ldx < C || ldx % 4 != 0 || ldy < Cout) return SEGSDE_ERR_UNSUPPORTED;
+  if (!segsde_winograd_fused_ok(B, H, W, C, Cout) || ldx < C || ldx % 4 != 0 || ldy < Cout || (accumulate && (stats || bias || act)))
+    return SEGSDE_ERR_UNSUPPORTED;
   const dim3 grid((unsigned)fused_blocks(B, H, W), (unsigned)(Cout / 64));
   if (stats) {
     auto k = wino_fused_kernel<true>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_LDS);
-    hipLaunchKernelGGL(k, grid, dim3(256), F_LDS, ST(stream), x, ldx, B, H, W, C, reflect, u_kn, Cout, bias, act, y, ldy, stats);
+    hipLaunchKernelGGL(k, grid, dim3(256), F_LDS, ST(stream), x, ldx, B, H, W, C, reflect, u_kn, Cout, bias, act, y, ldy, stats, accumulate);
   } else {
     auto k = wino_fused_kernel<false>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_LDS);
-    hipLaunchKernelGGL(k, grid, dim3(256), F_LDS, ST(stream), x, ldx, B, H, W, C, reflect, u_kn, Cout, bias, act, y, ldy, (double*)nullptr);
+    hipLaunchKernelGGL(k, grid, dim3(256), F_LDS, ST(stream), x, ldx, B, H, W, C, reflect, u_kn, Cout, bias, act, y, ldy, (double*)nullptr, accumulate);
   }
   SEGSDE_CHECK_LAUNCH();
   return 0;

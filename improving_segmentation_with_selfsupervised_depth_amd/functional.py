@@ -207,7 +207,8 @@ class ConvFn(Function):
             dx0 = None
             box = ctx.grad_box
             if box is not None and box.get("g") is not None and x1 is None:
-                dx0, dx1 = H.conv_dgrad(g, dz, wd, weight.detach(), ctx.in_hw, accumulate_into=box["g"], actgrad=actgrad)
+                dx0, dx1 = H.conv_dgrad(g, dz, wd, weight.detach(), ctx.in_hw, accumulate_into=box["g"], actgrad=actgrad,
+                                        wino=None if ctx.wino is None else ctx.wino[1])
                 if dx0 is not None:
                     box["fused"] = True      # dx0 IS the residual-path gradient, now holding the sum
             if dx0 is None:

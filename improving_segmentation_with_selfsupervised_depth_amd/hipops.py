@@ -248,19 +248,25 @@ def winograd_fused_pack(w_oihw, flip):
     return _kn(u)
 
 
-def winograd_fused(kind, x, u_kn, bias=None, act="none", want_stats=False, tag=None, reflect=False):
-    """x [B,H,W,C] NHWC -> act(conv3x3(x) + bias) [B,H,W,N] with u_kn [16][C][N]; (y, statistics partials or None)"""
+def winograd_fused(kind, x, u_kn, bias=None, act="none", want_stats=False, tag=None, reflect=False, accumulate_into=None):
+    """x [B,H,W,C] NHWC -> act(conv3x3(x) + bias) [B,H,W,N] with u_kn [16][C][N]; (y, statistics partials or None).
+    accumulate_into: a dense [B,H,W,N] tensor the result is added onto (and which is returned)"""
     B, H, W, C = x.shape
     N = u_kn.shape[2]
     assert u_kn.shape[1] == C
     L = _lib.lib()
-    y = torch.empty((B, H, W, N), dtype=torch.float32, device=x.device)
+    if accumulate_into is not None:
+        y = accumulate_into
+        if tuple(y.shape) != (B, H, W, N) or not y.is_contiguous() or bias is not None or act != "none" or want_stats:
+            return None
+    else:
+        y = torch.empty((B, H, W, N), dtype=torch.float32, device=x.device)
     part = None
     if want_stats:
         part = torch.empty((int(L.segsde_winograd_fused_stats_rows(B, H, W)), 2, N), dtype=torch.float64, device=x.device)
     flops = 2.0 * B * H * W * C * N * 9
     rc = _timed(kind, flops, x, lambda: L.segsde_conv2d_winograd_fused(_p(_f32(x)), nhwc_ld(x), B, H, W, C, 1 if reflect else 0, _p(u_kn), N, _p(bias),
-                                                                       ACT[act], _p(y), N, _p(part), _stream(x)),
+                                                                       ACT[act], _p(y), N, 1 if accumulate_into is not None else 0, _p(part), _stream(x)),
                 (tag or "%d+0->%d k3 s1 d1 %dx%d" % (C, N, H, W)) + " wino-fused", executed=flops * 16.0 / 36.0)
     if rc == -4:
         return None
@@ -500,8 +506,8 @@ def conv_dgrad(g, dy, wdpack, w_oihw, in_hw, need0=True, need1=True, accumulate_
         ag_ld = nhwc_ld(ag_y)
 
     if isinstance(wino, _KnPack):
-        if (accumulate_into is None and actgrad is None and winograd_fused_ok(g, B, H, W, dgrad=True) and (Ho, Wo) == (H, W)):
-            r = winograd_fused("conv_dgrad", dy, wino, tag=_tag(g, H, W))
+        if actgrad is None and winograd_fused_ok(g, B, H, W, dgrad=True) and (Ho, Wo) == (H, W):
+            r = winograd_fused("conv_dgrad", dy, wino, tag=_tag(g, H, W), accumulate_into=accumulate_into)
             if r is not None:
                 return r[0], None
     elif (wino is not None and accumulate_into is None and actgrad is None and not g.reflect and g.C1 == 0

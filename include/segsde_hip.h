@@ -272,14 +272,15 @@ int segsde_conv2d_wgrad_winograd(const segsde_conv_desc* d, const float* x0, con
  * (models/monodepth_layers.py:127-142, reflect = 1: mirrored padding, forward only) -- 3x3, stride 1, padding 1, one source, H and W
  * even, C % 64 == 0, Cout % 64 == 0.  segsde_winograd_fused_pack: OIHW -> U[16][K][N] with N fastest; flip = 0: the forward pack
  * (K = Cin, N = Cout), flip = 1: the data-gradient pack of the spatially flipped kernel (K = Cout, N = Cin; call the convolution
- * with x = dY, C = Cout, Cout = Cin).  y = act(Y + bias) (bias nullable); stats (nullable):
+ * with x = dY, C = Cout, Cout = Cin).  y = act(Y + bias) (bias nullable), or y += Y (accumulate = 1: no bias / activation /
+ * statistics; the gradient collector of DESIGN.md 3.2f); stats (nullable):
  * [segsde_winograd_fused_stats_rows(B, H, W)][2][Cout] doubles for segsde_bn_stats_from_partials.  SEGSDE_ERR_UNSUPPORTED outside
  * these shapes (segsde_winograd_fused_ok tells beforehand). */
 int segsde_winograd_fused_ok(int B, int H, int W, int C, int Cout);
 long segsde_winograd_fused_stats_rows(int B, int H, int W);
 int segsde_winograd_fused_pack(const float* w_oihw, int Cout, int Cin, int flip, float* u_kn, void* stream);
 int segsde_conv2d_winograd_fused(const float* x, int ldx, int B, int H, int W, int C, int reflect, const float* u_kn, int Cout,
-                                 const float* bias, int act, float* y, int ldy, double* stats, void* stream);
+                                 const float* bias, int act, float* y, int ldy, int accumulate, double* stats, void* stream);
 
 /* ------------------------------------------------------------------------------------------------ *
  * Pose: axis-angle + translation -> 4x4 (models/monodepth_layers.py:30-105)                         *

@@ -1397,6 +1397,11 @@ def run_winograd_fused_cases(device, shapes=((1, 8, 16, 64, 64), (2, 12, 20, 64,
         scg = float(wantg.abs().max())
         e_w, e_d = float((nchw(dx).double().cpu() - wantg).abs().max()), float((nchw(dxd).double().cpu() - wantg).abs().max())
         assert e_w <= 3 * e_d + 1e-6 * scg, (what, "data-gradient", e_w, e_d, scg)
+        base = torch.randn(B, Hh, W, C, generator=gen).to(device)
+        acc = base.clone()
+        r = H.winograd_fused("conv_dgrad", dyd, ud, accumulate_into=acc)
+        assert r is not None and r[0] is acc
+        assert_close(acc, base + dx, rtol=1e-6, atol=1e-6 * scg, what=what + " accumulate")
     # mirrored padding (the decoder's single-source Conv3x3, forward)
     B, Hh, W, C, Co = 2, 12, 24, 64, 64
     x = torch.randn(B, C, Hh, W, generator=gen)
