@@ -650,13 +650,21 @@ def main():
                                 "executed_frac")
             # the same split by route: the direct implicit-GEMM launches (what the matrix pipe's utilisation figure is about) and
             # the Winograd calls, whose time includes their HBM-side transforms while `executed` counts the position GEMMs only
-            wl = [v for (kind, tag), v in layers.items() if kind in ("conv_fwd", "conv_dgrad") and tag.endswith(" wino")]
+            wl = [v for (kind, tag), v in layers.items() if kind in ("conv_fwd", "conv_dgrad") and (tag.endswith(" wino") or tag.endswith(" wino-fused"))]
+            wfl = [v for (kind, tag), v in layers.items() if kind in ("conv_fwd", "conv_dgrad") and tag.endswith(" wino-fused")]
+            if wfl:
+                ff, ft, fn_, fx = (sum(v[i] for v in wfl) for i in range(4))
+                roof["winograd_fused"] = {"kernel": "wino_fused_kernel (both transforms inside the kernel, 64..256 channels)",
+                                          "launches": fn_, "ms_per_step": ft / args.steps * 1e3, "achieved": ff / ft / 1e12,
+                                          "executed_achieved": fx / ft / 1e12,
+                                          "executed_frac": fx / ft / 1e12 / PEAK_FP32_MATRIX_TFLOPS, "share_of_step": ft / dt}
             if wl:
                 wf, wt, wn, wx = (sum(v[i] for v in wl) for i in range(4))
                 roof["winograd"] = {"launches": wn, "ms_per_step": wt / args.steps * 1e3, "achieved": wf / wt / 1e12,
                                     "executed_achieved": wx / wt / 1e12, "share_of_step": wt / dt,
-                                    "note": "one launch = input transform + 16 position GEMMs + output transform; executed = the GEMMs' "
-                                            "multiply-adds (16/36 of the algorithmic ones) over the whole call's time"}
+                                    "note": "both Winograd routes (grouped: one call = input transform + 16 position GEMMs + output "
+                                            "transform; one-kernel: see winograd_fused); executed = 16/36 of the algorithmic "
+                                            "multiply-adds over the whole call's time"}
                 roof["direct"] = {"launches": nl - wn, "achieved": (fl - wf) / (tt - wt) / 1e12,
                                   "executed_achieved": (ex - wx) / (tt - wt) / 1e12,
                                   "executed_frac": (ex - wx) / (tt - wt) / 1e12 / PEAK_FP32_MATRIX_TFLOPS}

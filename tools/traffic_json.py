@@ -25,7 +25,8 @@ def main():
     groups = {"conv_igemm_kernel (forward + data-gradient, all tile shapes / modes)": "conv_igemm_kernel",
               "conv_wgrad_kernel": "conv_wgrad_kernel", "bn_bwd_apply_kernel": "bn_bwd_apply_kernel",
               "bn_apply_kernel": "bn_apply_kernel", "colreduce_kernel<BnBwdOp": "colreduce_kernel<BnBwdOp",
-              "photometric_bwd_kernel": "photometric_bwd_kernel", "photometric_fwd_kernel": "photometric_fwd_kernel",
+              "photometric_bwd_kernel": "photometric_bwd2_kernel", "photometric_fwd_kernel": "photometric_fwd2_kernel",
+              "wino_fused_kernel (one-kernel Winograd convolution)": "wino_fused_kernel",
               "wino_in_kernel (Winograd input transform)": "wino_in_kernel", "wino_out_kernel (Winograd output transform)": "wino_out_kernel",
               "wino_grad_kernel (Winograd output-gradient transform)": "wino_grad_kernel"}
     res = {"command": "rocprofv3 --kernel-trace --pmc <FETCH_SIZE | WRITE_SIZE> -- python bench.py --steps 2 --warmup 1 "
