@@ -28,6 +28,9 @@ __device__ __forceinline__ float4 segsde_buffer_load4(segsde_rsrc r, unsigned vo
   const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
   return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
+__device__ __forceinline__ float segsde_buffer_load1(segsde_rsrc r, unsigned voff, unsigned soff) {
+  return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
 __device__ __forceinline__ void segsde_buffer_store4(segsde_rsrc r, unsigned voff, unsigned soff, float4 v) {
   typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
   u32x4_t d;

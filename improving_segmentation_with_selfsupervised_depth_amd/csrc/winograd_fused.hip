@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256, 2) void wino_fused_kernel(const float* x, int 
   // rows of the patch that transform row `wave` combines: B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]
   const int a1 = wave == 0 ? 0 : (wave == 2 ? 2 : 1);
   const int a2 = wave == 0 ? 2 : (wave == 1 ? 2 : (wave == 2 ? 1 : 3));
-  const bool plus = wave == 1;
+  const float sgn = wave == 1 ? 1.f : -1.f;
   const float* pl = lds + kk * FPS + (2 * th) * FP_W + 2 * tw;
   const int o1 = a1 * FP_W, o2 = a2 * FP_W;
 
@@ -88,17 +88,26 @@ __global__ __launch_bounds__(256, 2) void wino_fused_kernel(const float* x, int 
       }
     }
     __syncthreads();
-    // U[p][c][n]: this lane's column n = co0 + nb * 32 + t of channel c0 + 2 s + kk, positions 4 wave + j
-    const float* up = U + ((long)(4 * wave) * C + c0 + kk) * Co + co0 + t;
-    const long upos = (long)C * Co;
+    // U[p][c][n]: this lane's column n = co0 + nb * 32 + t of channel c0 + 2 s + kk, positions 4 wave + j.  The address is
+    // split into a wave-uniform part (scalar registers, scalar adds) and the lane's constant 32-bit offset: the eight requests
+    // of a step cost no vector instructions (with per-lane 64-bit pointers they were two thirds of the loop's VALU work, and
+    // VALU issue slots are MFMA issue slots)
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const segsde_rsrc ur = segsde_make_rsrc(U);
+    const unsigned lane_off = (unsigned)(kk * Co + t) * 4u;                          // bytes
+    const unsigned ubase = (unsigned)((((long)(4 * wave_u) * C + c0) * Co + co0) * 4);   // bytes; 16 C Cout floats < 2^30
+    const unsigned upos = (unsigned)((long)C * Co * 4), ustep = (unsigned)(2 * Co * 4);
     // B operands come straight from L2 (a few hundred ns): requested PD steps (PD x 512 MFMA cycles) ahead; the raw pixels
     // (LDS) one step ahead
     constexpr int PD = 4, NS = FCH / 2;
     float bv[PD][8], rv[2][8];
     auto fetch_b = [&](int s, int q) {
-      const float* us = up + (long)(2 * s) * Co;
+      const unsigned so = ubase + (unsigned)s * ustep;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) { bv[q][2 * j] = us[j * upos]; bv[q][2 * j + 1] = us[j * upos + 32]; }
+      for (int j = 0; j < 4; ++j) {
+        bv[q][2 * j] = segsde_buffer_load1(ur, lane_off, so + j * upos);
+        bv[q][2 * j + 1] = segsde_buffer_load1(ur, lane_off, so + j * upos + 128u);
+      }
     };
     auto fetch_a = [&](int s, int q) {
       const float* src = pl + (2 * s) * FPS;
@@ -117,7 +126,7 @@ __global__ __launch_bounds__(256, 2) void wino_fused_kernel(const float* x, int 
       __builtin_amdgcn_sched_barrier(0);               // the scheduler otherwise sinks the requests to one step before their use
       float ev[4];
 #pragma unroll
-      for (int bb = 0; bb < 4; ++bb) ev[bb] = plus ? rv[q][bb] + rv[q][4 + bb] : rv[q][bb] - rv[q][4 + bb];
+      for (int bb = 0; bb < 4; ++bb) ev[bb] = __builtin_fmaf(rv[q][4 + bb], sgn, rv[q][bb]);   // r1 +- r2, exact: one issue slot
       const float A0 = ev[0] - ev[2], A1 = ev[1] + ev[2], A2 = ev[2] - ev[1], A3 = ev[1] - ev[3];
       acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A0, bv[qb][0], acc[0][0], 0, 0, 0);
       acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A0, bv[qb][1], acc[0][1], 0, 0, 0);

@@ -212,6 +212,12 @@ inline float4 segsde_buffer_load4(segsde_rsrc r, unsigned voff, unsigned soff) {
   memcpy(&v, r.base + (size_t)voff + soff, sizeof(v));
   return v;
 }
+inline float segsde_buffer_load1(segsde_rsrc r, unsigned voff, unsigned soff) {
+  if (voff >= r.n) return 0.f;
+  float v;
+  memcpy(&v, r.base + (size_t)voff + soff, sizeof(v));
+  return v;
+}
 inline void segsde_buffer_store4(segsde_rsrc r, unsigned voff, unsigned soff, float4 v) {
   if (voff >= r.n) return;
   memcpy(const_cast<char*>(r.base) + (size_t)voff + soff, &v, sizeof(v));
