@@ -126,6 +126,9 @@ _SIGS = {
     "segsde_ssim_map_backward": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P, P, P]),
     "segsde_backproject_depth": (c_int, [P, P, c_int, c_int, c_int, P, P]),
     "segsde_project3d": (c_int, [P, P, P, c_int, c_int, c_int, c_float, P, P]),
+    "segsde_backproject_depth_backward": (c_int, [P, P, c_int, c_int, c_int, P, P]),
+    "segsde_project3d_backward_workspace": (c_size_t, [c_int, c_int, c_int]),
+    "segsde_project3d_backward": (c_int, [P, P, P, P, c_int, c_int, c_int, c_float, P, P, P, c_size_t, P]),
     "segsde_cross_entropy_workspace": (c_size_t, [c_long]),
     "segsde_cross_entropy_forward": (c_int, [P, c_int, c_long, c_int, P, c_int64, P, P, P, P, c_size_t, P]),
     "segsde_cross_entropy_backward": (c_int, [P, c_int, c_long, c_int, P, c_int64, P, P, P, P, c_int, P]),

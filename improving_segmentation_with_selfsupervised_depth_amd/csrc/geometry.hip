@@ -117,6 +117,81 @@ __global__ __launch_bounds__(256) void project3d_kernel(const float* pts, const 
   out[((long)b * HW + n) * 2 + 1] = (cam[1] / den / (float)(H - 1) - 0.5f) * 2.f;
 }
 
+
+// adjoint of backproject_kernel w.r.t. the depth: d depth[p] = sum_r g[r][p] * (inv_K[r][:3] . (u, v, 1))
+__global__ __launch_bounds__(256) void backproject_bwd_kernel(const float* g, const float* inv_K, int H, int W, float* gdepth) {
+  const int b = blockIdx.y;
+  const long HW = (long)H * W, n = blockIdx.x * 256L + threadIdx.x;
+  if (n >= HW) return;
+  const float* k = inv_K + b * 16;
+  const float px = (float)(n % W), py = (float)(n / W);
+  const float* gp = g + (long)b * 4 * HW;
+  float a = 0.f;
+  for (int r = 0; r < 3; ++r) a += gp[r * HW + n] * (k[4 * r] * px + k[4 * r + 1] * py + k[4 * r + 2]);
+  gdepth[b * HW + n] = a;
+}
+
+// adjoint of project3d_kernel: d points [B,4,HW] (nullable) and, per block, the twelve partial sums of d P = d cam . points^T
+// (doubles, part[b][block][12]); project3d_bwd_finalize_kernel folds them in block order and applies K^T: d T = K[:3,:]^T d P
+__global__ __launch_bounds__(256) void project3d_bwd_kernel(const float* pts, const float* K, const float* T, const float* gout,
+                                                            int H, int W, float eps, float* gpts, double* part) {
+  SEGSDE_SMEM;
+  double* sh = reinterpret_cast<double*>(segsde_smem);
+  const int b = blockIdx.y;
+  const long HW = (long)H * W, n = blockIdx.x * 256L + threadIdx.x;
+  float P[12];
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 4; ++c) {
+      float a = 0.f;
+      for (int j = 0; j < 4; ++j) a += K[b * 16 + 4 * r + j] * T[b * 16 + 4 * j + c];
+      P[4 * r + c] = a;
+    }
+  float dc[3] = {0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
+  if (n < HW) {
+    const float* qp = pts + (long)b * 4 * HW;
+    for (int j = 0; j < 4; ++j) q[j] = qp[j * HW + n];
+    float cam[3];
+    for (int r = 0; r < 3; ++r) {
+      float a = 0.f;
+      for (int j = 0; j < 4; ++j) a += P[4 * r + j] * q[j];
+      cam[r] = a;
+    }
+    const float den = cam[2] + eps;
+    const float gx = gout[((long)b * HW + n) * 2] * 2.f / (float)(W - 1), gy = gout[((long)b * HW + n) * 2 + 1] * 2.f / (float)(H - 1);
+    dc[0] = gx / den; dc[1] = gy / den;
+    dc[2] = -(gx * cam[0] + gy * cam[1]) / (den * den);
+    if (gpts) {
+      float* o = gpts + (long)b * 4 * HW;
+      for (int j = 0; j < 4; ++j) o[j * HW + n] = P[j] * dc[0] + P[4 + j] * dc[1] + P[8 + j] * dc[2];
+    }
+  }
+  if (part) {
+    for (int r = 0; r < 3; ++r)
+      for (int j = 0; j < 4; ++j) {
+        const double s = segsde_block_sum((double)dc[r] * (double)q[j], sh);
+        if (threadIdx.x == 0) part[((long)b * gridDim.x + blockIdx.x) * 12 + 4 * r + j] = s;
+      }
+  }
+}
+
+__global__ __launch_bounds__(64) void project3d_bwd_finalize_kernel(const double* part, const float* K, int nblk, float* gT) {
+  const int b = blockIdx.x, e = threadIdx.x;
+  SEGSDE_SMEM;
+  double* dP = reinterpret_cast<double*>(segsde_smem);
+  if (e < 12) {
+    double a = 0.0;
+    for (int i = 0; i < nblk; ++i) a += part[((long)b * nblk + i) * 12 + e];
+    dP[e] = a;
+  }
+  __syncthreads();
+  if (e < 16) {                                            // d T[k][c] = sum_r K[r][k] d P[r][c], r < 3
+    const int k = e >> 2, c = e & 3;
+    double a = 0.0;
+    for (int r = 0; r < 3; ++r) a += (double)K[b * 16 + 4 * r + k] * dP[4 * r + c];
+    gT[b * 16 + e] = (float)a;
+  }
+}
+
 }  // namespace
 
 #define ST(s) static_cast<hipStream_t>(s)
@@ -157,5 +232,37 @@ extern "C" int segsde_project3d(const float* points, const float* K, const float
   hipLaunchKernelGGL(project3d_kernel, dim3(segsde_cdiv((long)H * W, 256), B), dim3(256), 0, ST(stream), points, K, T, H, W, eps,
                      pix_coords);
   SEGSDE_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int segsde_backproject_depth_backward(const float* g_cam_points, const float* inv_K, int B, int H, int W, float* g_depth,
+                                                 void* stream) {
+  if (!g_cam_points || !inv_K || !g_depth) return SEGSDE_ERR_NULL;
+  if (B <= 0 || H <= 0 || W <= 0) return SEGSDE_ERR_SHAPE;
+  hipLaunchKernelGGL(backproject_bwd_kernel, dim3(segsde_cdiv((long)H * W, 256), B), dim3(256), 0, ST(stream), g_cam_points, inv_K,
+                     H, W, g_depth);
+  SEGSDE_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" size_t segsde_project3d_backward_workspace(int B, int H, int W) {
+  if (B <= 0 || H < 2 || W < 2) return 0;
+  return (size_t)B * segsde_cdiv((long)H * W, 256) * 12 * sizeof(double);
+}
+
+extern "C" int segsde_project3d_backward(const float* points, const float* K, const float* T, const float* g_pix, int B, int H, int W,
+                                         float eps, float* g_points, float* g_T, void* workspace, size_t workspace_bytes,
+                                         void* stream) {
+  if (!points || !K || !T || !g_pix || (!g_points && !g_T)) return SEGSDE_ERR_NULL;
+  if (B <= 0 || H < 2 || W < 2) return SEGSDE_ERR_SHAPE;
+  if (g_T && (!workspace || workspace_bytes < segsde_project3d_backward_workspace(B, H, W))) return SEGSDE_ERR_WORKSPACE;
+  const int nblk = segsde_cdiv((long)H * W, 256);
+  double* part = g_T ? static_cast<double*>(workspace) : nullptr;
+  hipLaunchKernelGGL(project3d_bwd_kernel, dim3(nblk, B), dim3(256), 4 * sizeof(double), ST(stream), points, K, T, g_pix, H, W, eps, g_points, part);
+  SEGSDE_CHECK_LAUNCH();
+  if (g_T) {
+    hipLaunchKernelGGL(project3d_bwd_finalize_kernel, dim3(B), dim3(64), 12 * sizeof(double), ST(stream), part, K, nblk, g_T);
+    SEGSDE_CHECK_LAUNCH();
+  }
   return 0;
 }

@@ -1172,6 +1172,29 @@ def project3d(points, K, T, Hh, W, eps=1e-7):
     return out
 
 
+def backproject_depth_backward(g_cam, inv_K, Hh, W):
+    """adjoint of backproject_depth w.r.t. the depth: g_cam [B,4,H*W] -> [B,1,H,W]"""
+    B = g_cam.shape[0]
+    out = torch.empty((B, 1, Hh, W), dtype=torch.float32, device=g_cam.device)
+    check(_lib.lib().segsde_backproject_depth_backward(_p(_f32(g_cam.contiguous())), _p(_f32(inv_K.contiguous())), B, Hh, W, _p(out),
+                                                       _stream(g_cam)), "backproject_depth_backward")
+    return out
+
+
+def project3d_backward(points, K, T, g_pix, Hh, W, eps=1e-7, need_points=True, need_T=True):
+    """adjoint of project3d: g_pix [B,H,W,2] -> (d points [B,4,H*W] or None, d T [B,4,4] or None)"""
+    B = points.shape[0]
+    L = _lib.lib()
+    gp = torch.empty_like(points, memory_format=torch.contiguous_format) if need_points else None
+    gT = torch.empty((B, 4, 4), dtype=torch.float32, device=points.device) if need_T else None
+    nbytes = L.segsde_project3d_backward_workspace(B, Hh, W) if need_T else 0
+    ws = _ws(nbytes, points) if need_T else None
+    check(L.segsde_project3d_backward(_p(_f32(points.contiguous())), _p(_f32(K.contiguous())), _p(_f32(T.contiguous())),
+                                      _p(_f32(g_pix.contiguous())), B, Hh, W, float(eps), _p(gp), _p(gT), _p(ws), nbytes,
+                                      _stream(points)), "project3d_backward")
+    return gp, gT
+
+
 # ----------------------------------------------------------------------------------------------
 # segmentation loss, mix, masks
 # ----------------------------------------------------------------------------------------------

@@ -73,8 +73,8 @@ class ConvBlock(nn.Module):
 # The remaining public names of the reference module (monodepth_layers.py:48-105, 145-254).  Only the reference's own
 # loss/monodepth_loss.py imports them; this package's MonodepthLoss runs the same arithmetic inside its fused kernels.  They are
 # kept as thin callables on device kernels so that a user script importing them by name still works (NCHW tensors in and
-# out, like the reference).  SSIM and get_smooth_loss are differentiable; BackprojectDepth / Project3D return detached
-# tensors (gradients through the warp are what MonodepthLoss.compute_losses provides).
+# out, like the reference).  All four are differentiable like the reference's (BackprojectDepth w.r.t. the depth, Project3D
+# w.r.t. the points and the pose; the intrinsics are data and raise if they ask for a gradient).
 # ----------------------------------------------------------------------------------------------------------------------
 def get_translation_matrix(translation_vector):
     """reference :50-63: [B,1,1,3] / [B,3] translation -> [B,4,4]"""
@@ -88,26 +88,72 @@ def rot_from_axisangle(vec):
     return Fn.PoseMatrixFn.apply(v, torch.zeros_like(v), False)
 
 
+def _intrinsics_are_data(*ts):
+    if torch.is_grad_enabled() and any(t.requires_grad for t in ts):
+        raise NotImplementedError("the camera intrinsics are data here: no gradient is implemented for K / inv_K "
+                                  "(the reference never trains them: loader/sequence_segmentation_loader.py:278-290)")
+
+
+class _BackprojectFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, depth, inv_K):
+        ctx.hw = (depth.shape[2], depth.shape[3])
+        ctx.save_for_backward(inv_K)
+        return H.backproject_depth(depth, inv_K)
+
+    @staticmethod
+    def backward(ctx, g):
+        (inv_K,) = ctx.saved_tensors
+        return H.backproject_depth_backward(g, inv_K, *ctx.hw), None
+
+
 class BackprojectDepth(nn.Module):
-    """reference :145-174: depth image -> homogeneous camera points [B,4,H*W]"""
+    """reference :145-174: depth image -> homogeneous camera points [B,4,H*W]; differentiable w.r.t. the depth like the
+    reference's torch code.  The reference registers its pixel grid as three frozen parameters (:156-167); they are kept (same
+    names, shapes and values) so that a ``state_dict`` of a module that owns this layer has the same keys -- the kernel derives
+    the pixel coordinates from the index and never reads them."""
 
     def __init__(self, batch_size, height, width):
         super().__init__()
         self.batch_size, self.height, self.width = batch_size, height, width
+        ys, xs = torch.meshgrid(torch.arange(height, dtype=torch.float32), torch.arange(width, dtype=torch.float32), indexing="ij")
+        self.id_coords = nn.Parameter(torch.stack([xs, ys], 0), requires_grad=False)
+        self.ones = nn.Parameter(torch.ones(batch_size, 1, height * width), requires_grad=False)
+        pix = torch.stack([xs.reshape(-1), ys.reshape(-1)], 0).unsqueeze(0).repeat(batch_size, 1, 1)
+        self.pix_coords = nn.Parameter(torch.cat([pix, self.ones], 1), requires_grad=False)
 
     def forward(self, depth, inv_K):
-        return H.backproject_depth(depth.detach().reshape(self.batch_size, 1, self.height, self.width), inv_K.detach())
+        _intrinsics_are_data(inv_K)
+        return _BackprojectFn.apply(depth.float().reshape(self.batch_size, 1, self.height, self.width).contiguous(),
+                                    inv_K.detach().float())
+
+
+class _Project3DFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, points, K, T, height, width, eps):
+        ctx.cfg = (height, width, eps)
+        ctx.save_for_backward(points, K, T)
+        return H.project3d(points, K, T, height, width, eps)
+
+    @staticmethod
+    def backward(ctx, g):
+        points, K, T = ctx.saved_tensors
+        gp, gT = H.project3d_backward(points, K, T, g, *ctx.cfg, need_points=ctx.needs_input_grad[0], need_T=ctx.needs_input_grad[2])
+        return gp, None, gT, None, None, None
 
 
 class Project3D(nn.Module):
-    """reference :177-199: camera points -> normalised sampling grid [B,H,W,2] for intrinsics K at pose T"""
+    """reference :177-199: camera points -> normalised sampling grid [B,H,W,2] for intrinsics K at pose T; differentiable
+    w.r.t. the points (-> depth) and T (-> pose network) like the reference's torch code"""
 
     def __init__(self, batch_size, height, width, eps=1e-7):
         super().__init__()
         self.batch_size, self.height, self.width, self.eps = batch_size, height, width, eps
 
     def forward(self, points, K, T):
-        return H.project3d(points.detach(), K.detach(), T.detach(), self.height, self.width, self.eps)
+        _intrinsics_are_data(K)
+        return _Project3DFn.apply(points.float().contiguous(), K.detach().float(), T.float().contiguous(), self.height, self.width,
+                                  self.eps)
 
 
 class _UpsampleFn(torch.autograd.Function):

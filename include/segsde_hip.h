@@ -346,6 +346,15 @@ int segsde_ssim_map_backward(const float* x, const float* y, const float* gout, 
 int segsde_backproject_depth(const float* depth, const float* inv_K, int B, int H, int W, float* cam_points, void* stream);
 int segsde_project3d(const float* points, const float* K, const float* T, int B, int H, int W, float eps, float* pix_coords,
                      void* stream);
+/* Their adjoints (the reference layers are plain differentiable torch code, :169-174 / :188-199; the photometric gradient
+ * reaches the depth through BackprojectDepth and the pose through Project3D): d depth [B,H*W] from d cam_points [B,4,H*W];
+ * d points [B,4,H*W] (nullable) and d T [B,4,4] (nullable; needs the workspace: per-block partial sums in double, folded in
+ * block order) from d pix_coords [B,H,W,2].  The intrinsics are data: no gradient for K / inv_K. */
+int segsde_backproject_depth_backward(const float* g_cam_points, const float* inv_K, int B, int H, int W, float* g_depth,
+                                      void* stream);
+size_t segsde_project3d_backward_workspace(int B, int H, int W);
+int segsde_project3d_backward(const float* points, const float* K, const float* T, const float* g_pix, int B, int H, int W,
+                              float eps, float* g_points, float* g_T, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------ *
  * Segmentation loss and DepthMix / ClassMix (loss/loss.py:17-37, loader/transformsgpu.py:33-47,     *

@@ -67,8 +67,11 @@ def np_(t):
     return t.detach().cpu().numpy()
 
 
+OUT_DIR = [HERE]        # --check redirects the generators into a scratch directory
+
+
 def save(name, d):
-    path = os.path.join(HERE, name + ".npz")
+    path = os.path.join(OUT_DIR[0], name + ".npz")
     np.savez_compressed(path, **{k: (np_(v) if torch.is_tensor(v) else np.asarray(v)) for k, v in d.items()})
     print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024))
 
@@ -488,7 +491,7 @@ def gen_nets():
         print(name, len(contract[name]), "state_dict entries,",
               sum(p.numel() for p in m.parameters()) / 1e6, "M params")
         del m
-    with open(os.path.join(HERE, "state_dict_contract.json"), "w") as f:
+    with open(os.path.join(OUT_DIR[0], "state_dict_contract.json"), "w") as f:
         json.dump({"cfgs": cfgs, "contract": contract}, f)
     d = {}
     for name in ("r18_mono", "r18_jsd"):
@@ -632,7 +635,7 @@ def gen_trainer():
     d.update(cm_logits=logits, cm_gt=gt, cm_pred=pred, cm_matrix=rs.confusion_matrix,
              cm_scores=np.array([sc["Overall Acc: \t"], sc["Mean Acc : \t"], sc["FreqW Acc : \t"], sc["Mean IoU : \t"]]),
              cm_cls_iu=np.array([cls_iu[i] for i in range(n)]))
-    save("trainer", "usegt", d)
+    save("trainer", d)
 
 
 def gen_usegt():
@@ -766,8 +769,47 @@ def gen_valtail():
     save("valtail", d)
 
 
+ALL = ["loss", "geom", "ssim_smooth", "segmix", "blocks", "decoders", "encoder", "nets", "trainer", "usegt", "valtail", "poseall"]
+
+
+def check(which):
+    """Regenerate ``which`` into a scratch directory and compare every array with the committed file of the same name, bit for
+    bit (dtype, shape, bytes).  Returns the number of mismatching / missing arrays; prints one line per file."""
+    import tempfile
+    bad = 0
+    with tempfile.TemporaryDirectory() as tmp:
+        OUT_DIR[0] = tmp
+        try:
+            for w in which:
+                globals()["gen_" + w]()
+        finally:
+            OUT_DIR[0] = HERE
+        for fn in sorted(os.listdir(tmp)):
+            ref_path = os.path.join(HERE, fn)
+            if fn.endswith(".json"):
+                same = os.path.exists(ref_path) and json.load(open(ref_path)) == json.load(open(os.path.join(tmp, fn)))
+                print("CHECK %-32s %s" % (fn, "identical" if same else "DIFFERS"))
+                bad += 0 if same else 1
+                continue
+            new = np.load(os.path.join(tmp, fn), allow_pickle=False)
+            if not os.path.exists(ref_path):
+                print("CHECK %-32s no committed file" % fn)
+                bad += len(new.files)
+                continue
+            old = np.load(ref_path, allow_pickle=False)
+            diff = [k for k in sorted(set(new.files) | set(old.files))
+                    if k not in new.files or k not in old.files or new[k].dtype != old[k].dtype
+                    or new[k].shape != old[k].shape or new[k].tobytes() != old[k].tobytes()]
+            print("CHECK %-32s %4d arrays, %d differ%s" % (fn, len(new.files), len(diff), (": " + ", ".join(diff[:6])) if diff else ""))
+            bad += len(diff)
+    return bad
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["loss", "geom", "ssim_smooth", "segmix", "blocks", "decoders", "encoder", "nets", "trainer",
-                             "usegt", "valtail", "poseall"]
-    for w in which:
+    args = sys.argv[1:]
+    if args and args[0] == "--check":
+        n = check(args[1:] or ALL)
+        print("make_golden --check:", "OK" if n == 0 else "%d arrays differ from the committed fixtures" % n)
+        sys.exit(1 if n else 0)
+    for w in args or ALL:
         globals()["gen_" + w]()

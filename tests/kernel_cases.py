@@ -1128,6 +1128,27 @@ def run_monodepth_layer_callables(device, golden):
     assert_close(cam, q["cam_points"], rtol=1e-5, atol=1e-6, what="BackprojectDepth")
     grid = ML.Project3D(B, Hh, W)(d(q["cam_points"]), d(q["K"]), d(q["T"]))
     assert_close(grid, q["grid"], rtol=1e-4, atol=1e-5, what="Project3D")
+    # the two layers are differentiable like the reference's torch code: depth -> points -> grid, gradients w.r.t. the
+    # depth and the pose against the oracle's restatement under torch autograd (float64)
+    from oracle import geometry as OG
+    bp, pj = ML.BackprojectDepth(B, Hh, W), ML.Project3D(B, Hh, W)
+    assert sorted(k for k, _ in bp.named_parameters()) == ["id_coords", "ones", "pix_coords"]
+    assert tuple(bp.pix_coords.shape) == (B, 3, Hh * W) and not bp.pix_coords.requires_grad
+    gen0 = torch.Generator().manual_seed(11)
+    wgt0 = torch.randn(B, Hh, W, 2, generator=gen0)
+    dep = d(q["depth"]).clone().requires_grad_(True)
+    Tm = d(q["T"]).clone().requires_grad_(True)
+    (pj(bp(dep, d(q["inv_K"])), d(q["K"]), Tm) * d(wgt0)).sum().backward()
+    dep_o = q["depth"].double().clone().requires_grad_(True)
+    T_o = q["T"].double().clone().requires_grad_(True)
+    (OG.project(OG.backproject(dep_o, q["inv_K"].double()), q["K"].double(), T_o, Hh, W) * wgt0.double()).sum().backward()
+    assert_close(dep.grad, dep_o.grad.float(), rtol=2e-4, atol=1e-6 * float(dep_o.grad.abs().max()), what="d grid / d depth")
+    assert_close(Tm.grad[:, :3], T_o.grad.float()[:, :3], rtol=2e-4, atol=1e-5 * float(T_o.grad.abs().max()), what="d grid / d T")
+    try:
+        pj(bp(dep, d(q["inv_K"])), d(q["K"]).clone().requires_grad_(True), Tm)
+        raise AssertionError("a gradient for the intrinsics must be refused, not dropped")
+    except NotImplementedError:
+        pass
     R = ML.rot_from_axisangle(d(q["axisangle"]))
     T = ML.get_translation_matrix(d(q["translation"]))
     assert_close(torch.matmul(T.cpu(), R.cpu()), q["M_fwd"], rtol=1e-5, atol=1e-6, what="T @ R == transformation_from_parameters")

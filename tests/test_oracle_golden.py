@@ -475,6 +475,18 @@ def test_mix_use_gt_vs_reference(golden):
     torch.testing.assert_close(w.grad, g["grad_weight"], rtol=1e-5, atol=1e-8)
 
 
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="the reference tree exists in the build container only")
+def test_fixture_recipe_regenerates_committed_files():
+    """tests/golden/make_golden.py --check: the committed generator, run against the imported reference, reproduces the
+    committed fixtures bit for bit (the recipe had rotted unnoticed because nothing ran it).  The cheap generators
+    run here; ``python tests/golden/make_golden.py --check`` runs all of them."""
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), "golden", "make_golden.py"), "--check",
+                        "geom", "ssim_smooth", "segmix", "trainer", "usegt", "poseall"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "make_golden --check: OK" in r.stdout
+
+
 def test_trainstep_fixture_and_param_groups():
     """tests/golden/trainstep.npz (the reference's own ``Trainer.train_step``, tests/golden/make_trainstep.py): the fixture is
     complete, and the package's ``get_train_params`` (train.py:67-101) forms the same parameter groups over ``model.models``
