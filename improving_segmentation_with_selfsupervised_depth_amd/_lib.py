@@ -57,6 +57,13 @@ _SIGS = {
     "segsde_winograd_fused_stats_rows": (ctypes.c_long, [c_int, c_int, c_int]),
     "segsde_winograd_fused_pack": (c_int, [P, c_int, c_int, c_int, P, P]),
     "segsde_conv2d_winograd_fused": (c_int, [P, c_int, c_int, c_int, c_int, c_int, c_int, P, c_int, P, c_int, P, c_int, c_int, P, P]),
+    "segsde_conv2d_winograd_fused2": (c_int, [P, c_int, c_int, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, P, c_int, P, c_int, P,
+                                              c_int, P, P]),
+    "segsde_conv2d_winograd_fused_dgrad": (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, c_int, P, c_int, c_int, P, c_int, c_int, P]),
+    "segsde_reflect_adjoint_borders": (c_int, [P, P, P, P, P, c_int, c_int, P]),
+    "segsde_reflect_adjoint_borders_ok": (c_int, [P, c_int]),
+    "segsde_conv2d_wgrad_winograd_fused_workspace": (c_size_t, [P]),
+    "segsde_conv2d_wgrad_winograd_fused": (c_int, [P, P, P, P, c_int, P, P, c_size_t, P]),
     "segsde_upfold_pack": (c_int, [P, c_int, c_int, c_int, P, P, P]),
     "segsde_conv2d_forward_upfold": (c_int, [POINTER(ConvDesc), P, P, P, P, P, P, P]),
     "segsde_conv2d_dgrad_upfold": (c_int, [POINTER(ConvDesc), P, c_int, P, P, P, P, P, c_int, P, c_int, c_int, P]),

@@ -2020,7 +2020,7 @@ __global__ __launch_bounds__(256) void adjoint_corner_kernel(const float* dy, in
 // construction as the clamp adjoint of the upsample-folded route.  (The in-kernel variant, MODE 3, runs the one wave per tile
 // that owns a border pixel on a register-staged loop with extra loads; every chunk ends in a barrier, so that wave set the
 // pace of half the tiles of a 512-pixel-wide image: 108-135 TFLOP/s against 139-145 for the forward of the same layers.)
-int launch_adjoint_by_borders(const ConvP& p, hipStream_t s) {
+int launch_adjoint_by_borders(const ConvP& p, hipStream_t s, bool with_main = true) {
   ConvP q = p;
   q.pad_mode = SEGSDE_PAD_ZERO;
   ConvP bl[4];
@@ -2045,7 +2045,8 @@ int launch_adjoint_by_borders(const ConvP& p, hipStream_t s) {
     if (!igemm_fast_ok(b) || !b.vecout) return SEGSDE_ERR_UNSUPPORTED;
     bl[k] = b;
   }
-  if (int e = launch_by_n(q, s)) return e;
+  if (with_main)
+    if (int e = launch_by_n(q, s)) return e;
   for (int k = 0; k < 4; ++k)
     if (int e = launch_by_n(bl[k], s)) return e;
   hipLaunchKernelGGL(adjoint_corner_kernel, dim3(segsde_cdiv((long)p.B * 4 * p.N, 256)), dim3(256), 0, s, p.x0, p.ld0, p.w, p.y, p.ldy,
@@ -2061,6 +2062,43 @@ bool adjoint_by_borders_ok(const ConvP& p) {
          p.W >= 4 && p.C1 == 0 && p.KH == 3 && p.KW == 3 && p.nb == 0 && p.ne == p.N;
 }
 }  // namespace
+
+// The mirrored-padding part of a reflection-padded 3x3 / stride 1 convolution's data-gradient ALONE: four border launches of the
+// implicit-GEMM kernel + the corner terms, ADDED onto y (rows 1 / H-2, columns 1 / W-2), each term multiplied by the activation
+// derivative when act_out is given.  The zero-padded part is the caller's (the one-kernel Winograd data-gradient,
+// segsde_conv2d_winograd_fused_dgrad, which has no bordered tiles).  d: the descriptor of segsde_conv2d_dgrad_actgrad with
+// pad_mode = SEGSDE_PAD_REFLECT_ADJOINT.
+namespace {
+int borders_params(const segsde_conv_desc* d, const float* dy, const float* wdpack, float* y, const float* act_out, int act_ld,
+                   int act_kind, ConvP& p) {
+  if (int e = validate(d)) return e;
+  if (d->pad_mode != SEGSDE_PAD_REFLECT_ADJOINT || d->C1 || d->up0 || d->sum2x2 || d->in_div > 1 || d->act != 0) return SEGSDE_ERR_UNSUPPORTED;
+  p = make_params(d, dy, nullptr, wdpack, nullptr, y, nullptr);
+  if (act_out) {
+    if (act_kind < SEGSDE_ACT_RELU || act_kind > SEGSDE_ACT_SIGMOID || act_ld < p.nsplit || (act_ld % 4) || !aligned16(act_out))
+      return SEGSDE_ERR_UNSUPPORTED;
+    p.agy = act_out; p.agld = act_ld; p.agkind = act_kind;
+  }
+  if (!(igemm_fast_ok(p) && p.vecout && p.H >= 4 && p.W >= 4 && p.KH == 3 && p.KW == 3 && p.nb == 0 && p.ne == p.N))
+    return SEGSDE_ERR_UNSUPPORTED;
+  return 0;
+}
+}  // namespace
+
+// would segsde_reflect_adjoint_borders take this descriptor (asked BEFORE the zero-padded launch writes dx)
+extern "C" int segsde_reflect_adjoint_borders_ok(const segsde_conv_desc* d, int act_ld) {
+  ConvP p;
+  float* fake = reinterpret_cast<float*>(16);
+  return borders_params(d, fake, fake, fake, act_ld ? fake : nullptr, act_ld, SEGSDE_ACT_ELU, p) == 0;
+}
+
+extern "C" int segsde_reflect_adjoint_borders(const segsde_conv_desc* d, const float* dy, const float* wdpack, float* y,
+                                              const float* act_out, int act_ld, int act_kind, void* stream) {
+  if (!dy || !wdpack || !y) return SEGSDE_ERR_NULL;
+  ConvP p;
+  if (int e = borders_params(d, dy, wdpack, y, act_out, act_ld, act_kind, p)) return e;
+  return launch_adjoint_by_borders(p, static_cast<hipStream_t>(stream), false);
+}
 
 extern "C" long segsde_conv2d_stats_rows(const segsde_conv_desc* d) {
   if (validate(d)) return 0;

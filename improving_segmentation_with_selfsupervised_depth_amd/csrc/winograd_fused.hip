@@ -27,10 +27,19 @@ constexpr int FZP = 65;                               // row pitch of the epilog
 constexpr int F_FLOATS = 8 * 32 * FZP > FCH * FPS ? 8 * 32 * FZP : FCH * FPS;
 constexpr size_t F_LDS = (size_t)F_FLOATS * sizeof(float) + 2 * 4 * 64 * sizeof(double);
 
+// the sources of the virtual input [up2x?(x0) | x1]: channels [0, C0) from x0 (stored at half resolution when up0: the decoder's
+// nearest upsampling, models/depth_decoder.py:91, is index arithmetic of the patch loader), [C0, C) from x1 at full resolution;
+// one source: C0 = C, x1 unused.  C0 is a multiple of the 64-channel fill, so a fill reads one source.
+struct WinoSrc { const float* x0; const float* x1; int ld0, ld1, C0, up0; };
+// epilogue extras of the data-gradient: agy (nullable) = the saved OUTPUT of the activation whose input this gradient is for,
+// the result is multiplied by its derivative (monodepth_layers.py:108-125: ConvBlock = conv -> ELU, the gradient of the next
+// layer's input is the gradient of this ELU's output)
+struct WinoAg { const float* agy; int agld, agkind; };
+
 template <bool STATS>
-__global__ __launch_bounds__(256, 2) void wino_fused_kernel(const float* x, int ldx, int B, int H, int W, int C, int reflect,
+__global__ __launch_bounds__(256, 2) void wino_fused_kernel(WinoSrc src, int B, int H, int W, int C, int reflect,
                                                             const float* U, int Co, const float* bias, int act, float* y, int ldy,
-                                                            double* part, int accumulate) {
+                                                            double* part, int accumulate, WinoAg ag) {
   SEGSDE_SMEM;
   float* lds = reinterpret_cast<float*>(segsde_smem);
   double* sh = reinterpret_cast<double*>(lds + F_FLOATS);
@@ -64,6 +73,10 @@ __global__ __launch_bounds__(256, 2) void wino_fused_kernel(const float* x, int 
       // all requests of the fill first (12 independent 16-byte loads per thread), then the transposing LDS writes
       constexpr int NL = (FP_H * FP_W * (FCH / 4) + 255) / 256;
       float4 v[NL];
+      const bool s0 = c0 < src.C0;                       // wave-uniform: which source this fill reads
+      const float* xs = s0 ? src.x0 : src.x1;
+      const int lds_ = s0 ? src.ld0 : src.ld1, cb = s0 ? c0 : c0 - src.C0, sh_ = (s0 && src.up0) ? 1 : 0;
+      const int Hs = H >> sh_, Ws = W >> sh_;
 #pragma unroll
       for (int i = 0; i < NL; ++i) {
         const int e = tid + 256 * i;
@@ -76,7 +89,7 @@ __global__ __launch_bounds__(256, 2) void wino_fused_kernel(const float* x, int 
         }
         v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (e < FP_H * FP_W * (FCH / 4) && (unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W)
-          v[i] = *reinterpret_cast<const float4*>(x + ((long)(b * H + hh) * W + ww) * ldx + c0 + 4 * cq);
+          v[i] = *reinterpret_cast<const float4*>(xs + ((long)(b * Hs + (hh >> sh_)) * Ws + (ww >> sh_)) * lds_ + cb + 4 * cq);
       }
 #pragma unroll
       for (int i = 0; i < NL; ++i) {
@@ -179,6 +192,12 @@ __global__ __launch_bounds__(256, 2) void wino_fused_kernel(const float* x, int 
     const int tj = bw * FT_W + q;
     if (ti < H2 && tj < W2) {
       float* yp = y + ((long)(b * H + 2 * ti) * W + 2 * tj) * ldy + co;
+      if (ag.agy) {         // data-gradient w.r.t. the pre-activation of the producing ConvBlock
+        const float* ap = ag.agy + ((long)(b * H + 2 * ti) * W + 2 * tj) * ag.agld + co;
+        o[0] *= segsde_act_grad_from_out(ap[0], ag.agkind); o[1] *= segsde_act_grad_from_out(ap[ag.agld], ag.agkind);
+        o[2] *= segsde_act_grad_from_out(ap[(long)W * ag.agld], ag.agkind);
+        o[3] *= segsde_act_grad_from_out(ap[(long)W * ag.agld + ag.agld], ag.agkind);
+      }
       if (accumulate) {     // a data-gradient added onto the gradient another consumer of the tensor left there
         o[0] += yp[0]; o[1] += yp[ldy]; o[2] += yp[(long)W * ldy]; o[3] += yp[(long)W * ldy + ldy];
       }
@@ -255,22 +274,60 @@ extern "C" int segsde_winograd_fused_pack(const float* w_oihw, int O, int I, int
   return 0;
 }
 
+namespace {
+int launch_fused(const WinoSrc& src, int B, int H, int W, int C, int reflect, const float* u_kn, int Cout, const float* bias, int act,
+                 float* y, int ldy, int accumulate, double* stats, const WinoAg& ag, void* stream) {
+  const dim3 grid((unsigned)fused_blocks(B, H, W), (unsigned)(Cout / 64));
+  if (stats) {
+    auto k = wino_fused_kernel<true>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_LDS);
+    hipLaunchKernelGGL(k, grid, dim3(256), F_LDS, ST(stream), src, B, H, W, C, reflect, u_kn, Cout, bias, act, y, ldy, stats, accumulate, ag);
+  } else {
+    auto k = wino_fused_kernel<false>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_LDS);
+    hipLaunchKernelGGL(k, grid, dim3(256), F_LDS, ST(stream), src, B, H, W, C, reflect, u_kn, Cout, bias, act, y, ldy, (double*)nullptr, accumulate, ag);
+  }
+  SEGSDE_CHECK_LAUNCH();
+  return 0;
+}
+}  // namespace
+
 extern "C" int segsde_conv2d_winograd_fused(const float* x, int ldx, int B, int H, int W, int C, int reflect, const float* u_kn,
                                             int Cout, const float* bias, int act, float* y, int ldy, int accumulate, double* stats,
                                             void* stream) {
   if (!x || !u_kn || !y) return SEGSDE_ERR_NULL;
   if (!segsde_winograd_fused_ok(B, H, W, C, Cout) || ldx < C || ldx % 4 != 0 || ldy < Cout || (accumulate && (stats || bias || act)))
     return SEGSDE_ERR_UNSUPPORTED;
-  const dim3 grid((unsigned)fused_blocks(B, H, W), (unsigned)(Cout / 64));
-  if (stats) {
-    auto k = wino_fused_kernel<true>;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_LDS);
-    hipLaunchKernelGGL(k, grid, dim3(256), F_LDS, ST(stream), x, ldx, B, H, W, C, reflect, u_kn, Cout, bias, act, y, ldy, stats, accumulate);
-  } else {
-    auto k = wino_fused_kernel<false>;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_LDS);
-    hipLaunchKernelGGL(k, grid, dim3(256), F_LDS, ST(stream), x, ldx, B, H, W, C, reflect, u_kn, Cout, bias, act, y, ldy, (double*)nullptr, accumulate);
-  }
-  SEGSDE_CHECK_LAUNCH();
-  return 0;
+  const WinoSrc src{x, nullptr, ldx, 0, C, 0};
+  return launch_fused(src, B, H, W, C, reflect, u_kn, Cout, bias, act, y, ldy, accumulate, stats, WinoAg{nullptr, 0, 0}, stream);
+}
+
+// forward on the virtual input [up2x?(x0) | x1] (the decoder's Conv3x3 on the upsampled previous block and the encoder skip,
+// models/depth_decoder.py:88-101): x0 [B, H >> up0, W >> up0, C0], x1 [B, H, W, C1] (NULL: one source)
+extern "C" int segsde_conv2d_winograd_fused2(const float* x0, int ld0, int C0, int up0, const float* x1, int ld1, int C1, int B, int H,
+                                             int W, int reflect, const float* u_kn, int Cout, const float* bias, int act, float* y,
+                                             int ldy, double* stats, void* stream) {
+  if (!x0 || !u_kn || !y || (C1 > 0 && !x1)) return SEGSDE_ERR_NULL;
+  const int C = C0 + (C1 > 0 ? C1 : 0);
+  if (!segsde_winograd_fused_ok(B, H, W, C, Cout) || C0 <= 0 || C0 % FCH || ld0 < C0 || ld0 % 4 != 0 || (C1 > 0 && (ld1 < C1 || ld1 % 4 != 0)) ||
+      ldy < Cout)
+    return SEGSDE_ERR_UNSUPPORTED;
+  const WinoSrc src{x0, x1, ld0, ld1, C0, up0 ? 1 : 0};
+  return launch_fused(src, B, H, W, C, reflect, u_kn, Cout, bias, act, y, ldy, 0, stats, WinoAg{nullptr, 0, 0}, stream);
+}
+
+// data-gradient of the zero-padded 3x3 / stride 1 convolution (= the convolution of dy with the flipped, transposed pack) with
+// the epilogues of the direct route: accumulate onto dx (a gradient another consumer left there), act_out (nullable) = the
+// saved activation output whose derivative multiplies the result (before the accumulation, like segsde_conv2d_dgrad_actgrad).
+// A reflection-padded convolution's data-gradient is this call followed by segsde_reflect_adjoint_borders.
+extern "C" int segsde_conv2d_winograd_fused_dgrad(const float* dy, int lddy, int B, int H, int W, int Cout, const float* ud_kn, int Cin,
+                                                  float* dx, int lddx, int accumulate, const float* act_out, int act_ld, int act_kind,
+                                                  void* stream) {
+  if (!dy || !ud_kn || !dx) return SEGSDE_ERR_NULL;
+  if (!segsde_winograd_fused_ok(B, H, W, Cout, Cin) || lddy < Cout || lddy % 4 != 0 || lddx < Cin ||
+      (act_out && (act_kind < SEGSDE_ACT_RELU || act_kind > SEGSDE_ACT_SIGMOID || act_ld < Cin)))
+    return SEGSDE_ERR_UNSUPPORTED;
+  const WinoSrc src{dy, nullptr, lddy, 0, Cout, 0};
+  return launch_fused(src, B, H, W, Cout, 0, ud_kn, Cin, nullptr, SEGSDE_ACT_NONE, dx, lddx, accumulate, nullptr,
+                      WinoAg{act_out, act_ld, act_kind}, stream);
 }

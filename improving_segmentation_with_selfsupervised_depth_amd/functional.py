@@ -150,11 +150,15 @@ class ConvFn(Function):
         ctx.wino = None
         # kn: the one-kernel Winograd route (64 .. 256 channels, one source) and its [16][K][N] packs; otherwise the grouped-GEMM
         # route from 256 channels on (two sources, dilation, 512 channels)
-        kn = not g.up0 and x1 is None and H.winograd_fused_ok(g, x0.shape[0], x0.shape[1], x0.shape[2])
+        # (round 5: the one-kernel route also takes the decoder's [upsample(x0) | x1] layers, forward only)
+        up_f = 2 if g.up0 else 1
+        kn = H.winograd_fused_ok(g, x0.shape[0], x0.shape[1] * up_f, x0.shape[2] * up_f)
         if kn or (not g.up0 and H.winograd_ok(g, x0.shape[0], x0.shape[1], x0.shape[2])):
             if (wino_cache is not None and wino_cache.get("key") is not None and wino_cache.get("key") == wino_cache.get("want")
                     and bool(wino_cache.get("kn")) == kn):
                 ctx.wino = wino_cache["packs"]
+            elif kn and (g.up0 or x1 is not None) and (wino_cache is None or wino_cache.get("want") is None):
+                ctx.wino = (H.winograd_fused_pack(weight, False), None)     # two sources: the data-gradient stays on the folded route
             else:
                 ctx.wino = H.winograd_pack(weight, kn=kn)
                 if wino_cache is not None and wino_cache.get("want") is not None:
@@ -381,9 +385,17 @@ _FANS = collections.OrderedDict()      # at most _FANS_MAX entries: parked views
 _FANS_MAX = 16
 
 
-def fan_feature(x, n_spare, n_main=1):
+def release_fans(owner):
+    """drop the views an earlier forward of ``owner`` parked and nobody fetched (a decoder that was not run in that pass): they
+    would keep that forward's features -- and, under retain_graph, its graph -- alive until _FANS_MAX newer entries push them out"""
+    for k in [k for k, ent in _FANS.items() if ent[3] == owner]:
+        del _FANS[k]
+
+
+def fan_feature(x, n_spare, n_main=1, owner=None):
     """-> (the n_main views the producer's own module continues with, the shared box or None).  n_spare more views are parked for
-    ``take_fan_view``.  Without a gradient (or with nobody to share with) the views are x itself."""
+    ``take_fan_view``.  Without a gradient (or with nobody to share with) the views are x itself.  owner: an id the producer
+    passes to ``release_fans`` at the start of its next forward."""
     if n_spare + n_main <= 1 or not (torch.is_grad_enabled() and x.requires_grad):
         return (x,) * n_main, None
     box = {}
@@ -391,7 +403,7 @@ def fan_feature(x, n_spare, n_main=1):
     if n_spare > 0:
         base = views[0]._base if views[0]._base is not None else views[0]
         _FANS.pop(id(base), None)
-        _FANS[id(base)] = (weakref.ref(base), box, list(views[n_main:]))
+        _FANS[id(base)] = (weakref.ref(base), box, list(views[n_main:]), owner)
         while len(_FANS) > _FANS_MAX:          # a forward whose decoders never came for their views (or a dead feature)
             _FANS.popitem(last=False)
     return tuple(views[:n_main]), box

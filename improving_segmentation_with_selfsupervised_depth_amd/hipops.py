@@ -6,6 +6,7 @@ last dimension is contiguous (a channel slice of a wider buffer is fine: its pix
 """
 import ctypes
 import os
+import threading
 
 import torch
 
@@ -13,6 +14,28 @@ from . import _lib
 from ._lib import ConvDesc, check
 
 ACT = {"none": 0, "relu": 1, "elu": 2, "sigmoid": 3}
+
+
+class _Slot(threading.local):
+    """A one-element, per-thread side channel (``slot[0]``): conv_forward / conv_dgrad leave a route's by-product here (the
+    transformed input a Winograd forward kept, whether an epilogue fusion was applied) and the calling autograd Function
+    picks it up right after the call.  Per thread because autograd runs backward nodes on its own engine threads (one per
+    device): two devices or threads in one process must not see each other's values."""
+
+    def __init__(self, default=None):
+        self.default = default
+        self.v = default
+
+    def __getattr__(self, name):          # first touch from another thread: threading.local re-runs __init__ only with args
+        if name == "v":
+            return self.__dict__.setdefault("v", self.__dict__.get("default"))
+        raise AttributeError(name)
+
+    def __getitem__(self, i):
+        return self.v
+
+    def __setitem__(self, i, value):
+        self.v = value
 
 # Optional live kernel timing (bench.py): when set to a list, every implicit-GEMM launch -- and every launch (group) of the
 # HBM-bound kernel families, kind "hbm_*" -- is bracketed by HIP events recorded on the stream the kernel is launched on;
@@ -169,7 +192,7 @@ def winograd_packs_multi(weights, kn=False):
 
 
 WINOGRAD_KEEP_V = os.environ.get("SEGSDE_WINOGRAD_KEEP_V", "1") != "0"   # a training forward keeps its transformed input for the weight gradient
-WINO_V = [None]     # the transformed input of the last _winograd(..., keep_v=True) call (ConvFn picks it up)
+WINO_V = _Slot(None)     # the transformed input of the last _winograd(..., keep_v=True) call (ConvFn picks it up)
 
 
 def _winograd(kind, g, x0, x1, upack, Cout, want_stats, flops, tag, bias=None, act="none", reflect=False, keep_v=False):
@@ -208,17 +231,36 @@ def _winograd(kind, g, x0, x1, upack, Cout, want_stats, flops, tag, bias=None, a
 # it at 512 (where the grouped route also hands its transformed input to the weight gradient).  SEGSDE_WINO_FUSED=0: off.
 WINO_FUSED = os.environ.get("SEGSDE_WINO_FUSED", "1") != "0"
 WINO_FUSED_MAX_CH = int(os.environ.get("SEGSDE_WINO_FUSED_MAX_CH", "256"))
-WINO_FUSED_TAKEN = {"fwd": 0, "dgrad": 0}
+# round 5: the decoder's Conv3x3 on [upsample(x) | skip] (mirrored padding) through the same kernel -- upsampling and concat are
+# index arithmetic of its patch loader -- instead of the upsample-folded direct route, when the layer's folded multiply-add share
+# (4/9 on the upsampled channels, 9/9 on the skip) is above WINO_FUSED2_MIN_FOLD: the route runs all channels at 16/36 but at
+# ~0.75 of the direct kernel's multiply-add rate (profiles/probe_r05_*.log); SEGSDE_WINO_FUSED2=0: off
+WINO_FUSED2 = os.environ.get("SEGSDE_WINO_FUSED2", "1") != "0"
+WINO_FUSED2_MAX_CIN = int(os.environ.get("SEGSDE_WINO_FUSED2_MAX_CIN", "768"))
+WINO_FUSED2_MIN_FOLD = float(os.environ.get("SEGSDE_WINO_FUSED2_MIN_FOLD", "0.7"))
+# round 5: data-gradients of the mirrored-padding Conv3x3 (zero-padded one-kernel launch + border launches) and data-gradients
+# with the activation-derivative epilogue on the one-kernel route; SEGSDE_WINO_FUSED_DGRAD_EXT=0 keeps them on the direct kernel
+WINO_FUSED_DGRAD_EXT = os.environ.get("SEGSDE_WINO_FUSED_DGRAD_EXT", "1") != "0"
+WINO_FUSED_TAKEN = {"fwd": 0, "dgrad": 0, "fwd2": 0, "dgrad_refl": 0, "dgrad_actgrad": 0, "wgrad": 0}
 
 
 def winograd_fused_ok(g, B=None, H=None, W=None, dgrad=False):
-    """the shapes csrc/winograd_fused.hip takes: 3x3 / stride 1 / padding 1 / dilation 1, one source at output resolution, channel
-    counts multiples of 64 up to WINO_FUSED_MAX_CH; zero padding (forward and data-gradient) or mirrored padding (forward)"""
+    """the shapes csrc/winograd_fused.hip takes: 3x3 / stride 1 / padding 1 / dilation 1, channel counts multiples of 64.
+    One source at output resolution: up to WINO_FUSED_MAX_CH channels, zero or mirrored padding, forward and data-gradient
+    (mirrored: + segsde_reflect_adjoint_borders).  Forward on [upsample(x0) | x1] (g.up0): C0 % 64 == 0, up to
+    WINO_FUSED2_MAX_CIN input channels, when the folded route's multiply-add share is above WINO_FUSED2_MIN_FOLD."""
     cin, cout = (g.Cout, g.C0) if dgrad else (g.Cin, g.Cout)
-    if not (WINOGRAD and WINO_FUSED and g.k == 3 and g.stride == 1 and g.dil == 1 and g.pad == 1 and not g.up0 and not g.C1
-            and g.cin_alg is None and cin % 64 == 0 and cout % 64 == 0 and max(cin, cout) <= WINO_FUSED_MAX_CH
-            and not (dgrad and g.reflect)):
+    if not (WINOGRAD and WINO_FUSED and g.k == 3 and g.stride == 1 and g.dil == 1 and g.pad == 1 and g.cin_alg is None
+            and cin % 64 == 0 and cout % 64 == 0):
         return False
+    if g.up0 or g.C1:
+        # two sources without upsampling (the bottleneck-resolution layer) stay on the grouped route, which takes them
+        if dgrad or not (WINO_FUSED2 and g.up0 and g.C0 % 64 == 0 and cin <= WINO_FUSED2_MAX_CIN and cout <= WINO_FUSED_MAX_CH
+                         and _fold_frac(g) >= WINO_FUSED2_MIN_FOLD):
+            return False
+    else:
+        if max(cin, cout) > WINO_FUSED_MAX_CH or (dgrad and g.reflect and not WINO_FUSED_DGRAD_EXT):
+            return False
     if B is None:
         return True
     return bool(_lib.lib().segsde_winograd_fused_ok(B, H, W, cin, cout)) and 9.0 * B * H * W * cin * cout >= WINOGRAD_MIN_MACS
@@ -226,9 +268,14 @@ def winograd_fused_ok(g, B=None, H=None, W=None, dgrad=False):
 
 def winograd_fused_static_ok(conv):
     """could this nn.Conv2d ever take the one-kernel route (weight_pack_scope packs those in the [16][K][N] layout up front)"""
-    return (WINOGRAD and WINO_FUSED and conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1)
-            and conv.dilation == (1, 1) and conv.in_channels % 64 == 0 and conv.out_channels % 64 == 0
-            and max(conv.in_channels, conv.out_channels) <= WINO_FUSED_MAX_CH)
+    if not (WINOGRAD and WINO_FUSED and conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1)
+            and conv.dilation == (1, 1) and conv.in_channels % 64 == 0 and conv.out_channels % 64 == 0):
+        return False
+    if max(conv.in_channels, conv.out_channels) <= WINO_FUSED_MAX_CH:
+        return True
+    # the decoder's two-source layers ([upsample(x) | skip], mirrored padding)
+    return bool(WINO_FUSED2 and getattr(conv, "reflect", False) and conv.out_channels <= WINO_FUSED_MAX_CH
+                and conv.in_channels <= WINO_FUSED2_MAX_CIN)
 
 
 class _KnPack(torch.Tensor):
@@ -248,10 +295,17 @@ def winograd_fused_pack(w_oihw, flip):
     return _kn(u)
 
 
-def winograd_fused(kind, x, u_kn, bias=None, act="none", want_stats=False, tag=None, reflect=False, accumulate_into=None):
-    """x [B,H,W,C] NHWC -> act(conv3x3(x) + bias) [B,H,W,N] with u_kn [16][C][N]; (y, statistics partials or None).
-    accumulate_into: a dense [B,H,W,N] tensor the result is added onto (and which is returned)"""
-    B, H, W, C = x.shape
+def winograd_fused(kind, x, u_kn, bias=None, act="none", want_stats=False, tag=None, reflect=False, accumulate_into=None, x1=None,
+                   up0=False, actgrad=None, adjoint=None):
+    """[up2x?(x) | x1] [B,H,W,C] NHWC -> act(conv3x3(.) + bias) [B,H,W,N] with u_kn [16][C][N]; (y, statistics partials or None).
+    accumulate_into: a dense [B,H,W,N] tensor the result is added onto (and which is returned).
+    Data-gradient extras: actgrad = (saved activation output [B,H,W,N], kind): the result is multiplied by the activation's
+    derivative; adjoint = (ConvGeom, wdpack): the convolution was mirror-padded -- the gradient of the padding cells is added by
+    segsde_reflect_adjoint_borders after the zero-padded launch."""
+    B, H0, W0, C0 = x.shape
+    H, W = (2 * H0, 2 * W0) if up0 else (H0, W0)
+    C1 = 0 if x1 is None else x1.shape[3]
+    C = C0 + C1
     N = u_kn.shape[2]
     assert u_kn.shape[1] == C
     L = _lib.lib()
@@ -265,14 +319,85 @@ def winograd_fused(kind, x, u_kn, bias=None, act="none", want_stats=False, tag=N
     if want_stats:
         part = torch.empty((int(L.segsde_winograd_fused_stats_rows(B, H, W)), 2, N), dtype=torch.float64, device=x.device)
     flops = 2.0 * B * H * W * C * N * 9
+    tagf = (tag or "%d+%d->%d k3 s1 d1 %dx%d" % (C0, C1, N, H, W)) + " wino-fused"
+    if x1 is not None or up0:
+        assert accumulate_into is None and actgrad is None and adjoint is None
+        rc = _timed(kind, flops, x, lambda: L.segsde_conv2d_winograd_fused2(
+            _p(_f32(x)), nhwc_ld(x), C0, 1 if up0 else 0, _p(x1), nhwc_ld(x1) if x1 is not None else 0, C1, B, H, W, 1 if reflect else 0,
+            _p(u_kn), N, _p(bias), ACT[act], _p(y), N, _p(part), _stream(x)), tagf, executed=flops * 16.0 / 36.0)
+        if rc == -4:
+            return None
+        check(rc, "conv2d_winograd_fused2")
+        WINO_FUSED_TAKEN["fwd2"] += 1
+        return y, part
+    if actgrad is not None or adjoint is not None:
+        assert bias is None and act == "none" and not want_stats and not reflect
+        ag_y, ag_kind = (actgrad[0], ACT[actgrad[1]]) if actgrad is not None else (None, 0)
+        ag_ld = nhwc_ld(ag_y) if ag_y is not None else 0
+        acc = 1 if accumulate_into is not None else 0
+        d = None
+        if adjoint is not None:
+            g, wdpack = adjoint
+            d = _borders_desc(B, H, W, C, N, nhwc_ld(x))
+
+        def launch():
+            rc = L.segsde_conv2d_winograd_fused_dgrad(_p(_f32(x)), nhwc_ld(x), B, H, W, C, _p(u_kn), N, _p(y), N, acc, _p(ag_y), ag_ld,
+                                                      ag_kind, _stream(x))
+            if rc == 0 and d is not None:
+                rc = L.segsde_reflect_adjoint_borders(ctypes.byref(d), _p(x), _p(wdpack), _p(y), _p(ag_y), ag_ld, ag_kind, _stream(x))
+                if rc == -4:
+                    raise RuntimeError("segsde_reflect_adjoint_borders declined a shape the one-kernel data-gradient took: "
+                                       "the zero-padded part is already in dx (hipops.winograd_fused_ok must gate this)")
+            return rc
+        rc = _timed(kind, flops, x, launch, tagf, executed=flops * 16.0 / 36.0)
+        if rc == -4:
+            return None
+        check(rc, "conv2d_winograd_fused_dgrad")
+        WINO_FUSED_TAKEN["dgrad"] += 1
+        WINO_FUSED_TAKEN["dgrad_refl"] += adjoint is not None
+        WINO_FUSED_TAKEN["dgrad_actgrad"] += actgrad is not None
+        return y, None
     rc = _timed(kind, flops, x, lambda: L.segsde_conv2d_winograd_fused(_p(_f32(x)), nhwc_ld(x), B, H, W, C, 1 if reflect else 0, _p(u_kn), N, _p(bias),
                                                                        ACT[act], _p(y), N, 1 if accumulate_into is not None else 0, _p(part), _stream(x)),
-                (tag or "%d+0->%d k3 s1 d1 %dx%d" % (C, N, H, W)) + " wino-fused", executed=flops * 16.0 / 36.0)
+                tagf, executed=flops * 16.0 / 36.0)
     if rc == -4:
         return None
     check(rc, "conv2d_winograd_fused")
     WINO_FUSED_TAKEN["fwd" if kind == "conv_fwd" else "dgrad"] += 1
     return y, part
+
+
+def _borders_desc(B, H, W, Cout, Cin, lddy):
+    return ConvDesc(B=B, H=H, W=W, C0=Cout, C1=0, ld0=lddy, ld1=0, up0=0, Ho=H, Wo=W, Cout=Cin, ldy=Cin, ldy2=0, nsplit=Cin, KH=3, KW=3,
+                    stride=1, dil=1, pad=1, pad_mode=PAD_REFLECT_ADJOINT, in_div=1, act=0, sum2x2=0, accumulate=1)
+
+
+def reflect_borders_ok(B, H, W, Cout, Cin, lddy, ag_ld=0):
+    """does segsde_reflect_adjoint_borders add the mirrored-padding gradient of this [B,H,W,Cout] -> [B,H,W,Cin] data-gradient"""
+    return bool(_lib.lib().segsde_reflect_adjoint_borders_ok(ctypes.byref(_borders_desc(B, H, W, Cout, Cin, lddy)), int(ag_ld)))
+
+
+# round 5: the weight gradient on the one-kernel Winograd scheme (csrc/winograd_wgrad.hip): every 3x3 / stride-1 layer below 512
+# channels whose forward leaves no transformed input behind, incl. the decoder's two-source / upsampled layers when the folded
+# route's multiply-add share is above WINO_FUSED_WGRAD_MIN_FOLD.  SEGSDE_WINO_FUSED_WGRAD=0: off
+WINO_FUSED_WGRAD = os.environ.get("SEGSDE_WINO_FUSED_WGRAD", "1") != "0"
+WINO_FUSED_WGRAD_MAX_CH = int(os.environ.get("SEGSDE_WINO_FUSED_WGRAD_MAX_CH", "256"))
+WINO_FUSED_WGRAD_MAX_CIN2 = int(os.environ.get("SEGSDE_WINO_FUSED_WGRAD_MAX_CIN2", "768"))
+WINO_FUSED_WGRAD_MIN_FOLD = float(os.environ.get("SEGSDE_WINO_FUSED_WGRAD_MIN_FOLD", "0.6"))
+
+
+def winograd_fused_wgrad_ok(g, B=None, H=None, W=None):
+    if not (WINOGRAD and WINO_FUSED and WINO_FUSED_WGRAD and g.k == 3 and g.stride == 1 and g.dil == 1 and g.pad == 1
+            and g.cin_alg is None and g.C0 % 32 == 0 and g.C1 % 32 == 0 and g.Cout % 64 == 0 and g.Cout <= WINO_FUSED_WGRAD_MAX_CH):
+        return False
+    if g.up0 or g.C1:
+        if not (g.up0 and g.Cin <= WINO_FUSED_WGRAD_MAX_CIN2 and _fold_frac(g) >= WINO_FUSED_WGRAD_MIN_FOLD):
+            return False
+    elif g.Cin > WINO_FUSED_WGRAD_MAX_CH:
+        return False
+    if B is None:
+        return True
+    return H % 2 == 0 and W % 2 == 0 and H >= 4 and W >= 4 and 9.0 * B * H * W * g.Cin * g.Cout >= WINOGRAD_MIN_MACS
 
 
 def _fold_frac(g):
@@ -446,8 +571,9 @@ def conv_forward(g, x0, x1, wpack, bias, act="none", want_stats=False, wfold=Non
     flops = 2.0 * B * Ho * Wo * g.Cout * g.CinAlg * g.k * g.k
     flops_x = flops * g.Cin / g.CinAlg * _live_tap_frac(g, H, W)   # executed: zero pad channels of a stem are multiplied too, dead tap rows are not
     if isinstance(wino, _KnPack):
-        if (not want_stats or (bias is None and act == "none")) and winograd_fused_ok(g, B, H, W) and x1 is None:
-            r = winograd_fused("conv_fwd", x0, wino, bias=bias, act=act, want_stats=want_stats, tag=_tag(g, H, W), reflect=g.reflect)
+        if (not want_stats or (bias is None and act == "none")) and winograd_fused_ok(g, B, H, W):
+            r = winograd_fused("conv_fwd", x0, wino, bias=bias, act=act, want_stats=want_stats, tag=_tag(g, H, W), reflect=g.reflect,
+                               x1=x1, up0=g.up0)
             if r is not None:
                 return r if want_stats else r[0]
     elif wino is not None and not g.up0 and (not want_stats or (bias is None and act == "none")) and winograd_ok(g, B, H, W):
@@ -476,10 +602,10 @@ def conv_forward(g, x0, x1, wpack, bias, act="none", want_stats=False, wfold=Non
     return (y, part) if want_stats else y
 
 
-ACTGRAD_FUSED = [False]      # did the last conv_dgrad(actgrad=...) apply the derivative in its epilogue (functional.py counts from this)
+ACTGRAD_FUSED = _Slot(False)      # did the last conv_dgrad(actgrad=...) apply the derivative in its epilogue (functional.py counts from this)
 
 
-SKIP_ACCUMULATED = [False]   # did the last conv_dgrad(accumulate_skip_into=...) add its skip gradient onto that tensor
+SKIP_ACCUMULATED = _Slot(False)   # did the last conv_dgrad(accumulate_skip_into=...) add its skip gradient onto that tensor
 
 
 def conv_dgrad(g, dy, wdpack, w_oihw, in_hw, need0=True, need1=True, accumulate_into=None, actgrad=None, fold=None, wino=None,
@@ -506,9 +632,14 @@ def conv_dgrad(g, dy, wdpack, w_oihw, in_hw, need0=True, need1=True, accumulate_
         ag_ld = nhwc_ld(ag_y)
 
     if isinstance(wino, _KnPack):
-        if actgrad is None and winograd_fused_ok(g, B, H, W, dgrad=True) and (Ho, Wo) == (H, W):
-            r = winograd_fused("conv_dgrad", dy, wino, tag=_tag(g, H, W), accumulate_into=accumulate_into)
+        ext = actgrad is not None or g.reflect
+        if (winograd_fused_ok(g, B, H, W, dgrad=True) and (Ho, Wo) == (H, W) and (not ext or WINO_FUSED_DGRAD_EXT)
+                and (not g.reflect or reflect_borders_ok(B, H, W, Cout, g.C0, nhwc_ld(dy), ag_ld))
+                and (actgrad is None or (ag_ld % 4 == 0 and ag_y.data_ptr() % 16 == 0))):
+            r = winograd_fused("conv_dgrad", dy, wino, tag=_tag(g, H, W), accumulate_into=accumulate_into, actgrad=actgrad,
+                               adjoint=(g, wdpack) if g.reflect else None)
             if r is not None:
+                ACTGRAD_FUSED[0] = actgrad is not None
                 return r[0], None
     elif (wino is not None and accumulate_into is None and actgrad is None and not g.reflect and g.C1 == 0
             and winograd_ok(g, B, H, W, dgrad=True) and (Ho, Wo) == (H, W)):
@@ -620,6 +751,18 @@ def conv_wgrad(g, x0, x1, dy, wino_v=None):
     dw = torch.empty((Cout, g.Cin, g.k, g.k), dtype=torch.float32, device=dy.device)
     flops = 2.0 * B * Ho * Wo * Cout * g.CinAlg * g.k * g.k
     flops_x = flops * g.Cin / g.CinAlg * _live_tap_frac(g, H, W, wgrad=True)
+    if wino_v is None and (Ho, Wo) == (H, W) and winograd_fused_wgrad_ok(g, B, H, W):
+        nbytes = L.segsde_conv2d_wgrad_winograd_fused_workspace(ctypes.byref(d))
+        if nbytes:
+            ws = _ws(nbytes, dy)
+            rc = _timed("conv_wgrad", flops, dy, lambda: L.segsde_conv2d_wgrad_winograd_fused(
+                ctypes.byref(d), _p(_f32(x0)), _p(x1), _p(_f32(dy)), nhwc_ld(dy), _p(dw), _p(ws), nbytes, _stream(dy)),
+                _tag(g, H, W) + " wino-fused", executed=flops * 16.0 / 36.0)
+            if rc == 0:
+                WINO_FUSED_TAKEN["wgrad"] += 1
+                return dw
+            if rc != -4:
+                check(rc, "conv2d_wgrad_winograd_fused")
     if not g.up0 and winograd_ok(g, B, H, W) and (Ho, Wo) == (H, W):
         nbytes = L.segsde_conv2d_wgrad_winograd_workspace(ctypes.byref(d))
         if nbytes:

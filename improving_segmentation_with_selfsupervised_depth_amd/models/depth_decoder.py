@@ -81,6 +81,11 @@ class DepthDecoder(nn.Module):
                 out[("disp", i)] = self.convs[("dispconv", i)](x, act="sigmoid")
         return out
 
+    def takes_fan_views(self):
+        """does forward_nhwc fetch the encoder features' gradient-collector views (identity skip projections do)"""
+        return self.use_skips and any(isinstance(self.convs[("skip_proj", i)], nn.Identity) for i in range(1, self.n_upconv + 1)
+                                      if ("skip_proj", i) in self.convs)
+
     def forward(self, input_features, x=None, exec_layer=None):
         feats = [Fn.to_nhwc(f) for f in input_features]
         xn = None if x is None else Fn.to_nhwc(x)

@@ -20,8 +20,9 @@ class JointSegmentationMonodepth(nn.Module):
         # how many decoders read the encoder's features as skip sources: the encoder then hands every feature out as views of one
         # gradient collector (resnet_encoder.ResnetEncoder.forward_nhwc, Fn.fan_feature)
         from .depth_decoder import DepthDecoder
+        # (only the decoders that fetch their view: identity skip projections, depth_decoder.forward_nhwc)
         dec = [m for k, v in self.models.items() if k in ("depth", "segmentation", "mtl_decoder")
-               for m in v.modules() if isinstance(m, DepthDecoder) and m.use_skips]
+               for m in v.modules() if isinstance(m, DepthDecoder) and m.use_skips and m.takes_fan_views()]
         if "encoder" in self.models:
             self.models["encoder"].skip_consumers = len(dec)
 

@@ -156,7 +156,8 @@ class ResnetEncoder(nn.Module):
         # Fn.take_fan_view -- so that the consumers' data-gradients accumulate in their kernels instead of being
         # summed by autograd with one full-tensor pass per extra consumer.
         n = int(getattr(self, "skip_consumers", 0))
-        (x0,), box0 = Fn.fan_feature(f0, n, 1)
+        Fn.release_fans(id(self))          # views of the previous forward that no decoder came for
+        (x0,), box0 = Fn.fan_feature(f0, n, 1, owner=id(self))
         x = Fn.MaxPoolFn.apply(x0, box0)
         layers = (e.layer1, e.layer2, e.layer3, e.layer4)
         x_ds, box = None, None
@@ -166,7 +167,7 @@ class ResnetEncoder(nn.Module):
             feats.append(x)
             x_ds, box = None, None
             if li + 1 < len(layers) and n > 0 and layers[li + 1][0].downsample is not None:
-                (x, x_ds), box = Fn.fan_feature(x, n, 2)      # conv1 and the downsample convolution of the next stage + the decoders
+                (x, x_ds), box = Fn.fan_feature(x, n, 2, owner=id(self))      # conv1 and the downsample convolution of the next stage + the decoders
                 if box is None:
                     x_ds = None
         return feats

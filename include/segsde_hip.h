@@ -281,6 +281,33 @@ long segsde_winograd_fused_stats_rows(int B, int H, int W);
 int segsde_winograd_fused_pack(const float* w_oihw, int Cout, int Cin, int flip, float* u_kn, void* stream);
 int segsde_conv2d_winograd_fused(const float* x, int ldx, int B, int H, int W, int C, int reflect, const float* u_kn, int Cout,
                                  const float* bias, int act, float* y, int ldy, int accumulate, double* stats, void* stream);
+/* Round 5.  The same kernel on the decoder's virtual input [up2x?(x0) | x1] (models/depth_decoder.py:88-101: nearest-upsampled
+ * previous block, encoder skip): x0 [B, H >> up0, W >> up0, C0], x1 [B, H, W, C1] or NULL; C0 % 64 == 0, (C0 + C1) % 64 == 0 --
+ * upsampling, concat and mirrored padding are index arithmetic of the patch loader, all channels at 16 / 36 of the multiply-adds. */
+int segsde_conv2d_winograd_fused2(const float* x0, int ld0, int C0, int up0, const float* x1, int ld1, int C1, int B, int H, int W,
+                                  int reflect, const float* u_kn, int Cout, const float* bias, int act, float* y, int ldy,
+                                  double* stats, void* stream);
+/* Data-gradient on the one-kernel route with the direct route's epilogues: dx (+)= conv(dy, flipped pack) * act'(act_out)
+ * (act_out nullable: the saved output of the activation that produced this convolution's input, ConvBlock's ELU,
+ * monodepth_layers.py:108-125; accumulate: added onto what dx holds).  Zero padding; for the reflection-padded
+ * Conv3x3 follow it with segsde_reflect_adjoint_borders (conv_igemm.hip): the gradient that entered the mirrored padding cells, as
+ * four border launches + corner terms ADDED onto rows 1 / H-2 and columns 1 / W-2 of y (d = the descriptor of
+ * segsde_conv2d_dgrad_actgrad with pad_mode = SEGSDE_PAD_REFLECT_ADJOINT; act_out as above). */
+int segsde_conv2d_winograd_fused_dgrad(const float* dy, int lddy, int B, int H, int W, int Cout, const float* ud_kn, int Cin, float* dx,
+                                       int lddx, int accumulate, const float* act_out, int act_ld, int act_kind, void* stream);
+int segsde_reflect_adjoint_borders(const segsde_conv_desc* d, const float* dy, const float* wdpack, float* y, const float* act_out,
+                                   int act_ld, int act_kind, void* stream);
+/* 1 when segsde_reflect_adjoint_borders takes the descriptor (act_ld: pixel pitch of act_out, 0 without one) -- asked before the
+ * zero-padded launch writes dx */
+int segsde_reflect_adjoint_borders_ok(const segsde_conv_desc* d, int act_ld);
+/* Weight gradient on the one-kernel Winograd scheme (csrc/winograd_wgrad.hip): dU_p = V_p^T (A dY A^T)_p with both operands formed
+ * from the raw input patches and the raw output gradient in LDS, split over tile ranges into slabs, folded deterministically and
+ * transformed back (dW = G^T dU G, OIHW).  d as for segsde_conv2d_wgrad: 3x3 / stride 1 / padding 1 / dilation 1, zero or mirrored
+ * padding, one or two sources, up0 (the decoder's [upsample(x0) | x1], models/depth_decoder.py:88-101); C0 % 32 == 0, C1 % 32 == 0,
+ * Cout % 64 == 0, H and W even.  Workspace 0 = shape not taken. */
+size_t segsde_conv2d_wgrad_winograd_fused_workspace(const segsde_conv_desc* d);
+int segsde_conv2d_wgrad_winograd_fused(const segsde_conv_desc* d, const float* x0, const float* x1, const float* dy, int lddy,
+                                       float* dw_oihw, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------ *
  * Pose: axis-angle + translation -> 4x4 (models/monodepth_layers.py:30-105)                         *

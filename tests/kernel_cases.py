@@ -1431,6 +1431,78 @@ def run_winograd_fused_cases(device, shapes=((1, 8, 16, 64, 64), (2, 12, 20, 64,
     y, _ = H.winograd_fused("conv_fwd", nhwc(x).to(device).contiguous(), uf, reflect=True)
     want = torch.nn.functional.conv2d(torch.nn.functional.pad(x.double(), (1, 1, 1, 1), mode="reflect"), w.double())
     assert_close(nchw(y).cpu(), want.float(), rtol=1e-4, atol=3e-6 * float(want.abs().max()), what="fused Winograd, mirrored padding")
+    # round 5: data-gradient of the mirrored convolution on the one-kernel route (zero-padded launch + the border launches of
+    # segsde_reflect_adjoint_borders), with the activation derivative in its epilogue and accumulating onto a collector tensor --
+    # against float64 autograd of ReflectionPad2d(1) -> conv, error within 3x the direct (reflection-adjoint) kernel's
+    old_macs = H.WINOGRAD_MIN_MACS
+    H.WINOGRAD_MIN_MACS = 0.0
+    try:
+        for (B, Hh, W, C, Co) in ((2, 12, 24, 64, 64), (1, 8, 16, 128, 64), (1, 4, 8, 64, 128), (1, 10, 36, 64, 64)):
+            what = "fused Winograd, mirrored data-gradient %s" % ((B, Hh, W, C, Co),)
+            w = torch.randn(Co, C, 3, 3, generator=gen) * (2.0 / (9 * C)) ** 0.5
+            dy = torch.randn(B, Co, Hh, W, generator=gen)
+            a = torch.nn.functional.elu(torch.randn(B, C, Hh, W, generator=gen))        # the saved output of the producing ELU
+            xin = torch.zeros(B, C, Hh, W, dtype=torch.float64, requires_grad=True)
+            torch.nn.functional.conv2d(torch.nn.functional.pad(xin, (1, 1, 1, 1), mode="reflect"), w.double()).backward(dy.double())
+            wantg = xin.grad
+            deriv = torch.where(a > 0, torch.ones_like(a), a + 1).double()
+            scg = float(wantg.abs().max())
+            wd_, dyd, ad = w.to(device), nhwc(dy).to(device).contiguous(), nhwc(a).to(device).contiguous()
+            _, wdp = H.pack_weight_both(wd_)
+            ud = H.winograd_fused_pack(wd_, True)
+            g = H.ConvGeom(C, Co, 3, 1, 1, 1, True, 0, False)
+            n0 = dict(H.WINO_FUSED_TAKEN)
+            dx, _ = H.conv_dgrad(g, dyd, wdp, wd_, (Hh, W), wino=ud)
+            assert H.WINO_FUSED_TAKEN["dgrad_refl"] == n0["dgrad_refl"] + 1, what + ": the one-kernel route declined"
+            dxd, _ = H.conv_dgrad(g, dyd, wdp, wd_, (Hh, W))
+            e_w, e_d = float((nchw(dx).double().cpu() - wantg).abs().max()), float((nchw(dxd).double().cpu() - wantg).abs().max())
+            assert e_w <= 3 * e_d + 1e-6 * scg, (what, e_w, e_d, scg)
+            dz, _ = H.conv_dgrad(g, dyd, wdp, wd_, (Hh, W), wino=ud, actgrad=(ad, "elu"))
+            assert H.ACTGRAD_FUSED[0] and H.WINO_FUSED_TAKEN["dgrad_actgrad"] == n0["dgrad_actgrad"] + 1
+            assert_close(nchw(dz).cpu(), (wantg * deriv).float(), rtol=1e-4, atol=3 * e_d + 1e-6 * scg, what=what + " x ELU'")
+            base = torch.randn(B, Hh, W, C, generator=gen).to(device)
+            acc = base.clone()
+            dz2, _ = H.conv_dgrad(g, dyd, wdp, wd_, (Hh, W), wino=ud, actgrad=(ad, "elu"), accumulate_into=acc)
+            assert dz2 is acc and H.ACTGRAD_FUSED[0]
+            assert_close(acc, base + dz, rtol=1e-6, atol=1e-6 * scg, what=what + " x ELU', accumulated")
+            # zero padding + derivative (layer1 / layer2 never need it, but the epilogue is the same code)
+            g0 = H.ConvGeom(C, Co, 3, 1, 1, 1, False, 0, False)
+            want0 = torch.nn.functional.conv_transpose2d(dy.double(), w.double(), padding=1) * deriv
+            dz0, _ = H.conv_dgrad(g0, dyd, wdp, wd_, (Hh, W), wino=ud, actgrad=(ad, "elu"))
+            assert_close(nchw(dz0).cpu(), want0.float(), rtol=1e-4, atol=3 * e_d + 1e-6 * scg, what=what + " zero padding x ELU'")
+        # the decoder's Conv3x3 on [upsample(x0) | x1] with mirrored padding, bias, ELU: upsampling and concat in the patch loader
+        old_fold = H.WINO_FUSED2_MIN_FOLD
+        H.WINO_FUSED2_MIN_FOLD = 0.0
+        try:
+            for (B, Hh, W, C0, C1, Co) in ((1, 8, 16, 64, 64, 64), (2, 12, 24, 128, 64, 128), (1, 8, 16, 64, 0, 64), (1, 20, 12, 64, 128, 64)):
+                what = "fused Winograd on [up(x0) | x1] %s" % ((B, Hh, W, C0, C1, Co),)
+                x0 = torch.randn(B, C0, Hh // 2, W // 2, generator=gen)
+                x1 = torch.randn(B, C1, Hh, W, generator=gen) if C1 else None
+                w = torch.randn(Co, C0 + C1, 3, 3, generator=gen) * (2.0 / (9 * (C0 + C1))) ** 0.5
+                bias = torch.randn(Co, generator=gen)
+                xin = torch.nn.functional.interpolate(x0.double(), scale_factor=2, mode="nearest")
+                if C1:
+                    xin = torch.cat([xin, x1.double()], 1)
+                want = torch.nn.functional.elu(torch.nn.functional.conv2d(torch.nn.functional.pad(xin, (1, 1, 1, 1), mode="reflect"), w.double())
+                                               + bias.double().view(1, -1, 1, 1))
+                sc = float(want.abs().max())
+                x0d, x1d = nhwc(x0).to(device).contiguous(), (nhwc(x1).to(device).contiguous() if C1 else None)
+                wd_ = w.to(device)
+                wp = H.pack_weight(wd_)
+                uf = H.winograd_fused_pack(wd_, False)
+                g = H.ConvGeom(C0, Co, 3, 1, 1, 1, True, C1, True)
+                assert H.winograd_fused_ok(g, B, Hh, W)
+                n0 = H.WINO_FUSED_TAKEN["fwd2"]
+                y = H.conv_forward(g, x0d, x1d, wp, bias.to(device), act="elu", wino=uf)
+                assert H.WINO_FUSED_TAKEN["fwd2"] == n0 + 1, what + ": declined"
+                direct = H.conv_forward(g, x0d, x1d, wp, bias.to(device), act="elu")
+                e_w, e_d = float((nchw(y).double().cpu() - want).abs().max()), float((nchw(direct).double().cpu() - want).abs().max())
+                assert e_w <= 3 * e_d + 1e-6 * sc, (what, e_w, e_d, sc)
+        finally:
+            H.WINO_FUSED2_MIN_FOLD = old_fold
+    finally:
+        H.WINOGRAD_MIN_MACS = old_macs
+    B, Hh, W, C, Co = 2, 12, 24, 64, 64
     # autograd glue: Conv2d -> BatchNorm2d and a mirrored Conv2d + bias + ELU through the one-kernel route == the direct route;
     # a weight_pack_scope(model) transforms the eligible weights in one launch, in the route's own layout
     from improving_segmentation_with_selfsupervised_depth_amd.models import layers as L
@@ -1461,7 +1533,7 @@ def run_winograd_fused_cases(device, shapes=((1, 8, 16, 64, 64), (2, 12, 20, 64,
                 yv = conv2(bn(conv(xi), act="relu"), act="elu")
                 (yv * yv).sum().backward()
             took = (H.WINO_FUSED_TAKEN["fwd"] - n0["fwd"], H.WINO_FUSED_TAKEN["dgrad"] - n0["dgrad"])
-            assert took == ((2, 1) if on else (0, 0)), took      # conv + mirrored conv2 forward, conv's data-gradient
+            assert took == ((2, 2) if on else (0, 0)), took      # conv + mirrored conv2 forward, both data-gradients (round 5: the mirrored one too)
             res.append((yv.detach(), xi.grad.detach(), conv.weight.grad.detach().clone(), conv2.weight.grad.detach().clone(),
                         conv2.bias.grad.detach().clone(), bn.weight.grad.detach().clone()))
         for a, b, what in zip(res[0], res[1], ("output", "input gradient", "weight gradient", "mirrored conv weight gradient",
@@ -1469,3 +1541,71 @@ def run_winograd_fused_cases(device, shapes=((1, 8, 16, 64, 64), (2, 12, 20, 64,
             assert_close(a, b, rtol=1e-3, atol=1e-4 * float(b.abs().max()), what="fused Winograd vs direct through Conv2d + BatchNorm2d: " + what)
     finally:
         H.WINOGRAD_MIN_MACS, H.WINO_FUSED = old
+
+
+# ---------------------------------------------------------------------------------------------
+# round 5: weight gradient on the one-kernel Winograd scheme (csrc/winograd_wgrad.hip) against float64 autograd and against the
+# direct weight-gradient kernel: one / two sources, nearest-upsampled first source, zero / mirrored padding, whole and partial
+# tile blocks, every staging variant (SEGSDE_WGRAD_FUSED_VAR is read once per process: the variants are separate test runs)
+# ---------------------------------------------------------------------------------------------
+def run_winograd_fused_wgrad_cases(device, shapes=None):
+    gen = torch.Generator().manual_seed(41)
+    if shapes is None:
+        #          B  H   W   C0   C1  Co  up     reflect
+        shapes = ((1, 8, 16, 64, 0, 64, False, False), (2, 12, 20, 64, 0, 128, False, True), (1, 16, 32, 128, 0, 64, False, False),
+                  (1, 6, 36, 32, 0, 64, False, True), (2, 8, 16, 64, 32, 64, True, True), (1, 12, 24, 32, 96, 128, True, True),
+                  (1, 8, 16, 64, 0, 64, True, True), (1, 4, 4, 32, 32, 64, False, False))
+    old = (H.WINOGRAD_MIN_MACS, H.WINO_FUSED_WGRAD_MIN_FOLD)
+    H.WINOGRAD_MIN_MACS, H.WINO_FUSED_WGRAD_MIN_FOLD = 0.0, 0.0
+    try:
+        for (B, Hh, W, C0, C1, Co, up, refl) in shapes:
+            what = "fused Winograd weight gradient %s" % ((B, Hh, W, C0, C1, Co, up, refl),)
+            x0 = torch.randn(B, C0, Hh // 2 if up else Hh, W // 2 if up else W, generator=gen)
+            x1 = torch.randn(B, C1, Hh, W, generator=gen) if C1 else None
+            dy = torch.randn(B, Co, Hh, W, generator=gen)
+            xin = torch.nn.functional.interpolate(x0.double(), scale_factor=2, mode="nearest") if up else x0.double()
+            if C1:
+                xin = torch.cat([xin, x1.double()], 1)
+            w = torch.zeros(Co, C0 + C1, 3, 3, dtype=torch.float64, requires_grad=True)
+            xp = torch.nn.functional.pad(xin, (1, 1, 1, 1), mode="reflect" if refl else "constant")
+            torch.nn.functional.conv2d(xp, w).backward(dy.double())
+            want = w.grad
+            sc = float(want.abs().max())
+            g = H.ConvGeom(C0, Co, 3, 1, 1, 1, refl, C1, up)
+            x0d, x1d, dyd = nhwc(x0).to(device).contiguous(), (nhwc(x1).to(device).contiguous() if C1 else None), nhwc(dy).to(device).contiguous()
+            if not (g.up0 or g.C1) or g.up0:
+                assert H.winograd_fused_wgrad_ok(g, B, Hh, W), what
+                n0 = H.WINO_FUSED_TAKEN["wgrad"]
+                dw = H.conv_wgrad(g, x0d, x1d, dyd)
+                assert H.WINO_FUSED_TAKEN["wgrad"] == n0 + 1, what + ": declined"
+            else:
+                # two sources without upsampling: the router keeps them on the grouped route; the kernel itself takes them
+                dw = _wgrad_fused_direct(g, x0d, x1d, dyd)
+            H.WINO_FUSED_WGRAD = False
+            try:
+                dwd = H.conv_wgrad(g, x0d, x1d, dyd)
+            finally:
+                H.WINO_FUSED_WGRAD = True
+            e_w, e_d = float((dw.double().cpu() - want).abs().max()), float((dwd.double().cpu() - want).abs().max())
+            assert e_w <= 3 * e_d + 1e-6 * sc, (what, e_w, e_d, sc)
+    finally:
+        H.WINOGRAD_MIN_MACS, H.WINO_FUSED_WGRAD_MIN_FOLD = old
+
+
+def _wgrad_fused_direct(g, x0, x1, dy):
+    import ctypes
+    from improving_segmentation_with_selfsupervised_depth_amd import _lib
+    B, H0, W0, _ = x0.shape
+    Hh, W = (2 * H0, 2 * W0) if g.up0 else (H0, W0)
+    Co = dy.shape[3]
+    d = _lib.ConvDesc(B=B, H=Hh, W=W, C0=g.C0, C1=g.C1, ld0=H.nhwc_ld(x0), ld1=H.nhwc_ld(x1) if x1 is not None else 0, up0=int(g.up0),
+                      Ho=Hh, Wo=W, Cout=Co, ldy=Co, ldy2=0, nsplit=0, KH=3, KW=3, stride=1, dil=1, pad=1,
+                      pad_mode=H.PAD_REFLECT if g.reflect else H.PAD_ZERO, in_div=1, act=0, sum2x2=0)
+    L = _lib.lib()
+    nbytes = L.segsde_conv2d_wgrad_winograd_fused_workspace(ctypes.byref(d))
+    assert nbytes > 0
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dy.device)
+    dw = torch.empty((Co, g.Cin, 3, 3), dtype=torch.float32, device=dy.device)
+    H.check(L.segsde_conv2d_wgrad_winograd_fused(ctypes.byref(d), H._p(x0), H._p(x1), H._p(dy), H.nhwc_ld(dy), H._p(dw), H._p(ws), nbytes,
+                                                 H._stream(dy)), "wgrad_winograd_fused")
+    return dw

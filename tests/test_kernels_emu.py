@@ -1,4 +1,7 @@
 """CPU: run the real kernel sources through the fiber interpreter and compare with plain PyTorch."""
+import os
+import sys
+
 import pytest
 import torch
 
@@ -128,3 +131,15 @@ def test_winograd_route():
 def test_winograd_fused_kernel():
     KC.run_winograd_fused_cases("cpu")
 
+
+
+@pytest.mark.parametrize("variant", ["0", "1", "2"])
+def test_winograd_fused_wgrad_kernel(variant):
+    """csrc/winograd_wgrad.hip under the interpreter, one process per staging variant (the knob is read once per process)"""
+    import subprocess
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import emu; emu.install(); import kernel_cases as KC; "
+            "KC.run_winograd_fused_wgrad_cases('cpu'); print('wgrad-ok')" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                                            os.path.dirname(os.path.abspath(__file__))))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=1200,
+                       env=dict(os.environ, SEGSDE_WGRAD_FUSED_VAR=variant))
+    assert r.returncode == 0 and "wgrad-ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]

@@ -185,3 +185,7 @@ def test_winograd_route():
 def test_winograd_fused_kernel():
     KC.run_winograd_fused_cases("cuda")
 
+
+
+def test_winograd_fused_wgrad_kernel():
+    KC.run_winograd_fused_wgrad_cases("cuda")
