@@ -21,7 +21,16 @@ namespace {
 #define ST(s) static_cast<hipStream_t>(s)
 constexpr int FT_H = 4, FT_W = 8;                     // tiles of a block: 32 = the rows of the 32x32x2 MFMA
 constexpr int FP_H = 2 * FT_H + 2, FP_W = 2 * FT_W + 2;   // its 10 x 18 pixel patch
-constexpr int FPS = FP_H * FP_W + 1;                  // channel-plane pitch in LDS (odd: conflict-free staging writes)
+// LDS image of the patch (round 5: bank-conflict-free on both sides; PMC of the round-4 layout -- plane pitch 181, pixel (pr, pc)
+// at pr * 18 + pc -- showed 70 % of the kernel's LDS cycles as bank conflicts: ds_read_b32 serves the 32 lanes of a half-wave, bank =
+// dword address mod 32, and the 32 tiles of an A operand sat at 36 th + 2 tw: even banks only, four rows on top of each other).
+//  * a channel plane is 10 rows of pitch FROW = 20 with the EVEN pixel columns of a row first (positions 0..8), the odd ones behind
+//    (9..17): the 32 tiles of one operand read position 40 th + tw + const -> bank 8 th + tw: all 32 distinct;
+//  * plane c starts at c * FPS + 2 * (c >> 2), FPS = 256: the staging store of one float4 component covers planes 4 cq + j of 16
+//    channel quads and two neighbouring patch positions per half-wave -> banks 2 cq + position: all 32 distinct (pitch 181: 2-way).
+constexpr int FROW = 20, FODD = FP_W / 2;
+constexpr int FPS = 256;
+__device__ __forceinline__ constexpr int fplane(int c) { return c * FPS + 2 * (c >> 2); }
 constexpr int FCH = 64;                               // channels per LDS fill
 constexpr int FZP = 65;                               // row pitch of the epilogue's half-transformed blocks Z[8][32][FZP]
 constexpr int F_FLOATS = 8 * 32 * FZP > FCH * FPS ? 8 * 32 * FZP : FCH * FPS;
@@ -56,8 +65,8 @@ __global__ __launch_bounds__(256, 2) void wino_fused_kernel(WinoSrc src, int B, 
   const int a1 = wave == 0 ? 0 : (wave == 2 ? 2 : 1);
   const int a2 = wave == 0 ? 2 : (wave == 1 ? 2 : (wave == 2 ? 1 : 3));
   const float sgn = wave == 1 ? 1.f : -1.f;
-  const float* pl = lds + kk * FPS + (2 * th) * FP_W + 2 * tw;
-  const int o1 = a1 * FP_W, o2 = a2 * FP_W;
+  const float* pl = lds + kk * FPS + (2 * th) * FROW + tw;     // (the plane skew of channels 2 s + kk does not depend on kk)
+  const int o1 = a1 * FROW, o2 = a2 * FROW;
 
   f32x16 acc[4][2];
 #pragma unroll
@@ -81,7 +90,8 @@ __global__ __launch_bounds__(256, 2) void wino_fused_kernel(WinoSrc src, int B, 
       for (int i = 0; i < NL; ++i) {
         const int e = tid + 256 * i;
         const int pix = e >> 4, cq = e & 15;
-        const int pr = pix / FP_W, pc = pix - pr * FP_W;
+        const int pr = pix / FP_W, pos = pix - pr * FP_W;                 // pos: position inside the LDS row (even columns first)
+        const int pc = pos < FODD ? 2 * pos : 2 * (pos - FODD) + 1;
         int hh = h_top + pr, ww = w_left + pc;
         if (reflect) {       // ReflectionPad2d(1) (monodepth_layers.py:127-142); pixels of tiles past the image: any valid address
           hh = hh < 0 ? -hh : (hh >= H ? 2 * H - 2 - hh : hh); ww = ww < 0 ? -ww : (ww >= W ? 2 * W - 2 - ww : ww);
@@ -95,7 +105,8 @@ __global__ __launch_bounds__(256, 2) void wino_fused_kernel(WinoSrc src, int B, 
       for (int i = 0; i < NL; ++i) {
         const int e = tid + 256 * i;
         if (e < FP_H * FP_W * (FCH / 4)) {
-          float* d = lds + (4 * (e & 15)) * FPS + (e >> 4);
+          const int pix = e >> 4, pr = pix / FP_W;
+          float* d = lds + fplane(4 * (e & 15)) + pr * FROW + (pix - pr * FP_W);
           d[0] = v[i].x; d[FPS] = v[i].y; d[2 * FPS] = v[i].z; d[3 * FPS] = v[i].w;
         }
       }
@@ -123,9 +134,12 @@ __global__ __launch_bounds__(256, 2) void wino_fused_kernel(WinoSrc src, int B, 
       }
     };
     auto fetch_a = [&](int s, int q) {
-      const float* src = pl + (2 * s) * FPS;
+      const float* src = pl + fplane(2 * s);
 #pragma unroll
-      for (int bb = 0; bb < 4; ++bb) { rv[q][bb] = src[o1 + bb]; rv[q][4 + bb] = src[o2 + bb]; }
+      for (int bb = 0; bb < 4; ++bb) {       // patch column 2 tw + bb: even ones at position tw + bb / 2, odd ones behind the even half
+        const int cp = (bb & 1) ? FODD + (bb >> 1) : (bb >> 1);
+        rv[q][bb] = src[o1 + cp]; rv[q][4 + bb] = src[o2 + cp];
+      }
     };
 #pragma unroll
     for (int s = 0; s < PD - 1; ++s) fetch_b(s, s);

@@ -87,11 +87,41 @@ __global__ __launch_bounds__(256, MINB) void wino_wgrad_fused_kernel(WgradP p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[j][nb][r] = 0.f;
 
+  // Per-lane byte offsets of a block's tile loads relative to the block's own origin: the same for every INTERIOR block (patch
+  // and gradient pixels all inside the image: no padding, no mirroring, no tile past the edge), whose loads then cost no vector
+  // instructions at all -- the block's origin goes into the (scalar) resource base.  PMC of the first version: 6.0 vector
+  // instructions per MFMA over the kernel against 3.3 inside the loop; the difference was this index arithmetic.
+  unsigned relx[G::XI], rely[G::YI];
+#pragma unroll
+  for (int k = 0; k < G::XI; ++k) {
+    const int e = (k * 4 + wv) * 64 + lane;
+    const int px = e >> 3, cq = e & 7;
+    const int pr = px / PW, pc = px - pr * PW;
+    // source pixel of patch pixel (pr, pc) relative to the patch origin's source pixel (origin coordinates are odd: 2 m - 1)
+    relx[k] = px < G::XPX ? (unsigned)((((pr + sh) >> sh) * Ws + ((pc + sh) >> sh)) * ldx + 4 * cq) * 4u : SEGSDE_OOB;
+  }
+#pragma unroll
+  for (int k = 0; k < G::YI; ++k) {
+    const int e = (k * 4 + wv) * 64 + lane;
+    const int px = e >> 4, cq = e & 15;
+    rely[k] = (unsigned)(((px >> 4) * p.W + (px & 15)) * p.lddy + 4 * cq) * 4u;
+  }
+
   // tile loads of block q into the stage at byte offset `stage`
   auto issue = [&](int q, unsigned stage) {
     const int bw = q % p.nbw; int t = q / p.nbw;
     const int bh = t % p.nbh, b = t / p.nbh;
     const int h_top = 2 * bh * WT_H - 1, w_left = 2 * bw * WT_W - 1;
+    if (h_top >= 0 && w_left >= 0 && h_top + G::PH <= p.H && w_left + PW <= p.W) {
+      const segsde_rsrc rxi = segsde_make_rsrc(xs + (size_t)b * Hs * Ws * ldx + cb + ((size_t)(h_top >> sh) * Ws + (w_left >> sh)) * ldx);
+#pragma unroll
+      for (int k = 0; k < G::XI; ++k) segsde_buffer_load4_lds(rxi, relx[k], 0u, lds0 + stage + (unsigned)(k * 4 + wv) * 1024u);
+      const segsde_rsrc ryi = segsde_make_rsrc(p.dy + (size_t)b * p.H * p.W * p.lddy + co0 + ((size_t)(h_top + 1) * p.W + (w_left + 1)) * p.lddy);
+#pragma unroll
+      for (int k = 0; k < G::YI; ++k)
+        segsde_buffer_load4_lds(ryi, rely[k], 0u, lds0 + stage + (unsigned)(G::XF * 4) + (unsigned)(k * 4 + wv) * 1024u);
+      return;
+    }
     const segsde_rsrc rx = segsde_make_rsrc(xs + (size_t)b * Hs * Ws * ldx + cb);
 #pragma unroll
     for (int k = 0; k < G::XI; ++k) {
@@ -121,7 +151,11 @@ __global__ __launch_bounds__(256, MINB) void wino_wgrad_fused_kernel(WgradP p) {
     }
   };
 
-  // the sixteen position GEMMs over the tiles of one staged block
+  // the sixteen position GEMMs over the tiles of one staged block.  The operand transforms stay SCALAR fp32 instructions: this
+  // file is compiled with -fno-slp-vectorize (__graft_entry__.py) -- left to itself the compiler packs them into v_pk_fma_f32 /
+  // v_pk_add_f32 plus the moves that re-pair the ds_read2 results (26 vector instructions per 8 MFMAs), and a packed fp32
+  // instruction beside MFMAs costs ~22 cycles more than the two scalar ones it replaces (MI355X_MICROARCH.md, MFMA microbenchmarks;
+  // measured here: hand-packed 8 + 4 per step 104-107 TFLOP/s executed, scalar 16 + 4: see profiles/probe_r05_*)
   auto compute = [&](const float* X) {
     const float* Y = X + G::XF;
     const float* xp = X + xl;
@@ -222,10 +256,10 @@ int target_wgs() {
 }
 int variant() {
   static int v = -1;
-  if (v < 0) { const char* e = getenv("SEGSDE_WGRAD_FUSED_VAR"); v = e ? atoi(e) : 1; }
+  if (v < 0) { const char* e = getenv("SEGSDE_WGRAD_FUSED_VAR"); v = e ? atoi(e) : 0; }
   return v;
 }
-int block_h() { const int v = variant(); return v == 1 ? 2 : 4; }
+int block_h() { return variant() == 1 ? 2 : 4; }
 
 bool shape_ok(const segsde_conv_desc* d) {
   if (!d || d->B <= 0 || d->KH != 3 || d->KW != 3 || d->stride != 1 || d->dil != 1 || d->pad != 1 || d->in_div > 1 || d->sum2x2) return false;

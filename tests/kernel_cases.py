@@ -1554,7 +1554,9 @@ def run_winograd_fused_wgrad_cases(device, shapes=None):
         #          B  H   W   C0   C1  Co  up     reflect
         shapes = ((1, 8, 16, 64, 0, 64, False, False), (2, 12, 20, 64, 0, 128, False, True), (1, 16, 32, 128, 0, 64, False, False),
                   (1, 6, 36, 32, 0, 64, False, True), (2, 8, 16, 64, 32, 64, True, True), (1, 12, 24, 32, 96, 128, True, True),
-                  (1, 8, 16, 64, 0, 64, True, True), (1, 4, 4, 32, 32, 64, False, False))
+                  (1, 8, 16, 64, 0, 64, True, True), (1, 4, 4, 32, 32, 64, False, False),
+                  # maps with INTERIOR tile blocks (the loads' vector-instruction-free path), one source and [upsample | skip]
+                  (1, 40, 64, 32, 0, 64, False, True), (2, 24, 48, 32, 32, 64, True, True), (1, 26, 52, 32, 0, 64, False, False))
     old = (H.WINOGRAD_MIN_MACS, H.WINO_FUSED_WGRAD_MIN_FOLD)
     H.WINOGRAD_MIN_MACS, H.WINO_FUSED_WGRAD_MIN_FOLD = 0.0, 0.0
     try:
