@@ -62,6 +62,7 @@ _SIGS = {
     "segsde_conv2d_winograd_fused_dgrad": (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, c_int, P, c_int, c_int, P, c_int, c_int, P]),
     "segsde_reflect_adjoint_borders": (c_int, [P, P, P, P, P, c_int, c_int, P]),
     "segsde_reflect_adjoint_borders_ok": (c_int, [P, c_int]),
+    "segsde_reflect_adjoint_borders2": (c_int, [P, c_int, P, P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "segsde_conv2d_wgrad_winograd_fused_workspace": (c_size_t, [P]),
     "segsde_conv2d_wgrad_winograd_fused": (c_int, [P, P, P, P, c_int, P, P, c_size_t, P]),
     "segsde_upfold_pack": (c_int, [P, c_int, c_int, c_int, P, P, P]),

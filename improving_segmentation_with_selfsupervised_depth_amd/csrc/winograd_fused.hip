@@ -182,13 +182,37 @@ __global__ __launch_bounds__(256, 2) void wino_fused_kernel(WinoSrc src, int B, 
         zw[(32 + row) * FZP + nb * 32] = (m1 - m2) - m3;
       }
   }
-  __syncthreads();
   const int n = tid & 63, tg = tid >> 6;               // thread: filter n, tiles 8 tg .. 8 tg + 7 (tile row tg of the block)
   const bool post = bias != nullptr || act != SEGSDE_ACT_NONE;
   const int co = co0 + n;
+  const int ti = bh * FT_H + tg;
+  // the data-gradient epilogues read memory (the saved activation output for its derivative, the gradient already in dx for the
+  // accumulation): all 8 x 4 requests of a thread are issued HERE, before the barrier of the Z exchange -- inside the tile loop
+  // below every tile waited a full memory latency for its own four (round 5, first version: +55 % on a 64-channel layer)
+  float agv[FT_W][4], oldv[FT_W][4];
+  if (ag.agy) {
+#pragma unroll
+    for (int q = 0; q < FT_W; ++q) {
+      const int tj = bw * FT_W + q;
+      const bool ok = ti < H2 && tj < W2;
+      const float* ap = ag.agy + ((long)(b * H + 2 * ti) * W + 2 * tj) * ag.agld + co;
+      agv[q][0] = ok ? ap[0] : 0.f; agv[q][1] = ok ? ap[ag.agld] : 0.f;
+      agv[q][2] = ok ? ap[(long)W * ag.agld] : 0.f; agv[q][3] = ok ? ap[(long)W * ag.agld + ag.agld] : 0.f;
+    }
+  }
+  if (accumulate) {
+#pragma unroll
+    for (int q = 0; q < FT_W; ++q) {
+      const int tj = bw * FT_W + q;
+      const bool ok = ti < H2 && tj < W2;
+      const float* yp = y + ((long)(b * H + 2 * ti) * W + 2 * tj) * ldy + co;
+      oldv[q][0] = ok ? yp[0] : 0.f; oldv[q][1] = ok ? yp[ldy] : 0.f;
+      oldv[q][2] = ok ? yp[(long)W * ldy] : 0.f; oldv[q][3] = ok ? yp[(long)W * ldy + ldy] : 0.f;
+    }
+  }
+  __syncthreads();
   const float bsv = bias ? bias[co] : 0.f;
   double ssum = 0.0, ssq = 0.0;
-  const int ti = bh * FT_H + tg;
 #pragma unroll
   for (int q = 0; q < FT_W; ++q) {
     const int tl = tg * FT_W + q;
@@ -207,13 +231,12 @@ __global__ __launch_bounds__(256, 2) void wino_fused_kernel(WinoSrc src, int B, 
     if (ti < H2 && tj < W2) {
       float* yp = y + ((long)(b * H + 2 * ti) * W + 2 * tj) * ldy + co;
       if (ag.agy) {         // data-gradient w.r.t. the pre-activation of the producing ConvBlock
-        const float* ap = ag.agy + ((long)(b * H + 2 * ti) * W + 2 * tj) * ag.agld + co;
-        o[0] *= segsde_act_grad_from_out(ap[0], ag.agkind); o[1] *= segsde_act_grad_from_out(ap[ag.agld], ag.agkind);
-        o[2] *= segsde_act_grad_from_out(ap[(long)W * ag.agld], ag.agkind);
-        o[3] *= segsde_act_grad_from_out(ap[(long)W * ag.agld + ag.agld], ag.agkind);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] *= segsde_act_grad_from_out(agv[q][k], ag.agkind);
       }
       if (accumulate) {     // a data-gradient added onto the gradient another consumer of the tensor left there
-        o[0] += yp[0]; o[1] += yp[ldy]; o[2] += yp[(long)W * ldy]; o[3] += yp[(long)W * ldy + ldy];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] += oldv[q][k];
       }
       yp[0] = o[0]; yp[ldy] = o[1]; yp[(long)W * ldy] = o[2]; yp[(long)W * ldy + ldy] = o[3];
       if (STATS) {
@@ -264,6 +287,103 @@ __global__ __launch_bounds__(256) void wino_weight_kn_kernel(const float* w, int
     out[(4 * r + 1) * plane] = 0.5f * ((tq[r][0] + tq[r][1]) + tq[r][2]);
     out[(4 * r + 2) * plane] = 0.5f * ((tq[r][0] - tq[r][1]) + tq[r][2]);
     out[(4 * r + 3) * plane] = tq[r][2];
+  }
+}
+
+// ---- Mirrored-padding part of the data-gradient of a ReflectionPad2d(1) + 3x3 convolution (models/monodepth_layers.py:127-142), for
+// the zero-padded one-kernel launch above: the gradient that entered the padding cells flows back to rows 1 / H-2 and columns
+// 1 / W-2.  Per line a 3-tap 1-D convolution of the gradient's border row / column,
+//     dx[b, 1, w, c]   += sum_kw sum_o dy[b, 0,   w - kw + 1, o] * w[o][c][0][kw]        (row H-2: dy row H-1, kh = 2)
+//     dx[b, h, 1, c]   += sum_kh sum_o dy[b, h - kh + 1, 0,   o] * w[o][c][kh][0]        (column W-2: dy column W-1, kw = 2)
+// plus the doubly mirrored corner cells: dx[b, 1, 1, c] += sum_o dy[b, 0, 0, o] * w[o][c][0][0] (and the three other corners).
+// Round 4 ran this as four launches of the implicit-GEMM kernel + a corner kernel (~50 us each: fixed per-launch costs of a
+// kernel built for whole images); here TWO launches of a 32-pixel x Cin MFMA kernel: mode 0 = both row lines, mode 1 = both
+// column lines with the corner terms as two more taps of the workgroup that owns row 1 / H-2 (their source pixels are in its
+// staged line already).  Pixels (1,1) ... receive a row-line and a column-line term: from different launches, so no two
+// workgroups of a launch ever add to the same address (no atomics, deterministic).
+struct BorderP {
+  const float* dy; const float* wp /* forward pack [Cout][3][3][Cin] */; float* dx; const float* agy;
+  int lddy, lddx, agld, agkind, B, H, W, Cin, Cout, mode, nseg;
+};
+
+__global__ __launch_bounds__(256) void reflect_borders_kernel(BorderP p) {
+  SEGSDE_SMEM;
+  float* sh = reinterpret_cast<float*>(segsde_smem);                 // [34][Cout + 1]: the source line, positions p0 - 1 .. p0 + 32
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, m = lane & 31, kk = lane >> 5;
+  const int L = p.mode == 0 ? p.W : p.H;
+  int r = blockIdx.x;
+  const int seg = r % p.nseg; r /= p.nseg;
+  const int far = r & 1, b = r >> 1;
+  const int p0 = seg * 32, pitch = p.Cout + 1, cq4 = p.Cout >> 2;
+  const int fixed = p.mode == 0 ? (far ? p.H - 1 : 0) : (far ? p.W - 1 : 0);       // the gradient's border row / column
+  for (int idx = tid; idx < 34 * cq4; idx += 256) {
+    const int px = idx / cq4, q = idx - px * cq4, pos = p0 - 1 + px;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (pos >= 0 && pos < L) {
+      const long pix = p.mode == 0 ? ((long)(b * p.H + fixed) * p.W + pos) : ((long)(b * p.H + pos) * p.W + fixed);
+      v = *reinterpret_cast<const float4*>(p.dy + pix * p.lddy + 4 * q);
+    }
+    float* d = sh + px * pitch + 4 * q;
+    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+  }
+  __syncthreads();
+  // taps: 0..2 the line's own three (staged index m + 2 - t); 3 / 4 (mode 1 only) the corner terms of the pixels at line position
+  // 1 / H - 2, whose source is the staged line at position 0 / H - 1
+  const int ktap = far ? 2 : 0;
+  const bool top = p.mode == 1 && p0 <= 1 && 1 < p0 + 32, bot = p.mode == 1 && p0 <= p.H - 2 && p.H - 2 < p0 + 32;
+  const int steps = p.Cout >> 1;
+  for (int nb = wave; nb < (p.Cin >> 5); nb += 4) {
+    const int cin = nb * 32 + m;
+    f32x16 acc;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+    for (int t = 0; t < 5; ++t) {
+      if (t == 3 && !top) continue;
+      if (t == 4 && !bot) continue;
+      int kh, kw, src; bool mine = true;
+      if (t < 3) {
+        kh = p.mode == 0 ? ktap : t; kw = p.mode == 0 ? t : ktap; src = m + 2 - t;
+      } else {
+        kh = t == 3 ? 0 : 2; kw = ktap;
+        const int at = t == 3 ? 1 : p.H - 2;                 // the line position that receives this corner term
+        mine = p0 + m == at;
+        src = (t == 3 ? 0 : p.H - 1) - (p0 - 1);
+      }
+      const float* ap = sh + src * pitch + kk;
+      const float* bp = p.wp + ((long)kk * 9 + kh * 3 + kw) * p.Cin + cin;
+      const long bstep = 18L * p.Cin;
+      // weights straight from L2 (128-byte runs per half-wave): eight steps' requests in flight ahead of the eight being multiplied
+      float bv[2][8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) bv[0][u] = u < steps ? bp[u * bstep] : 0.f;
+      for (int s0 = 0; s0 < steps; s0 += 16) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          const int sb = s0 + 8 * half;
+          if (sb < steps) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) bv[half ^ 1][u] = sb + 8 + u < steps ? bp[(long)(sb + 8 + u) * bstep] : 0.f;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              if (sb + u < steps) {
+                const float a = mine ? ap[2 * (sb + u)] : 0.f;
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv[half][u], acc, 0, 0, 0);
+              }
+            }
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int row = (q & 3) + 8 * (q >> 2) + 4 * kk, pos = p0 + row;
+      if (pos < L) {
+        const long pix = p.mode == 0 ? ((long)(b * p.H + (far ? p.H - 2 : 1)) * p.W + pos) : ((long)(b * p.H + pos) * p.W + (far ? p.W - 2 : 1));
+        float v = acc[q];
+        if (p.agy) v *= segsde_act_grad_from_out(p.agy[pix * p.agld + cin], p.agkind);
+        p.dx[pix * p.lddx + cin] += v;
+      }
+    }
   }
 }
 
@@ -344,4 +464,26 @@ extern "C" int segsde_conv2d_winograd_fused_dgrad(const float* dy, int lddy, int
   const WinoSrc src{dy, nullptr, lddy, 0, Cout, 0};
   return launch_fused(src, B, H, W, Cout, 0, ud_kn, Cin, nullptr, SEGSDE_ACT_NONE, dx, lddx, accumulate, nullptr,
                       WinoAg{act_out, act_ld, act_kind}, stream);
+}
+
+// the mirrored-padding part of a reflection-padded 3x3 convolution's data-gradient, ADDED onto dx (after
+// segsde_conv2d_winograd_fused_dgrad wrote the zero-padded part): wpack = the FORWARD pack [Cout][3][3][Cin] (segsde_pack_weight,
+// for_dgrad = 0); act_out as in segsde_conv2d_winograd_fused_dgrad.  Two launches (row lines; column lines + corners).
+extern "C" int segsde_reflect_adjoint_borders2(const float* dy, int lddy, const float* wpack, float* dx, int lddx, const float* act_out,
+                                               int act_ld, int act_kind, int B, int H, int W, int Cin, int Cout, void* stream) {
+  if (!dy || !wpack || !dx) return SEGSDE_ERR_NULL;
+  if (B <= 0 || H < 4 || W < 4 || Cin <= 0 || Cin % 32 || Cout <= 0 || Cout % 32 || Cout > 1024 || lddy < Cout || lddy % 4 || lddx < Cin ||
+      ((uintptr_t)dy & 15) || (act_out && (act_kind < SEGSDE_ACT_RELU || act_kind > SEGSDE_ACT_SIGMOID || act_ld < Cin)))
+    return SEGSDE_ERR_UNSUPPORTED;
+  BorderP p;
+  p.dy = dy; p.wp = wpack; p.dx = dx; p.agy = act_out; p.lddy = lddy; p.lddx = lddx; p.agld = act_ld; p.agkind = act_kind;
+  p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
+  const size_t lb = (size_t)34 * (Cout + 1) * sizeof(float);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(reflect_borders_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
+  for (int mode = 0; mode < 2; ++mode) {
+    p.mode = mode; p.nseg = ((mode == 0 ? W : H) + 31) / 32;
+    hipLaunchKernelGGL(reflect_borders_kernel, dim3((unsigned)(B * 2 * p.nseg)), dim3(256), lb, ST(stream), p);
+    SEGSDE_CHECK_LAUNCH();
+  }
+  return 0;
 }

@@ -144,6 +144,7 @@ class ConvFn(Function):
             wp, ctx.wd = H.pack_weight_both(weight)     # the data-gradient pack is needed by backward: one launch for both
         else:
             wp = H.pack_weight(weight, False)
+        ctx.wp = wp if g.reflect else None      # the mirrored convolution's data-gradient border kernel reads the forward pack
         ctx.fold = None
         # Winograd route (3x3 / stride 1 / many channels): the transformed weight packs, cached by the owning module for the
         # active weight_pack_scope like the plain packs
@@ -212,7 +213,7 @@ class ConvFn(Function):
             box = ctx.grad_box
             if box is not None and box.get("g") is not None and x1 is None:
                 dx0, dx1 = H.conv_dgrad(g, dz, wd, weight.detach(), ctx.in_hw, accumulate_into=box["g"], actgrad=actgrad,
-                                        wino=None if ctx.wino is None else ctx.wino[1])
+                                        wino=None if ctx.wino is None else ctx.wino[1], wfpack=ctx.wp)
                 if dx0 is not None:
                     box["fused"] = True      # dx0 IS the residual-path gradient, now holding the sum
             if dx0 is None:
@@ -220,7 +221,7 @@ class ConvFn(Function):
                 dx0, dx1 = H.conv_dgrad(g, dz, wd, weight.detach(), ctx.in_hw, actgrad=actgrad, fold=ctx.fold,
                                         need0=ctx.needs_input_grad[0], need1=x1 is not None and ctx.needs_input_grad[1],
                                         wino=None if (ctx.wino is None or x1 is not None) else ctx.wino[1],
-                                        accumulate_skip_into=None if sbox is None else sbox.get("g"))
+                                        accumulate_skip_into=None if sbox is None else sbox.get("g"), wfpack=ctx.wp)
                 if sbox is not None and dx1 is not None:
                     if H.SKIP_ACCUMULATED[0]:
                         sbox["fused"] = True      # dx1 IS the shared tensor, now holding the sum

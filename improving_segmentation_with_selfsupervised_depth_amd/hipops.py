@@ -241,6 +241,11 @@ WINO_FUSED2_MIN_FOLD = float(os.environ.get("SEGSDE_WINO_FUSED2_MIN_FOLD", "0.7"
 # round 5: data-gradients of the mirrored-padding Conv3x3 (zero-padded one-kernel launch + border launches) and data-gradients
 # with the activation-derivative epilogue on the one-kernel route; SEGSDE_WINO_FUSED_DGRAD_EXT=0 keeps them on the direct kernel
 WINO_FUSED_DGRAD_EXT = os.environ.get("SEGSDE_WINO_FUSED_DGRAD_EXT", "1") != "0"
+# the mirrored convolution's data-gradient takes the route from this many pixels on (measured, profiles/probe_r05_winograd_dgrad_*.log:
+# 1.35-1.6x from 16 x 64 x 128 pixels; at 16 x 32 x 64 the two border launches -- 64 workgroups with long reductions -- cost more
+# than the Winograd launch saves: 395 vs 338 us)
+WINO_FUSED_REFLECT_DGRAD_MIN_PIX = int(os.environ.get("SEGSDE_WINO_FUSED_REFLECT_DGRAD_MIN_PIX", str(1 << 17)))
+BORDERS2 = os.environ.get("SEGSDE_BORDERS2", "1") != "0"     # 0: the mirrored-padding terms as implicit-GEMM border launches (first version)
 WINO_FUSED_TAKEN = {"fwd": 0, "dgrad": 0, "fwd2": 0, "dgrad_refl": 0, "dgrad_actgrad": 0, "wgrad": 0}
 
 
@@ -335,19 +340,24 @@ def winograd_fused(kind, x, u_kn, bias=None, act="none", want_stats=False, tag=N
         ag_y, ag_kind = (actgrad[0], ACT[actgrad[1]]) if actgrad is not None else (None, 0)
         ag_ld = nhwc_ld(ag_y) if ag_y is not None else 0
         acc = 1 if accumulate_into is not None else 0
-        d = None
+        d = wdpack = wfpack = None
         if adjoint is not None:
-            g, wdpack = adjoint
-            d = _borders_desc(B, H, W, C, N, nhwc_ld(x))
+            g, wdpack, wfpack = adjoint
+            if wfpack is None or not BORDERS2:
+                d = _borders_desc(B, H, W, C, N, nhwc_ld(x))
 
         def launch():
             rc = L.segsde_conv2d_winograd_fused_dgrad(_p(_f32(x)), nhwc_ld(x), B, H, W, C, _p(u_kn), N, _p(y), N, acc, _p(ag_y), ag_ld,
                                                       ag_kind, _stream(x))
-            if rc == 0 and d is not None:
-                rc = L.segsde_reflect_adjoint_borders(ctypes.byref(d), _p(x), _p(wdpack), _p(y), _p(ag_y), ag_ld, ag_kind, _stream(x))
+            if rc == 0 and adjoint is not None:
+                if d is None:      # the border kernel of csrc/winograd_fused.hip (two launches), forward pack
+                    rc = L.segsde_reflect_adjoint_borders2(_p(x), nhwc_ld(x), _p(wfpack), _p(y), N, _p(ag_y), ag_ld, ag_kind, B, H, W, N, C,
+                                                           _stream(x))
+                else:              # four border launches of the implicit-GEMM kernel + corner kernel, data-gradient pack
+                    rc = L.segsde_reflect_adjoint_borders(ctypes.byref(d), _p(x), _p(wdpack), _p(y), _p(ag_y), ag_ld, ag_kind, _stream(x))
                 if rc == -4:
-                    raise RuntimeError("segsde_reflect_adjoint_borders declined a shape the one-kernel data-gradient took: "
-                                       "the zero-padded part is already in dx (hipops.winograd_fused_ok must gate this)")
+                    raise RuntimeError("the mirrored-padding launches declined a shape the one-kernel data-gradient took: "
+                                       "the zero-padded part is already in dx (hipops.conv_dgrad must gate this)")
             return rc
         rc = _timed(kind, flops, x, launch, tagf, executed=flops * 16.0 / 36.0)
         if rc == -4:
@@ -609,8 +619,9 @@ SKIP_ACCUMULATED = _Slot(False)   # did the last conv_dgrad(accumulate_skip_into
 
 
 def conv_dgrad(g, dy, wdpack, w_oihw, in_hw, need0=True, need1=True, accumulate_into=None, actgrad=None, fold=None, wino=None,
-               accumulate_skip_into=None):
+               accumulate_skip_into=None, wfpack=None):
     """Data gradient(s) of conv_forward w.r.t. (x0, x1).  dy: [B,Ho,Wo,Cout]; in_hw = (H, W) of the virtual input.
+    wfpack: the FORWARD pack, if the caller has it (the mirrored-padding border kernel of the one-kernel Winograd route reads it).
     Returns (dx0, dx1); dx0 is at the *stored* resolution of x0 (2x2-summed when g.up0).
     accumulate_into: a dense [B,H,W,C0] tensor that already holds another gradient of x0 (single-source, non-upsampled
     convs): the result is ADDED to it in the kernel epilogue and that tensor is returned as dx0 (None is returned instead
@@ -634,10 +645,12 @@ def conv_dgrad(g, dy, wdpack, w_oihw, in_hw, need0=True, need1=True, accumulate_
     if isinstance(wino, _KnPack):
         ext = actgrad is not None or g.reflect
         if (winograd_fused_ok(g, B, H, W, dgrad=True) and (Ho, Wo) == (H, W) and (not ext or WINO_FUSED_DGRAD_EXT)
-                and (not g.reflect or reflect_borders_ok(B, H, W, Cout, g.C0, nhwc_ld(dy), ag_ld))
+                and (not g.reflect or B * H * W >= WINO_FUSED_REFLECT_DGRAD_MIN_PIX)
+                and (not g.reflect or (wfpack is not None and BORDERS2 and H >= 4 and W >= 4 and g.C0 % 32 == 0 and Cout % 32 == 0 and Cout <= 1024)
+                     or reflect_borders_ok(B, H, W, Cout, g.C0, nhwc_ld(dy), ag_ld))
                 and (actgrad is None or (ag_ld % 4 == 0 and ag_y.data_ptr() % 16 == 0))):
             r = winograd_fused("conv_dgrad", dy, wino, tag=_tag(g, H, W), accumulate_into=accumulate_into, actgrad=actgrad,
-                               adjoint=(g, wdpack) if g.reflect else None)
+                               adjoint=(g, wdpack, wfpack) if g.reflect else None)
             if r is not None:
                 ACTGRAD_FUSED[0] = actgrad is not None
                 return r[0], None

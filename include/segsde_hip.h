@@ -297,6 +297,11 @@ int segsde_conv2d_winograd_fused_dgrad(const float* dy, int lddy, int B, int H, 
                                        int lddx, int accumulate, const float* act_out, int act_ld, int act_kind, void* stream);
 int segsde_reflect_adjoint_borders(const segsde_conv_desc* d, const float* dy, const float* wdpack, float* y, const float* act_out,
                                    int act_ld, int act_kind, void* stream);
+/* The same mirrored-padding terms by a kernel of their own (csrc/winograd_fused.hip: two launches -- row lines, column lines +
+ * corners -- of a 32-pixel x Cin MFMA kernel instead of five launches of the image-sized implicit-GEMM machinery); wpack = the
+ * FORWARD pack [Cout][3][3][Cin] of segsde_pack_weight(for_dgrad = 0).  Cin % 32 == 0, Cout % 32 == 0, H, W >= 4. */
+int segsde_reflect_adjoint_borders2(const float* dy, int lddy, const float* wpack, float* dx, int lddx, const float* act_out, int act_ld,
+                                    int act_kind, int B, int H, int W, int Cin, int Cout, void* stream);
 /* 1 when segsde_reflect_adjoint_borders takes the descriptor (act_ld: pixel pitch of act_out, 0 without one) -- asked before the
  * zero-padded launch writes dx */
 int segsde_reflect_adjoint_borders_ok(const segsde_conv_desc* d, int act_ld);

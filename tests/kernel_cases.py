@@ -1383,6 +1383,15 @@ def run_winograd_cases(device, shapes=((2, 16, 32, 64, 64), (1, 32, 16, 96, 128)
 
 
 def run_winograd_fused_cases(device, shapes=((1, 8, 16, 64, 64), (2, 12, 20, 64, 128), (1, 16, 32, 128, 64), (1, 6, 4, 128, 128))):
+    keep = H.WINO_FUSED_REFLECT_DGRAD_MIN_PIX
+    H.WINO_FUSED_REFLECT_DGRAD_MIN_PIX = 0          # the router's size gate of the mirrored data-gradient: these are small maps
+    try:
+        _run_winograd_fused_cases(device, shapes)
+    finally:
+        H.WINO_FUSED_REFLECT_DGRAD_MIN_PIX = keep
+
+
+def _run_winograd_fused_cases(device, shapes):
     """the one-kernel Winograd route (csrc/winograd_fused.hip) against a float64 convolution: error within 3x the direct kernel's
     own, whole and partial 4x8-tile blocks, one and two channel fills, forward with bias + ELU, with the BatchNorm statistics
     partials, and the data-gradient through the flipped pack"""
@@ -1448,21 +1457,27 @@ def run_winograd_fused_cases(device, shapes=((1, 8, 16, 64, 64), (2, 12, 20, 64,
             deriv = torch.where(a > 0, torch.ones_like(a), a + 1).double()
             scg = float(wantg.abs().max())
             wd_, dyd, ad = w.to(device), nhwc(dy).to(device).contiguous(), nhwc(a).to(device).contiguous()
-            _, wdp = H.pack_weight_both(wd_)
+            wfp, wdp = H.pack_weight_both(wd_)
             ud = H.winograd_fused_pack(wd_, True)
             g = H.ConvGeom(C, Co, 3, 1, 1, 1, True, 0, False)
             n0 = dict(H.WINO_FUSED_TAKEN)
-            dx, _ = H.conv_dgrad(g, dyd, wdp, wd_, (Hh, W), wino=ud)
+            dx, _ = H.conv_dgrad(g, dyd, wdp, wd_, (Hh, W), wino=ud)          # border terms: implicit-GEMM border launches (no forward pack given)
             assert H.WINO_FUSED_TAKEN["dgrad_refl"] == n0["dgrad_refl"] + 1, what + ": the one-kernel route declined"
             dxd, _ = H.conv_dgrad(g, dyd, wdp, wd_, (Hh, W))
             e_w, e_d = float((nchw(dx).double().cpu() - wantg).abs().max()), float((nchw(dxd).double().cpu() - wantg).abs().max())
             assert e_w <= 3 * e_d + 1e-6 * scg, (what, e_w, e_d, scg)
-            dz, _ = H.conv_dgrad(g, dyd, wdp, wd_, (Hh, W), wino=ud, actgrad=(ad, "elu"))
-            assert H.ACTGRAD_FUSED[0] and H.WINO_FUSED_TAKEN["dgrad_actgrad"] == n0["dgrad_actgrad"] + 1
+            dx2, _ = H.conv_dgrad(g, dyd, wdp, wd_, (Hh, W), wino=ud, wfpack=wfp)   # border terms: the two-launch border kernel
+            e_2 = float((nchw(dx2).double().cpu() - wantg).abs().max())
+            assert e_2 <= 3 * e_d + 1e-6 * scg, (what, "border kernel", e_2, e_d, scg)
+            dz_old, _ = H.conv_dgrad(g, dyd, wdp, wd_, (Hh, W), wino=ud, actgrad=(ad, "elu"))
+            assert_close(nchw(dz_old).cpu(), (wantg * deriv).float(), rtol=1e-4, atol=3 * e_d + 1e-6 * scg, what=what + " x ELU' (border launches)")
+            wdp_keep = wdp
+            dz, _ = H.conv_dgrad(g, dyd, wdp, wd_, (Hh, W), wino=ud, actgrad=(ad, "elu"), wfpack=wfp)
+            assert H.ACTGRAD_FUSED[0] and H.WINO_FUSED_TAKEN["dgrad_actgrad"] == n0["dgrad_actgrad"] + 2
             assert_close(nchw(dz).cpu(), (wantg * deriv).float(), rtol=1e-4, atol=3 * e_d + 1e-6 * scg, what=what + " x ELU'")
             base = torch.randn(B, Hh, W, C, generator=gen).to(device)
             acc = base.clone()
-            dz2, _ = H.conv_dgrad(g, dyd, wdp, wd_, (Hh, W), wino=ud, actgrad=(ad, "elu"), accumulate_into=acc)
+            dz2, _ = H.conv_dgrad(g, dyd, wdp, wd_, (Hh, W), wino=ud, actgrad=(ad, "elu"), accumulate_into=acc, wfpack=wfp)
             assert dz2 is acc and H.ACTGRAD_FUSED[0]
             assert_close(acc, base + dz, rtol=1e-6, atol=1e-6 * scg, what=what + " x ELU', accumulated")
             # zero padding + derivative (layer1 / layer2 never need it, but the epilogue is the same code)

@@ -108,9 +108,23 @@ def test_conv_fullsize_sampled(geom):
         del dz, yact
     del dx0, dx1
     # ---- weight gradient (sampled taps; each one a reduction over all 16 x H x W output pixels)
-    t0 = dict(H.UPFOLD_TAKEN)
+    t0, t1 = dict(H.UPFOLD_TAKEN), dict(H.WINO_FUSED_TAKEN)
     dw = H.conv_wgrad(g, x0, x1, dy)
-    assert H.UPFOLD_TAKEN["wgrad"] == t0["wgrad"] + (1 if H.upfold_ok(g, B16 * Hh * W) else 0), "weight-gradient route"
+    # route: the one-kernel Winograd weight gradient where its gate takes the layer (round 5), else the folded route for the
+    # upsampled layers, else the direct kernel
+    fused = H.winograd_fused_wgrad_ok(g, B16, Hh, W)
+    assert H.WINO_FUSED_TAKEN["wgrad"] == t1["wgrad"] + (1 if fused else 0), "weight-gradient route (one-kernel Winograd)"
+    assert H.UPFOLD_TAKEN["wgrad"] == t0["wgrad"] + (1 if (H.upfold_ok(g, B16 * Hh * W) and not fused) else 0), "weight-gradient route"
+    if fused and H.upfold_ok(g, B16 * Hh * W):
+        # the folded weight gradient stays a supported route (SEGSDE_WINO_FUSED_WGRAD=0): same samples
+        H.WINO_FUSED_WGRAD = False
+        try:
+            dwf = H.conv_wgrad(g, x0, x1, dy)
+        finally:
+            H.WINO_FUSED_WGRAD = True
+        assert H.UPFOLD_TAKEN["wgrad"] == t0["wgrad"] + 1, "the folded weight gradient fell back"
+    else:
+        dwf = None
     rng = np.random.RandomState(5)
     taps = [(0, 0, 0, 0), (Cout - 1, C0 + C1 - 1, k - 1, k - 1), (Cout - 1, 0, 0, k - 1), (0, C0 + C1 - 1, k - 1, 0)]
     if C1:
@@ -120,6 +134,8 @@ def test_conv_fullsize_sampled(geom):
     want = torch.tensor(SC.wgrad_samples(x0, x1, up0, dy, k, 1, dil, pad, reflect, taps), dtype=torch.float64)
     got = torch.stack([dw[t] for t in taps])
     _cmp(got, want, name + " wgrad", rtol=1e-3, arel=2e-4)
+    if dwf is not None:
+        _cmp(torch.stack([dwf[t] for t in taps]), want, name + " wgrad (folded route)", rtol=1e-3, arel=2e-4)
 
 
 def test_loss_kernels_fullsize_last_image_vs_oracle():
@@ -613,8 +629,10 @@ def test_winograd_fullsize_vs_direct(geom):
         dxd, _ = H.conv_dgrad(g, dy, wd, w, (Hh, W))
         sc = float(dxd.abs().max())
         assert float((dxw - dxd).abs().max()) <= 1e-5 * sc, (name, "data-gradient", float((dxw - dxd).abs().max()), sc)
+    f0 = H.WINO_FUSED_TAKEN["wgrad"]
     dww = H.conv_wgrad(g, x0, x1, dy)
-    assert H.WINOGRAD_TAKEN["wgrad"] == n0["wgrad"] + 1
+    # (round 5: the 256-channel layers' weight gradient runs on the one-kernel scheme, the others on the grouped route)
+    assert (H.WINOGRAD_TAKEN["wgrad"] - n0["wgrad"]) + (H.WINO_FUSED_TAKEN["wgrad"] - f0) == 1
     H.WINOGRAD = False
     try:
         dwd = H.conv_wgrad(g, x0, x1, dy)
@@ -622,3 +640,60 @@ def test_winograd_fullsize_vs_direct(geom):
         H.WINOGRAD = True
     sc = float(dwd.abs().max())
     assert float((dww - dwd).abs().max()) <= 3e-5 * sc, (name, "weight gradient", float((dww - dwd).abs().max()), sc)
+
+
+@pytest.mark.parametrize("geom", [("128->64 refl @256x512", 256, 512, 128, 0, 64, False),
+                                  ("128->128 refl @128x256", 128, 256, 128, 0, 128, False),
+                                  ("256->128 refl @64x128", 64, 128, 256, 0, 128, False),
+                                  ("256->256 refl @32x64", 32, 64, 256, 0, 256, False),
+                                  ("[up 128 | 64]->128 refl @256x512", 256, 512, 128, 64, 128, True),
+                                  ("[up 128 | 256]->128 refl @128x256", 128, 256, 128, 256, 128, True),
+                                  ("[up 256 | 512]->256 refl @64x128", 64, 128, 256, 512, 256, True)],
+                         ids=["dec_128_64", "dec_128_128", "dec_256_128", "dec_256_256", "dec_up_128_64", "dec_up_128_256", "dec_up_256_512"])
+def test_winograd_fused_decoder_fullsize_vs_direct(geom):
+    """Round 5: the one-kernel Winograd route's new directions on the decoders' Conv3x3 geometries at the benchmark's batch (16),
+    WHOLE tensors against the direct route (itself checked against float64 samples at this size by test_conv_fullsize_sampled):
+    forward with mirrored padding + bias + ELU (single source, and [upsample(x0) | x1] through the patch loader), the mirrored
+    convolution's data-gradient with the ELU derivative in the epilogue (zero-padded launch + border launches), and the weight
+    gradient of csrc/winograd_wgrad.hip.  1e-5 (forward, data-gradient) / 3e-5 (weight gradient) of the largest value."""
+    name, Hh, W, C0, C1, Co, up = geom
+    dev = "cuda"
+    gen = torch.Generator().manual_seed(37)
+    g = H.ConvGeom(C0, Co, 3, 1, 1, 1, True, C1, up)
+    h0, w0 = (Hh // 2, W // 2) if up else (Hh, W)
+    x0 = torch.nn.functional.elu(torch.randn(B16, h0, w0, C0, generator=gen)).to(dev)      # the previous ConvBlock's output
+    x1 = torch.randn(B16, Hh, W, C1, generator=gen).to(dev) if C1 else None
+    w = (torch.randn(Co, C0 + C1, 3, 3, generator=gen) * (2.0 / (9 * (C0 + C1))) ** 0.5).to(dev)
+    bias = (torch.randn(Co, generator=gen) * 0.1).to(dev)
+    dy = torch.randn(B16, Hh, W, Co, generator=gen).to(dev)
+    wp, wd = H.pack_weight_both(w)
+    uf, ud = H.winograd_fused_pack(w, False), H.winograd_fused_pack(w, True)
+    old = (H.WINO_FUSED2_MIN_FOLD, H.WINO_FUSED_WGRAD_MIN_FOLD, H.WINO_FUSED_REFLECT_DGRAD_MIN_PIX)
+    H.WINO_FUSED2_MIN_FOLD = H.WINO_FUSED_WGRAD_MIN_FOLD = 0.0        # every geometry here, whatever the router's speed gates say
+    H.WINO_FUSED_REFLECT_DGRAD_MIN_PIX = 0
+    try:
+        n0 = dict(H.WINO_FUSED_TAKEN)
+        yw = H.conv_forward(g, x0, x1, wp, bias, "elu", wino=uf)
+        assert H.WINO_FUSED_TAKEN["fwd2" if (up or C1) else "fwd"] == n0["fwd2" if (up or C1) else "fwd"] + 1, name + ": forward declined"
+        yd = H.conv_forward(g, x0, x1, wp, bias, "elu")
+        sc = float(yd.abs().max())
+        assert float((yw - yd).abs().max()) <= 1e-5 * sc, (name, "forward", float((yw - yd).abs().max()), sc)
+        del yw, yd
+        if not (up or C1):
+            dxw, _ = H.conv_dgrad(g, dy, wd, w, (Hh, W), wino=ud, actgrad=(x0, "elu"), wfpack=wp)
+            assert H.WINO_FUSED_TAKEN["dgrad_refl"] == n0["dgrad_refl"] + 1 and H.ACTGRAD_FUSED[0], name + ": data-gradient declined"
+            dxd, _ = H.conv_dgrad(g, dy, wd, w, (Hh, W), actgrad=(x0, "elu"))
+            sc = float(dxd.abs().max())
+            assert float((dxw - dxd).abs().max()) <= 1e-5 * sc, (name, "data-gradient", float((dxw - dxd).abs().max()), sc)
+            del dxw, dxd
+        dww = H.conv_wgrad(g, x0, x1, dy)
+        assert H.WINO_FUSED_TAKEN["wgrad"] == n0["wgrad"] + 1, name + ": weight gradient declined"
+        H.WINO_FUSED_WGRAD = False
+        try:
+            dwd = H.conv_wgrad(g, x0, x1, dy)
+        finally:
+            H.WINO_FUSED_WGRAD = True
+        sc = float(dwd.abs().max())
+        assert float((dww - dwd).abs().max()) <= 3e-5 * sc, (name, "weight gradient", float((dww - dwd).abs().max()), sc)
+    finally:
+        H.WINO_FUSED2_MIN_FOLD, H.WINO_FUSED_WGRAD_MIN_FOLD, H.WINO_FUSED_REFLECT_DGRAD_MIN_PIX = old

@@ -45,20 +45,21 @@ if "dgrad" in what:
         g = H.ConvGeom(C, Co, 3, 1, 1, 1, refl, 0, False)
         dy, a = rnd(B, Hh, W, Co), torch.nn.functional.elu(rnd(B, Hh, W, C))
         w = rnd(Co, C, 3, 3) * (2.0 / (9 * C)) ** 0.5
-        _, wdp = H.pack_weight_both(w)
+        wfp, wdp = H.pack_weight_both(w)
         ud = H.winograd_fused_pack(w, True)
         ag = (a, "elu")
         t_d = timed(lambda: H.conv_dgrad(g, dy, wdp, w, (Hh, W), actgrad=ag))
-        t_f = timed(lambda: H.conv_dgrad(g, dy, wdp, w, (Hh, W), actgrad=ag, wino=ud))
+        t_f1 = timed(lambda: H.conv_dgrad(g, dy, wdp, w, (Hh, W), actgrad=ag, wino=ud))      # border terms: implicit-GEMM border launches
+        t_f = timed(lambda: H.conv_dgrad(g, dy, wdp, w, (Hh, W), actgrad=ag, wino=ud, wfpack=wfp))   # border kernel (two launches)
         H.WINO_FUSED_DGRAD_EXT = False
         t_fz = timed(lambda: H.winograd_fused("conv_dgrad", dy, ud))      # the zero-padded launch alone: what the borders + epilogue cost
         H.WINO_FUSED_DGRAD_EXT = True
         d1, _ = H.conv_dgrad(g, dy, wdp, w, (Hh, W), actgrad=ag)
-        d2, _ = H.conv_dgrad(g, dy, wdp, w, (Hh, W), actgrad=ag, wino=ud)
+        d2, _ = H.conv_dgrad(g, dy, wdp, w, (Hh, W), actgrad=ag, wino=ud, wfpack=wfp)
         err = float((d1 - d2).abs().max()) / float(d1.abs().max())
         gf = 2.0 * B * Hh * W * C * Co * 9 / 1e6
-        print("%-36s direct %7.1f us (%5.1f TF)  fused %7.1f us (%5.1f TF alg, %.2fx; zero-padded launch alone %7.1f us)  rel. diff %.1e"
-              % (name, t_d, gf / t_d, t_f, gf / t_f, t_d / t_f, t_fz, err), flush=True)
+        print("%-36s direct %7.1f us (%5.1f TF)  fused %7.1f us (%5.1f TF alg, %.2fx; with implicit-GEMM border launches %7.1f us; zero-padded launch alone, no derivative %7.1f us)  rel. diff %.1e"
+              % (name, t_d, gf / t_d, t_f, gf / t_f, t_d / t_f, t_f1, t_fz, err), flush=True)
 
 if "fwd2" in what:
     print("# (b) forward on [upsample(x0) | x1], mirrored padding, bias + ELU: upsample-folded direct route vs one-kernel Winograd")

@@ -4,7 +4,7 @@ OUT=$ROOT/gpurun_out
 TAG=${TAG:-ckpt}
 mkdir -p $OUT
 cd $ROOT
-timeout 2700 python -m pytest tests -m gpu -q -x 2>&1 | grep -v "RCCL\|HIP version\|ROCm version\|Hostname\|Librccl" | tail -15 > $OUT/r5_${TAG}_tests.log
+timeout 2700 python -m pytest tests -m gpu -q 2>&1 | grep -v "RCCL\|HIP version\|ROCm version\|Hostname\|Librccl" | tail -15 > $OUT/r5_${TAG}_tests.log
 python -c "import __graft_entry__ as g; g.smoke(); print('SMOKE OK')" > $OUT/r5_${TAG}_smoke.log 2>&1
 SEGSDE_BENCH_LAYERS=$OUT/layers_r05_${TAG}.txt python bench.py --no-cpu-baseline > $OUT/bench_r05_${TAG}.json 2> $OUT/bench_r05_${TAG}.err
 bash tools/runs/trace.sh r05_${TAG}
