@@ -59,10 +59,10 @@ _SIGS = {
     "segsde_conv2d_winograd_fused": (c_int, [P, c_int, c_int, c_int, c_int, c_int, c_int, P, c_int, P, c_int, P, c_int, c_int, P, P]),
     "segsde_conv2d_winograd_fused2": (c_int, [P, c_int, c_int, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, P, c_int, P, c_int, P,
                                               c_int, P, P]),
-    "segsde_conv2d_winograd_fused_dgrad": (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, c_int, P, c_int, c_int, P, c_int, c_int, P]),
+    "segsde_conv2d_winograd_fused_dgrad": (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, c_int, c_int, P, c_int, c_int, P, c_int, c_int, P]),
     "segsde_reflect_adjoint_borders": (c_int, [P, P, P, P, P, c_int, c_int, P]),
     "segsde_reflect_adjoint_borders_ok": (c_int, [P, c_int]),
-    "segsde_reflect_adjoint_borders2": (c_int, [P, c_int, P, P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "segsde_reflect_adjoint_borders2": (c_int, [P, c_int, P, c_int, P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "segsde_conv2d_wgrad_winograd_fused_workspace": (c_size_t, [P]),
     "segsde_conv2d_wgrad_winograd_fused": (c_int, [P, P, P, P, c_int, P, P, c_size_t, P]),
     "segsde_upfold_pack": (c_int, [P, c_int, c_int, c_int, P, P, P]),
@@ -104,6 +104,7 @@ _SIGS = {
     "segsde_axpby": (c_int, [c_long, c_float, P, c_float, P, P, P]),
     "segsde_axpby_dev": (c_int, [c_long, P, P, P, P, P, P]),
     "segsde_scale_channels": (c_int, [P, c_int, c_int, c_long, c_int, P, P, c_int, P]),
+    "segsde_dropout": (c_int, [P, c_int, c_long, c_int, c_float, c_uint64, P, c_int, P]),
     "segsde_copy_channels": (c_int, [P, c_int, P, c_int, c_long, c_int, P]),
     "segsde_nchw_to_nhwc": (c_int, [P, c_int, c_int, c_int, c_int, c_float, c_float, P, c_int, P]),
     "segsde_nhwc_to_nchw": (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, P]),

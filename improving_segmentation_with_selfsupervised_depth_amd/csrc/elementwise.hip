@@ -746,6 +746,16 @@ __global__ __launch_bounds__(256) void scale_channels_kernel(const float* x, int
     y[m * ldy + c] = x[m * ldx + c] * scale[b * C + c];
   }
 }
+// nn.Dropout on an NHWC tensor: y = keep(e) ? x / (1 - p) : 0 with the counter-based mask of (seed, element index) -- the same
+// draw the BatchNorm-fused dropout uses (segsde_uniform01), regenerated by the adjoint (the same call on the gradient)
+__global__ __launch_bounds__(256) void dropout_kernel(const float* x, int ldx, long M, int C, float p, uint64_t seed, float* y, int ldy) {
+  const float ks = 1.f / (1.f - p);
+  const long total = M * C;
+  for (long e = blockIdx.x * 256L + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const int c = (int)(e % C); const long m = e / C;
+    y[m * ldy + c] = segsde_uniform01(seed, (uint64_t)e) >= p ? x[m * ldx + c] * ks : 0.f;
+  }
+}
 __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* x, int B, int C, int H, int W, float mean, float sd,
                                                            float* y, int ldy) {
   // every one of the ldy channels of a pixel is written (channels past C: zeros -- the padded network input needs no
@@ -1147,6 +1157,13 @@ extern "C" int segsde_scale_channels(const float* x, int ldx, int B, long HW, in
   if (B <= 0 || HW <= 0 || C <= 0 || ldx < C || ldy < C) return SEGSDE_ERR_SHAPE;
   const long total = (long)B * HW * C;
   hipLaunchKernelGGL(scale_channels_kernel, dim3(ew_blocks(total)), dim3(256), 0, ST(stream), x, ldx, scale, HW, C, total, y, ldy);
+  SEGSDE_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int segsde_dropout(const float* x, int ldx, long M, int C, float p, uint64_t seed, float* y, int ldy, void* stream) {
+  if (!x || !y) return SEGSDE_ERR_NULL;
+  if (M <= 0 || C <= 0 || ldx < C || ldy < C || p < 0.f || p >= 1.f) return SEGSDE_ERR_SHAPE;
+  hipLaunchKernelGGL(dropout_kernel, dim3(ew_blocks(M * C)), dim3(256), 0, ST(stream), x, ldx, M, C, p, seed, y, ldy);
   SEGSDE_CHECK_LAUNCH();
   return 0;
 }

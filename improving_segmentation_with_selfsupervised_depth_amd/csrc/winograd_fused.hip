@@ -47,7 +47,7 @@ struct WinoAg { const float* agy; int agld, agkind; };
 
 template <bool STATS>
 __global__ __launch_bounds__(256, 2) void wino_fused_kernel(WinoSrc src, int B, int H, int W, int C, int reflect,
-                                                            const float* U, int Co, const float* bias, int act, float* y, int ldy,
+                                                            const float* U, int ldu, int Co, const float* bias, int act, float* y, int ldy,
                                                             double* part, int accumulate, WinoAg ag) {
   SEGSDE_SMEM;
   float* lds = reinterpret_cast<float*>(segsde_smem);
@@ -118,9 +118,10 @@ __global__ __launch_bounds__(256, 2) void wino_fused_kernel(WinoSrc src, int B, 
     // VALU issue slots are MFMA issue slots)
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const segsde_rsrc ur = segsde_make_rsrc(U);
-    const unsigned lane_off = (unsigned)(kk * Co + t) * 4u;                          // bytes
-    const unsigned ubase = (unsigned)((((long)(4 * wave_u) * C + c0) * Co + co0) * 4);   // bytes; 16 C Cout floats < 2^30
-    const unsigned upos = (unsigned)((long)C * Co * 4), ustep = (unsigned)(2 * Co * 4);
+    // (ldu: row pitch of U -- Co, or the width of the pack this launch takes a column slice of)
+    const unsigned lane_off = (unsigned)(kk * ldu + t) * 4u;                          // bytes
+    const unsigned ubase = (unsigned)((((long)(4 * wave_u) * C + c0) * ldu + co0) * 4);   // bytes; 16 C ldu floats < 2^30
+    const unsigned upos = (unsigned)((long)C * ldu * 4), ustep = (unsigned)(2 * ldu * 4);
     // B operands come straight from L2 (a few hundred ns): requested PD steps (PD x 512 MFMA cycles) ahead; the raw pixels
     // (LDS) one step ahead
     constexpr int PD = 4, NS = FCH / 2;
@@ -303,7 +304,7 @@ __global__ __launch_bounds__(256) void wino_weight_kn_kernel(const float* w, int
 // workgroups of a launch ever add to the same address (no atomics, deterministic).
 struct BorderP {
   const float* dy; const float* wp /* forward pack [Cout][3][3][Cin] */; float* dx; const float* agy;
-  int lddy, lddx, agld, agkind, B, H, W, Cin, Cout, mode, nseg;
+  int lddy, lddx, agld, agkind, B, H, W, Cin, Cout, mode, nseg, ldw;
 };
 
 __global__ __launch_bounds__(256) void reflect_borders_kernel(BorderP p) {
@@ -350,8 +351,8 @@ __global__ __launch_bounds__(256) void reflect_borders_kernel(BorderP p) {
         src = (t == 3 ? 0 : p.H - 1) - (p0 - 1);
       }
       const float* ap = sh + src * pitch + kk;
-      const float* bp = p.wp + ((long)kk * 9 + kh * 3 + kw) * p.Cin + cin;
-      const long bstep = 18L * p.Cin;
+      const float* bp = p.wp + ((long)kk * 9 + kh * 3 + kw) * p.ldw + cin;      // (ldw: the forward pack's channel count; a source's slice starts at wp + C0)
+      const long bstep = 18L * p.ldw;
       // weights straight from L2 (128-byte runs per half-wave): eight steps' requests in flight ahead of the eight being multiplied
       float bv[2][8];
 #pragma unroll
@@ -409,17 +410,17 @@ extern "C" int segsde_winograd_fused_pack(const float* w_oihw, int O, int I, int
 }
 
 namespace {
-int launch_fused(const WinoSrc& src, int B, int H, int W, int C, int reflect, const float* u_kn, int Cout, const float* bias, int act,
+int launch_fused(const WinoSrc& src, int B, int H, int W, int C, int reflect, const float* u_kn, int ldu, int Cout, const float* bias, int act,
                  float* y, int ldy, int accumulate, double* stats, const WinoAg& ag, void* stream) {
   const dim3 grid((unsigned)fused_blocks(B, H, W), (unsigned)(Cout / 64));
   if (stats) {
     auto k = wino_fused_kernel<true>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_LDS);
-    hipLaunchKernelGGL(k, grid, dim3(256), F_LDS, ST(stream), src, B, H, W, C, reflect, u_kn, Cout, bias, act, y, ldy, stats, accumulate, ag);
+    hipLaunchKernelGGL(k, grid, dim3(256), F_LDS, ST(stream), src, B, H, W, C, reflect, u_kn, ldu, Cout, bias, act, y, ldy, stats, accumulate, ag);
   } else {
     auto k = wino_fused_kernel<false>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_LDS);
-    hipLaunchKernelGGL(k, grid, dim3(256), F_LDS, ST(stream), src, B, H, W, C, reflect, u_kn, Cout, bias, act, y, ldy, (double*)nullptr, accumulate, ag);
+    hipLaunchKernelGGL(k, grid, dim3(256), F_LDS, ST(stream), src, B, H, W, C, reflect, u_kn, ldu, Cout, bias, act, y, ldy, (double*)nullptr, accumulate, ag);
   }
   SEGSDE_CHECK_LAUNCH();
   return 0;
@@ -433,7 +434,7 @@ extern "C" int segsde_conv2d_winograd_fused(const float* x, int ldx, int B, int 
   if (!segsde_winograd_fused_ok(B, H, W, C, Cout) || ldx < C || ldx % 4 != 0 || ldy < Cout || (accumulate && (stats || bias || act)))
     return SEGSDE_ERR_UNSUPPORTED;
   const WinoSrc src{x, nullptr, ldx, 0, C, 0};
-  return launch_fused(src, B, H, W, C, reflect, u_kn, Cout, bias, act, y, ldy, accumulate, stats, WinoAg{nullptr, 0, 0}, stream);
+  return launch_fused(src, B, H, W, C, reflect, u_kn, Cout, Cout, bias, act, y, ldy, accumulate, stats, WinoAg{nullptr, 0, 0}, stream);
 }
 
 // forward on the virtual input [up2x?(x0) | x1] (the decoder's Conv3x3 on the upsampled previous block and the encoder skip,
@@ -447,37 +448,41 @@ extern "C" int segsde_conv2d_winograd_fused2(const float* x0, int ld0, int C0, i
       ldy < Cout)
     return SEGSDE_ERR_UNSUPPORTED;
   const WinoSrc src{x0, x1, ld0, ld1, C0, up0 ? 1 : 0};
-  return launch_fused(src, B, H, W, C, reflect, u_kn, Cout, bias, act, y, ldy, 0, stats, WinoAg{nullptr, 0, 0}, stream);
+  return launch_fused(src, B, H, W, C, reflect, u_kn, Cout, Cout, bias, act, y, ldy, 0, stats, WinoAg{nullptr, 0, 0}, stream);
 }
 
 // data-gradient of the zero-padded 3x3 / stride 1 convolution (= the convolution of dy with the flipped, transposed pack) with
 // the epilogues of the direct route: accumulate onto dx (a gradient another consumer left there), act_out (nullable) = the
 // saved activation output whose derivative multiplies the result (before the accumulation, like segsde_conv2d_dgrad_actgrad).
+// ldu: row pitch of ud_kn -- Cin, or, for the gradient of ONE source of a two-source convolution (the decoder's skip input,
+// channels [C0, C0 + C1) of the weight), the full pack's width with ud_kn pointing at the slice's first column.
 // A reflection-padded convolution's data-gradient is this call followed by segsde_reflect_adjoint_borders.
-extern "C" int segsde_conv2d_winograd_fused_dgrad(const float* dy, int lddy, int B, int H, int W, int Cout, const float* ud_kn, int Cin,
-                                                  float* dx, int lddx, int accumulate, const float* act_out, int act_ld, int act_kind,
-                                                  void* stream) {
+extern "C" int segsde_conv2d_winograd_fused_dgrad(const float* dy, int lddy, int B, int H, int W, int Cout, const float* ud_kn, int ldu,
+                                                  int Cin, float* dx, int lddx, int accumulate, const float* act_out, int act_ld,
+                                                  int act_kind, void* stream) {
   if (!dy || !ud_kn || !dx) return SEGSDE_ERR_NULL;
-  if (!segsde_winograd_fused_ok(B, H, W, Cout, Cin) || lddy < Cout || lddy % 4 != 0 || lddx < Cin ||
+  if (!segsde_winograd_fused_ok(B, H, W, Cout, Cin) || ldu < Cin || (long)16 * Cout * ldu >= (1L << 28) || lddy < Cout || lddy % 4 != 0 || lddx < Cin ||
       (act_out && (act_kind < SEGSDE_ACT_RELU || act_kind > SEGSDE_ACT_SIGMOID || act_ld < Cin)))
     return SEGSDE_ERR_UNSUPPORTED;
   const WinoSrc src{dy, nullptr, lddy, 0, Cout, 0};
-  return launch_fused(src, B, H, W, Cout, 0, ud_kn, Cin, nullptr, SEGSDE_ACT_NONE, dx, lddx, accumulate, nullptr,
+  return launch_fused(src, B, H, W, Cout, 0, ud_kn, ldu, Cin, nullptr, SEGSDE_ACT_NONE, dx, lddx, accumulate, nullptr,
                       WinoAg{act_out, act_ld, act_kind}, stream);
 }
 
 // the mirrored-padding part of a reflection-padded 3x3 convolution's data-gradient, ADDED onto dx (after
 // segsde_conv2d_winograd_fused_dgrad wrote the zero-padded part): wpack = the FORWARD pack [Cout][3][3][Cin] (segsde_pack_weight,
-// for_dgrad = 0); act_out as in segsde_conv2d_winograd_fused_dgrad.  Two launches (row lines; column lines + corners).
-extern "C" int segsde_reflect_adjoint_borders2(const float* dy, int lddy, const float* wpack, float* dx, int lddx, const float* act_out,
-                                               int act_ld, int act_kind, int B, int H, int W, int Cin, int Cout, void* stream) {
+// for_dgrad = 0) with channel count ldw (Cin, or the full width when wpack points at one source's channel slice); act_out as in
+// segsde_conv2d_winograd_fused_dgrad.  Two launches (row lines; column lines + corners).
+extern "C" int segsde_reflect_adjoint_borders2(const float* dy, int lddy, const float* wpack, int ldw, float* dx, int lddx,
+                                               const float* act_out, int act_ld, int act_kind, int B, int H, int W, int Cin, int Cout,
+                                               void* stream) {
   if (!dy || !wpack || !dx) return SEGSDE_ERR_NULL;
-  if (B <= 0 || H < 4 || W < 4 || Cin <= 0 || Cin % 32 || Cout <= 0 || Cout % 32 || Cout > 1024 || lddy < Cout || lddy % 4 || lddx < Cin ||
+  if (B <= 0 || H < 4 || W < 4 || Cin <= 0 || Cin % 32 || ldw < Cin || Cout <= 0 || Cout % 32 || Cout > 1024 || lddy < Cout || lddy % 4 || lddx < Cin ||
       ((uintptr_t)dy & 15) || (act_out && (act_kind < SEGSDE_ACT_RELU || act_kind > SEGSDE_ACT_SIGMOID || act_ld < Cin)))
     return SEGSDE_ERR_UNSUPPORTED;
   BorderP p;
   p.dy = dy; p.wp = wpack; p.dx = dx; p.agy = act_out; p.lddy = lddy; p.lddx = lddx; p.agld = act_ld; p.agkind = act_kind;
-  p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
+  p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.ldw = ldw;
   const size_t lb = (size_t)34 * (Cout + 1) * sizeof(float);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(reflect_borders_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
   for (int mode = 0; mode < 2; ++mode) {

@@ -154,17 +154,19 @@ class ConvFn(Function):
         # (round 5: the one-kernel route also takes the decoder's [upsample(x0) | x1] layers, forward only)
         up_f = 2 if g.up0 else 1
         kn = H.winograd_fused_ok(g, x0.shape[0], x0.shape[1] * up_f, x0.shape[2] * up_f)
-        if kn or (not g.up0 and H.winograd_ok(g, x0.shape[0], x0.shape[1], x0.shape[2])):
+        # (and, whatever route the forward takes, the skip-source data-gradient of the two-source layers: the flipped pack)
+        kn_d2 = (x1 is not None and g.up0 and (ctx.needs_input_grad[1])
+                 and H.winograd_fused_dgrad2_ok(g, x0.shape[0], x0.shape[1] * up_f, x0.shape[2] * up_f))
+        if kn or kn_d2 or (not g.up0 and H.winograd_ok(g, x0.shape[0], x0.shape[1], x0.shape[2])):
+            knl = kn or kn_d2                              # pack layout: [16][K][N] of the one-kernel route
             if (wino_cache is not None and wino_cache.get("key") is not None and wino_cache.get("key") == wino_cache.get("want")
-                    and bool(wino_cache.get("kn")) == kn):
+                    and bool(wino_cache.get("kn")) == knl):
                 ctx.wino = wino_cache["packs"]
-            elif kn and (g.up0 or x1 is not None) and (wino_cache is None or wino_cache.get("want") is None):
-                ctx.wino = (H.winograd_fused_pack(weight, False), None)     # two sources: the data-gradient stays on the folded route
             else:
-                ctx.wino = H.winograd_pack(weight, kn=kn)
+                ctx.wino = H.winograd_pack(weight, kn=knl)
                 if wino_cache is not None and wino_cache.get("want") is not None:
-                    wino_cache["packs"], wino_cache["key"], wino_cache["kn"] = ctx.wino, wino_cache["want"], kn
-        wino_f = None if ctx.wino is None else ctx.wino[0]
+                    wino_cache["packs"], wino_cache["key"], wino_cache["kn"] = ctx.wino, wino_cache["want"], knl
+        wino_f = None if (ctx.wino is None or (kn_d2 and not kn)) else ctx.wino[0]
         keep_v = wino_f is not None and not kn and ctx.needs_input_grad[2]   # the weight gradient reuses the forward's transformed input
         H.WINO_V[0] = None
         if stats_out is not None:
@@ -220,7 +222,7 @@ class ConvFn(Function):
                 sbox = ctx.skip_box if (x1 is not None and ctx.needs_input_grad[1]) else None
                 dx0, dx1 = H.conv_dgrad(g, dz, wd, weight.detach(), ctx.in_hw, actgrad=actgrad, fold=ctx.fold,
                                         need0=ctx.needs_input_grad[0], need1=x1 is not None and ctx.needs_input_grad[1],
-                                        wino=None if (ctx.wino is None or x1 is not None) else ctx.wino[1],
+                                        wino=None if ctx.wino is None else ctx.wino[1],
                                         accumulate_skip_into=None if sbox is None else sbox.get("g"), wfpack=ctx.wp)
                 if sbox is not None and dx1 is not None:
                     if H.SKIP_ACCUMULATED[0]:
@@ -538,6 +540,19 @@ class ChannelDropFn(Function):
     def backward(ctx, dy):
         (scale,) = ctx.saved_tensors
         return H.scale_channels(_c(dy), scale), None
+
+
+class DropoutFn(Function):
+    """nn.Dropout on an NHWC tensor: the mask is a function of (seed, element index), so backward regenerates it"""
+
+    @staticmethod
+    def forward(ctx, x, p, seed):
+        ctx.p, ctx.seed = p, seed
+        return H.dropout(_c(x), p, seed)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return H.dropout(_c(dy), ctx.p, ctx.seed), None, None
 
 
 class PoseMatrixFn(Function):

@@ -237,7 +237,7 @@ WINO_FUSED_MAX_CH = int(os.environ.get("SEGSDE_WINO_FUSED_MAX_CH", "256"))
 # ~0.75 of the direct kernel's multiply-add rate (profiles/probe_r05_*.log); SEGSDE_WINO_FUSED2=0: off
 WINO_FUSED2 = os.environ.get("SEGSDE_WINO_FUSED2", "1") != "0"
 WINO_FUSED2_MAX_CIN = int(os.environ.get("SEGSDE_WINO_FUSED2_MAX_CIN", "768"))
-WINO_FUSED2_MIN_FOLD = float(os.environ.get("SEGSDE_WINO_FUSED2_MIN_FOLD", "0.7"))
+WINO_FUSED2_MIN_FOLD = float(os.environ.get("SEGSDE_WINO_FUSED2_MIN_FOLD", "0.6"))
 # round 5: data-gradients of the mirrored-padding Conv3x3 (zero-padded one-kernel launch + border launches) and data-gradients
 # with the activation-derivative epilogue on the one-kernel route; SEGSDE_WINO_FUSED_DGRAD_EXT=0 keeps them on the direct kernel
 WINO_FUSED_DGRAD_EXT = os.environ.get("SEGSDE_WINO_FUSED_DGRAD_EXT", "1") != "0"
@@ -245,8 +245,12 @@ WINO_FUSED_DGRAD_EXT = os.environ.get("SEGSDE_WINO_FUSED_DGRAD_EXT", "1") != "0"
 # 1.35-1.6x from 16 x 64 x 128 pixels; at 16 x 32 x 64 the two border launches -- 64 workgroups with long reductions -- cost more
 # than the Winograd launch saves: 395 vs 338 us)
 WINO_FUSED_REFLECT_DGRAD_MIN_PIX = int(os.environ.get("SEGSDE_WINO_FUSED_REFLECT_DGRAD_MIN_PIX", str(1 << 17)))
+# the skip-source gradient of the decoder's two-source layers (dy -> the C1 encoder channels, mirrored padding, accumulated onto the
+# feature's gradient collector) on the one-kernel route -- a column slice of the flipped pack -- while the upsampled source's
+# low-resolution gradient stays on the folded route's 4x4 / stride-2 launch.  SEGSDE_WINO_FUSED_DGRAD2=0: off
+WINO_FUSED_DGRAD2 = os.environ.get("SEGSDE_WINO_FUSED_DGRAD2", "1") != "0"
 BORDERS2 = os.environ.get("SEGSDE_BORDERS2", "1") != "0"     # 0: the mirrored-padding terms as implicit-GEMM border launches (first version)
-WINO_FUSED_TAKEN = {"fwd": 0, "dgrad": 0, "fwd2": 0, "dgrad_refl": 0, "dgrad_actgrad": 0, "wgrad": 0}
+WINO_FUSED_TAKEN = {"fwd": 0, "dgrad": 0, "fwd2": 0, "dgrad_refl": 0, "dgrad_actgrad": 0, "dgrad2": 0, "wgrad": 0}
 
 
 def winograd_fused_ok(g, B=None, H=None, W=None, dgrad=False):
@@ -269,6 +273,19 @@ def winograd_fused_ok(g, B=None, H=None, W=None, dgrad=False):
     if B is None:
         return True
     return bool(_lib.lib().segsde_winograd_fused_ok(B, H, W, cin, cout)) and 9.0 * B * H * W * cin * cout >= WINOGRAD_MIN_MACS
+
+
+def winograd_fused_dgrad2_ok(g, B=None, H=None, W=None):
+    """the skip-source data-gradient of a [upsample(x0) | x1] -> Cout mirrored 3x3 convolution as the one-kernel Winograd
+    convolution Cout -> C1 (+ border kernel)"""
+    if not (WINOGRAD and WINO_FUSED and WINO_FUSED_DGRAD_EXT and WINO_FUSED_DGRAD2 and BORDERS2 and g.k == 3 and g.stride == 1 and g.dil == 1
+            and g.pad == 1 and g.reflect and g.up0 and g.C1 and g.cin_alg is None and g.C1 % 64 == 0 and g.Cout % 64 == 0
+            and g.Cout <= WINO_FUSED_MAX_CH and g.Cin <= WINO_FUSED2_MAX_CIN):
+        return False
+    if B is None:
+        return True
+    return (B * H * W >= WINO_FUSED_REFLECT_DGRAD_MIN_PIX and bool(_lib.lib().segsde_winograd_fused_ok(B, H, W, g.Cout, g.C1))
+            and 9.0 * B * H * W * g.C1 * g.Cout >= WINOGRAD_MIN_MACS)
 
 
 def winograd_fused_static_ok(conv):
@@ -301,7 +318,7 @@ def winograd_fused_pack(w_oihw, flip):
 
 
 def winograd_fused(kind, x, u_kn, bias=None, act="none", want_stats=False, tag=None, reflect=False, accumulate_into=None, x1=None,
-                   up0=False, actgrad=None, adjoint=None):
+                   up0=False, actgrad=None, adjoint=None, cols=None):
     """[up2x?(x) | x1] [B,H,W,C] NHWC -> act(conv3x3(.) + bias) [B,H,W,N] with u_kn [16][C][N]; (y, statistics partials or None).
     accumulate_into: a dense [B,H,W,N] tensor the result is added onto (and which is returned).
     Data-gradient extras: actgrad = (saved activation output [B,H,W,N], kind): the result is multiplied by the activation's
@@ -311,8 +328,9 @@ def winograd_fused(kind, x, u_kn, bias=None, act="none", want_stats=False, tag=N
     H, W = (2 * H0, 2 * W0) if up0 else (H0, W0)
     C1 = 0 if x1 is None else x1.shape[3]
     C = C0 + C1
-    N = u_kn.shape[2]
-    assert u_kn.shape[1] == C
+    ldu = u_kn.shape[2]
+    n_off, N = (0, ldu) if cols is None else cols       # cols = (first column, count): the gradient of ONE source of a two-source convolution
+    assert u_kn.shape[1] == C and n_off + N <= ldu and (cols is None or (actgrad is not None or adjoint is not None or kind == "conv_dgrad"))
     L = _lib.lib()
     if accumulate_into is not None:
         y = accumulate_into
@@ -335,7 +353,7 @@ def winograd_fused(kind, x, u_kn, bias=None, act="none", want_stats=False, tag=N
         check(rc, "conv2d_winograd_fused2")
         WINO_FUSED_TAKEN["fwd2"] += 1
         return y, part
-    if actgrad is not None or adjoint is not None:
+    if actgrad is not None or adjoint is not None or cols is not None:
         assert bias is None and act == "none" and not want_stats and not reflect
         ag_y, ag_kind = (actgrad[0], ACT[actgrad[1]]) if actgrad is not None else (None, 0)
         ag_ld = nhwc_ld(ag_y) if ag_y is not None else 0
@@ -344,15 +362,16 @@ def winograd_fused(kind, x, u_kn, bias=None, act="none", want_stats=False, tag=N
         if adjoint is not None:
             g, wdpack, wfpack = adjoint
             if wfpack is None or not BORDERS2:
+                assert cols is None
                 d = _borders_desc(B, H, W, C, N, nhwc_ld(x))
 
         def launch():
-            rc = L.segsde_conv2d_winograd_fused_dgrad(_p(_f32(x)), nhwc_ld(x), B, H, W, C, _p(u_kn), N, _p(y), N, acc, _p(ag_y), ag_ld,
-                                                      ag_kind, _stream(x))
+            rc = L.segsde_conv2d_winograd_fused_dgrad(_p(_f32(x)), nhwc_ld(x), B, H, W, C, ctypes.c_void_p(u_kn.data_ptr() + 4 * n_off), ldu,
+                                                      N, _p(y), N, acc, _p(ag_y), ag_ld, ag_kind, _stream(x))
             if rc == 0 and adjoint is not None:
-                if d is None:      # the border kernel of csrc/winograd_fused.hip (two launches), forward pack
-                    rc = L.segsde_reflect_adjoint_borders2(_p(x), nhwc_ld(x), _p(wfpack), _p(y), N, _p(ag_y), ag_ld, ag_kind, B, H, W, N, C,
-                                                           _stream(x))
+                if d is None:      # the border kernel of csrc/winograd_fused.hip (two launches), forward pack (its channel slice)
+                    rc = L.segsde_reflect_adjoint_borders2(_p(x), nhwc_ld(x), ctypes.c_void_p(wfpack.data_ptr() + 4 * n_off), wfpack.shape[3],
+                                                           _p(y), N, _p(ag_y), ag_ld, ag_kind, B, H, W, N, C, _stream(x))
                 else:              # four border launches of the implicit-GEMM kernel + corner kernel, data-gradient pack
                     rc = L.segsde_reflect_adjoint_borders(ctypes.byref(d), _p(x), _p(wdpack), _p(y), _p(ag_y), ag_ld, ag_kind, _stream(x))
                 if rc == -4:
@@ -707,9 +726,27 @@ def conv_dgrad(g, dy, wdpack, w_oihw, in_hw, need0=True, need1=True, accumulate_
             acc1 = None
         if dx0 is None and dx1f is None:
             return None, None
+        # round 5: the skip-source gradient on the one-kernel Winograd route (flipped pack's columns [C0, C0 + C1), border kernel on
+        # the forward pack's same channels); the folded call below then computes the upsampled source's gradient only
+        w1 = None
+        if (dx1f is not None and isinstance(wino, _KnPack) and wfpack is not None and winograd_fused_dgrad2_ok(g, B, H, W)
+                and (Ho, Wo) == (H, W)):
+            r = winograd_fused("conv_dgrad", dy, wino, tag="%d+0->%d k3 s1 d1 %dx%d refl skip-of-%d+%d" % (Cout, g.C1, H, W, g.C0, g.C1),
+                               accumulate_into=acc1, adjoint=(g, wdpack, wfpack), cols=(g.C0, g.C1))
+            if r is not None:
+                w1 = r[0]
+                WINO_FUSED_TAKEN["dgrad2"] += 1
+        if w1 is not None:
+            if dx0 is None:
+                SKIP_ACCUMULATED[0] = acc1 is not None
+                return None, w1
+            dx1f = None
         df = ConvDesc(B=B, H=H, W=W, C0=g.C0, C1=g.C1, ld0=g.C0, ld1=g.C1, up0=1, Ho=Ho, Wo=Wo, Cout=Cout, ldy=Cout, ldy2=0,
                       nsplit=0, KH=3, KW=3, stride=1, dil=1, pad=1, pad_mode=PAD_REFLECT, in_div=1, act=0, sum2x2=0)
-        fr = ((4.0 * g.C0 if need0 else 0.0) + (9.0 * g.C1 if need1 else 0.0)) / (9.0 * g.Cin)
+        fr = ((4.0 * g.C0 if dx0 is not None else 0.0) + (9.0 * g.C1 if dx1f is not None else 0.0)) / (9.0 * g.Cin)
+        if w1 is not None:
+            flops = flops * g.C0 / g.Cin          # the skip channels' multiply-adds were counted (and timed) with the Winograd launch
+            fr = 4.0 / 9.0
         rc = _timed("conv_dgrad", flops, dy, lambda: L.segsde_conv2d_dgrad_upfold(
             ctypes.byref(df), _p(_f32(dy)), nhwc_ld(dy), _p(wdpack), _p(wfold), _p(wdfold), _p(dx0), _p(dx1f), 1 if acc1 is not None else 0,
             _p(ag_y) if dx0 is not None else None, ag_ld, ag_kind, _stream(dy)), _tag(g, H, W) + " fold", executed=flops * fr)
@@ -717,7 +754,9 @@ def conv_dgrad(g, dy, wdpack, w_oihw, in_hw, need0=True, need1=True, accumulate_
             UPFOLD_TAKEN["dgrad"] += 1
             SKIP_ACCUMULATED[0] = acc1 is not None
             ACTGRAD_FUSED[0] = actgrad is not None and dx0 is not None
-            return dx0, dx1f
+            return dx0, (w1 if w1 is not None else dx1f)
+        if w1 is not None:
+            check(rc, "conv2d_dgrad_upfold (upsampled source only)")
         if rc != -4:
             check(rc, "conv2d_dgrad_upfold")
     if g.up0:
@@ -1017,6 +1056,14 @@ def scale_channels(x, scale):
     y = torch.empty((B, Hh, W, C), dtype=torch.float32, device=x.device)
     check(_lib.lib().segsde_scale_channels(_p(_f32(x)), nhwc_ld(x), B, Hh * W, C, _p(_f32(scale.contiguous())), _p(y), C,
                                            _stream(x)), "scale_channels")
+    return y
+
+
+def dropout(x, p, seed):
+    """nn.Dropout(p) on an NHWC tensor with the counter-based mask of ``seed`` (its own adjoint with the same seed)"""
+    M, C, ld = _rows(x)
+    y = torch.empty(tuple(x.shape), dtype=torch.float32, device=x.device)
+    check(_lib.lib().segsde_dropout(_p(_f32(x)), ld, M, C, float(p), int(seed), _p(y), C, _stream(x)), "dropout")
     return y
 
 

@@ -1,8 +1,24 @@
 """Mirror of loader/transformmasks.py mask builders + the depthcomp mask of Trainer.generate_mix_mask
 (train.py:585-604), each one HIP kernel, bit-exact (comparisons only)."""
+import numpy as np
 import torch
 
 from .. import hipops as H
+
+
+def generate_cutout_mask(img_size, seed=None):
+    """transformmasks.py:8-24 (CutMix-style box mask; unused by the reference's trainer, kept for scripts that import it):
+    host-side numpy like the reference -- a [H, W] float64 array of ones with one zeroed box of half the image area, drawn
+    from numpy's global generator after ``np.random.seed(seed)`` (same draws, same order: bit-identical masks)."""
+    np.random.seed(seed)
+    area = img_size[0] * img_size[1] / 2
+    w = np.random.randint(img_size[1] / 2, img_size[1] + 1)
+    h = np.round(area / w)
+    x0 = np.random.randint(0, img_size[1] - w + 1)
+    y0 = np.random.randint(0, img_size[0] - h + 1)
+    mask = np.ones(img_size)
+    mask[y0:int(y0 + h), x0:int(x0 + w)] = 0
+    return mask.astype(float)
 
 
 def generate_class_mask(pred, classes):

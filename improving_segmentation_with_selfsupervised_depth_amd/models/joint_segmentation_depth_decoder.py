@@ -31,14 +31,15 @@ class JointSegDepthDecoder(nn.Module):
             project["seg%d" % layer] = nn.Sequential(Conv2d(int(ch), layer_out_channels, 1, bias=False))
         self.project = nn.ModuleDict(project)
         self.head_inter = head_inter
-        if layer_dropout > 0:
-            raise NotImplementedError("layer_dropout > 0 is not on the benchmarked path")
         if head_inter:
             head_conv = [Conv2d(accumulated_ch, head_inter_channels, 3, padding=1, bias=False),
                          BatchNorm2d(head_inter_channels), nn.ReLU(), nn.Dropout(head_dropout)]
         else:
             head_conv = [nn.Identity()]
-        self.head = nn.Sequential(nn.Identity(), *head_conv, Conv2d(head_inter_channels, self.num_classes, 1))
+        # reference :50: nn.Dropout on the stacked features (the module keeps its place in the Sequential -- index 0 -- and its
+        # train / eval switch; the mask itself is drawn and applied by the HIP dropout kernel, Fn.DropoutFn)
+        self.head = nn.Sequential(nn.Dropout(layer_dropout) if layer_dropout > 0 else nn.Identity(), *head_conv,
+                                  Conv2d(head_inter_channels, self.num_classes, 1))
 
     def forward(self, encoder_features):
         feats = [Fn.to_nhwc(f) for f in encoder_features]
@@ -56,6 +57,10 @@ class JointSegDepthDecoder(nn.Module):
             y = self.project["seg%d" % layer][0](_get_layer(feats, seg, layer))
             stacked.append(Fn.resize_bilinear(y, last_size, False))
         y = stacked[0] if len(stacked) == 1 else Fn.ConcatFn.apply(*stacked)
+        d0 = self.head[0]
+        if isinstance(d0, nn.Dropout) and d0.training and self.training and d0.p > 0:
+            from .layers import _seed
+            y = Fn.DropoutFn.apply(y, float(d0.p), _seed())
         if self.head_inter:
             drop = self.head[4]
             p = drop.p if (drop.training and self.training) else 0.0

@@ -224,6 +224,10 @@ int segsde_copy_channels(const float* src, int lds, float* dst, int ldd, long M,
 /* nn.Dropout2d inside ConvBlock (models/monodepth_layers.py:117-119, depth_args.dropout > 0): y[b,p,c] = x[b,p,c] * scale[b,c]
  * with scale = 0 or 1/(1-p) per (sample, channel); the same call is its adjoint. */
 int segsde_scale_channels(const float* x, int ldx, int B, long HW, int C, const float* scale, float* y, int ldy, void* stream);
+/* nn.Dropout(p) on [M, C] rows (JointSegDepthDecoder's layer_dropout on the stacked features,
+ * models/joint_segmentation_depth_decoder.py:50): y = x / (1 - p) where the counter-based draw of (seed, element index) keeps the
+ * element, else 0; the same call with the same seed on the gradient is its adjoint. */
+int segsde_dropout(const float* x, int ldx, long M, int C, float p, uint64_t seed, float* y, int ldy, void* stream);
 /* NCHW image -> NHWC with the encoder's input normalisation (x - mean) / std (models/resnet_encoder.py:92);
  * mean = 0, std = 1 gives a plain layout change.  All ldy channels of every pixel are written: channels C..ldy-1 become
  * zero (the 3 / 6-channel network input padded to 4 / 8).  nhwc_to_nchw is the inverse layout change. */
@@ -292,16 +296,19 @@ int segsde_conv2d_winograd_fused2(const float* x0, int ld0, int C0, int up0, con
  * monodepth_layers.py:108-125; accumulate: added onto what dx holds).  Zero padding; for the reflection-padded
  * Conv3x3 follow it with segsde_reflect_adjoint_borders (conv_igemm.hip): the gradient that entered the mirrored padding cells, as
  * four border launches + corner terms ADDED onto rows 1 / H-2 and columns 1 / W-2 of y (d = the descriptor of
- * segsde_conv2d_dgrad_actgrad with pad_mode = SEGSDE_PAD_REFLECT_ADJOINT; act_out as above). */
-int segsde_conv2d_winograd_fused_dgrad(const float* dy, int lddy, int B, int H, int W, int Cout, const float* ud_kn, int Cin, float* dx,
-                                       int lddx, int accumulate, const float* act_out, int act_ld, int act_kind, void* stream);
+ * segsde_conv2d_dgrad_actgrad with pad_mode = SEGSDE_PAD_REFLECT_ADJOINT; act_out as above).  ldu: row pitch of ud_kn (Cin; or,
+ * for the gradient of ONE source of a two-source convolution -- the decoder's skip input, weight channels [C0, C0 + C1) -- the
+ * full pack's width, ud_kn pointing at the slice's first column; segsde_reflect_adjoint_borders2 takes the matching slice of
+ * the forward pack through ldw). */
+int segsde_conv2d_winograd_fused_dgrad(const float* dy, int lddy, int B, int H, int W, int Cout, const float* ud_kn, int ldu, int Cin,
+                                       float* dx, int lddx, int accumulate, const float* act_out, int act_ld, int act_kind, void* stream);
 int segsde_reflect_adjoint_borders(const segsde_conv_desc* d, const float* dy, const float* wdpack, float* y, const float* act_out,
                                    int act_ld, int act_kind, void* stream);
 /* The same mirrored-padding terms by a kernel of their own (csrc/winograd_fused.hip: two launches -- row lines, column lines +
  * corners -- of a 32-pixel x Cin MFMA kernel instead of five launches of the image-sized implicit-GEMM machinery); wpack = the
  * FORWARD pack [Cout][3][3][Cin] of segsde_pack_weight(for_dgrad = 0).  Cin % 32 == 0, Cout % 32 == 0, H, W >= 4. */
-int segsde_reflect_adjoint_borders2(const float* dy, int lddy, const float* wpack, float* dx, int lddx, const float* act_out, int act_ld,
-                                    int act_kind, int B, int H, int W, int Cin, int Cout, void* stream);
+int segsde_reflect_adjoint_borders2(const float* dy, int lddy, const float* wpack, int ldw, float* dx, int lddx, const float* act_out,
+                                    int act_ld, int act_kind, int B, int H, int W, int Cin, int Cout, void* stream);
 /* 1 when segsde_reflect_adjoint_borders takes the descriptor (act_ld: pixel pitch of act_out, 0 without one) -- asked before the
  * zero-padded launch writes dx */
 int segsde_reflect_adjoint_borders_ok(const segsde_conv_desc* d, int act_ld);

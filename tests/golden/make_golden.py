@@ -286,6 +286,10 @@ def gen_segmix():
     mp, pl = torch.max(soft, dim=1)
     d["pl_label"] = pl
     d["pl_weight"] = torch.sum(mp.ge(0.968).long() == 1).item() / np.prod(pl.shape)
+    # generate_cutout_mask (transformmasks.py:8-24; numpy's global generator re-seeded per call)
+    for tag, size, seed in (("a", (24, 40), 3), ("b", (17, 33), 11), ("c", (64, 128), 2020)):
+        d["cutout_%s" % tag] = ref_tm.generate_cutout_mask(size, seed=seed)
+        d["cutout_%s_args" % tag] = np.array([size[0], size[1], seed])
     save("segmix", d)
 
 

@@ -1513,6 +1513,41 @@ def _run_winograd_fused_cases(device, shapes):
                 direct = H.conv_forward(g, x0d, x1d, wp, bias.to(device), act="elu")
                 e_w, e_d = float((nchw(y).double().cpu() - want).abs().max()), float((nchw(direct).double().cpu() - want).abs().max())
                 assert e_w <= 3 * e_d + 1e-6 * sc, (what, e_w, e_d, sc)
+            # the same layers' data-gradient: the upsampled source's low-resolution gradient on the folded route, the skip source's
+            # on the one-kernel Winograd route (a column slice of the flipped pack + the border kernel on the forward pack's slice),
+            # also accumulating onto a gradient another consumer of the skip feature left
+            old_fm = H.UPFOLD_MIN_SAVED_MACS
+            H.UPFOLD_MIN_SAVED_MACS = 0.0
+            try:
+                for (B, Hh, W, C0, C1, Co) in ((1, 8, 16, 64, 64, 64), (2, 12, 24, 32, 128, 64), (1, 20, 12, 64, 64, 128)):
+                    what = "data-gradient of [up(x0) | x1] %s" % ((B, Hh, W, C0, C1, Co),)
+                    w = torch.randn(Co, C0 + C1, 3, 3, generator=gen) * (2.0 / (9 * (C0 + C1))) ** 0.5
+                    dy = torch.randn(B, Co, Hh, W, generator=gen)
+                    x0r = torch.zeros(B, C0, Hh // 2, W // 2, dtype=torch.float64, requires_grad=True)
+                    x1r = torch.zeros(B, C1, Hh, W, dtype=torch.float64, requires_grad=True)
+                    xin = torch.cat([torch.nn.functional.interpolate(x0r, scale_factor=2, mode="nearest"), x1r], 1)
+                    torch.nn.functional.conv2d(torch.nn.functional.pad(xin, (1, 1, 1, 1), mode="reflect"), w.double()).backward(dy.double())
+                    wd_, dyd = w.to(device), nhwc(dy).to(device).contiguous()
+                    wfp, wdp = H.pack_weight_both(wd_)
+                    ud = H.winograd_fused_pack(wd_, True)
+                    g = H.ConvGeom(C0, Co, 3, 1, 1, 1, True, C1, True)
+                    assert H.upfold_ok(g, B * Hh * W) and H.winograd_fused_dgrad2_ok(g, B, Hh, W), what
+                    fold = H.upfold_pack(wd_, C0)
+                    d0, d1 = H.conv_dgrad(g, dyd, wdp, wd_, (Hh, W))                      # the plain route: the yardstick for the error
+                    n0 = dict(H.WINO_FUSED_TAKEN)
+                    f0, f1 = H.conv_dgrad(g, dyd, wdp, wd_, (Hh, W), fold=fold, wino=ud, wfpack=wfp)
+                    assert H.WINO_FUSED_TAKEN["dgrad2"] == n0["dgrad2"] + 1, what + ": the skip-source launch declined"
+                    for got, dir_, want, tag in ((f0, d0, x0r.grad, "upsampled source"), (f1, d1, x1r.grad, "skip source")):
+                        sc = float(want.abs().max())
+                        e_w, e_d = float((nchw(got).double().cpu() - want).abs().max()), float((nchw(dir_).double().cpu() - want).abs().max())
+                        assert e_w <= 3 * e_d + 2e-6 * sc, (what, tag, e_w, e_d, sc)
+                    base = torch.randn(B, Hh, W, C1, generator=gen).to(device)
+                    acc = base.clone()
+                    _, a1 = H.conv_dgrad(g, dyd, wdp, wd_, (Hh, W), fold=fold, wino=ud, wfpack=wfp, accumulate_skip_into=acc, need0=False)
+                    assert a1 is acc and H.SKIP_ACCUMULATED[0]
+                    assert_close(acc, base + f1, rtol=1e-6, atol=1e-6 * float(f1.abs().max()), what=what + ", accumulated onto the collector")
+            finally:
+                H.UPFOLD_MIN_SAVED_MACS = old_fm
         finally:
             H.WINO_FUSED2_MIN_FOLD = old_fold
     finally:
@@ -1626,3 +1661,51 @@ def _wgrad_fused_direct(g, x0, x1, dy):
     H.check(L.segsde_conv2d_wgrad_winograd_fused(ctypes.byref(d), H._p(x0), H._p(x1), H._p(dy), H.nhwc_ld(dy), H._p(dw), H._p(ws), nbytes,
                                                  H._stream(dy)), "wgrad_winograd_fused")
     return dw
+
+
+# ---------------------------------------------------------------------------------------------
+# round 5: nn.Dropout on the stacked segmentation features (JointSegDepthDecoder(layer_dropout > 0),
+# models/joint_segmentation_depth_decoder.py:50): the counter-based mask kernel and the module path
+# ---------------------------------------------------------------------------------------------
+def run_dropout_case(device):
+    from improving_segmentation_with_selfsupervised_depth_amd import functional as Fn
+    gen = torch.Generator().manual_seed(5)
+    x = (torch.randn(2, 24, 40, 48, generator=gen) + 3.0).to(device)          # no zeros in the input: a zero output is a dropped element
+    p, seed = 0.3, 12345
+    y = H.dropout(x, p, seed)
+    kept = y != 0
+    frac = float(kept.float().mean())
+    assert abs(frac - (1 - p)) < 0.02, frac
+    assert_close(y[kept], x[kept] / (1 - p), rtol=1e-6, atol=0, what="dropout: kept elements are scaled by 1 / (1 - p)")
+    assert torch.equal(H.dropout(x, p, seed), y), "same seed, same mask"
+    assert not torch.equal(H.dropout(x, p, seed + 1) != 0, kept), "another seed, another mask"
+    assert torch.equal(H.dropout(x, 0.0, seed), x)
+    xs = x[..., 8:40]                                                          # a channel slice: the kernel takes its pixel pitch
+    ys = H.dropout(xs, p, 77)
+    ks = ys != 0
+    assert_close(ys[ks], xs[ks] / (1 - p), rtol=1e-6, atol=0, what="dropout on a channel slice")
+    xi = x.clone().requires_grad_(True)
+    out = Fn.DropoutFn.apply(xi, p, seed)
+    w = torch.randn(x.shape, generator=gen).to(device)
+    (out * w).sum().backward()
+    assert_close(xi.grad, torch.where(kept, w / (1 - p), torch.zeros_like(w)), rtol=1e-6, atol=0, what="dropout adjoint: the same mask")
+    # the module: layer_dropout > 0 drops in train mode only, and the state_dict layout is the reference's (a parameter-free module at
+    # head.0 either way)
+    from improving_segmentation_with_selfsupervised_depth_amd.models.joint_segmentation_depth_decoder import JointSegDepthDecoder
+    torch.manual_seed(3)
+    args = dict(num_ch_enc=[16, 16, 32, 32, 32], num_ch_dec=[16, 16, 16, 16, 16], num_classes=5, layers=[9], head_inter=False,
+                layer_out_channels=16, head_inter_channels=16,
+                depth_args=dict(scales=range(4), max_scale_size=[64, 128], num_ch_dec=[16, 16, 16, 16, 16], intermediate_aspp=False))
+    net = JointSegDepthDecoder(layer_dropout=0.5, **args).to(device)
+    ref = JointSegDepthDecoder(layer_dropout=0, **args).to(device)
+    assert list(net.state_dict().keys()) == list(ref.state_dict().keys())
+    ref.load_state_dict(net.state_dict())
+    feats = [torch.randn(2, c, 32 >> i, 64 >> i, generator=gen).to(device) for i, c in enumerate([16, 16, 32, 32, 32])]
+    net.eval(), ref.eval()
+    with torch.no_grad():
+        assert_close(net(feats), ref(feats), rtol=0, atol=0, what="layer_dropout is the identity in eval mode")
+    net.train(), ref.train()
+    a, b = net(feats), net(feats)
+    assert not torch.equal(a, b), "train mode: a fresh mask per forward"
+    a.sum().backward()
+    assert all(torch.isfinite(q.grad).all() for q in net.parameters() if q.grad is not None)

@@ -143,3 +143,7 @@ def test_winograd_fused_wgrad_kernel(variant):
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=1200,
                        env=dict(os.environ, SEGSDE_WGRAD_FUSED_VAR=variant))
     assert r.returncode == 0 and "wgrad-ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_dropout_layer():
+    KC.run_dropout_case("cpu")

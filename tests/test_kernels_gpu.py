@@ -189,3 +189,7 @@ def test_winograd_fused_kernel():
 
 def test_winograd_fused_wgrad_kernel():
     KC.run_winograd_fused_wgrad_cases("cuda")
+
+
+def test_dropout_layer():
+    KC.run_dropout_case("cuda")
