@@ -531,6 +531,7 @@ def main():
         comm = {"allreduce_ms_per_step": float(q[1]), "allreduce_launches_per_step": ncoll / args.steps,
                 "allreduce_mb_per_step": nbytes / args.steps / 1e6, "buckets": len(reducer.buckets) if reducer.buckets else 0,
                 "bucket_mb": args.bucket_mb, "overlap": bool(reducer.overlap),
+                "zero_copy_members": dict(__import__("improving_segmentation_with_selfsupervised_depth_amd.ddp", fromlist=["ZERO_COPY"]).ZERO_COPY),
                 "ms_per_step_without_allreduce": float(q[0]), "per_rank_ms_per_step": [round(float(x), 3) for x in per_rank],
                 "rccl_env": rccl_env(),
                 "how": "allreduce_ms_per_step: union of the [start, end] event pairs of the buckets' collectives on the reducer's side "

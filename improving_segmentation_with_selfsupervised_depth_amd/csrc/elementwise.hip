@@ -7,6 +7,7 @@
 // accumulators per thread, a deterministic two-level tree (block partials -> finalize kernel): no atomics, so
 // results are run-to-run reproducible.  Pure elementwise kernels take a float4 path when C, the pitches and
 // the base pointers allow it.
+#include <stdlib.h>
 #include "segsde_common.h"
 #include <type_traits>
 #include <utility>
@@ -883,7 +884,45 @@ __global__ __launch_bounds__(256) void bn_stats_from_partials_kernel(const doubl
   }
 }
 
-namespace { constexpr int PARTIALS_NB = 64; }
+// the same in one launch for a few hundred partial rows (the 32 x 64 and 64 x 128 maps: most BatchNorms of a ResNet-101 step):
+// 4 channels (one 32-byte sector of doubles per row) x 64 row-lanes per block, every thread sums rows rl, rl + 64, ... in that
+// order, the lanes meet in LDS and are folded in lane order -- C / 4 blocks, no second launch (round 5; the two-launch path took
+// 7.9 + 4.8 us per BatchNorm, 148 of them per step)
+__global__ __launch_bounds__(256) void bn_stats_from_partials_wide_kernel(const double* part, long rows, long M, int C, float eps,
+                                                                          float momentum, float* mean, float* invstd,
+                                                                          float* running_mean, float* running_var, int64_t* nbt) {
+  SEGSDE_SMEM;
+  double* sh = reinterpret_cast<double*>(segsde_smem);   // [2][64][4]
+  const int cl = threadIdx.x & 3, rl = threadIdx.x >> 2, c = blockIdx.x * 4 + cl;
+  if (nbt && blockIdx.x == 0 && threadIdx.x == 0) nbt[0] += 1;
+  double a = 0.0, b = 0.0;
+  if (c < C)
+    for (long r = rl; r < rows; r += 64) { a += part[(r * 2) * C + c]; b += part[(r * 2 + 1) * C + c]; }
+  sh[rl * 4 + cl] = a; sh[256 + rl * 4 + cl] = b;
+  __syncthreads();
+  if (rl != 0 || c >= C) return;
+  double s = 0.0, q = 0.0;
+  for (int j = 0; j < 64; ++j) { s += sh[j * 4 + cl]; q += sh[256 + j * 4 + cl]; }
+  const double mu = s / (double)M;
+  double var = q / (double)M - mu * mu;
+  if (var < 0.0) var = 0.0;
+  mean[c] = (float)mu;
+  invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+  if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mu;
+  if (running_var) {
+    const double unb = M > 1 ? var * (double)M / (double)(M - 1) : var;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+  }
+}
+
+namespace {
+constexpr int PARTIALS_NB = 64;
+long partials_wide_max() {
+  static long v = -1;
+  if (v < 0) { const char* e = getenv("SEGSDE_BN_PARTIALS_WIDE_MAX"); v = e ? atol(e) : 1024; }
+  return v;
+}
+}
 
 extern "C" size_t segsde_bn_stats_from_partials_workspace(int C) { return (size_t)PARTIALS_NB * 2 * (C > 0 ? C : 1) * sizeof(double); }
 
@@ -895,6 +934,12 @@ extern "C" int segsde_bn_stats_from_partials(const double* partials, long rows, 
   if (ws_bytes < segsde_bn_stats_from_partials_workspace(C)) return SEGSDE_ERR_WORKSPACE;
   if (rows <= 64) {   // (tried for rows <= 2048: 16 serial row-lanes took 18.6 us against 8.7 + 4.8 us of the two parallel launches)
     hipLaunchKernelGGL(bn_stats_from_partials_kernel, dim3((C + 15) / 16), dim3(256), 4096, ST(stream), partials, rows, M, C, eps,
+                       momentum, mean, invstd, running_mean, running_var, num_batches_tracked);
+    SEGSDE_CHECK_LAUNCH();
+    return 0;
+  }
+  if (rows <= partials_wide_max()) {
+    hipLaunchKernelGGL(bn_stats_from_partials_wide_kernel, dim3((C + 3) / 4), dim3(256), 4096, ST(stream), partials, rows, M, C, eps,
                        momentum, mean, invstd, running_mean, running_var, num_batches_tracked);
     SEGSDE_CHECK_LAUNCH();
     return 0;

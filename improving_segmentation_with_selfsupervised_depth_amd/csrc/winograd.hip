@@ -196,34 +196,35 @@ __global__ __launch_bounds__(256) void wino_grad_kernel(const float* dy, int ld,
 }
 
 // part [16 * s][C][Co] (split slabs of the sixteen position GEMMs, s per position) -> dW [Co][C][3][3] = G^T dU G with
-// dU_p = the sum of position p's slabs in slab order (deterministic).  A block = 64 (c, co) pairs (co fastest: coalesced slab
-// reads) x the four rows of the 4x4 position grid: thread (q, pair) sums the slabs of positions 4q .. 4q+3, the rows meet in
-// LDS, threads q < 3 finish output row q.  (One thread per pair with all sixteen positions -- 16 s dependent-latency loads on
-// 4 waves per CU -- took 33 us per 256x256 weight for 34 MB; round 4.)
+// dU_p = the sum of position p's slabs in slab order (deterministic).  A block = 16 (c, co) pairs (co fastest) x the sixteen
+// positions: thread (p, pair) sums the s slabs of ONE position (four independent partial sums: the loads of a thread do not wait
+// for each other), the positions meet in LDS, threads p < 3 finish output row p.  (Round 4: 64 pairs x 4 position rows per block,
+// each thread 4 s loads -- a 128 x 64 weight was 128 blocks on 256 CUs and 36 us for 67 MB; the one-kernel weight gradient of
+// round 5 runs this 77 times per step.)
 __global__ __launch_bounds__(256) void wino_wgrad_finish_kernel(const float* part, int s, int C, int Co, float* dw) {
   SEGSDE_SMEM;
-  float* sh = reinterpret_cast<float*>(segsde_smem);   // [4 q][4 v][64]
+  float* sh = reinterpret_cast<float*>(segsde_smem);   // [16 p][16 pairs]
   const long total = (long)C * Co;
-  const int el = threadIdx.x & 63, q = threadIdx.x >> 6;
-  const long e = blockIdx.x * 64L + el;
+  const int el = threadIdx.x & 15, pp = threadIdx.x >> 4;
+  const long e = blockIdx.x * 16L + el;
   if (e < total) {
-#pragma unroll
-    for (int v = 0; v < 4; ++v) {
-      const float* src = part + (long)(4 * q + v) * s * total + e;
-      float a0 = 0.f, a1 = 0.f;
-      int z = 0;
-      for (; z + 1 < s; z += 2) { a0 += src[(long)z * total]; a1 += src[(long)(z + 1) * total]; }
-      if (z < s) a0 += src[(long)z * total];
-      sh[(q * 4 + v) * 64 + el] = a0 + a1;
+    const float* src = part + (long)pp * s * total + e;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int z = 0;
+    for (; z + 3 < s; z += 4) {
+      a0 += src[(long)z * total]; a1 += src[(long)(z + 1) * total]; a2 += src[(long)(z + 2) * total]; a3 += src[(long)(z + 3) * total];
     }
+    for (; z < s; ++z) a0 += src[(long)z * total];
+    sh[pp * 16 + el] = (a0 + a1) + (a2 + a3);
   }
   __syncthreads();
-  if (e >= total || q == 3) return;
+  if (e >= total || pp >= 3) return;
+  const int q = pp;
   const int co = (int)(e % Co), c = (int)(e / Co);
   float t[4];
 #pragma unroll
   for (int v = 0; v < 4; ++v) {          // row q of G^T dU
-    const float u0 = sh[(0 * 4 + v) * 64 + el], u1 = sh[(1 * 4 + v) * 64 + el], u2 = sh[(2 * 4 + v) * 64 + el], u3 = sh[(3 * 4 + v) * 64 + el];
+    const float u0 = sh[(0 * 4 + v) * 16 + el], u1 = sh[(1 * 4 + v) * 16 + el], u2 = sh[(2 * 4 + v) * 16 + el], u3 = sh[(3 * 4 + v) * 16 + el];
     t[v] = q == 0 ? u0 + 0.5f * (u1 + u2) : (q == 1 ? 0.5f * (u1 - u2) : 0.5f * (u1 + u2) + u3);
   }
   float* out = dw + ((long)co * C + c) * 9 + 3 * q;   // (.) G
@@ -346,7 +347,7 @@ int segsde_wino_grad(const float* dy, int ld, int B, int H, int W, int C, int di
 
 int segsde_wino_wgrad_finish(const float* part, int s, int C, int Co, float* dw_oihw, void* stream) {
   const long total = (long)C * Co;
-  hipLaunchKernelGGL(wino_wgrad_finish_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 16 * 64 * sizeof(float), ST(stream), part, s, C, Co, dw_oihw);
+  hipLaunchKernelGGL(wino_wgrad_finish_kernel, dim3((unsigned)((total + 15) / 16)), dim3(256), 16 * 16 * sizeof(float), ST(stream), part, s, C, Co, dw_oihw);
   SEGSDE_CHECK_LAUNCH();
   return 0;
 }

@@ -254,12 +254,21 @@ int target_wgs() {
   if (v < 0) { const char* e = getenv("SEGSDE_WGRAD_FUSED_WGS"); v = e ? atoi(e) : 512; if (v <= 0) v = 512; }
   return v;
 }
-int variant() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("SEGSDE_WGRAD_FUSED_VAR"); v = e ? atoi(e) : 0; }
+// staging variant: 0 = 32-tile blocks, one stage; 1 = 16-tile blocks, two stages (the next block's loads fly during the
+// multiplies); 2 = 32-tile blocks, two stages, one workgroup per CU.  Measured (profiles/probe_r05_winograd_wgrad_*.log): 1 is
+// 2-3 % ahead on the large maps (>= 128 x 256 at batch 16: many blocks per workgroup), 0 on the small ones, 2 loses everywhere.
+// SEGSDE_WGRAD_FUSED_VAR forces one (read once per process).
+int forced_variant() {
+  static int v = -2;
+  if (v == -2) { const char* e = getenv("SEGSDE_WGRAD_FUSED_VAR"); v = e ? atoi(e) : -1; }
   return v;
 }
-int block_h() { return variant() == 1 ? 2 : 4; }
+int variant(const segsde_conv_desc* d) {
+  const int f = forced_variant();
+  if (f >= 0) return f;
+  return (long)d->B * d->H * d->W >= (1L << 19) ? 1 : 0;
+}
+int block_h(const segsde_conv_desc* d) { return variant(d) == 1 ? 2 : 4; }
 
 bool shape_ok(const segsde_conv_desc* d) {
   if (!d || d->B <= 0 || d->KH != 3 || d->KW != 3 || d->stride != 1 || d->dil != 1 || d->pad != 1 || d->in_div > 1 || d->sum2x2) return false;
@@ -276,7 +285,7 @@ bool shape_ok(const segsde_conv_desc* d) {
 struct Plan { int nbh, nbw, nblk, ncol, S; };
 Plan make_plan(const segsde_conv_desc* d) {
   Plan pl;
-  const int bh = block_h();
+  const int bh = block_h(d);
   pl.nbh = ((d->H >> 1) + bh - 1) / bh; pl.nbw = ((d->W >> 1) + WT_W - 1) / WT_W;
   const long nblk = (long)d->B * pl.nbh * pl.nbw;
   pl.nblk = (int)nblk;
@@ -313,7 +322,7 @@ extern "C" int segsde_conv2d_wgrad_winograd_fused(const segsde_conv_desc* d, con
   p.nbh = pl.nbh; p.nbw = pl.nbw; p.nblk = pl.nblk; p.S = pl.S; p.ncol = pl.ncol;
   p.part = static_cast<float*>(workspace);
   const dim3 grid((unsigned)(pl.ncol * pl.S));
-  const int var = variant();
+  const int var = variant(d);
   if (var == 1) {
     auto k = wino_wgrad_fused_kernel<2, true, 2>;
     const size_t lb = (size_t)2 * Geo<2>::STAGE * sizeof(float);

@@ -16,19 +16,26 @@ Design notes
     ``with reducer.no_sync():`` (hooks then do nothing).  A step that forgets to do so is still reduced correctly --
     a hook that fires twice for one parameter marks its bucket dirty and ``finish()`` re-reduces it from the
     accumulated ``p.grad`` -- it only loses the overlap (and warns once);
-  * the averaged bucket is scaled once in place and ``p.grad`` is then RE-POINTED at its slice of the bucket (no copy
-    back).  With ``zero_grad(set_to_none=True)`` (torch's default) the next step's gradients are fresh tensors again, so an
-    in-flight collective can never be disturbed by a later accumulation and the dirty-bucket path below keeps working;
-    with ``set_to_none=False`` the gradients accumulate straight into the bucket and ``p.grad`` moves out of it when it is
-    handed over (one copy per step in either mode; round 2 had two);
+  * ZERO-COPY buckets (round 5).  The buckets' slices are registered as GRADIENT DESTINATIONS (``grad_destination``): the
+    package's backward kernels -- convolution weight gradients, BatchNorm dgamma / dbeta -- write their result straight into
+    the parameter's slice and hand autograd that view, which ``AccumulateGrad`` adopts as ``p.grad`` (no copy: the incoming
+    tensor is stolen).  A hook that finds ``p.grad`` aliasing its slice has nothing to pack; the few parameters whose gradient
+    arrives as a tensor of its own (biases, parameters with several consumers) are copied as before.  The one-rank RCCL run
+    of the benchmark cost 4.7 ms per step for the ~880 per-parameter pack copies in round 4;
+  * after a bucket's collective is launched every member's ``p.grad`` is set to None until ``finish()`` (the bucket owns the
+    data while the all-reduce runs in place): a second, un-synchronised ``backward()`` then produces fresh tensors that hold
+    ONLY the new contribution and cannot disturb the collective; ``finish()`` reduces those separately and adds them (the
+    dirty-bucket path).  ``finish()`` re-points ``p.grad`` at the averaged slices: they alias the bucket until the next
+    step's backward overwrites it -- a gradient kept across steps must be cloned by the caller (``copy_out=True`` makes
+    ``finish()`` hand out independent tensors instead, for gradient-inspection code);
+  * the average: ``ReduceOp.AVG`` on RCCL (no scaling pass); SUM + one in-place scale per bucket on backends without it;
   * which parameters are live is agreed on ACROSS ranks (one small MAX all-reduce of a bitmap per step): ranks whose
     losses touched different parameters (a data-dependent branch, a skipped batch) still issue identical collectives
     instead of hanging.  When that agreement says "rebuild" in a step in which some rank still holds old buckets back
     (a gradient that never arrived there), every rank first issues the old buckets it has not started, in index order, so
     that the old layout's collectives pair up on all ranks before the new layout's are issued;
   * a bucket member that NO rank produced a gradient for in this step keeps ``p.grad = None`` (as in the single-GPU
-    run: momentum / weight-decay optimizers skip it), everything else receives the average.  ``p.grad`` aliases the
-    bucket until the next step's ``pack``: a gradient kept past the next backward must be cloned by the caller;
+    run: momentum / weight-decay optimizers skip it), everything else receives the average;
   * BatchNorm statistics stay per replica, exactly like N independent runs of the single-GPU reference.
 """
 import contextlib
@@ -55,6 +62,27 @@ def seed_per_rank(base_seed, rank=None):
     return seed
 
 
+# Gradient destinations: parameter storage address -> [view of the parameter's bucket slice, step id of the claim].  The
+# package's autograd Functions ask ``grad_destination(param)`` for the tensor to write a parameter's gradient into; the first
+# asker of a step gets the slice (if the parameter has no gradient yet), everybody else None (they allocate as usual and
+# autograd adds).  Empty unless a GradAllReducer is active: single-process runs are untouched.
+_GRAD_DEST = {}
+_STEP = [0]
+ZERO_COPY = {"taken": 0, "copied": 0}      # diagnostics / tests: bucket members found in place / packed by a copy
+
+
+def grad_destination(param):
+    """-> a dense float32 view shaped like ``param`` to write its gradient into (and to return to autograd), or None"""
+    if not _GRAD_DEST:
+        return None
+    ent = _GRAD_DEST.get(param.data_ptr())
+    if ent is None or ent[1] == _STEP[0] or param.grad is not None or ent[0].shape != param.shape:
+        return None
+    ent[1] = _STEP[0]
+    # a tensor object of its own: AccumulateGrad adopts an incoming gradient without a copy only if nobody else holds it
+    return ent[0].view(ent[0].shape)
+
+
 class _Bucket:
     def __init__(self, params, device):
         self.params = params
@@ -64,38 +92,49 @@ class _Bucket:
             n += p.numel()
         self.flat = torch.zeros(n, dtype=torch.float32, device=device)
         self.work = None
+        # per-member slices, parameter-shaped views and addresses, made once: the hooks and finish() run per parameter per step
+        # (~460 of each for the R101 joint model) and a slice / view_as / data_ptr each time was most of their host cost
+        self.slots = [self.flat[o:o + p.numel()] for o, p in zip(self.offsets, params)]
+        self.views = [s.view_as(p) for s, p in zip(self.slots, params)]
+        self.ptrs = [s.data_ptr() for s in self.slots]
         self.reset()
 
     def reset(self):
         self.ready = [False] * len(self.params)
+        self.had = [False] * len(self.params)       # packed from a gradient (not a zero fill) this step
         self.pending = len(self.params)
         self.dirty = False
+        self.launched = False
 
     def slot(self, i):
-        p = self.params[i]
-        return self.flat[self.offsets[i]:self.offsets[i] + p.numel()]
+        return self.slots[i]
 
     def aliased(self, i):
         g = self.params[i].grad
-        return g is not None and g.data_ptr() == self.slot(i).data_ptr()
+        return g is not None and g.data_ptr() == self.ptrs[i]
 
     def pack(self, i):
-        p = self.params[i]
-        s = self.slot(i)
-        if p.grad is None:
-            s.zero_()
-        elif self.aliased(i):
-            # zero_grad(set_to_none=False) kept last step's bucket view as p.grad and this step accumulated into it: the
-            # bucket already holds the data.  p.grad moves out (one copy, as in the other branch) so that a later
-            # accumulation cannot disturb the collective and the dirty-bucket path still sees the full local gradient.
-            p.grad = p.grad.clone()
+        g = self.params[i].grad
+        if g is None:
+            self.slots[i].zero_()
+        elif g.data_ptr() == self.ptrs[i]:
+            self.had[i] = True                      # written in place by its backward kernel (or accumulated in place): nothing to move
+            ZERO_COPY["taken"] += 1
         else:
-            s.copy_(p.grad.reshape(-1))
+            self.slots[i].copy_(g.reshape(-1))
+            self.had[i] = True
+            ZERO_COPY["copied"] += 1
+
+    def own(self):
+        """the collective is about to run in place on ``flat``: the members' p.grad leave the bucket until finish()"""
+        for p in self.params:
+            p.grad = None
+        self.launched = True
 
 
 class GradAllReducer:
     def __init__(self, module, bucket_mb=32.0, process_group=None, overlap=True, always=False, control_group=None,
-                 timing=False):
+                 timing=False, copy_out=False):
         """control_group: a gloo group over the same ranks as ``process_group`` for the per-step agreement.  None creates
         one with ``dist.new_group`` -- a collective over the DEFAULT group, so every rank of the job must then construct
         its reducer (or pass a pre-created group when only a sub-group trains); False runs the agreement on
@@ -107,12 +146,16 @@ class GradAllReducer:
         # once the collective is done.  ``timing_ms()`` turns the pairs of the last step into the time the collectives
         # occupied (their union: consecutive buckets queue behind each other on the communicator's stream).
         self.timing = bool(timing)
+        self.copy_out = bool(copy_out)    # finish() hands out gradients that do not alias the buckets (one copy per parameter)
         self._comm_stream = None
         self._events = []
         self.module = module
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.backend = dist.get_backend(process_group) if dist.is_initialized() else None
+        # RCCL averages inside the collective; backends without ReduceOp.AVG (gloo) sum and the bucket is scaled once in place
+        self._avg = self.backend == "nccl"
+        self._dest_keys = []
         self.always = always       # run the bucket / hook / collective machinery even with a single rank (self-test)
         self.bucket_bytes = int(bucket_mb * 1024 * 1024)
         self.overlap = overlap
@@ -178,15 +221,38 @@ class GradAllReducer:
             self.buckets.append(_Bucket(cur, device))
         self._where = {}
         self._next = 0
+        self._unregister()
         for b in self.buckets:
             for i, p in enumerate(b.params):
                 self._where[p] = (b, i)
+                if p.dtype == torch.float32 and p.is_contiguous():
+                    _GRAD_DEST[p.data_ptr()] = [b.views[i], -1]
+                    self._dest_keys.append(p.data_ptr())
         if self.overlap:
             for p in used:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
         self.rebuilds += 1
 
-    def _launch(self, b):
+    def _unregister(self):
+        for k in self._dest_keys:
+            _GRAD_DEST.pop(k, None)
+        self._dest_keys = []
+
+    def close(self):
+        """stop handing the buckets out as gradient destinations (call before dropping the reducer)"""
+        self._unregister()
+
+    def __del__(self):
+        try:
+            self._unregister()
+        except Exception:
+            pass
+
+    def _launch(self, b, flat=None):
+        op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
+        buf = b.flat if flat is None else flat
+        if flat is None:
+            b.own()
         if self.timing and b.flat.is_cuda:
             if self._comm_stream is None:
                 self._comm_stream = torch.cuda.Stream(b.flat.device)
@@ -196,7 +262,7 @@ class GradAllReducer:
             b.t1 = None
             with torch.cuda.stream(cs):
                 b.t0.record(cs)
-                b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                b.work = dist.all_reduce(buf, op=op, group=self.group, async_op=True)
                 if self.backend == "nccl":
                     # RCCL: wait() only makes the side stream wait for the communicator's stream (the host does not block), so
                     # the end event can be queued right here and carries the collective's completion time.  (Queued in
@@ -205,7 +271,7 @@ class GradAllReducer:
                     b.t1 = torch.cuda.Event(enable_timing=True)
                     b.t1.record(cs)
         else:
-            b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            b.work = dist.all_reduce(buf, op=op, group=self.group, async_op=True)
         self.collectives += 1
 
     def _wait(self, b):
@@ -258,10 +324,13 @@ class GradAllReducer:
         if not self._sync:
             return
         b, i = self._where[p]
-        if b.ready[i] or b.work is not None:
-            # a second backward() of this step reached a parameter whose gradient was already handed over: what sits
-            # in the bucket is stale.  finish() re-reduces this bucket from the accumulated p.grad.
+        if b.launched:
+            # a second backward() of this step reached a parameter whose bucket is already being reduced: p.grad is a fresh
+            # tensor holding this contribution alone (own() took the first one); finish() reduces it separately and adds it
             b.dirty = True
+            return
+        if b.ready[i]:
+            b.pack(i)            # handed over but not launched yet (held back): take the accumulated gradient again
             return
         b.pack(i)
         b.ready[i] = True
@@ -274,11 +343,17 @@ class GradAllReducer:
         if not self.active:
             return
         cand = [p for p in self.module.parameters() if p.requires_grad]
-        live = [p for p in cand if p.grad is not None]
+
+        def has_grad(p):          # on this rank, this step: still in p.grad, or already taken over by a launched bucket
+            if p.grad is not None:
+                return True
+            w = self._where.get(p)
+            return w is not None and w[0].had[w[1]]
+        live = [p for p in cand if has_grad(p)]
         rebuild = self.buckets is None or any(p not in self._where for p in live)
         nb = len(self.buckets) if self.buckets is not None else 0
         dirty = [1 if b.dirty else 0 for b in self.buckets] if nb else []
-        touched = [1 if p.grad is not None else 0 for p in cand]      # has a gradient THIS step (on this rank)
+        touched = [1 if has_grad(p) else 0 for p in cand]      # has a gradient THIS step (on this rank)
         if self.world > 1:
             # the decision, the parameter set and the dirty buckets must be the same on every rank, or the collectives
             # diverge and the job hangs: one MAX all-reduce of [rebuild?, ever-had-a-gradient bitmap, has-one-this-step bitmap,
@@ -301,59 +376,77 @@ class GradAllReducer:
             union = [p for f, p in zip(pbits, cand) if f]
             dirty = fl[1 + 2 * n:]
         else:
-            union = [p for p in cand if p.grad is not None or p in self._where]
+            union = [p for p in cand if has_grad(p) or p in self._where]
         if not union:
             return                       # nothing has a gradient yet on any rank (e.g. a skipped batch on the first step)
         touched_ids = {id(p) for t, p in zip(touched, cand) if t}
+        inv = 1.0 / self.world
+
+        def settle(b, d):
+            """bucket b's first collective is issued; wait for it, fold in a later backward's contributions (d: dirty on some
+            rank), leave the AVERAGE in b.flat"""
+            self._wait(b)
+            if d:
+                if b.dirty and not self._warned:
+                    warnings.warn("GradAllReducer: backward() ran more than once in this step outside no_sync(); the later "
+                                  "contributions are reduced on their own after the last backward (correct, not overlapped)")
+                    self._warned = True
+                extra = torch.zeros_like(b.flat)
+                for i, p in enumerate(b.params):
+                    if p.grad is not None:
+                        extra[b.offsets[i]:b.offsets[i] + p.numel()].copy_(p.grad.reshape(-1))
+                        b.had[i] = True
+                        p.grad = None
+                self._launch(b, flat=extra)
+                self._wait(b)
+                b.flat.add_(extra)
+            if not self._avg and inv != 1.0:
+                b.flat.mul_(inv)
+
         if rebuild:
             # first step, or a parameter received its first gradient (on any rank): (re)build the buckets over everything
             # that has ever had a gradient, and reduce this step without overlap
             if self.buckets is not None:
                 # the old layout's collectives must pair up on every rank before the new layout's start: a rank that held
                 # buckets back (a gradient that did not arrive there) issues them now, in index order, like every other
-                # rank did from its hooks; their results are dropped (the local gradients still sit in p.grad)
+                # rank did from its hooks.  Their results are KEPT: every rank then holds the old members' average, hands it
+                # to the new layout as its "local" gradient (the average of identical values is that value), and only the
+                # newcomers are really reduced there.
                 for b in self.buckets:
-                    if b.work is None:
+                    if not b.launched:
                         for i in range(len(b.params)):
                             if not b.ready[i]:
                                 b.pack(i)
                         self._launch(b)
-                for b in self.buckets:
-                    self._wait(b)
+                for b, d in zip(self.buckets, dirty):
+                    settle(b, d)
+                    for i, p in enumerate(b.params):
+                        p.grad = b.views[i] if id(p) in touched_ids else None
+                    b.reset()
+                dirty = []
             self._build(union)
         # pass 1, index order like the hooks: whatever has not started yet (incomplete because a gradient did not show up in
         # the last backward, held back behind an incomplete one, overlap off, or fresh after a rebuild)
         for b in self.buckets:
-            if b.work is None:
+            if not b.launched:
                 for i in range(len(b.params)):
                     if not b.ready[i]:
                         b.pack(i)
                 self._launch(b)
-        # pass 2: buckets that went stale on ANY rank (a second un-synchronised backward) are reduced again from the
-        # accumulated p.grad -- after every first-pass launch, so that the issue order is the same on all ranks
-        if not rebuild:
-            for b, d in zip(self.buckets, dirty):
-                if d:
-                    if b.dirty and not self._warned:
-                        warnings.warn("GradAllReducer: backward() ran more than once in this step outside no_sync(); the "
-                                      "affected buckets are reduced again after the last backward (correct, not overlapped)")
-                        self._warned = True
-                    self._wait(b)
-                    b.reset()
-                    for i in range(len(b.params)):
-                        b.pack(i)
-                    self._launch(b)
-        inv = 1.0 / self.world
-        for b in self.buckets:
-            self._wait(b)
-            if inv != 1.0:
-                b.flat.mul_(inv)
+        # pass 2, after every first-pass launch (same issue order on all ranks): wait; buckets that a second un-synchronised
+        # backward reached on ANY rank reduce those later contributions on their own and add them
+        dirty = list(dirty) + [0] * (len(self.buckets) - len(dirty))
+        for b, d in zip(self.buckets, dirty):
+            settle(b, d)
             # every bucket member that had a gradient on SOME rank receives the average on every rank (a parameter that had
             # none locally still gets the other ranks' average: replicas stay identical); one that no rank touched keeps
             # grad = None, as in the single-GPU run.  No copy back: p.grad is re-pointed at its slice of the bucket (valid
-            # until the next step packs into it); the optimizer reads the bucket.
+            # until the next step's backward writes there); the optimizer reads the bucket.
             for i, p in enumerate(b.params):
                 if id(p) in touched_ids:
-                    p.grad = b.slot(i).view_as(p)
+                    p.grad = b.views[i].clone() if self.copy_out else b.views[i]
+                else:
+                    p.grad = None
             b.reset()
         self._next = 0
+        _STEP[0] += 1                # the destinations may be claimed again

@@ -21,6 +21,13 @@ from . import hipops as H
 FUSIONS = {}
 
 
+def _grad_dest(param):
+    """the parameter's slice of a data-parallel gradient bucket, if a GradAllReducer handed it out as the place to write this
+    step's gradient (ddp.grad_destination: zero-copy buckets); None in single-process runs"""
+    from . import ddp
+    return ddp.grad_destination(param) if ddp._GRAD_DEST else None
+
+
 def fusion(kind, taken):
     c = FUSIONS.setdefault(kind, [0, 0])
     c[0 if taken else 1] += 1
@@ -242,7 +249,7 @@ class ConvFn(Function):
             if x1 is None or not ctx.needs_input_grad[1]:
                 dx1 = None
         if ctx.needs_input_grad[2]:
-            dw = H.conv_wgrad(g, x0, x1, dz, wino_v=ctx.wino_v)
+            dw = H.conv_wgrad(g, x0, x1, dz, wino_v=ctx.wino_v, out=_grad_dest(weight))
             ctx.wino_v = None
         return dx0, dx1, dw, dbias, None, None, None, None, None, None, None, None, None, None
 
@@ -294,6 +301,7 @@ class BNActFn(Function):
         # the backward pass reads the saved output only where the activation mask is not a function of x alone
         remask = act in ("none", "relu") and residual is None and not drop_p
         ctx.cfg = (act, drop_p, seed, training, residual is not None, remask)
+        ctx.beta_param = beta          # (the parameter object: its gradient-bucket destination is looked up in backward)
         ctx.save_for_backward(x, gamma, beta if remask else None, mean, invstd, None if remask else y)
         return y
 
@@ -301,9 +309,14 @@ class BNActFn(Function):
     def backward(ctx, dy):
         x, gamma, beta, mean, invstd, y = ctx.saved_tensors
         act, drop_p, seed, training, has_res, remask = ctx.cfg
+        want_g = gamma is not None and ctx.needs_input_grad[1]
+        bp = ctx.beta_param
         dx, dres, dgamma, dbeta = H.bn_backward(_c(dy), y, x, mean, invstd, gamma, act, drop_p, seed, batch_stats=training,
                                                 need_dx=ctx.needs_input_grad[0],
-                                                need_dres=has_res and ctx.needs_input_grad[3], beta=beta)
+                                                need_dres=has_res and ctx.needs_input_grad[3], beta=beta,
+                                                dgamma_out=_grad_dest(gamma) if want_g else None,
+                                                dbeta_out=_grad_dest(bp) if (want_g and bp is not None and ctx.needs_input_grad[2]) else None)
+        ctx.beta_param = None
         if gamma is None or not ctx.needs_input_grad[1]:
             dgamma = dbeta = None
         if ctx.grad_box is not None and dres is not None:

@@ -791,8 +791,9 @@ def conv_dgrad(g, dy, wdpack, w_oihw, in_hw, need0=True, need1=True, accumulate_
     return (dx0 if fused else finish_unfused(dx0)), dx1
 
 
-def conv_wgrad(g, x0, x1, dy, wino_v=None):
-    """dW in OIHW layout.  wino_v: the transformed input the forward's Winograd call kept (hipops.WINO_V), if any."""
+def conv_wgrad(g, x0, x1, dy, wino_v=None, out=None):
+    """dW in OIHW layout.  wino_v: the transformed input the forward's Winograd call kept (hipops.WINO_V), if any.
+    out: a dense [Cout, Cin, k, k] tensor to write into (the parameter's slice of a gradient bucket, ddp.grad_destination)."""
     B, H0, W0, _ = x0.shape
     H, W = (2 * H0, 2 * W0) if g.up0 else (H0, W0)
     _, Ho, Wo, Cout = dy.shape
@@ -800,7 +801,10 @@ def conv_wgrad(g, x0, x1, dy, wino_v=None):
                  up0=int(g.up0), Ho=Ho, Wo=Wo, Cout=Cout, ldy=Cout, ldy2=0, nsplit=0, KH=g.k, KW=g.k, stride=g.stride,
                  dil=g.dil, pad=g.pad, pad_mode=PAD_REFLECT if g.reflect else PAD_ZERO, in_div=1, act=0, sum2x2=0)
     L = _lib.lib()
-    dw = torch.empty((Cout, g.Cin, g.k, g.k), dtype=torch.float32, device=dy.device)
+    if out is not None and tuple(out.shape) == (Cout, g.Cin, g.k, g.k) and out.is_contiguous() and out.dtype == torch.float32:
+        dw = out
+    else:
+        dw = torch.empty((Cout, g.Cin, g.k, g.k), dtype=torch.float32, device=dy.device)
     flops = 2.0 * B * Ho * Wo * Cout * g.CinAlg * g.k * g.k
     flops_x = flops * g.Cin / g.CinAlg * _live_tap_frac(g, H, W, wgrad=True)
     if wino_v is None and (Ho, Wo) == (H, W) and winograd_fused_wgrad_ok(g, B, H, W):
@@ -906,12 +910,16 @@ def bn_apply(x, mean, invstd, gamma, beta, residual=None, act="none", drop_p=0.0
 
 
 def bn_backward(dy, y, x, mean, invstd, gamma, act="none", drop_p=0.0, seed=0, batch_stats=True, need_dx=True,
-                need_dres=False, beta=None):
-    """y=None selects the remask mode of segsde_bn_backward (act none / plain ReLU: mask recomputed from x, beta needed)."""
+                need_dres=False, beta=None, dgamma_out=None, dbeta_out=None):
+    """y=None selects the remask mode of segsde_bn_backward (act none / plain ReLU: mask recomputed from x, beta needed).
+    dgamma_out / dbeta_out: dense [C] tensors to write into (gradient-bucket slices, ddp.grad_destination)."""
     M, C, ldx = _rows(x)
     L = _lib.lib()
-    dgamma = torch.empty(C, dtype=torch.float32, device=x.device)
-    dbeta = torch.empty_like(dgamma)
+
+    def _dst(t):
+        ok = t is not None and tuple(t.shape) == (C,) and t.is_contiguous() and t.dtype == torch.float32
+        return t if ok else torch.empty(C, dtype=torch.float32, device=x.device)
+    dgamma, dbeta = _dst(dgamma_out), _dst(dbeta_out)
     dx = torch.empty(x.shape, dtype=torch.float32, device=x.device) if need_dx else None
     dres = torch.empty(x.shape, dtype=torch.float32, device=x.device) if need_dres else None
     nb = L.segsde_bn_backward_workspace(M, C)

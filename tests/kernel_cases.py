@@ -1709,3 +1709,28 @@ def run_dropout_case(device):
     assert not torch.equal(a, b), "train mode: a fresh mask per forward"
     a.sum().backward()
     assert all(torch.isfinite(q.grad).all() for q in net.parameters() if q.grad is not None)
+
+
+# ---------------------------------------------------------------------------------------------
+# BatchNorm statistics from convolution-epilogue partials: the three launch plans of segsde_bn_stats_from_partials (few rows: one
+# small kernel; a few hundred: the one-launch wide kernel of round 5; thousands: reduce + finalize) against float64
+# ---------------------------------------------------------------------------------------------
+def run_bn_partials_case(device):
+    gen = torch.Generator().manual_seed(17)
+    for rows, C in ((40, 64), (300, 70), (256, 256), (1024, 64), (1500, 32), (65, 5)):
+        M = rows * 128
+        part = torch.rand(rows, 2, C, generator=gen, dtype=torch.float64)
+        part[:, 0] = (part[:, 0] - 0.5) * 128.0            # tile sums of x
+        part[:, 1] = part[:, 1] * 128.0 + 40.0             # tile sums of x^2 (keeps the variance positive)
+        s, q = part[:, 0].sum(0), part[:, 1].sum(0)
+        mu = s / M
+        var = (q / M - mu * mu).clamp_min(0)
+        rm, rv = torch.zeros(C).to(device), torch.ones(C).to(device)
+        nbt = torch.zeros((), dtype=torch.int64).to(device)
+        mean, invstd = H.bn_stats_from_partials(part.to(device), M, rm, rv, 0.1, 1e-5, num_batches_tracked=nbt)
+        what = "bn_stats_from_partials rows=%d C=%d" % (rows, C)
+        assert_close(mean, mu.float(), rtol=1e-6, atol=1e-7, what=what + " mean")
+        assert_close(invstd, (1.0 / torch.sqrt(var + 1e-5)).float(), rtol=1e-6, atol=0, what=what + " invstd")
+        assert_close(rm, (0.1 * mu).float(), rtol=1e-6, atol=1e-8, what=what + " running_mean")
+        assert_close(rv, (0.9 + 0.1 * var * M / (M - 1)).float(), rtol=1e-6, atol=0, what=what + " running_var")
+        assert int(nbt) == 1

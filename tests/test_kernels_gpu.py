@@ -193,3 +193,7 @@ def test_winograd_fused_wgrad_kernel():
 
 def test_dropout_layer():
     KC.run_dropout_case("cuda")
+
+
+def test_bn_stats_from_partials_plans():
+    KC.run_bn_partials_case("cuda")
