@@ -670,6 +670,14 @@ def main():
                 roof["direct"] = {"launches": nl - wn, "achieved": (fl - wf) / (tt - wt) / 1e12,
                                   "executed_achieved": (ex - wx) / (tt - wt) / 1e12,
                                   "executed_frac": (ex - wx) / (tt - wt) / 1e12 / PEAK_FP32_MATRIX_TFLOPS}
+            wgf = [v for (kind, tag), v in layers.items() if kind == "conv_wgrad" and tag.endswith(" wino-fused")]
+            if wgf:
+                gf_, gt_, gn_, gx_ = (sum(v[i] for v in wgf) for i in range(4))
+                roof["winograd_wgrad_fused"] = {"kernel": "wino_wgrad_fused_kernel (csrc/winograd_wgrad.hip: both operand transforms inside the "
+                                                          "kernel, LDS-DMA staging) + wino_wgrad_finish_kernel",
+                                                "launches": gn_, "ms_per_step": gt_ / args.steps * 1e3, "achieved": gf_ / gt_ / 1e12,
+                                                "executed_achieved": gx_ / gt_ / 1e12,
+                                                "executed_frac": gx_ / gt_ / 1e12 / PEAK_FP32_MATRIX_TFLOPS, "share_of_step": gt_ / dt}
             roof.update(achieved=ex / tt / 1e12, frac=ex / tt / 1e12 / PEAK_FP32_MATRIX_TFLOPS,
                         algorithmic_achieved=fl / tt / 1e12, algorithmic_frac=fl / tt / 1e12 / PEAK_FP32_MATRIX_TFLOPS, launches=nl,
                         avg_launch_ms=tt / nl * 1e3, avg_launch_gflop=fl / nl / 1e9, avg_launch_executed_gflop=ex / nl / 1e9,
@@ -718,7 +726,7 @@ def main():
                 else:
                     busy = {}
                     for line in lines:
-                        if line.startswith("conv_"):
+                        if line.startswith("conv_") or line.startswith("wino_fused") or line.startswith("wino_wgrad_fused"):
                             f = line.split()
                             busy[line[:72].strip()] = float(f[-1])
                     roof["mfma_busy"] = busy

@@ -28,7 +28,10 @@ def main():
               "photometric_bwd_kernel": "photometric_bwd2_kernel", "photometric_fwd_kernel": "photometric_fwd2_kernel",
               "wino_fused_kernel (one-kernel Winograd convolution)": "wino_fused_kernel",
               "wino_in_kernel (Winograd input transform)": "wino_in_kernel", "wino_out_kernel (Winograd output transform)": "wino_out_kernel",
-              "wino_grad_kernel (Winograd output-gradient transform)": "wino_grad_kernel"}
+              "wino_grad_kernel (Winograd output-gradient transform)": "wino_grad_kernel",
+              "wino_wgrad_fused_kernel (one-kernel Winograd weight gradient)": "wino_wgrad_fused_kernel",
+              "wino_wgrad_finish_kernel (slab fold + G^T dU G)": "wino_wgrad_finish_kernel",
+              "reflect_borders_kernel (mirrored-padding terms of the Winograd data-gradient)": "reflect_borders_kernel"}
     res = {"command": "rocprofv3 --kernel-trace --pmc <FETCH_SIZE | WRITE_SIZE> -- python bench.py --steps 2 --warmup 1 "
                       "--no-cpu-baseline --no-kernel-timing (tools/gpu_pmc.sh: one pass per counter)",
            "correction": "gfx950: read bytes = 2 x FETCH_SIZE KB x 1024 (64 B tallied per 128-B request on wide coalesced reads, "
