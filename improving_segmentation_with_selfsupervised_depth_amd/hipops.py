@@ -253,6 +253,19 @@ BORDERS2 = os.environ.get("SEGSDE_BORDERS2", "1") != "0"     # 0: the mirrored-p
 WINO_FUSED_TAKEN = {"fwd": 0, "dgrad": 0, "fwd2": 0, "dgrad_refl": 0, "dgrad_actgrad": 0, "dgrad2": 0, "wgrad": 0}
 
 
+_FUSED_SHAPE_OK = {}
+
+
+def _fused_shape_ok(B, H, W, cin, cout):
+    """segsde_winograd_fused_ok, remembered per shape (the routers ask three times per convolution call; on the launch-bound
+    small workloads a foreign-function call each time shows)"""
+    key = (B, H, W, cin, cout)
+    r = _FUSED_SHAPE_OK.get(key)
+    if r is None:
+        r = _FUSED_SHAPE_OK[key] = bool(_lib.lib().segsde_winograd_fused_ok(B, H, W, cin, cout))
+    return r
+
+
 def winograd_fused_ok(g, B=None, H=None, W=None, dgrad=False):
     """the shapes csrc/winograd_fused.hip takes: 3x3 / stride 1 / padding 1 / dilation 1, channel counts multiples of 64.
     One source at output resolution: up to WINO_FUSED_MAX_CH channels, zero or mirrored padding, forward and data-gradient
@@ -272,7 +285,7 @@ def winograd_fused_ok(g, B=None, H=None, W=None, dgrad=False):
             return False
     if B is None:
         return True
-    return bool(_lib.lib().segsde_winograd_fused_ok(B, H, W, cin, cout)) and 9.0 * B * H * W * cin * cout >= WINOGRAD_MIN_MACS
+    return _fused_shape_ok(B, H, W, cin, cout) and 9.0 * B * H * W * cin * cout >= WINOGRAD_MIN_MACS
 
 
 def winograd_fused_dgrad2_ok(g, B=None, H=None, W=None):
@@ -284,7 +297,7 @@ def winograd_fused_dgrad2_ok(g, B=None, H=None, W=None):
         return False
     if B is None:
         return True
-    return (B * H * W >= WINO_FUSED_REFLECT_DGRAD_MIN_PIX and bool(_lib.lib().segsde_winograd_fused_ok(B, H, W, g.Cout, g.C1))
+    return (B * H * W >= WINO_FUSED_REFLECT_DGRAD_MIN_PIX and _fused_shape_ok(B, H, W, g.Cout, g.C1)
             and 9.0 * B * H * W * g.C1 * g.Cout >= WINOGRAD_MIN_MACS)
 
 
