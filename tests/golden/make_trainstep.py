@@ -178,7 +178,11 @@ if args.impl == "reference":
     print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024))
 else:
     ref = dict(np.load(path, allow_pickle=False))
-    log = {"impl": "package on the kernel interpreter, under /root/reference/train.py", "scenarios": {}}
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    from trainstep_case import package_fingerprint
+    log = {"impl": "package on the kernel interpreter, under /root/reference/train.py", "scenarios": {},
+           # what this run executed: the test that reads this log refuses it once the kernels / host code have changed
+           "package_sha256": package_fingerprint()}
     for sc in args.scenarios.split(","):
         log["scenarios"][sc] = TC.compare(out, ref, sc)
         for it in range(TC.ITERS):

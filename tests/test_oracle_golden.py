@@ -524,6 +524,11 @@ def test_trainstep_fixture_and_param_groups():
     log = os.path.join(GOLDEN, "trainstep_package_run.json")
     if os.path.exists(log):
         run = json.load(open(log))
+        if run.get("package_sha256") != TC.package_fingerprint():
+            # a log of other sources proves nothing about these: the GPU replay of the same fixture
+            # (tests/test_models_gpu.py::test_train_step_replay_vs_reference_caller) is the live check; re-run
+            # `python tests/golden/make_trainstep.py --impl package` (kernel interpreter, ~10 min) to refresh the log
+            pytest.skip("tests/golden/trainstep_package_run.json was recorded from other sources than this tree's")
         assert set(run["scenarios"]) == set(TC.SCENARIOS)
         for sc in TC.SCENARIOS:
             assert run["scenarios"][sc]["loss"] < 2e-3
