@@ -52,6 +52,26 @@ def test_argument_validation_without_gpu():
     assert cdll.segsde_conv2d_forward(ctypes.byref(d), None, None, None, None, None, None, None) == -1
     assert cdll.segsde_conv2d_wgrad_workspace(ctypes.byref(d)) > 0
     assert cdll.segsde_bn_stats(None, 4, 10, 4, None, None, None, None, 0.1, 1e-5, None, None, 0, None) == -1
+    # round-5 entries: the one-kernel Winograd weight gradient / data-gradient, the border kernel, dropout, the geometry adjoints
+    dw = _lib.ConvDesc(B=2, H=8, W=16, C0=64, C1=0, ld0=64, Ho=8, Wo=16, Cout=64, ldy=64, KH=3, KW=3, stride=1, dil=1, pad=1)
+    assert cdll.segsde_conv2d_wgrad_winograd_fused_workspace(ctypes.byref(dw)) > 0
+    dw.KH = dw.KW = 1
+    dw.pad = 0
+    assert cdll.segsde_conv2d_wgrad_winograd_fused_workspace(ctypes.byref(dw)) == 0          # not a 3x3: the caller takes another route
+    assert cdll.segsde_conv2d_wgrad_winograd_fused(ctypes.byref(dw), None, None, None, 64, None, None, 0, None) == -1
+    fake = ctypes.c_void_p(4096)
+    assert cdll.segsde_conv2d_wgrad_winograd_fused(ctypes.byref(dw), fake, None, fake, 64, fake, fake, 1 << 30, None) == -4
+    assert cdll.segsde_conv2d_winograd_fused_dgrad(None, 64, 2, 8, 16, 64, None, 64, 64, None, 64, 0, None, 0, 0, None) == -1
+    assert cdll.segsde_conv2d_winograd_fused_dgrad(fake, 64, 2, 7, 16, 64, fake, 64, 64, fake, 64, 0, None, 0, 0, None) == -4   # odd height
+    assert cdll.segsde_conv2d_winograd_fused_dgrad(fake, 64, 2, 8, 16, 64, fake, 32, 64, fake, 64, 0, None, 0, 0, None) == -4   # pack narrower than its slice
+    assert cdll.segsde_conv2d_winograd_fused2(fake, 64, 48, 1, fake, 64, 16, 2, 8, 16, 1, fake, 64, None, 0, fake, 64, None, None) == -4  # C0 % 64
+    assert cdll.segsde_reflect_adjoint_borders2(None, 64, None, 64, None, 64, None, 0, 0, 2, 8, 16, 64, 64, None) == -1
+    assert cdll.segsde_reflect_adjoint_borders2(fake, 64, fake, 64, fake, 64, None, 0, 0, 2, 3, 16, 64, 64, None) == -4         # H < 4
+    assert cdll.segsde_dropout(None, 4, 10, 4, 0.5, 1, None, 4, None) == -1
+    assert cdll.segsde_dropout(fake, 4, 10, 4, 1.0, 1, fake, 4, None) == -2
+    assert cdll.segsde_project3d_backward_workspace(0, 8, 8) == 0 and cdll.segsde_project3d_backward_workspace(2, 8, 8) > 0
+    assert cdll.segsde_project3d_backward(fake, fake, fake, fake, 2, 8, 8, 1e-7, None, fake, None, 0, None) == -3               # d T needs the workspace
+    assert cdll.segsde_backproject_depth_backward(None, None, 2, 8, 8, None, None) == -1
 
 
 def test_product_never_imports_oracle_or_falls_back():
