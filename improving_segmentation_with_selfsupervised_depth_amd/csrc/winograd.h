@@ -24,3 +24,5 @@ int segsde_wino_weights_multi(const segsde_wino_job* jobs_device, int njobs, int
 // sixteen position GEMMs dU_p = V_p^T dM_p, s per position) -> dW [Co][Cin][3][3] = G^T dU G
 int segsde_wino_grad(const float* dy, int ld, int B, int H, int W, int C, int dil, float* dM, void* stream);
 int segsde_wino_wgrad_finish(const float* part, int s, int Cin, int Co, float* dw_oihw, void* stream);
+// 1: the one-kernel route's packs are in the blocked layout (winograd_fused.hip)
+int segsde_wino_ublk();

@@ -298,13 +298,18 @@ __global__ __launch_bounds__(256) void wino_weight_multi_kernel(const segsde_win
     t[3][c] = k[2][c];
   }
   const long plane = (long)A * Bn;
-  float* out = (tf ? jb.u_dgrad : jb.u_fwd) + e;
+  float* base = tf ? jb.u_dgrad : jb.u_fwd;
+  const bool blocked = (jb.reserved & 2) && (Bn % 64 == 0);      // the one-kernel route's blocked layout (winograd_fused.hip)
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    out[(4 * r + 0) * plane] = t[r][0];
-    out[(4 * r + 1) * plane] = 0.5f * ((t[r][0] + t[r][1]) + t[r][2]);
-    out[(4 * r + 2) * plane] = 0.5f * ((t[r][0] - t[r][1]) + t[r][2]);
-    out[(4 * r + 3) * plane] = t[r][2];
+    const float v0 = t[r][0], v1 = 0.5f * ((t[r][0] + t[r][1]) + t[r][2]), v2 = 0.5f * ((t[r][0] - t[r][1]) + t[r][2]), v3 = t[r][2];
+    if (blocked) {
+      float* o = base + (((((long)r * A + a) * (Bn >> 6) + (b >> 6)) * 32 + (b & 31)) * 4) * 2 + ((b >> 5) & 1);
+      o[0] = v0; o[2] = v1; o[4] = v2; o[6] = v3;
+    } else {
+      float* out = base + e;
+      out[(4 * r + 0) * plane] = v0; out[(4 * r + 1) * plane] = v1; out[(4 * r + 2) * plane] = v2; out[(4 * r + 3) * plane] = v3;
+    }
   }
 }
 

@@ -14,6 +14,7 @@
 //    double-precision column sums of what it stored (the following BatchNorm's batch statistics, same partial-row format as
 //    the implicit-GEMM epilogue's).
 // 16 instead of 36 multiply-adds per output, and no transform traffic: x is read once (+ halo), y written once.
+#include <stdlib.h>
 #include "segsde_common.h"
 #include "winograd.h"
 
@@ -45,7 +46,10 @@ struct WinoSrc { const float* x0; const float* x1; int ld0, ld1, C0, up0; };
 // layer's input is the gradient of this ELU's output)
 struct WinoAg { const float* agy; int agld, agkind; };
 
-template <bool STATS>
+// UBLK: the transformed weights in the BLOCKED layout U[row w][c][block of 64 filters][32 lanes][4 positions of the row][2 filter
+// halves] -- the eight B operands of a lane and step are 32 contiguous bytes (two 16-byte requests, 1 KiB per wave-instruction)
+// instead of eight 4-byte requests in eight position planes
+template <bool STATS, bool UBLK>
 __global__ __launch_bounds__(256, 2) void wino_fused_kernel(WinoSrc src, int B, int H, int W, int C, int reflect,
                                                             const float* U, int ldu, int Co, const float* bias, int act, float* y, int ldy,
                                                             double* part, int accumulate, WinoAg ag) {
@@ -119,19 +123,27 @@ __global__ __launch_bounds__(256, 2) void wino_fused_kernel(WinoSrc src, int B, 
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const segsde_rsrc ur = segsde_make_rsrc(U);
     // (ldu: row pitch of U -- Co, or the width of the pack this launch takes a column slice of)
-    const unsigned lane_off = (unsigned)(kk * ldu + t) * 4u;                          // bytes
-    const unsigned ubase = (unsigned)((((long)(4 * wave_u) * C + c0) * ldu + co0) * 4);   // bytes; 16 C ldu floats < 2^30
-    const unsigned upos = (unsigned)((long)C * ldu * 4), ustep = (unsigned)(2 * ldu * 4);
+    const unsigned nb64 = (unsigned)(ldu >> 6);
+    const unsigned lane_off = UBLK ? (unsigned)(kk * nb64 * 256 + t * 8) * 4u : (unsigned)(kk * ldu + t) * 4u;                          // bytes
+    const unsigned ubase = UBLK ? (unsigned)((((long)wave_u * C + c0) * nb64 + (co0 >> 6)) * 256 * 4)
+                                : (unsigned)((((long)(4 * wave_u) * C + c0) * ldu + co0) * 4);   // bytes; 16 C ldu floats < 2^30
+    const unsigned upos = (unsigned)((long)C * ldu * 4), ustep = UBLK ? 2u * nb64 * 256u * 4u : (unsigned)(2 * ldu * 4);
     // B operands come straight from L2 (a few hundred ns): requested PD steps (PD x 512 MFMA cycles) ahead; the raw pixels
     // (LDS) one step ahead
     constexpr int PD = 4, NS = FCH / 2;
     float bv[PD][8], rv[2][8];
     auto fetch_b = [&](int s, int q) {
       const unsigned so = ubase + (unsigned)s * ustep;
+      if constexpr (UBLK) {
+        const float4 lo = segsde_buffer_load4(ur, lane_off, so), hi = segsde_buffer_load4(ur, lane_off, so + 16u);
+        bv[q][0] = lo.x; bv[q][1] = lo.y; bv[q][2] = lo.z; bv[q][3] = lo.w;
+        bv[q][4] = hi.x; bv[q][5] = hi.y; bv[q][6] = hi.z; bv[q][7] = hi.w;
+      } else {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        bv[q][2 * j] = segsde_buffer_load1(ur, lane_off, so + j * upos);
-        bv[q][2 * j + 1] = segsde_buffer_load1(ur, lane_off, so + j * upos + 128u);
+        for (int j = 0; j < 4; ++j) {
+          bv[q][2 * j] = segsde_buffer_load1(ur, lane_off, so + j * upos);
+          bv[q][2 * j + 1] = segsde_buffer_load1(ur, lane_off, so + j * upos + 128u);
+        }
       }
     };
     auto fetch_a = [&](int s, int q) {
@@ -258,9 +270,13 @@ __global__ __launch_bounds__(256, 2) void wino_fused_kernel(WinoSrc src, int B, 
   }
 }
 
-// OIHW 3x3 weight -> U[16][K][N], N fastest: forward (flip = 0) K = I, N = O; data-gradient (flip = 1: the convolution of dY with
+// OIHW 3x3 weight -> U (logical [16][K][N]; stored blocked -- wino_ublk_index -- or as sixteen [K][N] planes): forward (flip = 0) K = I, N = O; data-gradient (flip = 1: the convolution of dY with
 // the spatially flipped kernel) K = O, N = I.  thread (k, n), n fastest: coalesced writes, the nine reads of a thread are contiguous.
-__global__ __launch_bounds__(256) void wino_weight_kn_kernel(const float* w, int O, int I, int flip, float* U) {
+// blocked layout (wino_fused_kernel<., true>): element (p = 4 r + q, k, n) at ((((r K + k) (N / 64) + n / 64) 32 + n % 32) 4 + q) 2 + (n / 32) % 2
+__device__ __forceinline__ long wino_ublk_index(int r, int q, int k, int n, int K, int N) {
+  return (((((long)r * K + k) * (N >> 6) + (n >> 6)) * 32 + (n & 31)) * 4 + q) * 2 + ((n >> 5) & 1);
+}
+__global__ __launch_bounds__(256) void wino_weight_kn_kernel(const float* w, int O, int I, int flip, float* U, int blocked) {
   const int K = flip ? O : I, N = flip ? I : O;
   const long e = blockIdx.x * 256L + threadIdx.x;
   if (e >= (long)K * N) return;
@@ -281,13 +297,16 @@ __global__ __launch_bounds__(256) void wino_weight_kn_kernel(const float* w, int
     tq[3][c] = k[2][c];
   }
   const long plane = (long)K * N;
-  float* out = U + e;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {          // (.) G^T
-    out[(4 * r + 0) * plane] = tq[r][0];
-    out[(4 * r + 1) * plane] = 0.5f * ((tq[r][0] + tq[r][1]) + tq[r][2]);
-    out[(4 * r + 2) * plane] = 0.5f * ((tq[r][0] - tq[r][1]) + tq[r][2]);
-    out[(4 * r + 3) * plane] = tq[r][2];
+    const float v0 = tq[r][0], v1 = 0.5f * ((tq[r][0] + tq[r][1]) + tq[r][2]), v2 = 0.5f * ((tq[r][0] - tq[r][1]) + tq[r][2]), v3 = tq[r][2];
+    if (blocked) {
+      float* o = U + wino_ublk_index(r, 0, kq, nn, K, N);      // the four positions of a row: stride 2 floats
+      o[0] = v0; o[2] = v1; o[4] = v2; o[6] = v3;
+    } else {
+      float* out = U + e;
+      out[(4 * r + 0) * plane] = v0; out[(4 * r + 1) * plane] = v1; out[(4 * r + 2) * plane] = v2; out[(4 * r + 3) * plane] = v3;
+    }
   }
 }
 
@@ -388,6 +407,15 @@ __global__ __launch_bounds__(256) void reflect_borders_kernel(BorderP p) {
   }
 }
 
+}  // namespace
+// layout of the one-kernel route's transformed weights: 1 = blocked (default), 0 = sixteen [K][N] planes (SEGSDE_WINO_FUSED_UBLK=0);
+// one answer per process -- the pack kernels (here and winograd.hip's multi-pack) and the convolution kernel must agree
+int segsde_wino_ublk() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("SEGSDE_WINO_FUSED_UBLK"); v = e ? (atoi(e) != 0) : 1; }
+  return v;
+}
+namespace {
 inline long fused_blocks(int B, int H, int W) {
   return (long)B * (((H >> 1) + FT_H - 1) / FT_H) * (((W >> 1) + FT_W - 1) / FT_W);
 }
@@ -404,7 +432,8 @@ extern "C" int segsde_winograd_fused_pack(const float* w_oihw, int O, int I, int
   if (!w_oihw || !U) return SEGSDE_ERR_NULL;
   if (O <= 0 || I <= 0) return SEGSDE_ERR_SHAPE;
   const long total = (long)O * I;
-  hipLaunchKernelGGL(wino_weight_kn_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ST(stream), w_oihw, O, I, flip, U);
+  const int blocked = segsde_wino_ublk() && ((flip ? I : O) % 64 == 0);
+  hipLaunchKernelGGL(wino_weight_kn_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ST(stream), w_oihw, O, I, flip, U, blocked);
   SEGSDE_CHECK_LAUNCH();
   return 0;
 }
@@ -413,15 +442,13 @@ namespace {
 int launch_fused(const WinoSrc& src, int B, int H, int W, int C, int reflect, const float* u_kn, int ldu, int Cout, const float* bias, int act,
                  float* y, int ldy, int accumulate, double* stats, const WinoAg& ag, void* stream) {
   const dim3 grid((unsigned)fused_blocks(B, H, W), (unsigned)(Cout / 64));
-  if (stats) {
-    auto k = wino_fused_kernel<true>;
+  const bool ublk = segsde_wino_ublk() != 0;
+  auto go = [&](auto k, double* st) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_LDS);
-    hipLaunchKernelGGL(k, grid, dim3(256), F_LDS, ST(stream), src, B, H, W, C, reflect, u_kn, ldu, Cout, bias, act, y, ldy, stats, accumulate, ag);
-  } else {
-    auto k = wino_fused_kernel<false>;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_LDS);
-    hipLaunchKernelGGL(k, grid, dim3(256), F_LDS, ST(stream), src, B, H, W, C, reflect, u_kn, ldu, Cout, bias, act, y, ldy, (double*)nullptr, accumulate, ag);
-  }
+    hipLaunchKernelGGL(k, grid, dim3(256), F_LDS, ST(stream), src, B, H, W, C, reflect, u_kn, ldu, Cout, bias, act, y, ldy, st, accumulate, ag);
+  };
+  if (stats) { if (ublk) go(wino_fused_kernel<true, true>, stats); else go(wino_fused_kernel<true, false>, stats); }
+  else { if (ublk) go(wino_fused_kernel<false, true>, (double*)nullptr); else go(wino_fused_kernel<false, false>, (double*)nullptr); }
   SEGSDE_CHECK_LAUNCH();
   return 0;
 }

@@ -181,7 +181,7 @@ def winograd_packs_multi(weights, kn=False):
             else:
                 uf, ud = flat[off:off + n].view(16, O, I), flat[off + n:off + 2 * n].view(16, I, O)
             off += 2 * n
-            jobs[i] = _lib.WinoJob(w.data_ptr(), uf.data_ptr(), ud.data_ptr(), O, I, blk, 1 if kn else 0)
+            jobs[i] = _lib.WinoJob(w.data_ptr(), uf.data_ptr(), ud.data_ptr(), O, I, blk, (3 if WINO_FUSED_UBLK else 1) if kn else 0)
             blk += 2 * ((O * I + 255) // 256)
             views.append((uf, ud))
         raw = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8).to(dev)
@@ -250,6 +250,9 @@ WINO_FUSED_REFLECT_DGRAD_MIN_PIX = int(os.environ.get("SEGSDE_WINO_FUSED_REFLECT
 # low-resolution gradient stays on the folded route's 4x4 / stride-2 launch.  SEGSDE_WINO_FUSED_DGRAD2=0: off
 WINO_FUSED_DGRAD2 = os.environ.get("SEGSDE_WINO_FUSED_DGRAD2", "1") != "0"
 BORDERS2 = os.environ.get("SEGSDE_BORDERS2", "1") != "0"     # 0: the mirrored-padding terms as implicit-GEMM border launches (first version)
+# layout of the route's transformed weights: blocked (the eight B operands of a lane and step contiguous: two 16-byte requests
+# instead of eight 4-byte ones) unless SEGSDE_WINO_FUSED_UBLK=0 -- the library reads the same variable (segsde_wino_ublk)
+WINO_FUSED_UBLK = os.environ.get("SEGSDE_WINO_FUSED_UBLK", "1") != "0"
 WINO_FUSED_TAKEN = {"fwd": 0, "dgrad": 0, "fwd2": 0, "dgrad_refl": 0, "dgrad_actgrad": 0, "dgrad2": 0, "wgrad": 0}
 
 
@@ -293,6 +296,7 @@ def winograd_fused_dgrad2_ok(g, B=None, H=None, W=None):
     convolution Cout -> C1 (+ border kernel)"""
     if not (WINOGRAD and WINO_FUSED and WINO_FUSED_DGRAD_EXT and WINO_FUSED_DGRAD2 and BORDERS2 and g.k == 3 and g.stride == 1 and g.dil == 1
             and g.pad == 1 and g.reflect and g.up0 and g.C1 and g.cin_alg is None and g.C1 % 64 == 0 and g.Cout % 64 == 0
+            and g.C0 % 64 == 0       # (the slice starts on a 64-filter block of the blocked pack layout)
             and g.Cout <= WINO_FUSED_MAX_CH and g.Cin <= WINO_FUSED2_MAX_CIN):
         return False
     if B is None:
@@ -314,7 +318,9 @@ def winograd_fused_static_ok(conv):
 
 
 class _KnPack(torch.Tensor):
-    """a transformed weight pack in the [16][K][N] layout (a plain tensor with a type the dispatch can see)"""
+    """a transformed weight pack of the one-kernel route: 16 K N floats, logical shape [16][K][N], stored in the blocked order the
+    kernel reads (WINO_FUSED_UBLK; the sixteen [K][N] planes with SEGSDE_WINO_FUSED_UBLK=0) -- a plain tensor with a type the
+    dispatch can see; only the library's pack and convolution kernels interpret its contents"""
 
 
 def _kn(t):
@@ -322,7 +328,8 @@ def _kn(t):
 
 
 def winograd_fused_pack(w_oihw, flip):
-    """OIHW 3x3 -> U[16][K][N] (N fastest): flip False = forward pack (K = Cin, N = Cout), True = data-gradient pack"""
+    """OIHW 3x3 -> U (logical [16][K][N], see _KnPack for the storage order): flip False = forward pack (K = Cin, N = Cout), True =
+    data-gradient pack"""
     O, I = w_oihw.shape[0], w_oihw.shape[1]
     w = _f32(w_oihw.detach()).contiguous()
     u = torch.empty((16, O, I) if flip else (16, I, O), dtype=torch.float32, device=w.device)
@@ -379,7 +386,9 @@ def winograd_fused(kind, x, u_kn, bias=None, act="none", want_stats=False, tag=N
                 d = _borders_desc(B, H, W, C, N, nhwc_ld(x))
 
         def launch():
-            rc = L.segsde_conv2d_winograd_fused_dgrad(_p(_f32(x)), nhwc_ld(x), B, H, W, C, ctypes.c_void_p(u_kn.data_ptr() + 4 * n_off), ldu,
+            # a column slice starts n_off floats into a row of the planar layout, n_off / 64 blocks of 256 floats into the blocked one
+            u_off = 4 * ((n_off // 64) * 256 if WINO_FUSED_UBLK else n_off)
+            rc = L.segsde_conv2d_winograd_fused_dgrad(_p(_f32(x)), nhwc_ld(x), B, H, W, C, ctypes.c_void_p(u_kn.data_ptr() + u_off), ldu,
                                                       N, _p(y), N, acc, _p(ag_y), ag_ld, ag_kind, _stream(x))
             if rc == 0 and adjoint is not None:
                 if d is None:      # the border kernel of csrc/winograd_fused.hip (two launches), forward pack (its channel slice)

@@ -274,7 +274,10 @@ int segsde_conv2d_wgrad_winograd(const segsde_conv_desc* d, const float* x0, con
 /* Winograd F(2x2,3x3) with both transforms inside ONE kernel (no V / M tensors): the 64- and 128-channel conv2 of layer1 / layer2
  * (models/resnet_encoder.py:90-101 via torchvision's Bottleneck / BasicBlock) and the decoder's single-source Conv3x3
  * (models/monodepth_layers.py:127-142, reflect = 1: mirrored padding, forward only) -- 3x3, stride 1, padding 1, one source, H and W
- * even, C % 64 == 0, Cout % 64 == 0.  segsde_winograd_fused_pack: OIHW -> U[16][K][N] with N fastest; flip = 0: the forward pack
+ * even, C % 64 == 0, Cout % 64 == 0.  segsde_winograd_fused_pack: OIHW -> the transformed weights U (16 K N floats) in the layout
+ * the kernel reads -- blocked: [transform row][k][block of 64 n][32 lanes][4 positions of the row][2 halves of the block], the
+ * eight B operands of a lane and step contiguous (round 5; SEGSDE_WINO_FUSED_UBLK=0 in the environment of the process selects
+ * the sixteen [K][N] planes of round 4 for packs and kernel alike); flip = 0: the forward pack
  * (K = Cin, N = Cout), flip = 1: the data-gradient pack of the spatially flipped kernel (K = Cout, N = Cin; call the convolution
  * with x = dY, C = Cout, Cout = Cin).  y = act(Y + bias) (bias nullable), or y += Y (accumulate = 1: no bias / activation /
  * statistics; the gradient collector of DESIGN.md 3.2f); stats (nullable):
@@ -298,8 +301,9 @@ int segsde_conv2d_winograd_fused2(const float* x0, int ld0, int C0, int up0, con
  * four border launches + corner terms ADDED onto rows 1 / H-2 and columns 1 / W-2 of y (d = the descriptor of
  * segsde_conv2d_dgrad_actgrad with pad_mode = SEGSDE_PAD_REFLECT_ADJOINT; act_out as above).  ldu: row pitch of ud_kn (Cin; or,
  * for the gradient of ONE source of a two-source convolution -- the decoder's skip input, weight channels [C0, C0 + C1) -- the
- * full pack's width, ud_kn pointing at the slice's first column; segsde_reflect_adjoint_borders2 takes the matching slice of
- * the forward pack through ldw). */
+ * full pack's width, ud_kn pointing at the slice's first 64-filter block (blocked layout: (first column / 64) * 256 floats into
+ * the pack; the slice starts on a multiple of 64); segsde_reflect_adjoint_borders2 takes the matching slice of the forward pack
+ * through ldw). */
 int segsde_conv2d_winograd_fused_dgrad(const float* dy, int lddy, int B, int H, int W, int Cout, const float* ud_kn, int ldu, int Cin,
                                        float* dx, int lddx, int accumulate, const float* act_out, int act_ld, int act_kind, void* stream);
 int segsde_reflect_adjoint_borders(const segsde_conv_desc* d, const float* dy, const float* wdpack, float* y, const float* act_out,

@@ -1519,7 +1519,7 @@ def _run_winograd_fused_cases(device, shapes):
             old_fm = H.UPFOLD_MIN_SAVED_MACS
             H.UPFOLD_MIN_SAVED_MACS = 0.0
             try:
-                for (B, Hh, W, C0, C1, Co) in ((1, 8, 16, 64, 64, 64), (2, 12, 24, 32, 128, 64), (1, 20, 12, 64, 64, 128)):
+                for (B, Hh, W, C0, C1, Co) in ((1, 8, 16, 64, 64, 64), (2, 12, 24, 64, 128, 64), (1, 20, 12, 128, 64, 128)):
                     what = "data-gradient of [up(x0) | x1] %s" % ((B, Hh, W, C0, C1, Co),)
                     w = torch.randn(Co, C0 + C1, 3, 3, generator=gen) * (2.0 / (9 * (C0 + C1))) ** 0.5
                     dy = torch.randn(B, Co, Hh, W, generator=gen)
