@@ -80,30 +80,54 @@ __global__ __launch_bounds__(256, 2) void wino_fused_kernel(WinoSrc src, int B, 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[j][nb][r] = 0.f;
 
+  // Per-thread byte offsets of the fill's 12 sixteen-byte requests inside one image of the source being read: they depend on the
+  // thread and the source only, not on the fill.  The first fill from a source computes them between its requests (division by
+  // 18, column interleave, mirroring, range tests: ~200 of a fill's ~700 vector instructions), the later fills re-issue raw
+  // buffer loads with the image base + the fill's channel offset in the scalar resource: no vector instructions in their load
+  // issue (+2.5-3 % from 256 channels on, +1-2 % below: profiles/probe_r05_hoist_*.log).  Computing all offsets ahead of the
+  // first request instead lost 2-4 % on the single-fill 64-channel layers (the first load left ~200 instructions later).
+  // Padding and tiles past the image: SEGSDE_OOB, the load returns zeros.
+  constexpr int NL = (FP_H * FP_W * (FCH / 4) + 255) / 256;
+  unsigned poff[NL];
+  int cur_src = -1, lds_ = 0;
+  long img = 0;
+  int sh_ = 0, Ws = 0;
+  auto patch_offset = [&](int i) -> unsigned {
+    const int e = tid + 256 * i;
+    const int pix = e >> 4, cq = e & 15;
+    const int pr = pix / FP_W, pos = pix - pr * FP_W;                 // pos: position inside the LDS row (even columns first)
+    const int pc = pos < FODD ? 2 * pos : 2 * (pos - FODD) + 1;
+    int hh = h_top + pr, ww = w_left + pc;
+    if (reflect) {       // ReflectionPad2d(1) (monodepth_layers.py:127-142); pixels of tiles past the image: any valid address
+      hh = hh < 0 ? -hh : (hh >= H ? 2 * H - 2 - hh : hh); ww = ww < 0 ? -ww : (ww >= W ? 2 * W - 2 - ww : ww);
+      hh = hh < 0 ? 0 : hh; ww = ww < 0 ? 0 : ww;
+    }
+    const bool ok = e < FP_H * FP_W * (FCH / 4) && (unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W;
+    return ok ? (unsigned)(((hh >> sh_) * Ws + (ww >> sh_)) * lds_ + 4 * cq) * 4u : SEGSDE_OOB;
+  };
+
   for (int c0 = 0; c0 < C; c0 += FCH) {
     __syncthreads();                                   // the previous fill's reads are done
     {
       // all requests of the fill first (12 independent 16-byte loads per thread), then the transposing LDS writes
-      constexpr int NL = (FP_H * FP_W * (FCH / 4) + 255) / 256;
       float4 v[NL];
-      const bool s0 = c0 < src.C0;                       // wave-uniform: which source this fill reads
-      const float* xs = s0 ? src.x0 : src.x1;
-      const int lds_ = s0 ? src.ld0 : src.ld1, cb = s0 ? c0 : c0 - src.C0, sh_ = (s0 && src.up0) ? 1 : 0;
-      const int Hs = H >> sh_, Ws = W >> sh_;
+      const int sidx = c0 < src.C0 ? 0 : 1;              // wave-uniform: which source this fill reads
+      const bool first = sidx != cur_src;                // the first fill from this source: offsets computed between its requests
+      if (first) {
+        cur_src = sidx;
+        sh_ = (sidx == 0 && src.up0) ? 1 : 0;
+        Ws = W >> sh_;
+        lds_ = sidx == 0 ? src.ld0 : src.ld1;
+        img = (long)(H >> sh_) * Ws * lds_;
+      }
+      const float* xs = sidx == 0 ? src.x0 : src.x1;
+      const segsde_rsrc xr = segsde_make_rsrc(xs + (size_t)b * img + (sidx == 0 ? c0 : c0 - src.C0));
+      if (first) {
 #pragma unroll
-      for (int i = 0; i < NL; ++i) {
-        const int e = tid + 256 * i;
-        const int pix = e >> 4, cq = e & 15;
-        const int pr = pix / FP_W, pos = pix - pr * FP_W;                 // pos: position inside the LDS row (even columns first)
-        const int pc = pos < FODD ? 2 * pos : 2 * (pos - FODD) + 1;
-        int hh = h_top + pr, ww = w_left + pc;
-        if (reflect) {       // ReflectionPad2d(1) (monodepth_layers.py:127-142); pixels of tiles past the image: any valid address
-          hh = hh < 0 ? -hh : (hh >= H ? 2 * H - 2 - hh : hh); ww = ww < 0 ? -ww : (ww >= W ? 2 * W - 2 - ww : ww);
-          hh = hh < 0 ? 0 : hh; ww = ww < 0 ? 0 : ww;
-        }
-        v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (e < FP_H * FP_W * (FCH / 4) && (unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W)
-          v[i] = *reinterpret_cast<const float4*>(xs + ((long)(b * Hs + (hh >> sh_)) * Ws + (ww >> sh_)) * lds_ + cb + 4 * cq);
+        for (int i = 0; i < NL; ++i) { poff[i] = patch_offset(i); v[i] = segsde_buffer_load4(xr, poff[i], 0u); }
+      } else {
+#pragma unroll
+        for (int i = 0; i < NL; ++i) v[i] = segsde_buffer_load4(xr, poff[i], 0u);
       }
 #pragma unroll
       for (int i = 0; i < NL; ++i) {
@@ -422,7 +446,9 @@ inline long fused_blocks(int B, int H, int W) {
 }  // namespace
 
 extern "C" int segsde_winograd_fused_ok(int B, int H, int W, int C, int Cout) {
+  // (one image of either side below 2^31 bytes: the patch loader's per-thread offsets are 32-bit byte offsets inside an image)
   return B > 0 && H >= 4 && W >= 4 && H % 2 == 0 && W % 2 == 0 && C >= FCH && C % FCH == 0 && Cout >= 64 && Cout % 64 == 0 &&
+         (long)H * W * (C > Cout ? C : Cout) * 4 < (1L << 31) &&
          fused_blocks(B, H, W) < (1L << 31) && (long)B * H * W * (C > Cout ? C : Cout) < (1L << 40);
 }
 
@@ -452,13 +478,15 @@ int launch_fused(const WinoSrc& src, int B, int H, int W, int C, int reflect, co
   SEGSDE_CHECK_LAUNCH();
   return 0;
 }
+// the patch loader addresses one image of a source with 32-bit byte offsets
+inline bool pitch_ok(int H, int W, int ld) { return (long)H * W * ld * 4 < (1L << 31); }
 }  // namespace
 
 extern "C" int segsde_conv2d_winograd_fused(const float* x, int ldx, int B, int H, int W, int C, int reflect, const float* u_kn,
                                             int Cout, const float* bias, int act, float* y, int ldy, int accumulate, double* stats,
                                             void* stream) {
   if (!x || !u_kn || !y) return SEGSDE_ERR_NULL;
-  if (!segsde_winograd_fused_ok(B, H, W, C, Cout) || ldx < C || ldx % 4 != 0 || ldy < Cout || (accumulate && (stats || bias || act)))
+  if (!segsde_winograd_fused_ok(B, H, W, C, Cout) || ldx < C || ldx % 4 != 0 || !pitch_ok(H, W, ldx) || ldy < Cout || (accumulate && (stats || bias || act)))
     return SEGSDE_ERR_UNSUPPORTED;
   const WinoSrc src{x, nullptr, ldx, 0, C, 0};
   return launch_fused(src, B, H, W, C, reflect, u_kn, Cout, Cout, bias, act, y, ldy, accumulate, stats, WinoAg{nullptr, 0, 0}, stream);
@@ -471,8 +499,8 @@ extern "C" int segsde_conv2d_winograd_fused2(const float* x0, int ld0, int C0, i
                                              int ldy, double* stats, void* stream) {
   if (!x0 || !u_kn || !y || (C1 > 0 && !x1)) return SEGSDE_ERR_NULL;
   const int C = C0 + (C1 > 0 ? C1 : 0);
-  if (!segsde_winograd_fused_ok(B, H, W, C, Cout) || C0 <= 0 || C0 % FCH || ld0 < C0 || ld0 % 4 != 0 || (C1 > 0 && (ld1 < C1 || ld1 % 4 != 0)) ||
-      ldy < Cout)
+  if (!segsde_winograd_fused_ok(B, H, W, C, Cout) || C0 <= 0 || C0 % FCH || ld0 < C0 || ld0 % 4 != 0 || (C1 > 0 && (ld1 < C1 || ld1 % 4 != 0 || !pitch_ok(H, W, ld1))) ||
+      !pitch_ok(H >> (up0 ? 1 : 0), W >> (up0 ? 1 : 0), ld0) || ldy < Cout)
     return SEGSDE_ERR_UNSUPPORTED;
   const WinoSrc src{x0, x1, ld0, ld1, C0, up0 ? 1 : 0};
   return launch_fused(src, B, H, W, C, reflect, u_kn, Cout, Cout, bias, act, y, ldy, 0, stats, WinoAg{nullptr, 0, 0}, stream);
@@ -488,7 +516,7 @@ extern "C" int segsde_conv2d_winograd_fused_dgrad(const float* dy, int lddy, int
                                                   int Cin, float* dx, int lddx, int accumulate, const float* act_out, int act_ld,
                                                   int act_kind, void* stream) {
   if (!dy || !ud_kn || !dx) return SEGSDE_ERR_NULL;
-  if (!segsde_winograd_fused_ok(B, H, W, Cout, Cin) || ldu < Cin || (long)16 * Cout * ldu >= (1L << 28) || lddy < Cout || lddy % 4 != 0 || lddx < Cin ||
+  if (!segsde_winograd_fused_ok(B, H, W, Cout, Cin) || ldu < Cin || (long)16 * Cout * ldu >= (1L << 28) || lddy < Cout || lddy % 4 != 0 || !pitch_ok(H, W, lddy) || lddx < Cin ||
       (act_out && (act_kind < SEGSDE_ACT_RELU || act_kind > SEGSDE_ACT_SIGMOID || act_ld < Cin)))
     return SEGSDE_ERR_UNSUPPORTED;
   const WinoSrc src{dy, nullptr, lddy, 0, Cout, 0};
