@@ -53,6 +53,11 @@ __device__ __forceinline__ void segsde_buffer_load4_lds(segsde_rsrc r, unsigned 
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(voff), "s"(r), "s"(soff), "s"(lds_wave_addr) : "memory");
 }
+// One LDS dword at p[i] (p: pointer into the workgroup's LDS, i: compile-time index after unrolling) as a single ds_read_b32
+// whose immediate carries i (16 bits of byte offset).  The volatile access keeps the load / store optimizer from pairing
+// neighbouring reads into ds_read2_b32: that instruction's two 8-bit dword offsets reach 1 KiB, and every pair beyond costs a
+// v_add_u32 to rebase -- vector issue slots taken from the matrix pipe in an MFMA loop.  Waits are still the compiler's.
+#define SEGSDE_LDS_READ_IMM(p, i) (((const volatile __attribute__((address_space(3))) float*)(p))[i])
 __device__ __forceinline__ void segsde_wait_vmcnt0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 // at most N of this wave's vector-memory operations still outstanding (N tile loads of later chunks may stay in flight)
 template <int N> __device__ __forceinline__ void segsde_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }

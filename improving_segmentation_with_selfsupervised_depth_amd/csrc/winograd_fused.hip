@@ -170,12 +170,15 @@ __global__ __launch_bounds__(256, 2) void wino_fused_kernel(WinoSrc src, int B, 
         }
       }
     };
+    // (SEGSDE_LDS_READ_IMM: single ds_read_b32 with the plane / column offset in the instruction's 16-bit immediate off the two
+    // row bases of the wave.  Left to itself the compiler pairs neighbouring columns into ds_read2_b32, whose 8-bit offsets do not
+    // reach past the first plane: 124 v_add_u32 per fill to rebase them -- a third of the loop's vector instructions)
     auto fetch_a = [&](int s, int q) {
       const float* src = pl + fplane(2 * s);
 #pragma unroll
       for (int bb = 0; bb < 4; ++bb) {       // patch column 2 tw + bb: even ones at position tw + bb / 2, odd ones behind the even half
         const int cp = (bb & 1) ? FODD + (bb >> 1) : (bb >> 1);
-        rv[q][bb] = src[o1 + cp]; rv[q][4 + bb] = src[o2 + cp];
+        rv[q][bb] = SEGSDE_LDS_READ_IMM(src + o1, cp); rv[q][4 + bb] = SEGSDE_LDS_READ_IMM(src + o2, cp);
       }
     };
 #pragma unroll

@@ -230,6 +230,7 @@ inline void segsde_buffer_load4_lds(segsde_rsrc r, unsigned voff, unsigned soff,
   const float4 v = segsde_buffer_load4(r, voff, soff);
   memcpy(::emu::S().lds + lds_wave_addr + 16 * emu::lane(), &v, sizeof(v));
 }
+#define SEGSDE_LDS_READ_IMM(p, i) ((p)[i])
 inline void segsde_wait_vmcnt0() {}
 template <int N> inline void segsde_wait_vmcnt() {}
 
