@@ -65,6 +65,10 @@ def test_argument_validation_without_gpu():
     assert cdll.segsde_conv2d_winograd_fused_dgrad(fake, 64, 2, 7, 16, 64, fake, 64, 64, fake, 64, 0, None, 0, 0, None) == -4   # odd height
     assert cdll.segsde_conv2d_winograd_fused_dgrad(fake, 64, 2, 8, 16, 64, fake, 32, 64, fake, 64, 0, None, 0, 0, None) == -4   # pack narrower than its slice
     assert cdll.segsde_conv2d_winograd_fused2(fake, 64, 48, 1, fake, 64, 16, 2, 8, 16, 1, fake, 64, None, 0, fake, 64, None, None) == -4  # C0 % 64
+    # the one-kernel forward addresses one image of a source with 32-bit byte offsets: 2048 x 2048 pixels at a pitch of 256 floats is 4 GiB
+    assert cdll.segsde_conv2d_winograd_fused(fake, 256, 1, 2048, 2048, 64, 0, fake, 64, None, 0, fake, 64, 0, None, None) == -4
+    assert cdll.segsde_conv2d_winograd_fused_dgrad(fake, 256, 1, 2048, 2048, 64, fake, 64, 64, fake, 64, 0, None, 0, 0, None) == -4
+    assert cdll.segsde_conv2d_winograd_fused2(fake, 64, 64, 0, fake, 256, 64, 1, 2048, 2048, 1, fake, 64, None, 0, fake, 64, None, None) == -4
     assert cdll.segsde_reflect_adjoint_borders2(None, 64, None, 64, None, 64, None, 0, 0, 2, 8, 16, 64, 64, None) == -1
     assert cdll.segsde_reflect_adjoint_borders2(fake, 64, fake, 64, fake, 64, None, 0, 0, 2, 3, 16, 64, 64, None) == -4         # H < 4
     assert cdll.segsde_dropout(None, 4, 10, 4, 0.5, 1, None, 4, None) == -1
