@@ -1,5 +1,7 @@
 # A/B of the one-kernel Winograd forward / data-gradient: patch-load offsets hoisted out of the fill loop (new) against
 # the previous kernel (libsegsde_prev.so = HEAD's winograd_fused.hip linked with the same other objects)
+# libsegsde_prev.so is built by hand before the call (not kept in the tree): `git show HEAD:<csrc file> > /tmp/prev/<file>`,
+# hipcc -c it with __graft_entry__.FLAGS and link it with the other objects of build/obj into the package directory.
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT

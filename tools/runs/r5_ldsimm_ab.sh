@@ -1,5 +1,7 @@
 # A/B of the Winograd kernels' LDS reads as single ds_read_b32 with immediate offsets (new) against the previous library
 # (libsegsde_prev.so: HEAD's sources linked the same way): weight gradient, forward on two sources, mirrored data-gradient
+# libsegsde_prev.so is built by hand before the call (not kept in the tree): `git show HEAD:<csrc file> > /tmp/prev/<file>`,
+# hipcc -c it with __graft_entry__.FLAGS and link it with the other objects of build/obj into the package directory.
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
