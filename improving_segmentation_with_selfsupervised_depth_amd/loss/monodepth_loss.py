@@ -194,10 +194,18 @@ class MonodepthLoss:
         self.disable_automasking = disable_automasking
         self.device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
         self.depth_metric_names = ["abs_rel", "sq_rel", "rms", "log_rms", "a1", "a2", "a3"]
-        if any(f == "s" for f in self.frame_ids):
-            raise NotImplementedError("stereo frame id 's' is not used by the reference's configs")
+        if len(self.frame_ids) != 3:
+            # the auto-mask / photometric kernels take the reference configs' two source frames (temporal, or one temporal + the
+            # stereo frame "s"); the stereo-only (0, "s") and four-frame (0, -1, 1, "s") sets of monodepth2 are not built
+            raise NotImplementedError("MonodepthLoss: two source frames expected, got frame_ids = %r" % (self.frame_ids,))
         self.tiebreak_noise = None    # tests: dict scale -> tensor replacing the fresh randn of reference :163-164
         self._cache = None
+
+    @staticmethod
+    def _pose(inputs, outputs, f):
+        """reference :82-85: the stereo frame "s" is warped with the fixed baseline transform of the batch, every other frame with
+        the pose network's prediction"""
+        return inputs["stereo_T"] if f == "s" else outputs[("cam_T_cam", 0, f)]
 
     def generate_depth_test_pred(self, outputs):
         """reference :54-62 (eval only)"""
@@ -215,7 +223,7 @@ class MonodepthLoss:
         for s in self.scales:
             disp = outputs[("disp", s)].detach().contiguous()
             for i, f in enumerate(self.frame_ids[1:]):
-                T = outputs[("cam_T_cam", 0, f)].detach().float().contiguous()
+                T = self._pose(inputs, outputs, f).detach().float().contiguous()
                 color, grid, depth = H.warp_forward(disp, inputs[("inv_K", 0)], inputs[("K", 0)], T,
                                                     inputs[("color", f, 0)], self.min_depth, self.max_depth,
                                                     want_grid=not lazy, want_depth=(i == 0 and not lazy))
@@ -253,7 +261,7 @@ class MonodepthLoss:
     def compute_losses(self, inputs, outputs):
         """reference :118-192 -> {"loss/0".."loss/3", "loss"}"""
         disps = [outputs[("disp", s)] for s in self.scales]
-        Ts = [outputs[("cam_T_cam", 0, f)].float() for f in self.frame_ids[1:]]
+        Ts = [self._pose(inputs, outputs, f).float() for f in self.frame_ids[1:]]
         cache = None
         if self._cache is not None and all(a is b for a, b in zip(self._cache[1], disps)):
             cache = self._cache[0]           # warped frames from generate_images_pred for these very tensors

@@ -64,6 +64,10 @@ def test_monodepth_loss_multi_tile_strips(golden, monkeypatch):
     MC.run_loss_vs_reference("cpu", golden)
 
 
+def test_monodepth_loss_stereo_frame(golden):
+    MC.run_loss_stereo_frame("cpu", golden)
+
+
 def test_convblock_dropout2d():
     MC.run_convblock_dropout2d("cpu")
 

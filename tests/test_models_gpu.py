@@ -24,6 +24,10 @@ def test_monodepth_loss_multi_tile_strips(golden, monkeypatch):
     MC.run_loss_vs_reference("cuda", golden)
 
 
+def test_monodepth_loss_stereo_frame(golden):
+    MC.run_loss_stereo_frame("cuda", golden)
+
+
 @pytest.mark.parametrize("which", ["dd1", "dd2", "jsd1", "jsd2", "pad1", "pad2"])
 def test_decoders(golden, which):
     MC.run_decoders("cuda", golden, (which,))
