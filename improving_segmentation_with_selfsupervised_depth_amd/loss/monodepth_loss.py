@@ -117,7 +117,13 @@ class _MonoLossFn(Function):
         automask = not obj.disable_automasking
         avg = bool(obj.avg_reprojection)
         nf = len(frames)
-        assert nf == 2, "the auto-mask kernel is written for the reference's two source frames"
+        assert nf in (1, 2), "the auto-mask kernel is written for the reference's two source frames"
+        # one source frame (the stereo-only set (0, "s")): the two-frame kernels run on that frame twice.  The minimum / mean over
+        # two identical candidates is the candidate, a tie goes to the first index like torch.min's, the tie-break noise of the one
+        # identity channel (reference :163-164, shape [B, 1, H, W]) sits in both slots, and the two pose-gradient slots add up
+        dup = nf == 1
+        if dup:
+            frames, Ts = frames * 2, Ts * 2
         srcs = [inputs[("color", f, 0)].contiguous() for f in frames]
         inv_K, K = inputs[("inv_K", 0)].contiguous(), inputs[("K", 0)].contiguous()
         ident = None
@@ -127,6 +133,9 @@ class _MonoLossFn(Function):
         for s in range(S):
             colors = []
             for j, f in enumerate(frames):
+                if dup and j == 1:
+                    colors.append(colors[0])
+                    continue
                 col = cache.get(("color", f, s)) if cache is not None else None
                 if col is None:
                     col, _, _ = H.warp_forward(disps[s], inv_K, K, Ts[j], srcs[j], obj.min_depth, obj.max_depth)
@@ -137,6 +146,8 @@ class _MonoLossFn(Function):
                     noise = obj.tiebreak_noise[s].to(dev).float().contiguous()
                 else:
                     noise = torch.randn((B, 1 if avg else nf, Hh, W), device=dev)
+                if dup and not avg:
+                    noise = noise.expand(B, 2, Hh, W).contiguous()
             ssum, sel, isel = H.photometric_forward(colors[0], colors[1], target, ident, noise, obj.no_ssim, avg)
             if automask:
                 outputs["identity_selection/{}".format(s)] = isel
@@ -151,7 +162,7 @@ class _MonoLossFn(Function):
         total = total / S
         ctx.obj, ctx.saved, ctx.disps, ctx.Ts, ctx.srcs, ctx.target = obj, saved, disps, Ts, srcs, target
         ctx.geo = (inv_K, K)
-        ctx.automask, ctx.avg = automask, avg
+        ctx.automask, ctx.avg, ctx.dup = automask, avg, dup
         return (total,) + tuple(losses)
 
     @staticmethod
@@ -173,6 +184,8 @@ class _MonoLossFn(Function):
             gdisp = H.resize_bilinear_backward(gup.reshape(B, Hh, W, 1), (hs, ws), False).reshape(B, 1, hs, ws)
             H.smoothness_backward(ctx.disps[s], color_s, mean_disp, obj.disparity_smoothness / (2 ** s), gdisp)
             gd_out.append(H.axpby_dev(w_s, gdisp))
+        if ctx.dup:
+            gT_acc = [gT_acc[0] + gT_acc[1]]
         return (None, None, None, None) + tuple(gd_out) + tuple(gT_acc)
 
 
@@ -194,10 +207,11 @@ class MonodepthLoss:
         self.disable_automasking = disable_automasking
         self.device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
         self.depth_metric_names = ["abs_rel", "sq_rel", "rms", "log_rms", "a1", "a2", "a3"]
-        if len(self.frame_ids) != 3:
-            # the auto-mask / photometric kernels take the reference configs' two source frames (temporal, or one temporal + the
-            # stereo frame "s"); the stereo-only (0, "s") and four-frame (0, -1, 1, "s") sets of monodepth2 are not built
-            raise NotImplementedError("MonodepthLoss: two source frames expected, got frame_ids = %r" % (self.frame_ids,))
+        if len(self.frame_ids) not in (2, 3):
+            # the auto-mask / photometric kernels take two source frames (the reference configs' temporal pair, or one temporal +
+            # the stereo frame "s") or one (the stereo-only set (0, "s"), run as a pair of itself); the four-frame set
+            # (0, -1, 1, "s") of monodepth2 is not built
+            raise NotImplementedError("MonodepthLoss: one or two source frames expected, got frame_ids = %r" % (self.frame_ids,))
         self.tiebreak_noise = None    # tests: dict scale -> tensor replacing the fresh randn of reference :163-164
         self._cache = None
 

@@ -167,6 +167,56 @@ def gen_loss():
         save("loss_" + name, d)
 
 
+def gen_loss_stereo():
+    """the stereo-only frame set (0, "s") of the reference's loss (monodepth_loss.py:82-85: the stereo frame is warped with the
+    batch's fixed inputs["stereo_T"]; one source frame, so the auto-mask's noise is [B, 1, H, W] and no pose takes a gradient),
+    with and without auto-masking / averaging"""
+    B, H, W = 2, 32, 64
+    base = dict(num_scales=4, frame_ids=[0, "s"], height=H, width=W, batch_size=B, min_depth=0.1, max_depth=100,
+                test_min_depth=1e-3, test_max_depth=80, disparity_smoothness=1e-3, no_ssim=False,
+                avg_reprojection=False, disable_automasking=False)
+    variants = {"default": {}, "avg_reprojection": {"avg_reprojection": True}, "disable_automasking": {"disable_automasking": True}}
+    d = {}
+    for vi, (name, over) in enumerate(variants.items()):
+        gen = torch.Generator().manual_seed(300 + vi)
+        inputs, disps, _, _ = make_loss_inputs(B, H, W, gen)
+        inputs[("color", "s", 0)] = inputs.pop(("color", 1, 0))
+        inputs.pop(("color", -1, 0))
+        T = torch.eye(4).unsqueeze(0).repeat(B, 1, 1)
+        T[0, 0, 3], T[1, 0, 3] = 0.1, -0.1                  # monodepth2's baseline: +-0.1 by the side of the camera
+        T[:, 1, 3] = 0.003 * torch.randn(B, generator=gen)
+        inputs["stereo_T"] = T
+        cfg = dict(base, **over)
+        loss_obj = RefMonodepthLoss(**cfg)
+        dleaf = {s_: disps[s_].clone().requires_grad_(True) for s_ in range(4)}
+        out = {("disp", s_): dleaf[s_] for s_ in range(4)}
+        noise = {s_: torch.randn(B, 1, H, W, generator=gen) for s_ in range(4)}
+        queue = [noise[s_] for s_ in range(4)]
+        real_randn = torch.randn
+        loss_obj.generate_images_pred(inputs, out)
+        torch.randn = lambda *a, **k: queue.pop(0)
+        try:
+            losses = loss_obj.compute_losses(inputs, out)
+        finally:
+            torch.randn = real_randn
+        losses["loss"].backward()
+        d[name + "_cfg_json"] = json.dumps(cfg)
+        for k in (("color", 0, 0), ("color", "s", 0), ("color", 0, 1), ("color", 0, 2), ("color", 0, 3), ("K", 0), ("inv_K", 0)):
+            d[name + "_in_" + "_".join(str(x) for x in k)] = inputs[k]
+        d[name + "_stereo_T"] = T
+        d[name + "_loss"] = losses["loss"]
+        for s_ in range(4):
+            d[name + "_disp_%d" % s_] = disps[s_]
+            d[name + "_grad_disp_%d" % s_] = dleaf[s_].grad
+            d[name + "_loss_%d" % s_] = losses["loss/%d" % s_]
+            if not cfg["disable_automasking"]:
+                d[name + "_noise_%d" % s_] = noise[s_]
+                d[name + "_identity_selection_%d" % s_] = out["identity_selection/%d" % s_]
+        d[name + "_color_s_0"] = out[("color", "s", 0)]
+        d[name + "_sample_s_0"] = out[("sample", "s", 0)]
+    save("loss_stereo", d)
+
+
 def gen_geom():
     gen = torch.Generator().manual_seed(7)
     B, H, W = 3, 6, 10
@@ -773,7 +823,7 @@ def gen_valtail():
     save("valtail", d)
 
 
-ALL = ["loss", "geom", "ssim_smooth", "segmix", "blocks", "decoders", "encoder", "nets", "trainer", "usegt", "valtail", "poseall"]
+ALL = ["loss", "loss_stereo", "geom", "ssim_smooth", "segmix", "blocks", "decoders", "encoder", "nets", "trainer", "usegt", "valtail", "poseall"]
 
 
 def check(which):

@@ -68,6 +68,10 @@ def test_monodepth_loss_stereo_frame(golden):
     MC.run_loss_stereo_frame("cpu", golden)
 
 
+def test_monodepth_loss_stereo_only(golden):
+    MC.run_loss_stereo_only("cpu", golden)
+
+
 def test_convblock_dropout2d():
     MC.run_convblock_dropout2d("cpu")
 

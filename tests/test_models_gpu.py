@@ -28,6 +28,10 @@ def test_monodepth_loss_stereo_frame(golden):
     MC.run_loss_stereo_frame("cuda", golden)
 
 
+def test_monodepth_loss_stereo_only(golden):
+    MC.run_loss_stereo_only("cuda", golden)
+
+
 @pytest.mark.parametrize("which", ["dd1", "dd2", "jsd1", "jsd2", "pad1", "pad2"])
 def test_decoders(golden, which):
     MC.run_decoders("cuda", golden, (which,))

@@ -69,6 +69,38 @@ def test_loss_matches_reference(golden, variant):
     close(G.pose_matrix(aa[:, 1], tr[:, 1], invert=False), g["T_p1"])
 
 
+def stereo_only_case(g, name):
+    """inputs of one variant of tests/golden/loss_stereo.npz (reference loss with frame_ids = [0, "s"])"""
+    cfg = json.loads(str(g[name + "_cfg_json"]))
+    inputs = {("color", 0, 0): g[name + "_in_color_0_0"], ("color", "s", 0): g[name + "_in_color_s_0"],
+              ("K", 0): g[name + "_in_K_0"], ("inv_K", 0): g[name + "_in_inv_K_0"], "stereo_T": g[name + "_stereo_T"]}
+    for s in range(1, 4):
+        inputs[("color", 0, s)] = g[name + "_in_color_0_%d" % s]
+    return cfg, inputs
+
+
+@pytest.mark.parametrize("variant", ["default", "avg_reprojection", "disable_automasking"])
+def test_loss_stereo_only_matches_reference(golden, variant):
+    """the oracle on the reference's stereo-only frame set (monodepth_loss.py:82-85)"""
+    g = golden("loss_stereo")
+    cfg, inputs = stereo_only_case(g, variant)
+    obj = P.MonodepthLossOracle(**cfg)
+    disps = {s: g["%s_disp_%d" % (variant, s)].clone().requires_grad_(True) for s in range(4)}
+    out = {("disp", s): disps[s] for s in range(4)}
+    obj.generate_images_pred(inputs, out)
+    noise = None if cfg["disable_automasking"] else {s: g["%s_noise_%d" % (variant, s)] for s in range(4)}
+    losses = obj.compute_losses(inputs, out, tiebreak_noise=noise)
+    losses["loss"].backward()
+    close(losses["loss"], g[variant + "_loss"])
+    for s in range(4):
+        close(losses["loss/%d" % s], g["%s_loss_%d" % (variant, s)])
+        close(disps[s].grad, g["%s_grad_disp_%d" % (variant, s)], rtol=1e-4, atol=1e-8)
+        if not cfg["disable_automasking"]:
+            assert torch.equal(out["identity_selection/%d" % s], g["%s_identity_selection_%d" % (variant, s)])
+    close(out[("color", "s", 0)], g[variant + "_color_s_0"], atol=1e-5)
+    close(out[("sample", "s", 0)], g[variant + "_sample_s_0"], atol=1e-5)
+
+
 def test_geometry(golden):
     g = golden("geom")
     sdisp, depth = G.disp_to_depth(g["disp"], 0.1, 100)
@@ -489,7 +521,7 @@ def test_fixture_recipe_regenerates_committed_files():
     run here; ``python tests/golden/make_golden.py --check`` runs all of them."""
     import subprocess
     r = subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), "golden", "make_golden.py"), "--check",
-                        "geom", "ssim_smooth", "segmix", "trainer", "usegt", "poseall"], capture_output=True, text=True, timeout=600)
+                        "geom", "ssim_smooth", "segmix", "trainer", "usegt", "poseall", "loss_stereo"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "make_golden --check: OK" in r.stdout
 
