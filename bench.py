@@ -229,6 +229,12 @@ def main():
                     help="capture one whole training step (forward, loss, backward, clip, optimiser) as a hipGraph after the warm-up and "
                          "replay it for the timed steps: the launch-bound regime (cfg1: ~1 500 launches of 5-20 us per step through "
                          "Python / ctypes).  Single GPU, labeled step only; implies --no-kernel-timing")
+    ap.add_argument("--step", choices=["summed", "reference"], default="summed",
+                    help="what the timed step is.  summed (the headline): the losses of a forward are added and back-propagated with one "
+                         "backward() call.  reference: trainer.train_step, the reference's own call sequence (train.py:486,510: one "
+                         "backward() per loss, the shared encoder back-propagated once through the deferred trunk backward).  The "
+                         "default run times `summed` and reports the reference sequence next to it as `reference_step`")
+    ap.add_argument("--no-reference-step", action="store_true", help="skip the `reference_step` block of the default run")
     ap.add_argument("--bucket-mb", type=float, default=32.0, help="gradient all-reduce bucket size (N > 1)")
     ap.add_argument("--no-overlap", action="store_true",
                     help="N > 1: start every gradient all-reduce after the last backward instead of from the gradient hooks")
@@ -377,6 +383,32 @@ def main():
             T.update_ema_variables(ema_model, model, 0.99, it[0], segmentation_name=cfg["segmentation_name"])
         it[0] += 1
         return total
+
+    # The reference's own call sequence for the same work: trainer.train_step is Trainer.train_step
+    # (train.py:442-549) -- one backward() per loss (486: retain_graph=True, 510), clip_grad_norm_, optimizer.step(), for cfg5 the
+    # unlabeled step and the EMA update inside.  ``defer``: the package's deferred trunk backward (functional.defer_trunk; the
+    # default of trainer.train_step when the segmentation loss is on) -- off, the encoder is back-propagated once per call.
+    has_seg = cfg.get("segmentation_name") is not None
+    ref_cfg = {"model": dict(cfg), "training": {
+        "amp": False, "monodepth_lambda": 1.0, "segmentation_lambda": 1.0 if has_seg else 0.0, "pseudo_depth_lambda": 0.0,
+        "feat_dist_lambda": 0.0, "clip_grad_norm": clip, "save_monodepth_ema": False, "defer_trunk_backward": True,
+        "unlabeled_segmentation": None if not unlabeled else dict(
+            mix_mask="depthcomp", depthmix_online_depth=True, consistency_weight=1.0, backward_first_pseudo_label=False,
+            depthcomp_margin=0.03, depthcomp_foreground_threshold=0.0, color_jitter=True, blur=True, mix_use_gt=True)}}
+    backward_calls = {"summed": (1 if not unlabeled else 3), "reference": (1 + int(has_seg)) + (2 if unlabeled else 0)}
+
+    def step_reference():
+        with weight_pack_scope(model):
+            out = T.train_step(model, optimizer, inputs, it[0], ref_cfg, lambda input, target: cross_entropy2d(input, target),
+                               loss_obj, ema_model=ema_model if unlabeled else None,
+                               unlabeled_inputs=dict(unlabeled_inputs) if unlabeled else None,
+                               reducer=reducer if use_reducer[0] else None)
+        it[0] += 1
+        return out["total_loss"]
+
+    step_summed = step
+    if args.step == "reference":
+        step = step_reference
 
     def barrier():
         if world > 1:
@@ -537,6 +569,51 @@ def main():
                 "how": "allreduce_ms_per_step: union of the [start, end] event pairs of the buckets' collectives on the reducer's side "
                        "stream (max over ranks); exposed_comm_ms = median step - median of %d steps of the same work with every backward "
                        "under no_sync() and no finish() (max over ranks each)" % n2}
+    # the other call sequence on the same model, inputs and optimizer state, right after the timed region (not part of `value`)
+    ref_block = None
+    if not (args.no_reference_step or args.hip_graph):
+        from improving_segmentation_with_selfsupervised_depth_amd import functional as Fn_
+
+        def time_steps(fn, n, warm):
+            for _ in range(warm):
+                fn()
+            mk = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
+            mk[0].record()
+            for i in range(n):
+                fn()
+                mk[i + 1].record()
+            barrier()
+            return [mk[i].elapsed_time(mk[i + 1]) for i in range(n)]
+
+        other = step_summed if args.step == "reference" else step_reference
+        n_ref = max(3, min(args.steps, 10))
+        g0 = (Fn_.TrunkGateFn.trunk_backwards, Fn_.TrunkGateFn.parked_passes)
+        other_ms = time_steps(other, n_ref, 2)
+        g1 = (Fn_.TrunkGateFn.trunk_backwards, Fn_.TrunkGateFn.parked_passes)
+        t = torch.tensor([float(np.median(other_ms))], device=dev, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        other_med = float(t[0])
+        nodefer_med = None
+        if has_seg and args.step != "reference":
+            ref_cfg["training"]["defer_trunk_backward"] = False         # the same sequence with the encoder walked by every call
+            t = torch.tensor([float(np.median(time_steps(step_reference, 3, 1)))], device=dev, dtype=torch.float64)
+            ref_cfg["training"]["defer_trunk_backward"] = True
+            if world > 1:
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            nodefer_med = float(t[0])
+        which = "summed" if args.step == "reference" else "reference"
+        ref_block = {"step": which, "ms_per_step": other_med, "img_s": B * world / (other_med * 1e-3), "steps": n_ref,
+                     "backward_calls": backward_calls[which],
+                     "ms_per_step_all": [round(x, 2) for x in other_ms]}
+        if which == "reference":
+            ref_block.update(
+                sequence="trainer.train_step = Trainer.train_step (train.py:442-549): forward, mono_total_loss.backward(retain_graph=True), "
+                         "segmentation_total_loss.backward(), clip_grad_norm_, optimizer.step()" + (" + unlabeled step + EMA" if unlabeled else ""),
+                deferred_trunk_backward=bool(has_seg),
+                encoder_backward_passes_per_step=(g1[0] - g0[0]) / (n_ref + 2) if has_seg else backward_calls[which],
+                parked_passes_per_step=(g1[1] - g0[1]) / (n_ref + 2),
+                ms_per_step_encoder_walked_by_every_call=nodefer_med)
     if world > 1:
         t = torch.tensor([dt, med_ms], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -561,6 +638,7 @@ def main():
                                                "height": Hh, "width": W,
                                                "optimizer": opt_name + (" (torch fused)" if getattr(optimizer, "defaults", {}).get("fused") else ""),
                                                "parallelism": "dp%d" % world, "final_loss": loss_val, "hip_graph": bool(args.hip_graph),
+                                               "step": args.step, "backward_calls": backward_calls[args.step],
                                                "ranks": dist.get_world_size() if dist.is_initialized() else 1,
                                                "backend": (dist.get_backend() + (" (RCCL)" if dist.get_backend() == "nccl" else "")) if dist.is_initialized() else None,
                                                "allreduce_launches": reducer.collectives if reducer is not None else 0,
@@ -570,6 +648,8 @@ def main():
             res["config"]["images_per_step"] = {"labeled": B * world, "unlabeled": B * world}
         if comm is not None:
             res["comm"] = comm
+        if ref_block is not None:
+            res["reference_step" if ref_block["step"] == "reference" else "summed_step"] = ref_block
         # fusion hand-offs of the timed steps, per step (functional.FUSIONS): a hand-off that stopped working shows up as "missed"
         res["fusions_per_step"] = {k: {kk: vv / args.steps for kk, vv in v.items()} for k, v in Fn.fusion_report().items()}
         res["fusions_per_step"]["upsample_folded_launches"] = {k: v / (args.steps + args.warmup) for k, v in H.UPFOLD_TAKEN.items()}

@@ -1002,7 +1002,9 @@ extern "C" int segsde_bn_backward(const float* dy, int lddy, const float* y, int
     SEGSDE_CHECK_LAUNCH();
   }
   if (dx || dres) {
-    const bool v4 = vec && (!dx || ((lddx % 4 == 0) && al16p(dx))) && (!dres || ((lddres % 4 == 0) && al16p(dres)));
+    // (dgamma / dbeta may be slices of a gradient bucket: ddp.py aligns them, callers of the C ABI need not)
+    const bool v4 = vec && (!dx || ((lddx % 4 == 0) && al16p(dx))) && (!dres || ((lddres % 4 == 0) && al16p(dres))) &&
+                    al16p(dgamma) && al16p(dbeta);
     if (v4)
       hipLaunchKernelGGL(bn_bwd_apply_kernel<4>, dim3(ew_blocks_cv(M * C / 4, C / 4)), dim3(256), 0, ST(stream), dy, lddy, y, ldy, x,
                          ldx, M, C, mean, invstd, gamma, beta, act, drop_p, seed, batch_stats, (const float*)dgamma,

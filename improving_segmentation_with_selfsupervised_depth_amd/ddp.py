@@ -62,7 +62,7 @@ def seed_per_rank(base_seed, rank=None):
     return seed
 
 
-# Gradient destinations: parameter storage address -> [view of the parameter's bucket slice, step id of the claim].  The
+# Gradient destinations: parameter storage address -> [view of the parameter's bucket slice, step id of the claim, bucket, index].  The
 # package's autograd Functions ask ``grad_destination(param)`` for the tensor to write a parameter's gradient into; the first
 # asker of a step gets the slice (if the parameter has no gradient yet), everybody else None (they allocate as usual and
 # autograd adds).  Empty unless a GradAllReducer is active: single-process runs are untouched.
@@ -78,6 +78,13 @@ def grad_destination(param):
     ent = _GRAD_DEST.get(param.data_ptr())
     if ent is None or ent[1] == _STEP[0] or param.grad is not None or ent[0].shape != param.shape:
         return None
+    b, i = ent[2], ent[3]
+    if b.launched or b.ready[i]:
+        # the slice already holds this step's gradient (handed over by a hook, maybe being reduced in place right now) although it
+        # was never CLAIMED -- zero_grad(set_to_none=False) leaves p.grad pointing at the slice, so the first backward accumulated
+        # into it without asking: a later un-synchronised backward() must not write there (its tensor of its own is
+        # picked up by the dirty-bucket path of finish())
+        return None
     ent[1] = _STEP[0]
     # a tensor object of its own: AccumulateGrad adopts an incoming gradient without a copy only if nobody else holds it
     return ent[0].view(ent[0].shape)
@@ -89,7 +96,7 @@ class _Bucket:
         self.offsets, n = [], 0
         for p in params:
             self.offsets.append(n)
-            n += p.numel()
+            n += -(-p.numel() // 4) * 4           # every slice starts on 16 bytes: the kernels that write gradients there use 16-byte accesses
         self.flat = torch.zeros(n, dtype=torch.float32, device=device)
         self.work = None
         # per-member slices, parameter-shaped views and addresses, made once: the hooks and finish() run per parameter per step
@@ -205,6 +212,44 @@ class GradAllReducer:
         finally:
             self._sync = old
 
+    def complete_unreachable(self, losses):
+        """Between two ``backward()`` calls of a step, right before the LAST one: ``losses`` are the tensors still to be
+        back-propagated.  Every bucket member that already holds a gradient (from the calls made under ``no_sync()``) and cannot be
+        reached from those losses is complete -- the monodepth decoder and the pose networks once train.py:486 has run -- so it is
+        handed over now; buckets that fill up start their all-reduce at once and run under the last backward instead of waiting in
+        ``finish()`` behind the hooks that never fire for them (buckets start strictly in index order).  The walk follows
+        ``grad_fn.next_functions`` and, through a deferred-trunk gate (functional.TrunkGateFn), the trunk it will back-propagate.
+        A member that receives a gradient after all is picked up by the dirty-bucket path: a wrong answer here costs time, not
+        correctness."""
+        if not self.active or self.buckets is None or not self.overlap or not self._sync:
+            return 0
+        reach, seen = set(), set()
+        stack = [l.grad_fn for l in losses if torch.is_tensor(l) and l.grad_fn is not None]
+        while stack:
+            fn = stack.pop()
+            if fn in seen:
+                continue
+            seen.add(fn)
+            v = getattr(fn, "variable", None)
+            if v is not None:
+                reach.add(v)
+            st = getattr(fn, "st", None)           # TrunkGateFn: the encoder graph behind the gate runs inside that backward
+            if st is not None and getattr(st, "roots", None):
+                stack.extend(r.grad_fn for r in st.roots if r.grad_fn is not None)
+            stack.extend(nf for nf, _ in fn.next_functions if nf is not None)
+        n = 0
+        for b in self.buckets:
+            if b.launched:
+                continue
+            for i, p in enumerate(b.params):
+                if not b.ready[i] and p.grad is not None and p not in reach:
+                    b.pack(i)
+                    b.ready[i] = True
+                    b.pending -= 1
+                    n += 1
+        self._launch_ready()
+        return n
+
     def _build(self, used):
         for h in self._hooks:
             h.remove()
@@ -226,20 +271,26 @@ class GradAllReducer:
             for i, p in enumerate(b.params):
                 self._where[p] = (b, i)
                 if p.dtype == torch.float32 and p.is_contiguous():
-                    _GRAD_DEST[p.data_ptr()] = [b.views[i], -1]
-                    self._dest_keys.append(p.data_ptr())
+                    _GRAD_DEST[p.data_ptr()] = [b.views[i], -1, b, i]
+                    self._dest_keys.append((p.data_ptr(), b.views[i]))
         if self.overlap:
             for p in used:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
         self.rebuilds += 1
 
     def _unregister(self):
-        for k in self._dest_keys:
-            _GRAD_DEST.pop(k, None)
+        # only the entries that are still THIS reducer's: a replacement reducer over the same parameters may have registered its own
+        # slices by the time the garbage collector finalises this one (the reducer sits in a reference cycle through its hooks)
+        for k, view in self._dest_keys:
+            ent = _GRAD_DEST.get(k)
+            if ent is not None and ent[0] is view:
+                del _GRAD_DEST[k]
         self._dest_keys = []
 
     def close(self):
-        """stop handing the buckets out as gradient destinations (call before dropping the reducer)"""
+        """stop handing the buckets out as gradient destinations.  MANDATORY before dropping a reducer whose model lives on: the
+        destinations are process-global, and a dropped reducer that was never closed keeps receiving the kernels' gradient writes
+        in its dead buckets until the garbage collector gets to it"""
         self._unregister()
 
     def __del__(self):

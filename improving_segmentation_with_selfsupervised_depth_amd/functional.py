@@ -440,6 +440,168 @@ def take_fan_view(t):
     return v, ent[1]
 
 
+# ---------------------------------------------------------------------------------------------------------------------------
+# Deferred trunk backward.  The reference's Trainer.train_step (train.py:486, 499, 510) back-propagates every loss with its own
+# ``backward()`` call -- ``mono_total_loss.backward(retain_graph=True)``, then ``segmentation_total_loss.backward()`` -- so the
+# shared encoder is walked once per loss (two ResNet-101 backward passes per step, +17 % of the step's multiply-adds).
+# Gradients are linear in the loss: the encoder backward of the sum equals the sum of the encoder backwards.  ``defer_trunk``
+# cuts the graph at the encoder's features: the decoders read detached leaves behind a gate; a backward pass that KEEPS its
+# graph (``retain_graph=True``: by the reference's own convention more losses of this forward are to come) only parks the
+# feature gradients at the gate, and the pass that RELEASES its graph runs the encoder backward once on the sum (a re-entrant
+# ``torch.autograd.backward`` from inside the gate's node, i.e. still inside the caller's last ``backward()``: parameter
+# hooks, the gradient all-reduce of ddp.GradAllReducer and ``clip_grad_norm_`` see complete gradients afterwards).
+#
+# How the gate knows which kind of pass it is in: the engine releases a node's saved variables right after running it unless
+# the pass keeps the graph.  A sentinel node sits between the gate and the decoders -- it runs, and is released, before the
+# gate's node runs; reading ``saved_tensors`` of a released node raises, and that is the test.
+#
+# A forward whose LAST backward keeps the graph (a monodepth-only step: the reference passes retain_graph=True there too)
+# would park its encoder gradient for ever; deferral is therefore opt-in per model (``model.defer_trunk_backward``, set by
+# ``trainer.train_step`` / the INTEGRATION.md shim only for configurations that end on a releasing call), parked gradients
+# can be flushed by hand (``flush_deferred_trunks``), and a gradient that is still parked at the next forward of the same
+# encoder or at ANY ``optimizer.step()`` raises instead of training on half a gradient.
+class _TrunkState(object):
+    __slots__ = ("roots", "pending", "eboxes", "sentinel", "owner", "passes", "__weakref__")
+
+    def has_pending(self):
+        return any(p is not None for p in self.pending)
+
+    def flush(self):
+        roots, grads = [], []
+        for i, (v, p) in enumerate(zip(self.roots, self.pending)):
+            if p is None:
+                continue
+            roots.append(v)
+            grads.append(p)
+            box = self.eboxes[i]
+            if box is not None and box.get("publish") and box.get("g") is None and p.is_contiguous():
+                # the next stage's first convolutions (and the stem's max-pooling) add their data-gradients onto the parked
+                # tensor inside their kernels, like they do onto a decoder's skip gradient without the gate
+                box["g"], box["fused"] = p, True
+        self.pending = [None] * len(self.pending)
+        self.roots = None                    # the encoder graph is consumed by this call
+        if _TRUNKS.get(self.owner) is not None and _TRUNKS[self.owner]() is self:
+            del _TRUNKS[self.owner]
+        if roots:
+            TrunkGateFn.trunk_backwards += 1
+            torch.autograd.backward(roots, grads)
+
+
+_TRUNKS = {}                 # owner id -> weak reference to the state of that encoder's latest deferred forward (the graph owns it)
+_TRUNK_HOOK = [None]
+
+
+def _trunk_states():
+    out = []
+    for k, r in list(_TRUNKS.items()):
+        st = r()
+        if st is None:
+            del _TRUNKS[k]
+        else:
+            out.append(st)
+    return out
+
+
+def _trunk_guard(*_a, **_k):
+    for st in _trunk_states():
+        if st.has_pending():
+            raise RuntimeError(
+                "deferred trunk backward: %d backward pass(es) of the last forward kept their graph (retain_graph=True) and none "
+                "released it, so the shared encoder has not been back-propagated -- its gradients are incomplete.  End the "
+                "forward's losses on a plain backward(), call functional.flush_deferred_trunks() before the gradients are "
+                "read, or switch model.defer_trunk_backward off for this configuration." % st.passes)
+
+
+def flush_deferred_trunks():
+    """run the encoder backward of every forward whose feature gradients are still parked (see ``defer_trunk``)"""
+    for st in _trunk_states():
+        if st.has_pending():
+            st.flush()
+
+
+def pending_deferred_trunks():
+    return sum(1 for st in _trunk_states() if st.has_pending())
+
+
+class TrunkSentinelFn(Function):
+    """identity on the decoders' side of the gate; its only job is to be released by the engine before the gate's node runs"""
+
+    @staticmethod
+    def forward(ctx, st, *xs):
+        ctx.set_materialize_grads(False)
+        st.sentinel = ctx
+        return tuple(x.view_as(x) for x in xs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        return (None,) + grads
+
+
+class TrunkGateFn(Function):
+    trunk_backwards = 0      # diagnostics / tests: encoder backward passes started by a gate
+    parked_passes = 0        # ... and passes that only parked their feature gradients
+
+    @staticmethod
+    def forward(ctx, st, *leaves):
+        ctx.set_materialize_grads(False)
+        ctx.st = st
+        return tuple(x.view_as(x) for x in leaves)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        st = ctx.st
+        if st.roots is None:
+            raise RuntimeError("deferred trunk backward: the encoder of this forward has already been back-propagated (a pass "
+                               "that released its graph came before this one)")
+        for i, g in enumerate(grads):
+            if g is None:
+                continue
+            g, p = _c(g), st.pending[i]
+            st.pending[i] = g if p is None else H.axpby(1.0, p, 1.0, g)
+        st.passes += 1
+        try:
+            st.sentinel.saved_tensors        # raises once the engine has released the sentinel: this pass frees its graph
+            final = False
+        except RuntimeError:
+            final = True
+        if final:
+            st.flush()
+        else:
+            TrunkGateFn.parked_passes += 1
+        return (None,) * (1 + len(grads))
+
+
+def defer_trunk(feats, owner, n_consumers=0):
+    """feats: the encoder's NHWC features (graph attached).  -> the tensors the decoders read instead: detached leaves behind a
+    TrunkGateFn whose backward parks the feature gradients until a pass releases its graph (see the comment above).
+    n_consumers: decoders that fetch a view of every feature with ``take_fan_view`` (the gradient collector moves to the
+    decoders' side of the gate; on the encoder's side the gate is the one outside consumer)."""
+    if not (torch.is_grad_enabled() and any(f.requires_grad for f in feats)):
+        return feats
+    old = _TRUNKS.get(owner)
+    old = old() if old is not None else None
+    if old is not None and old.has_pending():
+        _trunk_guard()
+    if _TRUNK_HOOK[0] is None:
+        from torch.optim.optimizer import register_optimizer_step_pre_hook
+        _TRUNK_HOOK[0] = register_optimizer_step_pre_hook(_trunk_guard)
+    st = _TrunkState()
+    st.owner, st.passes, st.sentinel = owner, 0, None
+    st.roots, st.eboxes = [], []
+    for f in feats:
+        v, box = take_fan_view(f)            # the view the encoder parked for the gate (its gradient collector's box)
+        st.roots.append(v)
+        st.eboxes.append(box)
+    st.pending = [None] * len(feats)
+    _TRUNKS[owner] = weakref.ref(st)
+    leaves = [v.detach().requires_grad_(True) for v in st.roots]
+    outs = TrunkSentinelFn.apply(st, *TrunkGateFn.apply(st, *leaves))
+    for o, box in zip(outs, st.eboxes):
+        if box is not None and n_consumers > 1:
+            fan_feature(o, n_consumers, 0, owner=owner)      # parks the decoders' views; they share one in-kernel accumulation
+    return list(outs)
+
+
 class MaxPoolFn(Function):
     """box: the shared box of the pooled tensor's gradient collector (Fn.fan_feature), if it has one: the pooling gradient is
     added onto the gradient another consumer already left there"""
@@ -561,10 +723,14 @@ class DropoutFn(Function):
     @staticmethod
     def forward(ctx, x, p, seed):
         ctx.p, ctx.seed = p, seed
+        if p >= 1.0:                         # nn.Dropout(1.0) is legal in the reference: everything is dropped
+            return torch.zeros_like(x, memory_format=torch.contiguous_format)
         return H.dropout(_c(x), p, seed)
 
     @staticmethod
     def backward(ctx, dy):
+        if ctx.p >= 1.0:
+            return torch.zeros_like(dy, memory_format=torch.contiguous_format), None, None
         return H.dropout(_c(dy), ctx.p, ctx.seed), None, None
 
 

@@ -25,6 +25,10 @@ class JointSegmentationMonodepth(nn.Module):
                for m in v.modules() if isinstance(m, DepthDecoder) and m.use_skips and m.takes_fan_views()]
         if "encoder" in self.models:
             self.models["encoder"].skip_consumers = len(dec)
+        # opt-in: one encoder backward per forward however many ``backward()`` calls the training step makes on its losses
+        # (train.py:486,499,510 make up to three); see functional.defer_trunk for the contract -- the forward's last backward must
+        # release its graph.  trainer.train_step and the INTEGRATION.md shim switch it on per configuration.
+        self.defer_trunk_backward = False
 
     def predict_poses(self, inputs, features):
         """reference :20-70"""
@@ -59,6 +63,7 @@ class JointSegmentationMonodepth(nn.Module):
     def forward(self, x):
         from ..loss.monodepth_loss import LazyOutputs
         outputs, inputs = LazyOutputs(), x     # a dict; MonodepthLoss registers its API-visible grids / depths as lazy entries
+        self.models["encoder"].defer_backward = bool(self.defer_trunk_backward)
         features = self.models["encoder"](inputs["color_aug", 0, 0])
         outputs["bottleneck"] = features[-1]
         if "mtl_decoder" in self.models:

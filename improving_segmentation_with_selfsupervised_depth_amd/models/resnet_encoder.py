@@ -155,7 +155,11 @@ class ResnetEncoder(nn.Module):
         # feature becomes a set of Fn.FanoutFn views -- the ones for the next stage are used here, the decoders fetch theirs with
         # Fn.take_fan_view -- so that the consumers' data-gradients accumulate in their kernels instead of being
         # summed by autograd with one full-tensor pass per extra consumer.
-        n = int(getattr(self, "skip_consumers", 0))
+        n_dec = int(getattr(self, "skip_consumers", 0))
+        # ``defer_backward`` (set through JointSegmentationMonodepth.defer_trunk_backward): the decoders read the features behind a
+        # gate that runs this encoder's backward once per forward, however many backward() calls the step makes (Fn.defer_trunk)
+        defer = bool(getattr(self, "defer_backward", False)) and torch.is_grad_enabled()
+        n = 1 if defer else n_dec          # outside consumers of every feature: the gate alone, or the decoders
         Fn.release_fans(id(self))          # views of the previous forward that no decoder came for
         (x0,), box0 = Fn.fan_feature(f0, n, 1, owner=id(self))
         x = Fn.MaxPoolFn.apply(x0, box0)
@@ -170,6 +174,8 @@ class ResnetEncoder(nn.Module):
                 (x, x_ds), box = Fn.fan_feature(x, n, 2, owner=id(self))      # conv1 and the downsample convolution of the next stage + the decoders
                 if box is None:
                     x_ds = None
+        if defer:
+            feats = Fn.defer_trunk(feats, id(self), n_dec)
         return feats
 
     def forward(self, input_image):

@@ -10,6 +10,7 @@ the reference's ``Trainer`` (train.py), as free functions taking the config valu
 import numpy as np
 import torch
 
+from . import functional as Fn
 from . import hipops as H
 from .loss.loss import cross_entropy2d
 
@@ -234,6 +235,8 @@ def train_step_segmentation_unlabeled(model, ema_model, monodepth_loss_calculato
     softmax_u_w_mixed, _ = strong_transform(strong_parameters, data=softmax_u_w)
     L_2, pseudo_label = calc_pseudo_label_loss(softmax_u_w_mixed, outputs["semantics"], consistency_weight)
     if last_backward:
+        if reducer is not None:
+            reducer.complete_unreachable([L_2])
         L_2.backward()
     else:
         with nosync():
@@ -339,6 +342,13 @@ def train_step(model, optimizer, inputs, step, cfg, loss_fn, monodepth_loss_calc
     def hold(last):           # all but the last backward() of the step keep the gradient all-reduce back
         return reducer.no_sync() if (reducer is not None and not last) else contextlib.nullcontext()
 
+    # One encoder backward per forward, whatever the number of backward() calls on its losses (functional.defer_trunk).  The
+    # contract is that the forward's LAST backward() releases its graph: true whenever the segmentation loss is on (train.py:510 is
+    # a plain backward(); the unlabeled step's forwards end on plain calls as well, train.py:687,696 + the mixed pass) and false
+    # for a monodepth-only step, which ends on retain_graph=True (train.py:486) -- there the gate stays off.
+    # ``cfg["training"]["defer_trunk_backward"] = False`` switches it off for any configuration.
+    if hasattr(model, "defer_trunk_backward"):
+        model.defer_trunk_backward = bool(tr.get("defer_trunk_backward", True)) and do_seg and (do_mono or do_pd or unl is not None)
     outputs = model(inputs)
     if do_mono:
         monodepth_loss_calculator.generate_images_pred(inputs, outputs)
@@ -361,6 +371,8 @@ def train_step(model, optimizer, inputs, step, cfg, loss_fn, monodepth_loss_calc
             segmentation_loss = (segmentation_loss + loss_fn(input=outputs["intermediate_semantics"], target=inputs["lbl"])) / 2
         segmentation_loss = segmentation_loss * tr["segmentation_lambda"]
         segmentation_total = segmentation_loss
+        if reducer is not None and unl is None and (do_mono or do_pd):
+            reducer.complete_unreachable([segmentation_total])     # the depth / pose gradients are final: reduce them under this backward
         with hold(unl is None):
             segmentation_total.backward()
         if unl is not None:
@@ -377,6 +389,7 @@ def train_step(model, optimizer, inputs, step, cfg, loss_fn, monodepth_loss_calc
             segmentation_total = segmentation_total + u_loss
             segmentation_loss = segmentation_total
             mono_total = mono_total + u_mono
+    Fn.flush_deferred_trunks()      # (nothing is parked when the sequence above ended on a releasing call)
     if reducer is not None:
         reducer.finish()
     if tr.get("clip_grad_norm") is not None:

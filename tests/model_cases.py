@@ -840,3 +840,82 @@ def run_skip_gradient_fanout(device):
     top = max(float(v.abs().max()) for v in g0.values())
     for k in g0:
         assert_close(g1[k], g0[k], rtol=2e-4, atol=1e-5 * top, what="gradient collector vs plain autograd: " + k)
+
+
+def run_deferred_trunk_backward(device):
+    """The reference's call sequence -- ``mono.backward(retain_graph=True)`` then ``seg.backward()`` (train.py:486,510) -- on an
+    encoder read by two decoders: with ``defer_backward`` the encoder is back-propagated ONCE (in the releasing call) and every
+    parameter gradient equals the two-pass one to fp32 round-off; a single ``backward()`` behaves as without the gate; a step
+    that only ever keeps its graph raises at ``optimizer.step()`` (and at the encoder's next forward) until it is flushed."""
+    from improving_segmentation_with_selfsupervised_depth_amd import functional as Fn
+    from improving_segmentation_with_selfsupervised_depth_amd.models.resnet_encoder import ResnetEncoder
+    from improving_segmentation_with_selfsupervised_depth_amd.models.depth_decoder import DepthDecoder
+    torch.manual_seed(13)
+    enc = ResnetEncoder(18, False).to(device).train()
+    kw = dict(num_ch_dec=[32, 32, 32, 64, 64], max_scale_size=[64, 64])
+    decs = [DepthDecoder(enc.num_ch_enc, range(4), **kw).to(device).train() for _ in range(2)]
+    enc.skip_consumers = 2
+    img = torch.rand(2, 3, 64, 64).to(device)
+    mods = [enc] + decs
+
+    def grads():
+        return {"%d.%s" % (i, k): p.grad.detach().clone() for i, m in enumerate(mods) for k, p in m.named_parameters()
+                if p.grad is not None}
+
+    def losses():
+        feats = enc(img)
+        return [sum((k + 1.0) * (d(feats)[("disp", s)] ** 2).mean() for s in range(4)) for k, d in enumerate(decs)]
+
+    def run(defer, calls):
+        enc.defer_backward = defer
+        for m in mods:
+            m.zero_grad(set_to_none=True)
+        t0, p0 = Fn.TrunkGateFn.trunk_backwards, Fn.TrunkGateFn.parked_passes
+        l = losses()
+        if calls == 2:
+            l[0].backward(retain_graph=True)
+            if defer:
+                assert all(p.grad is None for p in enc.parameters()), "the keeping pass must not walk the encoder"
+                assert Fn.pending_deferred_trunks() == 1
+            l[1].backward()
+        else:
+            (l[0] + l[1]).backward()
+        assert Fn.pending_deferred_trunks() == 0
+        return grads(), Fn.TrunkGateFn.trunk_backwards - t0, Fn.TrunkGateFn.parked_passes - p0
+
+    try:
+        g_two, t, p = run(False, 2)
+        assert (t, p) == (0, 0)
+        g_def, t, p = run(True, 2)
+        assert (t, p) == (1, 1), (t, p)
+        g_one, t, p = run(True, 1)
+        assert (t, p) == (1, 0), (t, p)
+        assert set(g_two) == set(g_def) == set(g_one)
+        top = max(float(v.abs().max()) for v in g_two.values())
+        for k in g_two:
+            assert_close(g_def[k], g_two[k], rtol=2e-4, atol=1e-5 * top, what="deferred vs two encoder passes: " + k)
+            assert_close(g_one[k], g_two[k], rtol=2e-4, atol=1e-5 * top, what="one call through the gate vs two passes: " + k)
+        # a forward that only keeps its graph: the gradient is parked, readers of the gradients are stopped loudly
+        enc.defer_backward = True
+        for m in mods:
+            m.zero_grad(set_to_none=True)
+        l = losses()
+        l[0].backward(retain_graph=True)
+        opt = torch.optim.SGD([p for m in mods for p in m.parameters()], lr=0.0)
+        for what in (opt.step, lambda: enc(img)):
+            try:
+                what()
+            except RuntimeError as e:
+                assert "deferred trunk backward" in str(e)
+            else:
+                raise AssertionError("parked encoder gradient went unnoticed")
+        Fn.flush_deferred_trunks()
+        assert Fn.pending_deferred_trunks() == 0 and all(p.grad is not None for p in enc.encoder.layer1.parameters())
+        opt.step()
+        # without a gradient (validation) the gate is not built at all
+        with torch.no_grad():
+            f = enc(img)
+        assert not f[0].requires_grad and Fn.pending_deferred_trunks() == 0
+    finally:
+        enc.defer_backward = False
+        Fn.flush_deferred_trunks()

@@ -164,7 +164,9 @@ class DestNet(torch.nn.Module):
 
 def _worker_zero_copy(rank, world, port, q, mode):
     """mode: 'single' one backward per step; 'nosync' two backwards, the first under no_sync (accumulates in place in the bucket);
-    'dirty' two backwards in sync mode (the second one's contributions are reduced on their own and added); 'copy_out'"""
+    'dirty' two backwards in sync mode (the second one's contributions are reduced on their own and added); 'copy_out';
+    'dirty_keep': 'dirty' with zero_grad(set_to_none=False) -- p.grad then still aliases the bucket slice when the first backward
+    accumulates into it, unclaimed, and the second backward must not be handed that slice"""
     import warnings
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -182,7 +184,7 @@ def _worker_zero_copy(rank, world, port, q, mode):
         warnings.simplefilter("ignore")
         for step in range(5):
             xs, ts = data[step].chunk(world)[rank], tgt[step].chunk(world)[rank]
-            net.zero_grad(set_to_none=True)
+            net.zero_grad(set_to_none=(mode != "dirty_keep"))
             ref.zero_grad(set_to_none=True)
             t0 = ddp.ZERO_COPY["taken"]
             out = net(xs)
@@ -215,7 +217,7 @@ def _worker_zero_copy(rank, world, port, q, mode):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["single", "nosync", "dirty", "copy_out"])
+@pytest.mark.parametrize("mode", ["single", "nosync", "dirty", "dirty_keep", "copy_out"])
 def test_zero_copy_buckets(mode):
     """Round 5: the backward writes the weight gradients straight into the bucket slices (ddp.grad_destination): from the second
     step on (the buckets exist) the three matrices are found in place by the hooks -- no pack copy --, the averaged gradients
@@ -552,3 +554,96 @@ def run_real_model_two_ranks(device, timeout):
                     "the GPU box in seconds (tests/test_models_gpu.py::test_real_model_two_ranks_one_gpu); set SEGSDE_SLOW_TESTS=1")
 def test_real_model_two_ranks_gloo_interpreter():
     run_real_model_two_ranks("cpu", 3000)
+
+
+class TrunkNet(torch.nn.Module):
+    """a shared trunk whose two features are read by two heads, each with a loss of its own that the step back-propagates with its
+    own backward() call (train.py:486,510); ``defer`` routes the features through functional.defer_trunk"""
+
+    def __init__(self):
+        super().__init__()
+        self.t1 = torch.nn.Linear(6, 48)
+        self.t2 = torch.nn.Linear(48, 48)
+        self.ha = torch.nn.Linear(48, 1)
+        self.hb = torch.nn.Linear(48, 1)
+        self.defer = False
+
+    def forward(self, x):
+        f1 = torch.relu(self.t1(x))
+        f2 = torch.relu(self.t2(f1))
+        feats = [f1, f2]
+        if self.defer:
+            from improving_segmentation_with_selfsupervised_depth_amd import functional as Fn
+            feats = Fn.defer_trunk(feats, id(self))
+        return self.ha(feats[1] + feats[0]), self.hb(feats[1] * feats[0])
+
+
+def _worker_deferred(rank, world, port, q):
+    """the reference's two-call step with the first call under no_sync() and the trunk deferred: the trunk's parameters see ONE
+    gradient hook per step (fired from the re-entrant trunk backward inside the releasing call, so their buckets start from the
+    hooks), the averaged gradients are the global-batch gradients"""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import emu
+    emu.install()                      # the gate adds the second call's feature gradients with the package's axpby kernel
+    from improving_segmentation_with_selfsupervised_depth_amd import ddp
+    from improving_segmentation_with_selfsupervised_depth_amd import functional as Fn
+    torch.manual_seed(5)
+    net, ref = TrunkNet(), TrunkNet()
+    net.defer = True
+    red = ddp.GradAllReducer(net, bucket_mb=0.004)
+    ref.load_state_dict(net.state_dict())
+    torch.manual_seed(0)
+    data, tgt = torch.randn(4, 8, 6), torch.randn(4, 8, 2)
+    worst, hooks = 0.0, []
+    for p in net.t1.parameters():
+        p.register_post_accumulate_grad_hook(lambda p_: hooks.append(1))
+    t0 = (Fn.TrunkGateFn.trunk_backwards, Fn.TrunkGateFn.parked_passes)
+    launched_by_hooks = 0
+    for step in range(4):
+        xs, ts = data[step].chunk(world)[rank], tgt[step].chunk(world)[rank]
+        net.zero_grad(set_to_none=True)
+        ref.zero_grad(set_to_none=True)
+        ya, yb = net(xs)
+        with red.no_sync():
+            ((ya[:, 0] - ts[:, 0]) ** 2).mean().backward(retain_graph=True)
+        assert net.t1.weight.grad is None and Fn.pending_deferred_trunks() == 1
+        c0 = red.collectives
+        lb = ((yb[:, 0] - ts[:, 1]) ** 2).mean()
+        marked = red.complete_unreachable([lb])           # head a is done; the trunk behind the gate and head b are not
+        assert marked == (2 if step >= 1 else 0), marked
+        lb.backward()
+        launched_by_hooks += red.collectives - c0
+        assert Fn.pending_deferred_trunks() == 0
+        red.finish()
+        ra, rb = ref(data[step])
+        (((ra[:, 0] - tgt[step][:, 0]) ** 2).mean() + ((rb[:, 0] - tgt[step][:, 1]) ** 2).mean()).backward()
+        for p, r in zip(net.parameters(), ref.parameters()):
+            worst = max(worst, float((p.grad - r.grad).abs().max() / (r.grad.abs().max() + 1e-12)))
+        with torch.no_grad():
+            for p, r in zip(net.parameters(), ref.parameters()):
+                p -= 0.1 * p.grad
+                r -= 0.1 * r.grad
+    red.close()
+    q.put((rank, worst, len(hooks), Fn.TrunkGateFn.trunk_backwards - t0[0], Fn.TrunkGateFn.parked_passes - t0[1], launched_by_hooks))
+    dist.destroy_process_group()
+
+
+def test_deferred_trunk_backward_with_no_sync_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 35500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker_deferred, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(60)
+    for rank, worst, hooks, ran, parked, by_hooks in res:
+        assert worst < 1e-5, (rank, worst)
+        assert hooks == 4 * 2, hooks            # t1.weight, t1.bias: one accumulation per step, not one per backward() call
+        assert (ran, parked) == (4, 4), (ran, parked)
+        assert by_hooks == 3 * 2, by_hooks      # from the second step on (buckets exist) BOTH buckets start inside the last backward

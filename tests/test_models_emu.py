@@ -94,3 +94,7 @@ def test_fusion_handoffs_are_counted():
 
 def test_skip_gradient_fanout():
     MC.run_skip_gradient_fanout("cpu")
+
+
+def test_deferred_trunk_backward():
+    MC.run_deferred_trunk_backward("cpu")

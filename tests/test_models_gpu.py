@@ -480,15 +480,17 @@ def test_hip_graph_replay_matches_eager_steps():
     assert worst <= 1e-6, worst
 
 
+@pytest.mark.parametrize("defer", [True, False], ids=["deferred_trunk", "encoder_per_call"])
 @pytest.mark.parametrize("scenario", ["joint", "depthmix"])
-def test_train_step_replay_vs_reference_caller(scenario):
+def test_train_step_replay_vs_reference_caller(scenario, defer):
     """VERDICT r3 item 5a.  tests/golden/trainstep.npz holds what the reference's OWN ``Trainer.train_step`` (imported from
     /root/reference/train.py by tests/golden/make_trainstep.py, reference modules underneath) left after each of two
     iterations: the returned losses, per-parameter gradient / update norms, parameter, BatchNorm and EMA checksums.  The same
     script runs the same train.py over this package's modules on the kernel interpreter (log:
     tests/golden/trainstep_package_run.json).  Here the package's mirror of the call sequence (``trainer.train_step``:
     five ``backward()`` calls, ``freeze_backbone_bn``, parameter groups over ``model.models``, clipping, EMA) replays it
-    on the GPU."""
+    on the GPU -- with the encoder back-propagated once per forward (``defer``: functional.defer_trunk, the default of
+    ``trainer.train_step`` for these configurations) and once per ``backward()`` call like the reference."""
     import numpy as np
     import trainstep_case as TC
     from improving_segmentation_with_selfsupervised_depth_amd import trainer as T
@@ -497,7 +499,10 @@ def test_train_step_replay_vs_reference_caller(scenario):
     from conftest import GOLDEN
     import os
     ref = dict(np.load(os.path.join(GOLDEN, "trainstep.npz"), allow_pickle=False))
+    from improving_segmentation_with_selfsupervised_depth_amd import functional as Fn
     cfg = TC.full_cfg(scenario)
+    cfg["training"]["defer_trunk_backward"] = defer
+    gate0 = (Fn.TrunkGateFn.trunk_backwards, Fn.TrunkGateFn.parked_passes)
     model = get_model(cfg["model"], TC.NCLS)
     model.load_state_dict(TC.state_dict(scenario), strict=True)
     TC.no_dropout(model)
@@ -521,7 +526,16 @@ def test_train_step_replay_vs_reference_caller(scenario):
         losses = T.train_step(model, opt, TC.batch(100 + it), it, cfg, loss_fn, mono, ema_model=ema, unlabeled_inputs=unl)
         TC.record(out, scenario, it, losses, model, ema, before)
     TC.compare(out, ref, scenario)
+    ran, parked = Fn.TrunkGateFn.trunk_backwards - gate0[0], Fn.TrunkGateFn.parked_passes - gate0[1]
+    # joint: one forward, two calls; depthmix: three forwards per iteration (labeled: 2 calls, unmixed and mixed: 1 call each)
+    want = {"joint": (TC.ITERS, TC.ITERS), "depthmix": (3 * TC.ITERS, TC.ITERS)}[scenario] if defer else (0, 0)
+    assert (ran, parked) == want, (ran, parked, want)
 
 
 def test_skip_gradient_fanout():
     MC.run_skip_gradient_fanout("cuda")
+
+
+@pytest.mark.gpu
+def test_deferred_trunk_backward():
+    MC.run_deferred_trunk_backward("cuda")
