@@ -122,6 +122,11 @@ __global__ __launch_bounds__(256, 2) void wino_fused_kernel(WinoSrc src, int B, 
       }
       const float* xs = sidx == 0 ? src.x0 : src.x1;
       const segsde_rsrc xr = segsde_make_rsrc(xs + (size_t)b * img + (sidx == 0 ? c0 : c0 - src.C0));
+#ifdef WINO_DBG_SKIP_LOAD      // phase-cost probe (tools/build_variant.sh): no global patch loads, the rest of the fill unchanged
+      (void)xr; (void)first;
+#pragma unroll
+      for (int i = 0; i < NL; ++i) { poff[i] = patch_offset(i); v[i] = make_float4((float)poff[i], 1.f, 2.f, 3.f); }
+#else
       if (first) {
 #pragma unroll
         for (int i = 0; i < NL; ++i) { poff[i] = patch_offset(i); v[i] = segsde_buffer_load4(xr, poff[i], 0u); }
@@ -129,6 +134,7 @@ __global__ __launch_bounds__(256, 2) void wino_fused_kernel(WinoSrc src, int B, 
 #pragma unroll
         for (int i = 0; i < NL; ++i) v[i] = segsde_buffer_load4(xr, poff[i], 0u);
       }
+#endif
 #pragma unroll
       for (int i = 0; i < NL; ++i) {
         const int e = tid + 256 * i;
@@ -181,12 +187,17 @@ __global__ __launch_bounds__(256, 2) void wino_fused_kernel(WinoSrc src, int B, 
         rv[q][bb] = SEGSDE_LDS_READ_IMM(src + o1, cp); rv[q][4 + bb] = SEGSDE_LDS_READ_IMM(src + o2, cp);
       }
     };
+#ifdef WINO_DBG_SKIP_K         // phase-cost probe: one step of the K loop instead of 32
+    constexpr int NS_RUN = 1;
+#else
+    constexpr int NS_RUN = NS;
+#endif
 #pragma unroll
     for (int s = 0; s < PD - 1; ++s) fetch_b(s, s);
     fetch_a(0, 0);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int s = 0; s < NS; ++s) {
+    for (int s = 0; s < NS_RUN; ++s) {
       const int q = s & 1, qb = s % PD;
       if (s + PD - 1 < NS) fetch_b(s + PD - 1, (s + PD - 1) % PD);
       if (s + 1 < NS) fetch_a(s + 1, q ^ 1);
@@ -206,6 +217,19 @@ __global__ __launch_bounds__(256, 2) void wino_fused_kernel(WinoSrc src, int B, 
     }
   }
 
+#ifdef WINO_DBG_SKIP_EPI       // phase-cost probe: no Z exchange, no output
+  {
+    float sdbg = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sdbg += acc[j][nb][r];
+    if (sdbg == 1.2345678f) y[0] = sdbg;
+    return;
+  }
+#endif
   // ---- epilogue.  Y = A^T M A with A^T = [1 1 1 0; 0 1 -1 -1]: wave w holds row w of the 4 x 4 position grid, so the column
   // half (.) A runs on its accumulators (four values -> two); the rows meet in LDS as Z[w][column 0 / 1][tile][filter] (the
   // patch is dead by then), one round for all 64 filters, and every thread finishes eight tiles of one filter
