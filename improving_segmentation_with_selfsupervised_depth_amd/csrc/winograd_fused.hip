@@ -33,9 +33,17 @@ constexpr int FROW = 20, FODD = FP_W / 2;
 constexpr int FPS = 256;
 __device__ __forceinline__ constexpr int fplane(int c) { return c * FPS + 2 * (c >> 2); }
 constexpr int FCH = 64;                               // channels per LDS fill
-constexpr int FZP = 65;                               // row pitch of the epilogue's half-transformed blocks Z[8][32][FZP]
-constexpr int F_FLOATS = 8 * 32 * FZP > FCH * FPS ? 8 * 32 * FZP : FCH * FPS;
+// the epilogue's half-transformed blocks Z[4 transform rows][2 output columns][64 filters][FZP]: the 32 tiles of a filter are
+// contiguous (pitch 36: lanes with consecutive filters cover the 32 banks with their 16-byte accesses), so that a thread moves the
+// four tiles its accumulator registers hold side by side, and the eight tiles it finishes, with ds_write_b128 / ds_read_b128 --
+// 16 + 16 LDS instructions per thread instead of 64 + 64 (round 6: the epilogue was 5-14 % of the kernel, probe_r06_wino_phases.log)
+constexpr int FZP = 36;
+constexpr int F_FLOATS = 8 * 64 * FZP > FCH * FPS ? 8 * 64 * FZP : FCH * FPS;
+#ifdef WINO_DBG_OCC1           // phase-cost probe: one workgroup per CU (LDS request above half of the 160 KiB)
+constexpr size_t F_LDS = 96 * 1024;
+#else
 constexpr size_t F_LDS = (size_t)F_FLOATS * sizeof(float) + 2 * 4 * 64 * sizeof(double);
+#endif
 
 // the sources of the virtual input [up2x?(x0) | x1]: channels [0, C0) from x0 (stored at half resolution when up0: the decoder's
 // nearest upsampling, models/depth_decoder.py:91, is index arithmetic of the patch loader), [C0, C) from x1 at full resolution;
@@ -58,12 +66,16 @@ __global__ __launch_bounds__(256, 2) void wino_fused_kernel(WinoSrc src, int B, 
   double* sh = reinterpret_cast<double*>(lds + F_FLOATS);
   const int H2 = H >> 1, W2 = W >> 1;
   const int nbw = (W2 + FT_W - 1) / FT_W, nbh = (H2 + FT_H - 1) / FT_H;
-  int blk = segsde_xcd_remap(blockIdx.x, gridDim.x);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int t = lane & 31, kk = lane >> 5, th = t >> 3, tw = t & 7;
+  // (round 6, negative: PERSISTENT workgroups walking over their share of the items -- so that an item's output stores drain under
+  // the next item's fill -- spill: with the item loop around it the compiler keeps ~20 more values live across the K loop, whose
+  // 128 accumulators + prefetch registers leave 10 free; 55-87 spilled registers, 1.25-1.3x slower.  experiments_r06.md)
+  const int bidx = blockIdx.x;
+  int blk = segsde_xcd_remap(bidx, gridDim.x);
   const int bw = blk % nbw; blk /= nbw;
   const int bh = blk % nbh; const int b = blk / nbh;
   const int co0 = blockIdx.y * 64;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int t = lane & 31, kk = lane >> 5, th = t >> 3, tw = t & 7;
   const int h_top = 2 * bh * FT_H - 1, w_left = 2 * bw * FT_W - 1;   // image position of patch pixel (0, 0)
   // rows of the patch that transform row `wave` combines: B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]
   const int a1 = wave == 0 ? 0 : (wave == 2 ? 2 : 1);
@@ -107,6 +119,10 @@ __global__ __launch_bounds__(256, 2) void wino_fused_kernel(WinoSrc src, int B, 
   };
 
   for (int c0 = 0; c0 < C; c0 += FCH) {
+#ifdef WINO_DBG_LOOP_ONLY      // phase-cost probe: the fill (loads, LDS writes, barriers) only once per workgroup
+    if (c0 == 0)
+#endif
+    {
     __syncthreads();                                   // the previous fill's reads are done
     {
       // all requests of the fill first (12 independent 16-byte loads per thread), then the transposing LDS writes
@@ -146,6 +162,7 @@ __global__ __launch_bounds__(256, 2) void wino_fused_kernel(WinoSrc src, int B, 
       }
     }
     __syncthreads();
+    }
     // U[p][c][n]: this lane's column n = co0 + nb * 32 + t of channel c0 + 2 s + kk, positions 4 wave + j.  The address is
     // split into a wave-uniform part (scalar registers, scalar adds) and the lane's constant 32-bit offset: the eight requests
     // of a step cost no vector instructions (with per-lane 64-bit pointers they were two thirds of the loop's VALU work, and
@@ -179,41 +196,55 @@ __global__ __launch_bounds__(256, 2) void wino_fused_kernel(WinoSrc src, int B, 
     // (SEGSDE_LDS_READ_IMM: single ds_read_b32 with the plane / column offset in the instruction's 16-bit immediate off the two
     // row bases of the wave.  Left to itself the compiler pairs neighbouring columns into ds_read2_b32, whose 8-bit offsets do not
     // reach past the first plane: 124 v_add_u32 per fill to rebase them -- a third of the loop's vector instructions)
-    auto fetch_a = [&](int s, int q) {
-      const float* src = pl + fplane(2 * s);
-#pragma unroll
-      for (int bb = 0; bb < 4; ++bb) {       // patch column 2 tw + bb: even ones at position tw + bb / 2, odd ones behind the even half
-        const int cp = (bb & 1) ? FODD + (bb >> 1) : (bb >> 1);
-        rv[q][bb] = SEGSDE_LDS_READ_IMM(src + o1, cp); rv[q][4 + bb] = SEGSDE_LDS_READ_IMM(src + o2, cp);
-      }
-    };
 #ifdef WINO_DBG_SKIP_K         // phase-cost probe: one step of the K loop instead of 32
     constexpr int NS_RUN = 1;
 #else
     constexpr int NS_RUN = NS;
 #endif
+    // Software-pipelined step (round 6): the A operands of step s + 1 are formed during step s, and every request of a step sits
+    // in the shadow of one of its MFMAs -- slots 0..3 issue the eight raw-pixel reads of the next step (two each), 4 / 5 the two
+    // weight requests of step s + PD - 1, 6 / 7 the eight additions that turn the pixels into the next step's operands.  One wave
+    // alone on its SIMD (the sibling workgroup in its fill or epilogue) then keeps the matrix pipe fed: with the ten requests in
+    // one bunch between two MFMAs and the additions in front of the MFMAs that use them a lone wave reached 0.75 of the pipe.
+    float An[2][4];
+    auto form_a = [&](int q, int h) {          // h = 0: A0, A1 of buffer q from rv[0]; h = 1: A2, A3
+      if (h == 0) {
+        const float e0 = __builtin_fmaf(rv[0][4], sgn, rv[0][0]), e1 = __builtin_fmaf(rv[0][5], sgn, rv[0][1]);
+        const float e2 = __builtin_fmaf(rv[0][6], sgn, rv[0][2]);
+        An[q][0] = e0 - e2; An[q][1] = e1 + e2; An[q][2] = e2 - e1; rv[1][0] = e1;
+      } else {
+        const float e3 = __builtin_fmaf(rv[0][7], sgn, rv[0][3]);
+        An[q][3] = rv[1][0] - e3;
+      }
+    };
+    auto fetch_a2 = [&](int s, int bb) {       // raw pixels of step s, patch column 2 tw + bb: both rows
+      const float* src = pl + fplane(2 * s);
+      const int cp = (bb & 1) ? FODD + (bb >> 1) : (bb >> 1);
+      rv[0][bb] = SEGSDE_LDS_READ_IMM(src + o1, cp); rv[0][4 + bb] = SEGSDE_LDS_READ_IMM(src + o2, cp);
+    };
 #pragma unroll
     for (int s = 0; s < PD - 1; ++s) fetch_b(s, s);
-    fetch_a(0, 0);
+#pragma unroll
+    for (int bb = 0; bb < 4; ++bb) fetch_a2(0, bb);
+    form_a(0, 0); form_a(0, 1);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int s = 0; s < NS_RUN; ++s) {
       const int q = s & 1, qb = s % PD;
+      const bool nx = s + 1 < NS;
+#define WINO_MF_(j, nb, bi) acc[j][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(An[q][j], bv[qb][bi], acc[j][nb], 0, 0, 0); __builtin_amdgcn_sched_barrier(0)
+      WINO_MF_(0, 0, 0); if (nx) fetch_a2(s + 1, 0); __builtin_amdgcn_sched_barrier(0);
+      WINO_MF_(0, 1, 1); if (nx) fetch_a2(s + 1, 1); __builtin_amdgcn_sched_barrier(0);
+      WINO_MF_(1, 0, 2); if (nx) fetch_a2(s + 1, 2); __builtin_amdgcn_sched_barrier(0);
+      WINO_MF_(1, 1, 3); if (nx) fetch_a2(s + 1, 3); __builtin_amdgcn_sched_barrier(0);
+      WINO_MF_(2, 0, 4); __builtin_amdgcn_sched_barrier(0);
+      WINO_MF_(2, 1, 5); __builtin_amdgcn_sched_barrier(0);
+      // (the weight requests of step s + PD - 1 overwrite bv[(s - 1) % PD]: last read by the previous step)
       if (s + PD - 1 < NS) fetch_b(s + PD - 1, (s + PD - 1) % PD);
-      if (s + 1 < NS) fetch_a(s + 1, q ^ 1);
-      __builtin_amdgcn_sched_barrier(0);               // the scheduler otherwise sinks the requests to one step before their use
-      float ev[4];
-#pragma unroll
-      for (int bb = 0; bb < 4; ++bb) ev[bb] = __builtin_fmaf(rv[q][4 + bb], sgn, rv[q][bb]);   // r1 +- r2, exact: one issue slot
-      const float A0 = ev[0] - ev[2], A1 = ev[1] + ev[2], A2 = ev[2] - ev[1], A3 = ev[1] - ev[3];
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A0, bv[qb][0], acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A0, bv[qb][1], acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A1, bv[qb][2], acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A1, bv[qb][3], acc[1][1], 0, 0, 0);
-      acc[2][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A2, bv[qb][4], acc[2][0], 0, 0, 0);
-      acc[2][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A2, bv[qb][5], acc[2][1], 0, 0, 0);
-      acc[3][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A3, bv[qb][6], acc[3][0], 0, 0, 0);
-      acc[3][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A3, bv[qb][7], acc[3][1], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      WINO_MF_(3, 0, 6); if (nx) form_a(q ^ 1, 0); __builtin_amdgcn_sched_barrier(0);
+      WINO_MF_(3, 1, 7); if (nx) form_a(q ^ 1, 1); __builtin_amdgcn_sched_barrier(0);
+#undef WINO_MF_
     }
   }
 
@@ -235,15 +266,24 @@ __global__ __launch_bounds__(256, 2) void wino_fused_kernel(WinoSrc src, int B, 
   // patch is dead by then), one round for all 64 filters, and every thread finishes eight tiles of one filter
   __syncthreads();                                     // the last fill's patch reads are done
   {
-    float* zw = lds + ((2 * wave) * 32 + 4 * kk) * FZP + t;
+    // accumulator register r of a lane is tile (r & 3) + 8 (r >> 2) + 4 kk of filter nb * 32 + t: four consecutive tiles per r >> 2
+    float* zw = lds + ((2 * wave) * 64 + t) * FZP + 4 * kk;
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float m0 = acc[0][nb][r], m1 = acc[1][nb][r], m2 = acc[2][nb][r], m3 = acc[3][nb][r];
-        const int row = (r & 3) + 8 * (r >> 2);
-        zw[row * FZP + nb * 32] = (m0 + m1) + m2;
-        zw[(32 + row) * FZP + nb * 32] = (m1 - m2) - m3;
+      for (int rg = 0; rg < 4; ++rg) {
+        float4 c0v, c1v;
+        float* a0 = reinterpret_cast<float*>(&c0v);
+        float* a1 = reinterpret_cast<float*>(&c1v);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int r = 4 * rg + i;
+          const float m0 = acc[0][nb][r], m1 = acc[1][nb][r], m2 = acc[2][nb][r], m3 = acc[3][nb][r];
+          a0[i] = (m0 + m1) + m2;
+          a1[i] = (m1 - m2) - m3;
+        }
+        *reinterpret_cast<float4*>(zw + (nb * 32) * FZP + 8 * rg) = c0v;
+        *reinterpret_cast<float4*>(zw + (64 + nb * 32) * FZP + 8 * rg) = c1v;
       }
   }
   const int n = tid & 63, tg = tid >> 6;               // thread: filter n, tiles 8 tg .. 8 tg + 7 (tile row tg of the block)
@@ -264,7 +304,7 @@ __global__ __launch_bounds__(256, 2) void wino_fused_kernel(WinoSrc src, int B, 
       agv[q][2] = ok ? ap[(long)W * ag.agld] : 0.f; agv[q][3] = ok ? ap[(long)W * ag.agld + ag.agld] : 0.f;
     }
   }
-  if (accumulate) {
+  if (accumulate & 1) {
 #pragma unroll
     for (int q = 0; q < FT_W; ++q) {
       const int tj = bw * FT_W + q;
@@ -277,13 +317,24 @@ __global__ __launch_bounds__(256, 2) void wino_fused_kernel(WinoSrc src, int B, 
   __syncthreads();
   const float bsv = bias ? bias[co] : 0.f;
   double ssum = 0.0, ssq = 0.0;
+  float zall[4][2][FT_W];                              // [transform row][output column][tile of this thread's tile row]
+  {
+    const float* zp = lds + n * FZP + tg * FT_W;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int h = 0; h < FT_W / 4; ++h) {
+          const float4 v = *reinterpret_cast<const float4*>(zp + ((2 * i + c) * 64) * FZP + 4 * h);
+          zall[i][c][4 * h] = v.x; zall[i][c][4 * h + 1] = v.y; zall[i][c][4 * h + 2] = v.z; zall[i][c][4 * h + 3] = v.w;
+        }
+  }
 #pragma unroll
   for (int q = 0; q < FT_W; ++q) {
-    const int tl = tg * FT_W + q;
-    const float* zp = lds + tl * FZP + n;
     float z0[4], z1[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { z0[i] = zp[(2 * i) * 32 * FZP]; z1[i] = zp[(2 * i + 1) * 32 * FZP]; }
+    for (int i = 0; i < 4; ++i) { z0[i] = zall[i][0][q]; z1[i] = zall[i][1][q]; }
     float o[4];                                        // (0,0) (0,1) (1,0) (1,1)
     o[0] = (z0[0] + z0[1]) + z0[2]; o[1] = (z1[0] + z1[1]) + z1[2];
     o[2] = (z0[1] - z0[2]) - z0[3]; o[3] = (z1[1] - z1[2]) - z1[3];
@@ -298,11 +349,17 @@ __global__ __launch_bounds__(256, 2) void wino_fused_kernel(WinoSrc src, int B, 
 #pragma unroll
         for (int k = 0; k < 4; ++k) o[k] *= segsde_act_grad_from_out(agv[q][k], ag.agkind);
       }
-      if (accumulate) {     // a data-gradient added onto the gradient another consumer of the tensor left there
+      if (accumulate & 1) { // a data-gradient added onto the gradient another consumer of the tensor left there
 #pragma unroll
         for (int k = 0; k < 4; ++k) o[k] += oldv[q][k];
       }
-      yp[0] = o[0]; yp[ldy] = o[1]; yp[(long)W * ldy] = o[2]; yp[(long)W * ldy + ldy] = o[3];
+#ifdef WINO_DBG_FEW_STORES     // phase-cost probe: one tile of eight is stored
+      if (q == 0)
+#endif
+      if (accumulate & 2) {   // streaming stores (the launcher sets the bit for outputs that no cache level can hold)
+        __builtin_nontemporal_store(o[0], yp); __builtin_nontemporal_store(o[1], yp + ldy);
+        __builtin_nontemporal_store(o[2], yp + (long)W * ldy); __builtin_nontemporal_store(o[3], yp + (long)W * ldy + ldy);
+      } else { yp[0] = o[0]; yp[ldy] = o[1]; yp[(long)W * ldy] = o[2]; yp[(long)W * ldy + ldy] = o[3]; }
       if (STATS) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) { const double v = (double)o[k]; ssum += v; ssq += v * v; }
@@ -315,8 +372,8 @@ __global__ __launch_bounds__(256, 2) void wino_fused_kernel(WinoSrc src, int B, 
     if (tid < 64) {
       double a = 0.0, c2 = 0.0;
       for (int l = 0; l < 4; ++l) { a += sh[l * 64 + tid]; c2 += sh[256 + l * 64 + tid]; }
-      part[((long)blockIdx.x * 2 + 0) * Co + co0 + tid] = a;
-      part[((long)blockIdx.x * 2 + 1) * Co + co0 + tid] = c2;
+      part[((long)bidx * 2 + 0) * Co + co0 + tid] = a;
+      part[((long)bidx * 2 + 1) * Co + co0 + tid] = c2;
     }
   }
 }
@@ -496,6 +553,12 @@ int launch_fused(const WinoSrc& src, int B, int H, int W, int C, int reflect, co
                  float* y, int ldy, int accumulate, double* stats, const WinoAg& ag, void* stream) {
   const dim3 grid((unsigned)fused_blocks(B, H, W), (unsigned)(Cout / 64));
   const bool ublk = segsde_wino_ublk() != 0;
+  // Outputs far beyond the 256 MiB of memory-side cache are written with streaming stores: nothing of them would be found in a cache by
+  // their reader anyway, and they no longer push the patches' halo rows (re-read by the neighbouring workgroups) out of L2 / MALL
+  // (probe_r06_wino_nt.log: 128 -> 128 @128x256, a 268 MB output, -6 %; small maps unchanged).  SEGSDE_WINO_NT_MB: threshold, 0 = never.
+  static long nt_bytes = -1;
+  if (nt_bytes < 0) { const char* e = getenv("SEGSDE_WINO_NT_MB"); nt_bytes = (e ? atol(e) : 200L) << 20; }
+  accumulate = (accumulate ? 1 : 0) | ((nt_bytes > 0 && (long)B * H * W * Cout * 4 >= nt_bytes) ? 2 : 0);
   auto go = [&](auto k, double* st) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_LDS);
     hipLaunchKernelGGL(k, grid, dim3(256), F_LDS, ST(stream), src, B, H, W, C, reflect, u_kn, ldu, Cout, bias, act, y, ldy, st, accumulate, ag);

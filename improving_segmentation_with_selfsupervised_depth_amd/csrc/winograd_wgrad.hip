@@ -161,45 +161,57 @@ __global__ __launch_bounds__(256, MINB) void wino_wgrad_fused_kernel(WgradP p) {
     const float* xp = X + xl;
     const float* yp = Y + yl;
     constexpr int NS = G::NT / 2;
-    float rv[2][8], yv[2][8];
-    auto fetch = [&](int s, int slot) {
+    // Software-pipelined step (round 6, like wino_fused_kernel): the operands of step s + 1 are formed during step s, and every
+    // LDS read / vector instruction of a step sits in the shadow of one of its eight MFMAs -- slots 0..3 issue the sixteen reads
+    // of the next step (four each), slots 4..7 the sixteen additions that turn them into its operands.  Before, the sixteen reads
+    // came in one bunch and the twenty additions stood in front of the MFMAs that use them: a wave alone on its SIMD (the sibling
+    // workgroup waiting for its stage) could not keep the matrix pipe fed.
+    float rv[8], yv[8], An[2][4], Bn[2][2][4], e1k = 0.f;
+    auto rd_x = [&](int s, int h) {            // raw pixels of step s: patch columns 2 h, 2 h + 1 of both rows
       const int th = s >> 2, tw = 2 * (s & 3);
       const float* xq = xp + ((2 * th) * PW + 2 * tw) * KC;
+#pragma unroll
+      for (int bb = 2 * h; bb < 2 * h + 2; ++bb) { rv[bb] = xq[xo1 + bb * KC]; rv[4 + bb] = xq[xo2 + bb * KC]; }
+    };
+    auto rd_y = [&](int s, int nb) {           // output gradients of step s, filter half nb
+      const int th = s >> 2, tw = 2 * (s & 3);
       const float* yq = yp + ((2 * th) * 2 * WT_W + 2 * tw) * NC;
 #pragma unroll
-      for (int bb = 0; bb < 4; ++bb) { rv[slot][bb] = xq[xo1 + bb * KC]; rv[slot][4 + bb] = xq[xo2 + bb * KC]; }
-#pragma unroll
-      for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-        for (int bb = 0; bb < 2; ++bb) {
-          yv[slot][4 * nb + bb] = yq[yo0 + bb * NC + 32 * nb];
-          yv[slot][4 * nb + 2 + bb] = yq[yo1 + bb * NC + 32 * nb];
-        }
+      for (int bb = 0; bb < 2; ++bb) { yv[4 * nb + bb] = yq[yo0 + bb * NC + 32 * nb]; yv[4 * nb + 2 + bb] = yq[yo1 + bb * NC + 32 * nb]; }
     };
-    fetch(0, 0);
+    auto form_a = [&](int q, int h) {
+      if (h == 0) {
+        const float e0 = __builtin_fmaf(rv[4], sgn, rv[0]), e1 = __builtin_fmaf(rv[5], sgn, rv[1]), e2 = __builtin_fmaf(rv[6], sgn, rv[2]);
+        An[q][0] = e0 - e2; An[q][1] = e1 + e2; An[q][2] = e2 - e1; e1k = e1;
+      } else {
+        const float e3 = __builtin_fmaf(rv[7], sgn, rv[3]);
+        An[q][3] = e1k - e3;
+      }
+    };
+    auto form_b = [&](int q, int nb, int h) {
+      if (h == 0) {
+        Bn[q][nb][0] = __builtin_fmaf(yv[4 * nb + 2], c1, yv[4 * nb]); Bn[q][nb][3] = __builtin_fmaf(yv[4 * nb + 3], c1, yv[4 * nb + 1]);
+      } else {
+        Bn[q][nb][1] = Bn[q][nb][0] + Bn[q][nb][3]; Bn[q][nb][2] = Bn[q][nb][0] - Bn[q][nb][3];
+      }
+    };
+    rd_x(0, 0); rd_x(0, 1); rd_y(0, 0); rd_y(0, 1);
+    form_a(0, 0); form_a(0, 1); form_b(0, 0, 0); form_b(0, 0, 1); form_b(0, 1, 0); form_b(0, 1, 1);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
-      const int sl = s & 1;
-      if (s + 1 < NS) fetch(s + 1, sl ^ 1);
-      __builtin_amdgcn_sched_barrier(0);
-      float ev[4];
-#pragma unroll
-      for (int bb = 0; bb < 4; ++bb) ev[bb] = __builtin_fmaf(rv[sl][4 + bb], sgn, rv[sl][bb]);
-      const float A0 = ev[0] - ev[2], A1 = ev[1] + ev[2], A2 = ev[2] - ev[1], A3 = ev[1] - ev[3];
-      float Bq[2][4];
-#pragma unroll
-      for (int nb = 0; nb < 2; ++nb) {
-        const float r0 = __builtin_fmaf(yv[sl][4 * nb + 2], c1, yv[sl][4 * nb]), r1 = __builtin_fmaf(yv[sl][4 * nb + 3], c1, yv[sl][4 * nb + 1]);
-        Bq[nb][0] = r0; Bq[nb][1] = r0 + r1; Bq[nb][2] = r0 - r1; Bq[nb][3] = r1;
-      }
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A0, Bq[0][0], acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A0, Bq[1][0], acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A1, Bq[0][1], acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A1, Bq[1][1], acc[1][1], 0, 0, 0);
-      acc[2][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A2, Bq[0][2], acc[2][0], 0, 0, 0);
-      acc[2][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A2, Bq[1][2], acc[2][1], 0, 0, 0);
-      acc[3][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A3, Bq[0][3], acc[3][0], 0, 0, 0);
-      acc[3][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A3, Bq[1][3], acc[3][1], 0, 0, 0);
+      const int q = s & 1;
+      const bool nx = s + 1 < NS;
+#define WG_MF_(j, nb) acc[j][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(An[q][j], Bn[q][nb][j], acc[j][nb], 0, 0, 0); __builtin_amdgcn_sched_barrier(0)
+      WG_MF_(0, 0); if (nx) rd_x(s + 1, 0); __builtin_amdgcn_sched_barrier(0);
+      WG_MF_(0, 1); if (nx) rd_x(s + 1, 1); __builtin_amdgcn_sched_barrier(0);
+      WG_MF_(1, 0); if (nx) rd_y(s + 1, 0); __builtin_amdgcn_sched_barrier(0);
+      WG_MF_(1, 1); if (nx) rd_y(s + 1, 1); __builtin_amdgcn_sched_barrier(0);
+      WG_MF_(2, 0); if (nx) form_a(q ^ 1, 0); __builtin_amdgcn_sched_barrier(0);
+      WG_MF_(2, 1); if (nx) { form_a(q ^ 1, 1); form_b(q ^ 1, 0, 0); } __builtin_amdgcn_sched_barrier(0);
+      WG_MF_(3, 0); if (nx) { form_b(q ^ 1, 0, 1); form_b(q ^ 1, 1, 0); } __builtin_amdgcn_sched_barrier(0);
+      WG_MF_(3, 1); if (nx) form_b(q ^ 1, 1, 1); __builtin_amdgcn_sched_barrier(0);
+#undef WG_MF_
     }
   };
 

@@ -48,6 +48,9 @@ inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset
 inline hipError_t hipMemset(void* p, int v, size_t n) { memset(p, v, n); return 0; }
 inline hipError_t hipMalloc(void** p, size_t n) { *p = malloc(n); return *p ? 0 : 2; }
 inline hipError_t hipGetDevice(int* d) { *d = 0; return 0; }
+// two "CUs": persistent kernels (wino_fused_kernel) then run four workgroups that each walk over several items
+enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount = 63 };
+inline hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t, int) { *v = 2; return 0; }
 inline hipError_t hipDeviceSynchronize() { return 0; }
 inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 enum hipMemcpyKind { hipMemcpyDeviceToDevice = 3 };
