@@ -167,6 +167,10 @@ def cpu_baseline(workload, H, W, budget_s):
     sd = {k: (v.requires_grad_(True) if v.is_floating_point() and "running" not in k else v) for k, v in sd.items()}
     inp = synthetic_inputs(B, H, W, "cpu", 99, with_labels=cfg.get("segmentation_name") is not None)
     lo = P.MonodepthLossOracle(**loss_cfg(B, H, W)["training"]["monodepth_loss"], batch_size=B)
+    # the same tail as the GPU step: clip_grad_norm_ (sgd workloads, train.py:516-524) + the stock optimizer's step
+    leaves = [v for v in sd.values() if v.is_floating_point() and v.requires_grad]
+    opt_name = WORKLOADS[workload][3]
+    opt = torch.optim.SGD(leaves, lr=1e-2, momentum=0.9, weight_decay=5e-4) if opt_name == "sgd" else torch.optim.Adam(leaves, lr=1e-4)
 
     def step():
         for v in sd.values():
@@ -181,6 +185,9 @@ def cpu_baseline(workload, H, W, budget_s):
                 seg = (seg + S.cross_entropy2d(out["intermediate_semantics"], inp["lbl"])) / 2
             total = total + seg
         total.backward()
+        if opt_name == "sgd":
+            torch.nn.utils.clip_grad_norm_([v for v in leaves if v.grad is not None], 10.0)
+        opt.step()
 
     t0 = time.time()
     step()
@@ -194,7 +201,8 @@ def cpu_baseline(workload, H, W, budget_s):
     med = float(np.median(times))
     return {"value": B / med, "unit": "img/s", "cores": cores, "kind": "port",
             "sample": "oracle (CPU PyTorch restatement, validated against the reference): %s at batch %d, 1 warm-up step "
-                      "(%.1f s) + %d timed train steps fwd+loss+bwd (median %.2f s, min %.2f s), %d threads on %s, torch %s"
+                      "(%.1f s) + %d timed train steps fwd + losses + ONE backward() of their sum + clip_grad_norm_ + optimizer step, "
+                      "like the GPU's `summed` step (median %.2f s, min %.2f s), %d threads on %s, torch %s"
                       % (workload_model, B, warm, len(times), med, min(times), cores, cpu_model_name(), torch.__version__)}
 
 
@@ -656,7 +664,12 @@ def main():
         gflop_img = GFLOP_PER_IMG[args.workload]
         res["step_tflops"] = value * gflop_img / 1e3 / world
         roof = {"bound": "mfma", "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s", "traffic": None,
-                "kernel": "conv_igemm_kernel (implicit-GEMM forward + data-gradient, v_mfma_f32_32x32x2_f32)"}
+                "kernel": "CLASS: every forward + data-gradient call of the C ABI's convolution entries, whatever kernel it runs -- "
+                          "conv_igemm_kernel (direct / upsample-folded; its own figure: roofline.direct), wino_fused_kernel "
+                          "(roofline.winograd_fused), grouped Winograd calls (roofline.winograd); v_mfma_f32_32x32x2_f32 throughout",
+                "recompute": "frac = launches x avg_launch_executed_gflop / (launches x avg_launch_ms) / peak; every sub-block carries the "
+                             "same three numbers for its own kernel (launches, avg_launch_ms, avg_launch_executed_gflop), to be checked "
+                             "against that kernel's line of the rocprofv3 trace in profiles/"}
         if prof:
             agg = {}
             layers = {}
@@ -738,6 +751,7 @@ def main():
                 ff, ft, fn_, fx = (sum(v[i] for v in wfl) for i in range(4))
                 roof["winograd_fused"] = {"kernel": "wino_fused_kernel (both transforms inside the kernel, 64..256 channels)",
                                           "launches": fn_, "ms_per_step": ft / args.steps * 1e3, "achieved": ff / ft / 1e12,
+                                          "avg_launch_ms": ft / fn_ * 1e3, "avg_launch_executed_gflop": fx / fn_ / 1e9,
                                           "executed_achieved": fx / ft / 1e12,
                                           "executed_frac": fx / ft / 1e12 / PEAK_FP32_MATRIX_TFLOPS, "share_of_step": ft / dt}
             if wl:
@@ -747,15 +761,19 @@ def main():
                                     "note": "both Winograd routes (grouped: one call = input transform + 16 position GEMMs + output "
                                             "transform; one-kernel: see winograd_fused); executed = 16/36 of the algorithmic "
                                             "multiply-adds over the whole call's time"}
-                roof["direct"] = {"launches": nl - wn, "achieved": (fl - wf) / (tt - wt) / 1e12,
+                roof["direct"] = {"kernel": "conv_igemm_kernel (implicit-GEMM forward + data-gradient, direct and upsample-folded launches)",
+                                  "launches": nl - wn, "achieved": (fl - wf) / (tt - wt) / 1e12,
                                   "executed_achieved": (ex - wx) / (tt - wt) / 1e12,
-                                  "executed_frac": (ex - wx) / (tt - wt) / 1e12 / PEAK_FP32_MATRIX_TFLOPS}
+                                  "executed_frac": (ex - wx) / (tt - wt) / 1e12 / PEAK_FP32_MATRIX_TFLOPS,
+                                  "ms_per_step": (tt - wt) / args.steps * 1e3, "avg_launch_ms": (tt - wt) / (nl - wn) * 1e3,
+                                  "avg_launch_executed_gflop": (ex - wx) / (nl - wn) / 1e9, "share_of_step": (tt - wt) / dt}
             wgf = [v for (kind, tag), v in layers.items() if kind == "conv_wgrad" and tag.endswith(" wino-fused")]
             if wgf:
                 gf_, gt_, gn_, gx_ = (sum(v[i] for v in wgf) for i in range(4))
                 roof["winograd_wgrad_fused"] = {"kernel": "wino_wgrad_fused_kernel (csrc/winograd_wgrad.hip: both operand transforms inside the "
                                                           "kernel, LDS-DMA staging) + wino_wgrad_finish_kernel",
                                                 "launches": gn_, "ms_per_step": gt_ / args.steps * 1e3, "achieved": gf_ / gt_ / 1e12,
+                                                "avg_launch_ms": gt_ / gn_ * 1e3, "avg_launch_executed_gflop": gx_ / gn_ / 1e9,
                                                 "executed_achieved": gx_ / gt_ / 1e12,
                                                 "executed_frac": gx_ / gt_ / 1e12 / PEAK_FP32_MATRIX_TFLOPS, "share_of_step": gt_ / dt}
             roof.update(achieved=ex / tt / 1e12, frac=ex / tt / 1e12 / PEAK_FP32_MATRIX_TFLOPS,

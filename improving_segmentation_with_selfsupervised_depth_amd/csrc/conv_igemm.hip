@@ -76,6 +76,7 @@ struct ConvP {
   // Grouped weights (the sixteen position GEMMs of a Winograd convolution as one launch, FAST / LDS-DMA path only): a tile
   // whose first row lies in image b of the B-image input reads its weight rows from w + b * wbstride floats.  0: one weight.
   long wbstride;
+  int nt;       // 1: the staged epilogue's full-tile stores are streaming stores (set by the launcher for outputs beyond the caches)
 };
 constexpr int SEGSDE_PAD_CLAMP_ = 3;   // internal (never crosses the ABI)
 
@@ -945,7 +946,7 @@ __global__ __launch_bounds__(256, VAR == 6 ? 3 : 2) void conv_igemm_kernel(ConvP
             v.z *= segsde_act_grad_from_out(yv.z, pe.agkind); v.w *= segsde_act_grad_from_out(yv.w, pe.agkind);
           }
           if (pe.accum) { v.x += o[t].x; v.y += o[t].y; v.z += o[t].z; v.w += o[t].w; }
-          segsde_buffer_store4(rd, vo, so, v);
+          if (pe.nt) segsde_buffer_store4_nt(rd, vo, so, v); else segsde_buffer_store4(rd, vo, so, v);
           so += step; soa += stepa;
         }
         return;
@@ -1854,6 +1855,12 @@ ConvP make_params(const segsde_conv_desc* d, const float* x0, const float* x1, c
   p.kh0 = 0; p.khs = 1; p.kw0 = 0; p.kws = 1; p.KWf = p.KW; p.Kfull = p.Ktot; p.os = 1; p.oph = 0; p.opw = 0; p.OHf = p.Ho; p.OWf = p.Wo;
   p.stats = nullptr;
   p.accum = d->accumulate ? 1 : 0;
+  {
+    // streaming stores for outputs far beyond the memory-side cache (SEGSDE_CONV_NT_MB: threshold in MiB, 0 = never; default off until measured)
+    static long nt_bytes = -1;
+    if (nt_bytes < 0) { const char* e = getenv("SEGSDE_CONV_NT_MB"); nt_bytes = (e ? atol(e) : 0L) << 20; }
+    p.nt = (nt_bytes > 0 && (long)p.M * p.N * 4 >= nt_bytes) ? 1 : 0;
+  }
   p.agy = nullptr; p.agld = 0; p.agkind = 0;
   p.lin = d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && d->in_div <= 1 && !d->up0 && !d->sum2x2 && d->C1 == 0 &&
           d->H == d->Ho && d->W == d->Wo;

@@ -37,6 +37,13 @@ __device__ __forceinline__ void segsde_buffer_store4(segsde_rsrc r, unsigned vof
   d.x = __float_as_uint(v.x); d.y = __float_as_uint(v.y); d.z = __float_as_uint(v.z); d.w = __float_as_uint(v.w);
   __builtin_amdgcn_raw_buffer_store_b128(d, r, voff, soff, 0);   // out-of-range voff: the store is dropped
 }
+// the same store with the non-temporal ("nt": streaming) cache policy -- for outputs no cache level can hold until they are read
+__device__ __forceinline__ void segsde_buffer_store4_nt(segsde_rsrc r, unsigned voff, unsigned soff, float4 v) {
+  typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+  u32x4_t d;
+  d.x = __float_as_uint(v.x); d.y = __float_as_uint(v.y); d.z = __float_as_uint(v.z); d.w = __float_as_uint(v.w);
+  __builtin_amdgcn_raw_buffer_store_b128(d, r, voff, soff, 2);
+}
 // LDS-DMA: the same raw buffer load, but the 16 bytes of lane l land in LDS at lds_wave_base + 16*l without passing
 // through VGPRs (buffer_load_dwordx4 ... offen lds; destination = M0 + 16*lane, so the LDS image of one instruction is
 // 1 KiB lane-linear -- a swizzled layout is obtained by permuting which SOURCE element each lane fetches).  Out-of-range

@@ -68,9 +68,11 @@ __global__ __launch_bounds__(256, 2) void wino_fused_kernel(WinoSrc src, int B, 
   const int nbw = (W2 + FT_W - 1) / FT_W, nbh = (H2 + FT_H - 1) / FT_H;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int t = lane & 31, kk = lane >> 5, th = t >> 3, tw = t & 7;
-  // (round 6, negative: PERSISTENT workgroups walking over their share of the items -- so that an item's output stores drain under
-  // the next item's fill -- spill: with the item loop around it the compiler keeps ~20 more values live across the K loop, whose
-  // 128 accumulators + prefetch registers leave 10 free; 55-87 spilled registers, 1.25-1.3x slower.  experiments_r06.md)
+  // (round 6, negative twice: PERSISTENT workgroups walking over their share of the items.  First build: 55-112 spilled registers
+  // (values of the previous item looked live across the item loop), 1.25x slower; with per-item re-initialisation no spill, but
+  // still 3-6 % slower than one workgroup per item, persistent grid or not -- the output stores that cost a tenth of this kernel
+  // (probe_r06_wino_fewstores.log) are not a slot-retirement effect.  16-byte stores (thread = four filters): 2-4 % slower.
+  // profiles/experiments_r06.md)
   const int bidx = blockIdx.x;
   int blk = segsde_xcd_remap(bidx, gridDim.x);
   const int bw = blk % nbw; blk /= nbw;
