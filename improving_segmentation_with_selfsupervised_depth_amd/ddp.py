@@ -107,6 +107,7 @@ class _Bucket:
         self.reset()
 
     def reset(self):
+        self.todo = []                              # members whose gradient still has to be copied into its slot (flush_pack)
         self.ready = [False] * len(self.params)
         self.had = [False] * len(self.params)       # packed from a gradient (not a zero fill) this step
         self.pending = len(self.params)
@@ -121,19 +122,33 @@ class _Bucket:
         return g is not None and g.data_ptr() == self.ptrs[i]
 
     def pack(self, i):
+        """member i's gradient into its slot.  A gradient that lives in a tensor of its own (biases, parameters with several
+        consumers: ~120 of the R101 joint model's 880) is only NOTED here; ``flush_pack`` moves all of a bucket's in one
+        multi-tensor copy right before the collective (one launch per bucket instead of one small copy kernel per parameter)."""
         g = self.params[i].grad
         if g is None:
             self.slots[i].zero_()
+            self.todo = [j for j in self.todo if j != i]
         elif g.data_ptr() == self.ptrs[i]:
             self.had[i] = True                      # written in place by its backward kernel (or accumulated in place): nothing to move
             ZERO_COPY["taken"] += 1
         else:
-            self.slots[i].copy_(g.reshape(-1))
+            if i not in self.todo:
+                self.todo.append(i)
+                ZERO_COPY["copied"] += 1
             self.had[i] = True
-            ZERO_COPY["copied"] += 1
+
+    def flush_pack(self):
+        if self.todo:
+            srcs = [self.params[i].grad for i in self.todo]
+            keep = [k for k, g in enumerate(srcs) if g is not None and g.data_ptr() != self.ptrs[self.todo[k]]]
+            if keep:
+                torch._foreach_copy_([self.views[self.todo[k]] for k in keep], [srcs[k] for k in keep])
+            self.todo = []
 
     def own(self):
         """the collective is about to run in place on ``flat``: the members' p.grad leave the bucket until finish()"""
+        self.flush_pack()
         for p in self.params:
             p.grad = None
         self.launched = True

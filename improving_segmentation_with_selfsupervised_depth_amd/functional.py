@@ -28,6 +28,23 @@ def _grad_dest(param):
     return ddp.grad_destination(param) if ddp._GRAD_DEST else None
 
 
+def fp32_region(fn):
+    """Entry points the reference calls under ``torch.cuda.amp.autocast`` when ``amp: True`` (train.py:468, 502: the model's forward
+    and the segmentation loss).  This package computes in fp32 -- at least the reference's precision -- so autocast is switched off
+    for the duration of the call (ATen helpers inside, e.g. the pose networks' ``torch.cat``, then stay fp32 whatever their
+    autocast policy) and floating-point tensor arguments arrive as fp32.  The reference's GradScaler protocol around it works
+    unchanged: every backward kernel is linear in the incoming gradient, and scaling by a power of two is exact."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(*args, **kwargs):
+        if torch.is_autocast_enabled("cuda"):
+            with torch.autocast(device_type="cuda", enabled=False):
+                return fn(*args, **kwargs)
+        return fn(*args, **kwargs)
+    return wrapped
+
+
 def fusion(kind, taken):
     c = FUSIONS.setdefault(kind, [0, 0])
     c[0 if taken else 1] += 1

@@ -27,6 +27,7 @@ class _CrossEntropyFn(Function):
         return H.cross_entropy_backward(logits, target, IGNORE_INDEX, scale, cw, pw), None, None, None, None
 
 
+@Fn.fp32_region
 def cross_entropy2d(input, target, class_weight=None, pixel_weights=None):
     """reference loss.py:17-37.  input: [N,C,H,W] logits (NCHW-logical), target: int64 [N,Ht,Wt]."""
     n, c, h, w = input.size()

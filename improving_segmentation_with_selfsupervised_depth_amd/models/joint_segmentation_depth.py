@@ -60,6 +60,7 @@ class JointSegmentationMonodepth(nn.Module):
     def predict_test_disp(self, x):
         return self.models["depth"](self.models["encoder"](x[("color", 0, 0)]))
 
+    @Fn.fp32_region
     def forward(self, x):
         from ..loss.monodepth_loss import LazyOutputs
         outputs, inputs = LazyOutputs(), x     # a dict; MonodepthLoss registers its API-visible grids / depths as lazy entries

@@ -142,7 +142,7 @@ def train_step_segmentation_unlabeled(model, ema_model, monodepth_loss_calculato
                                       depthmix_online_depth=True, monodepth_lambda=1.0, consistency_weight=1.0,
                                       backward_first_pseudo_label=False, depthcomp_margin=0.03,
                                       depthcomp_foreground_threshold=0.0, color_jitter=False, blur=False, reducer=None,
-                                      last_backward=True, mix_use_gt=False):
+                                      last_backward=True, mix_use_gt=False, scaler=None):
     """Trainer.train_step_segmentation_unlabeled (train.py:653-724) with the ``self.*`` values as arguments: teacher
     forward -> softmax; student forward on the unmixed frames -> monodepth loss backward and the online depth; mix mask;
     DepthMix of images and teacher softmax; student forward on the mixed frames; pseudo-label loss backward.
@@ -178,6 +178,9 @@ def train_step_segmentation_unlabeled(model, ema_model, monodepth_loss_calculato
             if new:
                 torch._foreach_add_(new, old)
 
+    def _scaled(loss):           # train.py:687, 696, 724: every loss of the unlabeled step goes through the GradScaler too
+        return scaler.scale(loss) if scaler is not None else loss
+
     def strong_transform(parameters, data=None, target=None):
         data, target = transformsgpu.mix(mask=parameters["Mix"], data=data, target=target)
         data, target = transformsgpu.color_jitter(jitter=parameters["ColorJitter"], data=data, target=target)
@@ -207,14 +210,14 @@ def train_step_segmentation_unlabeled(model, ema_model, monodepth_loss_calculato
                 mono_losses = monodepth_loss_calculator.compute_losses(unlabeled_inputs, outputs_1)
                 mono_loss = monodepth_lambda * mono_losses["loss"]
                 with nosync():
-                    mono_loss.backward(retain_graph=backward_first_pseudo_label)
+                    _scaled(mono_loss).backward(retain_graph=backward_first_pseudo_label)
                 depths = normalize_online_depth(outputs_1[("disp", 0)])
             else:
                 depths = unlabeled_inputs["pseudo_depth"]
             if backward_first_pseudo_label:
                 L_1, _ = calc_pseudo_label_loss(softmax_u_w, outputs_1["semantics"], consistency_weight)
                 with nosync():
-                    L_1.backward()
+                    _scaled(L_1).backward()
             del outputs_1
         elif "pseudo_depth" in unlabeled_inputs:
             depths = unlabeled_inputs["pseudo_depth"]
@@ -237,10 +240,10 @@ def train_step_segmentation_unlabeled(model, ema_model, monodepth_loss_calculato
     if last_backward:
         if reducer is not None:
             reducer.complete_unreachable([L_2])
-        L_2.backward()
+        _scaled(L_2).backward()
     else:
         with nosync():
-            L_2.backward()
+            _scaled(L_2).backward()
     train_step_segmentation_unlabeled.last = {"MixMask": MixMask, "depths": depths, "pseudo_label": pseudo_label,
                                               "softmax_u_w": softmax_u_w, "inputs_u_s": inputs_u_s}   # debug images :726-744
     return L_2 + L_1, mono_loss
@@ -305,18 +308,27 @@ def get_train_params(model, cfg):
 
 
 def train_step(model, optimizer, inputs, step, cfg, loss_fn, monodepth_loss_calculator, ema_model=None, scheduler=None,
-               unlabeled_inputs=None, reducer=None, mIoU=0):
+               unlabeled_inputs=None, reducer=None, mIoU=0, scaler=None):
     """``Trainer.train_step`` (train.py:442-549) as a free function over the objects the method reads from ``self``
     (``cfg`` is the same nested dict; ``unlabeled_inputs`` the batch the method draws from its unlabeled loader when
     ``cfg["training"]["unlabeled_segmentation"]`` is set).  Same order of forward / ``backward()`` calls, gradient clipping,
-    optimizer / scheduler step and EMA update; returns the same dict of detached losses.  fp32 only (``amp: False``, as in
-    every shipped non-dec6 config).  ``reducer`` (ddp.GradAllReducer): every backward but the step's last runs under
-    ``no_sync()`` and ``finish()`` is called before the clipping."""
+    optimizer / scheduler step and EMA update; returns the same dict of detached losses.  ``amp: True`` (the dec6 configs,
+    train.py:300,468-528) keeps the reference's protocol -- forward and segmentation loss under ``autocast``, every loss through
+    ``scaler.scale(...)``, ``unscale_`` before the clipping, ``scaler.step`` / ``update`` -- while the kernels compute in fp32
+    (functional.fp32_region): at least the reference's precision, no reduced-precision speed-up.  ``scaler``: a
+    ``torch.amp.GradScaler`` kept by the caller across steps (one is created and kept on the optimizer object otherwise).
+    ``reducer`` (ddp.GradAllReducer): every backward but the step's last runs under ``no_sync()`` and ``finish()`` is called
+    before the clipping."""
     import contextlib
     from .loss.loss import berhu
     tr = cfg["training"]
-    if tr.get("amp", False):
-        raise NotImplementedError("amp: True is the reference's separate mixed-precision mode; this path computes in fp32")
+    amp = bool(tr.get("amp", False))
+    if scaler is None:
+        scaler = getattr(optimizer, "_segsde_scaler", None)
+        if scaler is None or scaler.is_enabled() != amp:
+            scaler = torch.amp.GradScaler("cuda", enabled=amp)          # train.py:300
+            optimizer._segsde_scaler = scaler
+    autocast = lambda: torch.autocast(device_type="cuda", enabled=amp)   # noqa: E731
     unl = tr.get("unlabeled_segmentation", None)
     dev = next(model.parameters()).device
     model.train()
@@ -349,32 +361,38 @@ def train_step(model, optimizer, inputs, step, cfg, loss_fn, monodepth_loss_calc
     # ``cfg["training"]["defer_trunk_backward"] = False`` switches it off for any configuration.
     if hasattr(model, "defer_trunk_backward"):
         model.defer_trunk_backward = bool(tr.get("defer_trunk_backward", True)) and do_seg and (do_mono or do_pd or unl is not None)
-    outputs = model(inputs)
+    with autocast():
+        outputs = model(inputs)
     if do_mono:
+        if amp:
+            for k, v in list(outputs.items()):       # train.py:472-474
+                if ("depth" in k or "cam_T_cam" in k) and torch.is_tensor(v) and v.dtype != torch.float32:
+                    outputs[k] = v.to(torch.float32)
         monodepth_loss_calculator.generate_images_pred(inputs, outputs)
         mono_loss = tr["monodepth_lambda"] * monodepth_loss_calculator.compute_losses(inputs, outputs)["loss"]
         if tr["feat_dist_lambda"] > 0:
             feat_dist_loss = tr["feat_dist_lambda"] * torch.dist(outputs["encoder_features"], outputs["imnet_features"], p=2)
         mono_total = mono_loss + feat_dist_loss
         with hold(not (do_pd or do_seg)):
-            mono_total.backward(retain_graph=True)
+            scaler.scale(mono_total).backward(retain_graph=True)
     if do_pd:
         with torch.no_grad():      # the bottom tenth of the frame (the ego vehicle) does not count, train.py:491-494
             keep = torch.ones(outputs["disp", 0].shape, device=dev)
             keep[:, :, int(outputs["disp", 0].shape[2] * 0.9):, :] = 0
         pseudo_depth_loss = berhu(outputs["disp", 0], inputs["pseudo_depth"], keep) * tr["pseudo_depth_lambda"]
         with hold(not do_seg):
-            pseudo_depth_loss.backward(retain_graph=True)
+            scaler.scale(pseudo_depth_loss).backward(retain_graph=True)
     if do_seg:
-        segmentation_loss = loss_fn(input=outputs["semantics"], target=inputs["lbl"])
-        if "intermediate_semantics" in outputs:
-            segmentation_loss = (segmentation_loss + loss_fn(input=outputs["intermediate_semantics"], target=inputs["lbl"])) / 2
-        segmentation_loss = segmentation_loss * tr["segmentation_lambda"]
-        segmentation_total = segmentation_loss
+        with autocast():
+            segmentation_loss = loss_fn(input=outputs["semantics"], target=inputs["lbl"])
+            if "intermediate_semantics" in outputs:
+                segmentation_loss = (segmentation_loss + loss_fn(input=outputs["intermediate_semantics"], target=inputs["lbl"])) / 2
+            segmentation_loss = segmentation_loss * tr["segmentation_lambda"]
+            segmentation_total = segmentation_loss
         if reducer is not None and unl is None and (do_mono or do_pd):
             reducer.complete_unreachable([segmentation_total])     # the depth / pose gradients are final: reduce them under this backward
         with hold(unl is None):
-            segmentation_total.backward()
+            scaler.scale(segmentation_total).backward()
         if unl is not None:
             u_loss, u_mono = train_step_segmentation_unlabeled(
                 model, ema_model, monodepth_loss_calculator, unlabeled_inputs, mix_mask=unl.get("mix_mask", None),
@@ -382,7 +400,7 @@ def train_step(model, optimizer, inputs, step, cfg, loss_fn, monodepth_loss_calc
                 consistency_weight=unl["consistency_weight"], backward_first_pseudo_label=unl["backward_first_pseudo_label"],
                 depthcomp_margin=unl["depthcomp_margin"], depthcomp_foreground_threshold=unl["depthcomp_foreground_threshold"],
                 color_jitter=unl.get("color_jitter"), blur=unl.get("blur"), reducer=reducer,
-                mix_use_gt=unl.get("mix_use_gt", False))
+                mix_use_gt=unl.get("mix_use_gt", False), scaler=scaler)
             # train.py:510-514: ``segmentation_total_loss = segmentation_loss`` binds a second NAME to the same tensor and the
             # unlabeled loss is then added IN PLACE -- the reference's returned 'segmentation_loss' includes the unlabeled term
             # whenever the unlabeled step runs (and equals 'segmentation_total_loss'); kept, so that logged curves compare
@@ -393,10 +411,12 @@ def train_step(model, optimizer, inputs, step, cfg, loss_fn, monodepth_loss_calc
     if reducer is not None:
         reducer.finish()
     if tr.get("clip_grad_norm") is not None:
+        scaler.unscale_(optimizer)           # train.py:517-518 (a no-op scaler without amp)
         clipped = get_params(model, ["encoder", "segmentation"]) if tr.get("disable_depth_grad_clip", False) \
             else model.parameters()
         torch.nn.utils.clip_grad_norm_(clipped, tr["clip_grad_norm"])
-    optimizer.step()
+    scaler.step(optimizer)                   # train.py:527-528
+    scaler.update()
     if scheduler is not None:
         if isinstance(scheduler, torch.optim.lr_scheduler.ReduceLROnPlateau):
             scheduler.step(metrics=mIoU)

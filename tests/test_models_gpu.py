@@ -532,6 +532,44 @@ def test_train_step_replay_vs_reference_caller(scenario, defer):
     assert (ran, parked) == want, (ran, parked, want)
 
 
+def test_train_step_under_the_amp_protocol():
+    """``amp: True`` (train.py:300,468-528; the dec6 configs): ``trainer.train_step`` keeps the reference's protocol -- autocast around
+    the forward and the segmentation loss, every loss through ``GradScaler.scale``, ``unscale_`` before the clipping,
+    ``scaler.step`` / ``update`` -- and the kernels compute in fp32 (functional.fp32_region).  Loss scaling by a power of two is
+    exact and every backward kernel is linear in the incoming gradient, so two iterations must reproduce the records of the
+    reference's own fp32 ``Trainer.train_step`` (tests/golden/trainstep.npz) exactly like the ``amp: False`` replay does -- and
+    the scaler must have grown no ``found_inf``."""
+    import numpy as np
+    import os
+    import trainstep_case as TC
+    from conftest import GOLDEN
+    from improving_segmentation_with_selfsupervised_depth_amd import trainer as T
+    from improving_segmentation_with_selfsupervised_depth_amd.loss import get_monodepth_loss, get_segmentation_loss_function
+    from improving_segmentation_with_selfsupervised_depth_amd.models import get_model
+    scenario = "joint"
+    ref = dict(np.load(os.path.join(GOLDEN, "trainstep.npz"), allow_pickle=False))
+    cfg = TC.full_cfg(scenario)
+    cfg["training"]["amp"] = True
+    model = get_model(cfg["model"], TC.NCLS)
+    model.load_state_dict(TC.state_dict(scenario), strict=True)
+    TC.no_dropout(model)
+    model.cuda()
+    o = cfg["training"]["optimizer"]
+    opt = torch.optim.SGD(T.get_train_params(model, cfg), lr=o["lr"], weight_decay=o["weight_decay"], momentum=o["momentum"])
+    loss_fn = get_segmentation_loss_function(cfg)
+    mono = get_monodepth_loss(cfg, is_train=True)
+    mono.tiebreak_noise = {s: n.cuda() for s, n in TC.noise().items()}
+    scaler = torch.amp.GradScaler("cuda", enabled=True)
+    out = {}
+    for it in range(TC.ITERS):
+        before = {k: p.detach().cpu().clone() for k, p in model.named_parameters()}
+        losses = T.train_step(model, opt, TC.batch(100 + it), it, cfg, loss_fn, mono, scaler=scaler)
+        assert all(v.dtype == torch.float32 for v in losses.values())
+        TC.record(out, scenario, it, losses, model, None, before)
+    TC.compare(out, ref, scenario)
+    assert float(scaler.get_scale()) == 65536.0          # no overflow was seen: the scale never backed off
+
+
 def test_skip_gradient_fanout():
     MC.run_skip_gradient_fanout("cuda")
 
