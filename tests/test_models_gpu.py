@@ -564,7 +564,7 @@ def test_train_step_under_the_amp_protocol():
     for it in range(TC.ITERS):
         before = {k: p.detach().cpu().clone() for k, p in model.named_parameters()}
         losses = T.train_step(model, opt, TC.batch(100 + it), it, cfg, loss_fn, mono, scaler=scaler)
-        assert all(v.dtype == torch.float32 for v in losses.values())
+        assert all(v.dtype == torch.float32 for v in losses.values() if v.is_floating_point())   # (absent losses are int zeros, train.py:460-464)
         TC.record(out, scenario, it, losses, model, None, before)
     TC.compare(out, ref, scenario)
     assert float(scaler.get_scale()) == 65536.0          # no overflow was seen: the scale never backed off
