@@ -10,7 +10,7 @@ TAG=${PMC_TAG:-r04}
 rocprofv3 -L > $OUT/${TAG}_counters_list.txt 2>&1 || true
 run() {  # name, counters...
   local name=$1; shift
-  rocprofv3 --kernel-trace --pmc "$@" -d $OUT/pmc_$name -o pmc -- python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing > $OUT/${TAG}_pmc_$name.log 2>&1
+  rocprofv3 --kernel-trace --pmc "$@" -d $OUT/pmc_$name -o pmc -- python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-reference-step > $OUT/${TAG}_pmc_$name.log 2>&1
   local db=$(ls $OUT/pmc_$name/*.db 2>/dev/null | head -1)
   [ -n "$db" ] && python $ROOT/tools/pmc_table.py $db $OUT/${TAG}_pmc_$name.txt > /dev/null
   rm -rf $OUT/pmc_$name      # the databases are tens of MB each: only the summaries travel back
