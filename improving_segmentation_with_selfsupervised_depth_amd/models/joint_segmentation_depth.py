@@ -28,33 +28,35 @@ class JointSegmentationMonodepth(nn.Module):
         # opt-in: one encoder backward per forward however many ``backward()`` calls the training step makes on its losses
         # (train.py:486,499,510 make up to three); see functional.defer_trunk for the contract -- the forward's last backward must
         # release its graph.  trainer.train_step and the INTEGRATION.md shim switch it on per configuration.
-        self.defer_trunk_backward = False
+        import os
+        self.defer_trunk_backward = os.environ.get("SEGSDE_DEFER_TRUNK", "0") not in ("", "0")
+
+    def _run_pose_nets(self, frames):
+        """channel-concatenated frames -> (axisangle, translation), each [B, n_poses, 1, 3]"""
+        return self.models["pose"]([self.models["pose_encoder"](frames)])
 
     def predict_poses(self, inputs, features):
-        """reference :20-70"""
-        outputs = {}
+        """reference :20-70.  Two regimes: "pairs" -- one pass of the pose networks per temporal source frame over
+        (earlier frame, later frame), the matrix inverted for frames before the target --, or every frame in one pass with one pose
+        per source frame.  The stereo frame "s" has no predicted pose (MonodepthLoss takes ``inputs["stereo_T"]`` for it)."""
         key = "color_full_aug" if self.provide_uncropped_for_pose else "color_aug"
+        frame = lambda f: inputs[key, f, 0]                                      # noqa: E731
+        temporal = [(slot, f) for slot, f in enumerate(self.frame_ids[1:]) if f != "s"]
+        outputs = {}
+
+        def emit(f, axisangle, translation, column, invert):
+            outputs[("axisangle", 0, f)] = axisangle
+            outputs[("translation", 0, f)] = translation
+            outputs[("cam_T_cam", 0, f)] = Fn.PoseMatrixFn.apply(axisangle[:, column:column + 1], translation[:, column:column + 1], invert)
+
         if self.num_pose_frames == 2:
-            pose_feats = {f_i: inputs[key, f_i, 0] for f_i in self.frame_ids}
-            for f_i in self.frame_ids[1:]:
-                if f_i == "s":
-                    continue
-                pair = [pose_feats[f_i], pose_feats[0]] if f_i < 0 else [pose_feats[0], pose_feats[f_i]]
-                pose_inputs = [self.models["pose_encoder"](torch.cat(pair, 1))]
-                axisangle, translation = self.models["pose"](pose_inputs)
-                outputs[("axisangle", 0, f_i)] = axisangle
-                outputs[("translation", 0, f_i)] = translation
-                outputs[("cam_T_cam", 0, f_i)] = Fn.PoseMatrixFn.apply(axisangle, translation, f_i < 0)
+            for _, f in temporal:
+                first, second = (f, 0) if f < 0 else (0, f)                      # always in temporal order
+                emit(f, *self._run_pose_nets(torch.cat([frame(first), frame(second)], 1)), 0, f < 0)
         else:
-            # all frames go through the pose network together and all poses are predicted at once (reference :52-68)
-            pose_inputs = torch.cat([inputs[(key, i, 0)] for i in self.frame_ids if i != "s"], 1)
-            pose_inputs = [self.models["pose_encoder"](pose_inputs)]
-            axisangle, translation = self.models["pose"](pose_inputs)
-            for i, f_i in enumerate(self.frame_ids[1:]):
-                if f_i != "s":
-                    outputs[("axisangle", 0, f_i)] = axisangle
-                    outputs[("translation", 0, f_i)] = translation
-                    outputs[("cam_T_cam", 0, f_i)] = Fn.PoseMatrixFn.apply(axisangle[:, i:i + 1], translation[:, i:i + 1], False)
+            both = self._run_pose_nets(torch.cat([frame(f) for f in self.frame_ids if f != "s"], 1))
+            for slot, f in temporal:
+                emit(f, *both, slot, False)
         return outputs
 
     def predict_test_disp(self, x):
@@ -120,19 +122,13 @@ def joint_segmentation_depth(name, backbone_name, segmentation_name, segmentatio
         if segmentation_name is not None:
             models["segmentation"] = get_segmentation_network(segmentation_name, num_ch_enc, (height, width),
                                                               num_classes, segmentation_args, depth_args)
-    if freeze_backbone:
-        for p in models["encoder"].parameters():
-            p.requires_grad = False
-    if not disable_monodepth and freeze_depth:
-        for p in models["depth"].parameters():
-            p.requires_grad = False
-    if not disable_monodepth and freeze_pose:
-        if "pose_encoder" in models:
-            for p in models["pose_encoder"].parameters():
-                p.requires_grad = False
-        for p in models["pose"].parameters():
-            p.requires_grad = False
-    if "segmentation" in models and freeze_segmentation:
-        for p in models["segmentation"].parameters():
-            p.requires_grad = False
+    # which sub-models a freeze flag covers (reference :158-180).  `must`: the reference indexes these without a test, so asking to
+    # freeze a sub-model the configuration does not build (the depth decoder of a PAD model, the pose decoder with disable_pose)
+    # is a KeyError there and here; the pose encoder and the segmentation decoder are frozen only if present
+    frozen = [(freeze_backbone, "encoder", True), (freeze_depth and not disable_monodepth, "depth", True),
+              (freeze_pose and not disable_monodepth, "pose_encoder", False), (freeze_pose and not disable_monodepth, "pose", True),
+              (freeze_segmentation, "segmentation", False)]
+    for flag, name, must in frozen:
+        if flag and (must or name in models):
+            models[name].requires_grad_(False)
     return JointSegmentationMonodepth(models, frame_ids, use_pose_net, num_pose_frames, provide_uncropped_for_pose)
