@@ -478,7 +478,7 @@ def take_fan_view(t):
 # can be flushed by hand (``flush_deferred_trunks``), and a gradient that is still parked at the next forward of the same
 # encoder or at ANY ``optimizer.step()`` raises instead of training on half a gradient.
 class _TrunkState(object):
-    __slots__ = ("roots", "pending", "eboxes", "sentinel", "owner", "passes", "__weakref__")
+    __slots__ = ("roots", "pending", "eboxes", "sentinel", "owner", "passes", "group", "serial", "__weakref__")
 
     def has_pending(self):
         return any(p is not None for p in self.pending)
@@ -486,7 +486,7 @@ class _TrunkState(object):
     def flush(self):
         roots, grads = [], []
         for i, (v, p) in enumerate(zip(self.roots, self.pending)):
-            if p is None:
+            if p is None or not v.requires_grad:
                 continue
             roots.append(v)
             grads.append(p)
@@ -496,7 +496,7 @@ class _TrunkState(object):
                 # tensor inside their kernels, like they do onto a decoder's skip gradient without the gate
                 box["g"], box["fused"] = p, True
         self.pending = [None] * len(self.pending)
-        self.roots = None                    # the encoder graph is consumed by this call
+        self.roots = None                    # the graph behind the gate is consumed by this call
         if _TRUNKS.get(self.owner) is not None and _TRUNKS[self.owner]() is self:
             del _TRUNKS[self.owner]
         if roots:
@@ -504,8 +504,11 @@ class _TrunkState(object):
             torch.autograd.backward(roots, grads)
 
 
-_TRUNKS = {}                 # owner id -> weak reference to the state of that encoder's latest deferred forward (the graph owns it)
+_TRUNKS = {}                 # owner id -> weak reference to the state of that module's latest deferred forward (the graph owns it)
 _TRUNK_HOOK = [None]
+_TRUNK_SERIAL = [0]          # creation order of the gates
+_TRUNK_GROUP = [0]           # one group per model forward: the encoder's gate opens it, gates further up the model join it
+_TASK_GROUPS = {}            # autograd graph-task id -> groups whose gates fired in that (releasing) task
 
 
 def _trunk_states():
@@ -516,7 +519,7 @@ def _trunk_states():
             del _TRUNKS[k]
         else:
             out.append(st)
-    return out
+    return sorted(out, key=lambda st: st.serial)
 
 
 def _trunk_guard(*_a, **_k):
@@ -529,10 +532,12 @@ def _trunk_guard(*_a, **_k):
                 "read, or switch model.defer_trunk_backward off for this configuration." % st.passes)
 
 
-def flush_deferred_trunks():
-    """run the encoder backward of every forward whose feature gradients are still parked (see ``defer_trunk``)"""
-    for st in _trunk_states():
-        if st.has_pending():
+def flush_deferred_trunks(groups=None):
+    """run the parked backward of every gate that still holds gradients (see ``defer_trunk``), the gate created LAST first: a
+    gate further up the model (PAD's, between the two halves of its decoders) back-propagates into the encoder's gate, never
+    the other way round"""
+    for st in reversed(_trunk_states()):
+        if st.has_pending() and (groups is None or st.group in groups):
             st.flush()
 
 
@@ -540,8 +545,24 @@ def pending_deferred_trunks():
     return sum(1 for st in _trunk_states() if st.has_pending())
 
 
+def _flush_after_task(st):
+    """called from a gate's node in a pass that releases its graph: the gates of this forward are flushed ONCE, after the whole
+    graph task has run (an engine callback), so that each of them holds every contribution of the pass -- the encoder's gate is
+    reached both by the decoders' skip connections in the outer task and, later, by the nested backward of a gate above it"""
+    tid = torch._C._current_graph_task_id()
+    groups = _TASK_GROUPS.get(tid)
+    if groups is not None:
+        groups.add(st.group)
+        return
+    _TASK_GROUPS[tid] = {st.group}
+
+    def run():
+        flush_deferred_trunks(_TASK_GROUPS.pop(tid, None))
+    torch.autograd.Variable._execution_engine.queue_callback(run)
+
+
 class TrunkSentinelFn(Function):
-    """identity on the decoders' side of the gate; its only job is to be released by the engine before the gate's node runs"""
+    """identity on the consumers' side of the gate; its only job is to be released by the engine before the gate's node runs"""
 
     @staticmethod
     def forward(ctx, st, *xs):
@@ -555,8 +576,8 @@ class TrunkSentinelFn(Function):
 
 
 class TrunkGateFn(Function):
-    trunk_backwards = 0      # diagnostics / tests: encoder backward passes started by a gate
-    parked_passes = 0        # ... and passes that only parked their feature gradients
+    trunk_backwards = 0      # diagnostics / tests: parked backward passes started by a gate
+    parked_passes = 0        # ... and passes that only parked their gradients
 
     @staticmethod
     def forward(ctx, st, *leaves):
@@ -568,7 +589,7 @@ class TrunkGateFn(Function):
     def backward(ctx, *grads):
         st = ctx.st
         if st.roots is None:
-            raise RuntimeError("deferred trunk backward: the encoder of this forward has already been back-propagated (a pass "
+            raise RuntimeError("deferred trunk backward: the graph behind this gate has already been back-propagated (a pass "
                                "that released its graph came before this one)")
         for i, g in enumerate(grads):
             if g is None:
@@ -582,19 +603,18 @@ class TrunkGateFn(Function):
         except RuntimeError:
             final = True
         if final:
-            st.flush()
+            _flush_after_task(st)
         else:
             TrunkGateFn.parked_passes += 1
         return (None,) * (1 + len(grads))
 
 
-def defer_trunk(feats, owner, n_consumers=0):
-    """feats: the encoder's NHWC features (graph attached).  -> the tensors the decoders read instead: detached leaves behind a
-    TrunkGateFn whose backward parks the feature gradients until a pass releases its graph (see the comment above).
-    n_consumers: decoders that fetch a view of every feature with ``take_fan_view`` (the gradient collector moves to the
-    decoders' side of the gate; on the encoder's side the gate is the one outside consumer)."""
-    if not (torch.is_grad_enabled() and any(f.requires_grad for f in feats)):
-        return feats
+def defer_gate(tensors, owner, eboxes=None, new_group=False):
+    """tensors (graph attached) -> the tensors their consumers read instead: detached leaves behind a TrunkGateFn whose backward
+    parks the incoming gradients until a pass releases its graph (see the comment above).  owner: an id of the calling module
+    (one live gate per owner); new_group: this gate opens a model forward (the encoder's), later gates join its group."""
+    if not (torch.is_grad_enabled() and any(t.requires_grad for t in tensors)):
+        return list(tensors)
     old = _TRUNKS.get(owner)
     old = old() if old is not None else None
     if old is not None and old.has_pending():
@@ -602,21 +622,35 @@ def defer_trunk(feats, owner, n_consumers=0):
     if _TRUNK_HOOK[0] is None:
         from torch.optim.optimizer import register_optimizer_step_pre_hook
         _TRUNK_HOOK[0] = register_optimizer_step_pre_hook(_trunk_guard)
+    if new_group:
+        _TRUNK_GROUP[0] += 1
+    _TRUNK_SERIAL[0] += 1
     st = _TrunkState()
-    st.owner, st.passes, st.sentinel = owner, 0, None
-    st.roots, st.eboxes = [], []
+    st.owner, st.passes, st.sentinel, st.group, st.serial = owner, 0, None, _TRUNK_GROUP[0], _TRUNK_SERIAL[0]
+    st.roots = list(tensors)
+    st.eboxes = list(eboxes) if eboxes is not None else [None] * len(tensors)
+    st.pending = [None] * len(tensors)
+    _TRUNKS[owner] = weakref.ref(st)
+    leaves = [v.detach().requires_grad_(v.requires_grad) for v in st.roots]
+    return list(TrunkSentinelFn.apply(st, *TrunkGateFn.apply(st, *leaves)))
+
+
+def defer_trunk(feats, owner, n_consumers=0):
+    """feats: the encoder's NHWC features (graph attached).  -> the tensors the decoders read instead (``defer_gate``).
+    n_consumers: decoders that fetch a view of every feature with ``take_fan_view`` (the gradient collector moves to the
+    decoders' side of the gate; on the encoder's side the gate is the one outside consumer)."""
+    if not (torch.is_grad_enabled() and any(f.requires_grad for f in feats)):
+        return feats
+    roots, eboxes = [], []
     for f in feats:
         v, box = take_fan_view(f)            # the view the encoder parked for the gate (its gradient collector's box)
-        st.roots.append(v)
-        st.eboxes.append(box)
-    st.pending = [None] * len(feats)
-    _TRUNKS[owner] = weakref.ref(st)
-    leaves = [v.detach().requires_grad_(True) for v in st.roots]
-    outs = TrunkSentinelFn.apply(st, *TrunkGateFn.apply(st, *leaves))
-    for o, box in zip(outs, st.eboxes):
+        roots.append(v)
+        eboxes.append(box)
+    outs = defer_gate(roots, owner, eboxes, new_group=True)
+    for o, box in zip(outs, eboxes):
         if box is not None and n_consumers > 1:
             fan_feature(o, n_consumers, 0, owner=owner)      # parks the decoders' views; they share one in-kernel accumulation
-    return list(outs)
+    return outs
 
 
 class MaxPoolFn(Function):

@@ -67,6 +67,8 @@ class JointSegmentationMonodepth(nn.Module):
         from ..loss.monodepth_loss import LazyOutputs
         outputs, inputs = LazyOutputs(), x     # a dict; MonodepthLoss registers its API-visible grids / depths as lazy entries
         self.models["encoder"].defer_backward = bool(self.defer_trunk_backward)
+        if "mtl_decoder" in self.models:     # PAD's two decoders cross half-way up: a second gate there (PAD.forward)
+            self.models["mtl_decoder"].defer_backward = bool(self.defer_trunk_backward)
         features = self.models["encoder"](inputs["color_aug", 0, 0])
         outputs["bottleneck"] = features[-1]
         if "mtl_decoder" in self.models:

@@ -1,5 +1,6 @@
 """Mirror of models/joint_segmentation_depth_decoder.py (JointSegDepthDecoder, PAD)."""
 import numpy as np
+import torch
 from torch import nn
 
 from .. import functional as Fn
@@ -123,6 +124,17 @@ class PAD(nn.Module):
         second = list(range(di - 1, -1, -1))
         d = self.depth_dec.forward_nhwc(feats, exec_layer=first)
         s = self.seg_dec.forward_nhwc(feats, exec_layer=first)
+        if getattr(self, "defer_backward", False) and torch.is_grad_enabled():
+            # One backward per forward under the reference's call-per-loss step (functional.defer_gate).  The two
+            # decoders exchange attention maps at the distillation layer, so the monodepth loss reaches BOTH first halves (through
+            # `for_depth` and, with the low-resolution disparities, directly) and so does the segmentation loss: without a gate
+            # here the bottleneck-side halves -- the two ASPP modules among them -- are back-propagated once per backward() call.
+            # Everything the first halves hand on goes behind the gate; its parked backward then runs once, into the encoder's gate.
+            dk = list(d)
+            gated = Fn.defer_gate([d[k] for k in dk] + [s[name]], id(self))
+            d = dict(zip(dk, gated[:-1]))
+            s = dict(s)
+            s[name] = gated[-1]
         inter = self.seg_intermediate_head[0](s[name]) if self.side_output else None
         fd = self.sa_depth(d[name])
         fs = self.sa_seg(s[name])

@@ -852,10 +852,11 @@ def run_deferred_trunk_backward(device):
     from improving_segmentation_with_selfsupervised_depth_amd.models.depth_decoder import DepthDecoder
     torch.manual_seed(13)
     enc = ResnetEncoder(18, False).to(device).train()
-    kw = dict(num_ch_dec=[32, 32, 32, 64, 64], max_scale_size=[64, 64])
+    # (sized for the kernel interpreter of the CPU suite: one 64 x 64 image, narrow decoders)
+    kw = dict(num_ch_dec=[16, 16, 16, 32, 32], max_scale_size=[64, 64])
     decs = [DepthDecoder(enc.num_ch_enc, range(4), **kw).to(device).train() for _ in range(2)]
     enc.skip_consumers = 2
-    img = torch.rand(2, 3, 64, 64).to(device)
+    img = torch.rand(1, 3, 64, 64).to(device)
     mods = [enc] + decs
 
     def grads():

@@ -1,6 +1,8 @@
 """CPU: product modules (autograd glue + real kernel sources under the interpreter) vs the reference's golden vectors."""
 import json
 
+import os
+
 import pytest
 import torch
 
@@ -96,5 +98,7 @@ def test_skip_gradient_fanout():
     MC.run_skip_gradient_fanout("cpu")
 
 
+@pytest.mark.skipif(not os.environ.get("SEGSDE_SLOW_TESTS"), reason="~7 min under the interpreter (five ResNet-18 passes); the protocol: "
+                    "tests/test_deferred_gate.py, the models: the GPU suite.  SEGSDE_SLOW_TESTS=1 runs it")
 def test_deferred_trunk_backward():
     MC.run_deferred_trunk_backward("cpu")

@@ -527,8 +527,9 @@ def test_train_step_replay_vs_reference_caller(scenario, defer):
         TC.record(out, scenario, it, losses, model, ema, before)
     TC.compare(out, ref, scenario)
     ran, parked = Fn.TrunkGateFn.trunk_backwards - gate0[0], Fn.TrunkGateFn.parked_passes - gate0[1]
-    # joint: one forward, two calls; depthmix: three forwards per iteration (labeled: 2 calls, unmixed and mixed: 1 call each)
-    want = {"joint": (TC.ITERS, TC.ITERS), "depthmix": (3 * TC.ITERS, TC.ITERS)}[scenario] if defer else (0, 0)
+    # joint: one forward with one gate (the encoder's), two calls.  depthmix: the PAD decoder adds a gate of its own where its two
+    # halves meet -- three forwards per iteration (labeled: 2 calls, unmixed and mixed: 1 call each) x two gates
+    want = {"joint": (TC.ITERS, TC.ITERS), "depthmix": (6 * TC.ITERS, 2 * TC.ITERS)}[scenario] if defer else (0, 0)
     assert (ran, parked) == want, (ran, parked, want)
 
 
