@@ -8,9 +8,20 @@ import collections
 import weakref
 
 import torch
-from torch.autograd import Function
+from torch.autograd import Function as _TorchFunction
 
 from . import hipops as H
+
+
+class Function(_TorchFunction):
+    """torch.autograd.Function whose ``apply`` goes straight to the C++ binding.  The stock Python ``apply`` first looks for a
+    ``setup_context``, asks functorch whether a transform is active and walks the arguments for dead functorch wrappers -- 3-4 us
+    for a 14-argument ConvFn, x 211 Functions per cfg1 step whose whole budget is ~20 us per launch.  Nothing here uses functorch
+    transforms or ``setup_context``; arguments are positional."""
+
+    @classmethod
+    def apply(cls, *args):
+        return super(_TorchFunction, cls).apply(*args)
 
 
 # Fusion hand-offs travel as attributes / shared boxes next to the tensors (conv -> BatchNorm statistics partials, conv -> fused

@@ -1,7 +1,6 @@
 """Mirror of loss/loss.py: cross_entropy2d on the fused HIP log-softmax + NLL kernels (reads NHWC logits in place:
 the reference's NCHW -> (NHW, C) transpose copy, loss.py:25, disappears)."""
 import torch
-from torch.autograd import Function
 
 from .. import functional as Fn
 from .. import hipops as H
@@ -9,7 +8,7 @@ from .. import hipops as H
 IGNORE_INDEX = 250
 
 
-class _CrossEntropyFn(Function):
+class _CrossEntropyFn(Fn.Function):
     @staticmethod
     def forward(ctx, logits, target, class_weight, pixel_weights, mean_over_all):
         logits = Fn._c(logits)

@@ -8,9 +8,9 @@ Gradients flow to ("disp", s) and ("cam_T_cam", 0, f) exactly as in the referenc
 import weakref
 
 import torch
-from torch.autograd import Function
 
 from .. import hipops as H
+from ..functional import Function
 
 _ONES = {}
 

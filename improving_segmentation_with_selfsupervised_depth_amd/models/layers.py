@@ -48,14 +48,20 @@ class weight_pack_scope:
     @staticmethod
     def _prepack(model, scope_id):
         from .. import _lib
-        convs = [m for m in model.modules() if isinstance(m, Conv2d) and (m.weight.is_cuda or _lib.HOST_POINTERS_OK) and m.weight.is_contiguous()
+        # the walk over the module tree once per model (~2 000 generator steps per training step otherwise); a model whose tree
+        # changes later drops the attribute (``del model._segsde_convs``) or simply packs the newcomers at their first forward
+        allc = model.__dict__.get("_segsde_convs")
+        if allc is None:
+            allc = model.__dict__["_segsde_convs"] = [m for m in model.modules() if isinstance(m, Conv2d)]
+        convs = [m for m in allc if (m.weight.is_cuda or _lib.HOST_POINTERS_OK) and m.weight.is_contiguous()
                  and m.weight.dtype == torch.float32 and m.in_channels % 4 == 0]   # (stems pad their weight per call)
         if not convs:
             return
         packs = H.pack_weights_multi([m.weight for m in convs])
         for m, pk in zip(convs, packs):
             w = m.weight
-            m._packs, m._pack_key = pk, (scope_id, w._version, w.data_ptr(), w.device)
+            d = m.__dict__        # (plain attributes, set ~250 times per step: nn.Module.__setattr__ costs 2 us each on a launch-bound step)
+            d["_packs"], d["_pack_key"] = pk, (scope_id, w._version, w.data_ptr(), w.device)
         # the Winograd-transformed packs of the 3x3 / stride-1 convolutions with many channels, likewise in one launch
         # (the one-kernel route's packs have their own layout: two launches, one per layout)
         for kn in (True, False):
@@ -91,13 +97,14 @@ class Conv2d(nn.Conv2d):
     def _weight_packs(self, weight):
         """(forward pack, data-gradient pack) cached for the active weight_pack_scope, None outside one (ConvFn then packs
         per call, as the weights may have been rewritten behind autograd's back)"""
+        d = self.__dict__
         if not _PACK_SCOPE[0]:
-            self._packs = None
+            d["_packs"] = None
             return None
         key = (_PACK_SCOPE[0], weight._version, weight.data_ptr(), weight.device)
-        if key != self._pack_key or self._packs is None:
-            self._packs, self._pack_key = H.pack_weight_both(weight), key
-        return self._packs
+        if key != d["_pack_key"] or d["_packs"] is None:
+            d["_packs"], d["_pack_key"] = H.pack_weight_both(weight), key
+        return d["_packs"]
 
     def forward_image(self, image, mean, std):
         """Network stem: self((image - mean) / std) for an NCHW image, as one layout pass + the dedicated 7x7 / stride-2
@@ -114,7 +121,8 @@ class Conv2d(nn.Conv2d):
             if self._stats_wanted is None and self._stats_offered:
                 self._stats_wanted = False
                 return Fn.StemFn.apply(image, self.weight, mean, std, None, wstem)
-            self._stats_offered = True
+            if not self._stats_offered:
+                self._stats_offered = True
             holder = []
             y = Fn.StemFn.apply(image, self.weight, mean, std, holder, wstem)
             y._bn_partials = (holder[0], y._version, self) if holder and holder[0] is not None else None
@@ -152,7 +160,8 @@ class Conv2d(nn.Conv2d):
             if self._stats_wanted is None and self._stats_offered:
                 self._stats_wanted = False
                 return Fn.ConvFn.apply(x, skip, weight, self.bias, g, act, None, grad_box, packs, x0_act, None, None, wc)
-            self._stats_offered = True
+            if not self._stats_offered:
+                self._stats_offered = True
             holder = []
             y = Fn.ConvFn.apply(x, skip, weight, self.bias, g, act, holder, grad_box, packs, x0_act, None, None, wc)
             y._bn_partials = (holder[0], y._version, self) if holder and holder[0] is not None else None
@@ -199,7 +208,7 @@ class BatchNorm2d(nn.BatchNorm2d):
             partials, version, producer = partials
             if partials.shape[-1] != self.num_features or x._version != version:
                 partials = None
-            else:
+            elif producer._stats_wanted is not True:
                 producer._stats_wanted = True
         if training:
             Fn.fusion("bn_stats_from_conv_epilogue", partials is not None)
