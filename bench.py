@@ -596,33 +596,38 @@ def main():
 
         other = step_summed if args.step == "reference" else step_reference
         n_ref = max(3, min(args.steps, 10))
-        g0 = (Fn_.TrunkGateFn.trunk_backwards, Fn_.TrunkGateFn.parked_passes)
-        other_ms = time_steps(other, n_ref, 2)
-        g1 = (Fn_.TrunkGateFn.trunk_backwards, Fn_.TrunkGateFn.parked_passes)
-        t = torch.tensor([float(np.median(other_ms))], device=dev, dtype=torch.float64)
-        if world > 1:
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        other_med = float(t[0])
-        nodefer_med = None
-        if has_seg and args.step != "reference":
-            ref_cfg["training"]["defer_trunk_backward"] = False         # the same sequence with the encoder walked by every call
-            t = torch.tensor([float(np.median(time_steps(step_reference, 3, 1)))], device=dev, dtype=torch.float64)
-            ref_cfg["training"]["defer_trunk_backward"] = True
+        try:
+            g0 = (Fn_.TrunkGateFn.trunk_backwards, Fn_.TrunkGateFn.parked_passes)
+            other_ms = time_steps(other, n_ref, 2)
+            g1 = (Fn_.TrunkGateFn.trunk_backwards, Fn_.TrunkGateFn.parked_passes)
+            t = torch.tensor([float(np.median(other_ms))], device=dev, dtype=torch.float64)
             if world > 1:
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            nodefer_med = float(t[0])
-        which = "summed" if args.step == "reference" else "reference"
-        ref_block = {"step": which, "ms_per_step": other_med, "img_s": B * world / (other_med * 1e-3), "steps": n_ref,
-                     "backward_calls": backward_calls[which],
-                     "ms_per_step_all": [round(x, 2) for x in other_ms]}
-        if which == "reference":
-            ref_block.update(
-                sequence="trainer.train_step = Trainer.train_step (train.py:442-549): forward, mono_total_loss.backward(retain_graph=True), "
-                         "segmentation_total_loss.backward(), clip_grad_norm_, optimizer.step()" + (" + unlabeled step + EMA" if unlabeled else ""),
-                deferred_trunk_backward=bool(has_seg),
-                encoder_backward_passes_per_step=(g1[0] - g0[0]) / (n_ref + 2) if has_seg else backward_calls[which],
-                parked_passes_per_step=(g1[1] - g0[1]) / (n_ref + 2),
-                ms_per_step_encoder_walked_by_every_call=nodefer_med)
+            other_med = float(t[0])
+            nodefer_med = None
+            if has_seg and args.step != "reference":
+                ref_cfg["training"]["defer_trunk_backward"] = False         # the same sequence with the encoder walked by every call
+                t = torch.tensor([float(np.median(time_steps(step_reference, 3, 1)))], device=dev, dtype=torch.float64)
+                ref_cfg["training"]["defer_trunk_backward"] = True
+                if world > 1:
+                    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                nodefer_med = float(t[0])
+            which = "summed" if args.step == "reference" else "reference"
+            ref_block = {"step": which, "ms_per_step": other_med, "img_s": B * world / (other_med * 1e-3), "steps": n_ref,
+                         "backward_calls": backward_calls[which],
+                         "ms_per_step_all": [round(x, 2) for x in other_ms]}
+            if which == "reference":
+                ref_block.update(
+                    sequence="trainer.train_step = Trainer.train_step (train.py:442-549): forward, mono_total_loss.backward(retain_graph=True), "
+                             "segmentation_total_loss.backward(), clip_grad_norm_, optimizer.step()" + (" + unlabeled step + EMA" if unlabeled else ""),
+                    deferred_trunk_backward=bool(has_seg),
+                    gate_flushes_per_step=(g1[0] - g0[0]) / (n_ref + 2),       # one per gate and forward (PAD: two gates; cfg5: three forwards)
+                    parked_passes_per_step=(g1[1] - g0[1]) / (n_ref + 2),
+                    ms_per_step_encoder_walked_by_every_call=nodefer_med)
+        except Exception as ex:       # the second sequence must never cost the headline its line
+            ref_block = {"step": "reference" if args.step != "reference" else "summed", "error": repr(ex)}
+            model.defer_trunk_backward = False
+            Fn_.flush_deferred_trunks()
     if world > 1:
         t = torch.tensor([dt, med_ms], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -70,9 +70,9 @@ __global__ __launch_bounds__(256, 2) void wino_fused_kernel(WinoSrc src, int B, 
   const int t = lane & 31, kk = lane >> 5, th = t >> 3, tw = t & 7;
   // (round 6, negative twice: PERSISTENT workgroups walking over their share of the items.  First build: 55-112 spilled registers
   // (values of the previous item looked live across the item loop), 1.25x slower; with per-item re-initialisation no spill, but
-  // still 3-6 % slower than one workgroup per item, persistent grid or not -- the output stores that cost a tenth of this kernel
-  // (probe_r06_wino_fewstores.log) are not a slot-retirement effect.  16-byte stores (thread = four filters): 2-4 % slower.
-  // profiles/experiments_r06.md)
+  // still 3-6 % slower than one workgroup per item, persistent grid or not: the epilogue's cost (5-14 % of this kernel, half of it
+  // the store stream, half the vector instructions that finish the tiles) is not a slot-retirement effect.  16-byte stores
+  // (thread = four filters): 2-4 % slower.  profiles/experiments_r06.md)
   const int bidx = blockIdx.x;
   int blk = segsde_xcd_remap(bidx, gridDim.x);
   const int bw = blk % nbw; blk /= nbw;
