@@ -243,6 +243,7 @@ def main():
                          "backward() per loss, the shared encoder back-propagated once through the deferred trunk backward).  The "
                          "default run times `summed` and reports the reference sequence next to it as `reference_step`")
     ap.add_argument("--no-reference-step", action="store_true", help="skip the `reference_step` block of the default run")
+    ap.add_argument("--no-amp-step", action="store_true", help="skip the `amp_step` block (amp: True with f16 convolution operands)")
     ap.add_argument("--bucket-mb", type=float, default=32.0, help="gradient all-reduce bucket size (N > 1)")
     ap.add_argument("--no-overlap", action="store_true",
                     help="N > 1: start every gradient all-reduce after the last backward instead of from the gradient hooks")
@@ -628,6 +629,38 @@ def main():
             ref_block = {"step": "reference" if args.step != "reference" else "summed", "error": repr(ex)}
             model.defer_trunk_backward = False
             Fn_.flush_deferred_trunks()
+    # `amp: True` with the reference's reduced-precision arithmetic (train.py:300,468-528 + torch autocast): the same
+    # trainer.train_step under autocast / GradScaler with the convolutions' operands rounded to fp16 in the kernels
+    # (SEGSDE_AMP_COMPUTE=f16, functional.AMP_COMPUTE).  A workload of its own -- never `value`: the metric is the fp32 line.
+    amp_block = None
+    if ref_block is not None and "error" not in ref_block and not args.no_amp_step:
+        try:
+            old_amp = Fn_.AMP_COMPUTE[0]
+            Fn_.AMP_COMPUTE[0] = "f16"
+            ref_cfg["training"]["amp"] = True
+            n_amp = max(3, min(args.steps, 8))
+            amp_ms = time_steps(step_reference, n_amp, 3)
+            t = torch.tensor([float(np.median(amp_ms))], device=dev, dtype=torch.float64)
+            if world > 1:
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            amp_med = float(t[0])
+            amp_loss = float(step_reference().detach())
+            sc = getattr(optimizer, "_segsde_scaler", None)
+            amp_block = {"ms_per_step": amp_med, "img_s": B * world / (amp_med * 1e-3), "steps": n_amp,
+                         "dtype": "convolution operands rounded to f16 in the kernels (v_mfma_f32_32x32x16_f16), f32 accumulation; "
+                                  "activations, weights, BatchNorm, losses, optimizer f32",
+                         "sequence": "trainer.train_step with amp: True -- autocast around forward and segmentation loss, GradScaler around "
+                                     "every backward / clip / step, like train.py:468-528",
+                         "algorithmic_tflops": B / (amp_med * 1e-3) * GFLOP_PER_IMG[args.workload] / 1e3,
+                         "frac_of_dense_f16_peak_2500": B / (amp_med * 1e-3) * GFLOP_PER_IMG[args.workload] / 1e3 / 2500.0,
+                         "loss_scale": float(sc.get_scale()) if sc is not None and sc.is_enabled() else None,
+                         "loss_after": amp_loss, "speedup_over_f32_headline": med_ms / amp_med,
+                         "ms_per_step_all": [round(x, 2) for x in amp_ms]}
+        except Exception as ex:
+            amp_block = {"error": repr(ex)}
+        finally:
+            Fn_.AMP_COMPUTE[0] = old_amp
+            ref_cfg["training"]["amp"] = False
     if world > 1:
         t = torch.tensor([dt, med_ms], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -664,6 +697,8 @@ def main():
             res["comm"] = comm
         if ref_block is not None:
             res["reference_step" if ref_block["step"] == "reference" else "summed_step"] = ref_block
+        if amp_block is not None:
+            res["amp_step"] = amp_block
         # fusion hand-offs of the timed steps, per step (functional.FUSIONS): a hand-off that stopped working shows up as "missed"
         res["fusions_per_step"] = {k: {kk: vv / args.steps for kk, vv in v.items()} for k, v in Fn.fusion_report().items()}
         res["fusions_per_step"]["upsample_folded_launches"] = {k: v / (args.steps + args.warmup) for k, v in H.UPFOLD_TAKEN.items()}

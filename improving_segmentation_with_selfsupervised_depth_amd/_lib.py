@@ -9,7 +9,7 @@ from ctypes import c_int, c_long, c_float, c_void_p, c_size_t, c_uint64, c_int64
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SEGSDE_LIB") or os.path.join(_HERE, "libsegsde_hip.so")   # override: kernel experiments
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 _LIB = None
 # Set only by the test-suite when it injects the host-interpreted build of the same kernel sources
@@ -32,7 +32,7 @@ class ConvDesc(ctypes.Structure):
     """mirror of ``segsde_conv_desc`` (include/segsde_hip.h)"""
     _fields_ = [(n, c_int) for n in (
         "B", "H", "W", "C0", "C1", "ld0", "ld1", "up0", "Ho", "Wo", "Cout", "ldy", "ldy2", "nsplit",
-        "KH", "KW", "stride", "dil", "pad", "pad_mode", "in_div", "act", "sum2x2", "accumulate")]
+        "KH", "KW", "stride", "dil", "pad", "pad_mode", "in_div", "act", "sum2x2", "accumulate", "compute")]
 
 
 P = c_void_p

@@ -77,6 +77,7 @@ struct ConvP {
   // whose first row lies in image b of the B-image input reads its weight rows from w + b * wbstride floats.  0: one weight.
   long wbstride;
   int nt;       // 1: the staged epilogue's full-tile stores are streaming stores (set by the launcher for outputs beyond the caches)
+  int f16;      // 1: half-precision operands on the LDS-DMA loop (segsde_conv_desc.compute)
 };
 constexpr int SEGSDE_PAD_CLAMP_ = 3;   // internal (never crosses the ABI)
 
@@ -259,8 +260,17 @@ __device__ __forceinline__ float4 fast_fetch(const ConvP& p, const SrcSel& s, in
 // VAR: experiment variants of the LDS-DMA loop (SEGSDE_TUNE="var=N"; 0 = shipped): 1 = all tile loads of a chunk issued
 // up front, 2 = no scheduling fences between the MFMA units, 3 = raised wave priority around the MFMA units, 4 = (with BK = 16)
 // four LDS stages: the loads of chunk k+3 are issued during chunk k, two chunks of loads stay in flight across barriers
-template <int BM, int BN, int WM, int WN, int MODE, int BK, int VAR = 0>
-__global__ __launch_bounds__(256, VAR == 6 ? 3 : 2) void conv_igemm_kernel(ConvP p) {
+// VARX >= 16 (MODE 4 only): HALF-PRECISION OPERANDS, the arithmetic of the reference's `amp: True` mode (torch autocast runs its
+// convolutions on fp16 inputs with fp32 accumulation).  Tiles still travel as fp32 (LDS-DMA cannot convert); a lane's two
+// fragment reads of a 16-deep k block (4 + 4 consecutive floats per operand row) are rounded to eight halves
+// (v_cvt_pk_f16_f32, round to nearest even) and ONE v_mfma_f32_32x32x16_f16 replaces eight v_mfma_f32_32x32x2_f32 -- which k
+// sits in which of the instruction's sixteen slots does not matter as long as both operands agree, and they do (same read
+// pattern).  Accumulators, epilogues, statistics: unchanged fp32.
+template <int BM, int BN, int WM, int WN, int MODE, int BK, int VARX = 0>
+__global__ __launch_bounds__(256, (VARX & 15) == 6 ? 3 : 2) void conv_igemm_kernel(ConvP p) {
+  constexpr int VAR = VARX & 15;
+  constexpr bool F16 = VARX >= 16;
+  static_assert(!F16 || MODE == 4, "half-precision operands: LDS-DMA loop only");
   constexpr bool VEC = MODE >= 1;
   constexpr bool FAST = MODE >= 2;
   constexpr bool ADJ = MODE == 3;
@@ -709,12 +719,28 @@ __global__ __launch_bounds__(256, VAR == 6 ? 3 : 2) void conv_igemm_kernel(ConvP
           for (int u = 0; u < U; ++u) {
             const int g = u / 4, st = u % 4;
             if (st == 2 && g + 1 < NG) fread(buf, g + 1, (g + 1) & 1);
+            if constexpr (F16) {
+              // groups g - 1 (slot 0) and g (slot 1) together are one 16-deep k block: issued once both have been read
+              if ((g & 1) == 1 && st == 0) {
+                f16x8 ha[TM], hb[TN];
+  #pragma unroll
+                for (int i = 0; i < TM; ++i) ha[i] = segsde_pack_f16(fa[0][i], fa[1][i]);
+  #pragma unroll
+                for (int j = 0; j < TN; ++j) hb[j] = segsde_pack_f16(fb[0][j], fb[1][j]);
+  #pragma unroll
+                for (int i = 0; i < TM; ++i)
+  #pragma unroll
+                  for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ha[i], hb[j], (FIRST && u == 4) ? f32x16{} : acc[i][j], 0, 0, 0);
+              }
+            } else {
   #pragma unroll
             for (int i = 0; i < TM; ++i)
   #pragma unroll
               for (int j = 0; j < TN; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(comp(fa[g & 1][i], st), comp(fb[g & 1][j], st),
                                                                  (FIRST && u == 0) ? f32x16{} : acc[i][j], 0, 0, 0);
+            }
             if constexpr (VAR != 1) {
   #pragma unroll
               for (int i = 0; i < AR; ++i)
@@ -1138,9 +1164,15 @@ constexpr int BP = 32;  // pixels per staged chunk
 // ~14 us stay.  tickets == nullptr (default): partial slabs only, a separate reduce kernel follows.
 struct WRed { unsigned* tickets; float* dw; int CtotDst, cOff, taps, srcC0; };
 
-template <int BKT, int BN, int WM, int WN, int MODE>
+// MODEX >= 16 (with MODE 5): half-precision operands, like conv_igemm_kernel's VARX >= 16 -- the eight scalars a lane reads for
+// eight consecutive fp32 MFMAs of a 16-pixel block (pixels 2 u + lane half of two fragment groups) become ONE operand of
+// v_mfma_f32_32x32x16_f16; both operands are read with the same pattern, so the k slots agree
+template <int BKT, int BN, int WM, int WN, int MODEX>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(ConvP p, const float* dy, int lddy, float* part,
                                                          int chunks_per_split, WRed wr) {
+  constexpr int MODE = MODEX & 15;
+  constexpr bool F16 = MODEX >= 16;
+  static_assert(!F16 || MODE == 5, "half-precision operands: the pipelined LDS-DMA loop only");
   // MODE 0: scalar gather, 1: float4 gather, 2: FAST A side + vector dY + rows at least 32 pixels wide (straight-line
   // loop), 3: FAST A side with the general row walk / scalar dY (odd Cout, tiny feature maps), 4: MODE 2 with the tile
   // loads writing LDS themselves (LDS-DMA, see the forward kernel), 5: MODE 4 with the chunk's barrier moved into the chunk
@@ -1549,11 +1581,27 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(ConvP p, const float
           segsde_wait_vmcnt0();
           __syncthreads();
         }
+        if constexpr (F16) {
+          if ((g & 1) == 1 && st == 0) {           // groups g - 1 (slot 0) and g (slot 1): sixteen pixels
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+              const f16x8 ha = segsde_pack_f16(make_float4(fa[0][0][i], fa[0][1][i], fa[0][2][i], fa[0][3][i]),
+                                               make_float4(fa[1][0][i], fa[1][1][i], fa[1][2][i], fa[1][3][i]));
+#pragma unroll
+              for (int j = 0; j < TN; ++j) {
+                const f16x8 hd = segsde_pack_f16(make_float4(fd[0][0][j], fd[0][1][j], fd[0][2][j], fd[0][3][j]),
+                                                 make_float4(fd[1][0][j], fd[1][1][j], fd[1][2][j], fd[1][3][j]));
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ha, hd, acc[i][j], 0, 0, 0);
+              }
+            }
+          }
+        } else {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[g & 1][st][i], fd[g & 1][st][j], acc[i][j], 0, 0, 0);
+        }
         if (u == 12 && left > 0) { issue((unsigned)buf * STG); --left; }
         if (u == 14) fread(buf ^ 1, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
@@ -1861,6 +1909,7 @@ ConvP make_params(const segsde_conv_desc* d, const float* x0, const float* x1, c
     if (nt_bytes < 0) { const char* e = getenv("SEGSDE_CONV_NT_MB"); nt_bytes = (e ? atol(e) : 0L) << 20; }
     p.nt = (nt_bytes > 0 && (long)p.M * p.N * 4 >= nt_bytes) ? 1 : 0;
   }
+  p.f16 = d->compute == 1 ? 1 : 0;
   p.agy = nullptr; p.agld = 0; p.agkind = 0;
   p.lin = d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && d->in_div <= 1 && !d->up0 && !d->sum2x2 && d->C1 == 0 &&
           d->H == d->Ho && d->W == d->Wo;
@@ -1924,8 +1973,10 @@ int launch_igemm(const ConvP& p, hipStream_t stream) {
   if (igemm_fast_ok(p) && p.pad_mode == SEGSDE_PAD_REFLECT_ADJOINT && !(tune().adjfix && !p.sum2x2) && tune().adjfix < 2)
     return tune().var == 8 ? launch_igemm_mode<BM, BN, WM, WN, 3, 32, 8>(p, stream)
            : (tune().adjlds ? launch_igemm_mode<BM, BN, WM, WN, 3, 32>(p, stream) : launch_igemm_mode<BM, BN, WM, WN, 3, 32, 5>(p, stream));
-  if (p.pad_mode == SEGSDE_PAD_CLAMP_)   // upsample-folded class launches (host guarantees the FAST conditions)
-    return igemm_fast_ok(p) ? launch_igemm_mode<BM, BN, WM, WN, 4, 32, 9>(p, stream) : SEGSDE_ERR_UNSUPPORTED;
+  if (p.pad_mode == SEGSDE_PAD_CLAMP_) { // upsample-folded class launches (host guarantees the FAST conditions)
+    if (!igemm_fast_ok(p)) return SEGSDE_ERR_UNSUPPORTED;
+    return p.f16 ? launch_igemm_mode<BM, BN, WM, WN, 4, 32, 16 + 9>(p, stream) : launch_igemm_mode<BM, BN, WM, WN, 4, 32, 9>(p, stream);
+  }
   if (tune().bk64 && bk64_ok(p)) return launch_igemm_mode<BM, BN, WM, WN, 2, 64>(p, stream);
   if (igemm_fast_ok(p) && tune().dma) {
     if (tune().var == 1) return launch_igemm_mode<BM, BN, WM, WN, 4, 32, 1>(p, stream);
@@ -1938,6 +1989,7 @@ int launch_igemm(const ConvP& p, hipStream_t stream) {
     if constexpr (BN == 64) {
       if (tune().var == 6) return launch_igemm_mode<BM, BN, WM, WN, 4, 16, 6>(p, stream);
     }
+    if (p.f16) return launch_igemm_mode<BM, BN, WM, WN, 4, 32, 16>(p, stream);
     return launch_igemm_mode<BM, BN, WM, WN, 4, 32>(p, stream);
   }
   if (igemm_fast_ok(p)) return launch_igemm_mode<BM, BN, WM, WN, 2, 32>(p, stream);
@@ -2237,13 +2289,14 @@ extern "C" int segsde_conv2d_dgrad_actgrad(const segsde_conv_desc* d, const floa
 }
 
 namespace {
-template <int BKT, int BN, int WM, int WN, int MODE>
+template <int BKT, int BN, int WM, int WN, int MODEX>
 int launch_wgrad_mode(const ConvP& p, const float* dy, int lddy, float* ws, int splits, int cps, hipStream_t stream, WRed wr) {
+  constexpr int MODE = MODEX & 15;
   const dim3 grid(segsde_cdiv(p.Ktot, BKT) * segsde_cdiv(p.N, BN) * splits);
   size_t smem = 2 * (size_t)BP * (BKT + BN) * sizeof(float);
   if (MODE == 2 || MODE == 4 || MODE == 5)   // + the four offset tables (padded rows / columns of the two sources)
     smem += 2 * (size_t)((p.Ho - 1) * p.stride + (p.KH - 1) * p.dil + 1 + (p.Wo - 1) * p.stride + (p.KW - 1) * p.dil + 1) * sizeof(unsigned);
-  auto k = conv_wgrad_kernel<BKT, BN, WM, WN, MODE>;
+  auto k = conv_wgrad_kernel<BKT, BN, WM, WN, MODEX>;
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   hipLaunchKernelGGL(k, grid, dim3(256), smem, stream, p, dy, lddy, ws, cps, wr);
   SEGSDE_CHECK_LAUNCH();
@@ -2266,7 +2319,8 @@ template <int BKT, int BN, int WM, int WN>
 int launch_wgrad(const ConvP& p, const float* dy, int lddy, float* ws, int splits, int cps, hipStream_t stream, WRed wr = WRed{}) {
   switch (wgrad_mode(p, dy, lddy)) {
     case 2:
-      if (tune().wdma == 2) return launch_wgrad_mode<BKT, BN, WM, WN, 5>(p, dy, lddy, ws, splits, cps, stream, wr);
+      if (tune().wdma == 2) return p.f16 ? launch_wgrad_mode<BKT, BN, WM, WN, 16 + 5>(p, dy, lddy, ws, splits, cps, stream, wr)
+                                         : launch_wgrad_mode<BKT, BN, WM, WN, 5>(p, dy, lddy, ws, splits, cps, stream, wr);
       if (tune().wdma) return launch_wgrad_mode<BKT, BN, WM, WN, 4>(p, dy, lddy, ws, splits, cps, stream, wr);
       return launch_wgrad_mode<BKT, BN, WM, WN, 2>(p, dy, lddy, ws, splits, cps, stream, wr);
     case 3: return launch_wgrad_mode<BKT, BN, WM, WN, 3>(p, dy, lddy, ws, splits, cps, stream, wr);

@@ -6,6 +6,19 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+// eight halves = one operand of v_mfma_f32_32x32x16_f16 (the `amp: True` arithmetic of the convolutions, conv_igemm.hip)
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f16x8 segsde_pack_f16(const float4& a, const float4& b) {
+  typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  f16x8 r;
+  h2 t;
+  t = __builtin_convertvector(f2{a.x, a.y}, h2); r[0] = t[0]; r[1] = t[1];      // v_cvt_pk_f16_f32: round to nearest even
+  t = __builtin_convertvector(f2{a.z, a.w}, h2); r[2] = t[0]; r[3] = t[1];
+  t = __builtin_convertvector(f2{b.x, b.y}, h2); r[4] = t[0]; r[5] = t[1];
+  t = __builtin_convertvector(f2{b.z, b.w}, h2); r[6] = t[0]; r[7] = t[1];
+  return r;
+}
 
 // all LDS lives in the dynamic region (16-byte aligned base, cdna_hip_programming.md G17)
 #ifndef SEGSDE_SMEM

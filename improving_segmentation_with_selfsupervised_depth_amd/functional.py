@@ -50,10 +50,24 @@ def fp32_region(fn):
     @functools.wraps(fn)
     def wrapped(*args, **kwargs):
         if torch.is_autocast_enabled("cuda"):
-            with torch.autocast(device_type="cuda", enabled=False):
-                return fn(*args, **kwargs)
+            old = H.COMPUTE_F16[0]
+            H.COMPUTE_F16[0] = AMP_COMPUTE[0] == "f16"
+            try:
+                with torch.autocast(device_type="cuda", enabled=False):
+                    return fn(*args, **kwargs)
+            finally:
+                H.COMPUTE_F16[0] = old
         return fn(*args, **kwargs)
     return wrapped
+
+
+# What the convolutions compute in under autocast.  "f32" (default): the fp32 kernels -- an `amp: True` run is then a run at the
+# reference's `amp: False` precision.  "f16" (SEGSDE_AMP_COMPUTE=f16): the reference's reduced-precision arithmetic -- every
+# convolution created inside an autocast region rounds its operands to fp16 in the kernel and multiplies them on
+# v_mfma_f32_32x32x16_f16 with fp32 accumulation (hipops.ConvGeom.compute; forward, data-gradient and weight gradient of that
+# convolution alike, like autocast's own backward), the Winograd routes are not taken, BatchNorm / losses / optimizer stay fp32
+# like under autocast.  Activations and weights stay fp32 in memory.
+AMP_COMPUTE = [__import__("os").environ.get("SEGSDE_AMP_COMPUTE", "f32").lower()]
 
 
 def fusion(kind, taken):

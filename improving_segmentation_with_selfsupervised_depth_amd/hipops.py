@@ -121,6 +121,8 @@ def winograd_ok(g, B=None, H=None, W=None, dgrad=False):
     transforms' traffic eats the 2.25x fewer multiply-adds.  The multiply-add floor keeps tiny launches (and the small-shape
     golden tests of the direct kernels) on the direct route.  Forward: one or two sources, zero / mirrored padding (mirrored:
     dilation 1), any dilation that divides the map into even sub-lattices.  Data-gradient: one source, zero padding."""
+    if g.compute:
+        return False
     cin, cout = (g.Cout, g.C0) if dgrad else (g.Cin, g.Cout)      # the data-gradient is the convolution Cout -> C0
     if not (WINOGRAD and g.k == 3 and g.stride == 1 and g.pad == g.dil and not g.up0 and g.cin_alg is None and g.C0 % 4 == 0
             and cin % 32 == 0 and cout % 64 == 0 and min(g.Cin, g.Cout) >= WINOGRAD_MIN_CH and not (g.reflect and g.dil != 1)):
@@ -274,6 +276,8 @@ def winograd_fused_ok(g, B=None, H=None, W=None, dgrad=False):
     One source at output resolution: up to WINO_FUSED_MAX_CH channels, zero or mirrored padding, forward and data-gradient
     (mirrored: + segsde_reflect_adjoint_borders).  Forward on [upsample(x0) | x1] (g.up0): C0 % 64 == 0, up to
     WINO_FUSED2_MAX_CIN input channels, when the folded route's multiply-add share is above WINO_FUSED2_MIN_FOLD."""
+    if g.compute:
+        return False
     cin, cout = (g.Cout, g.C0) if dgrad else (g.Cin, g.Cout)
     if not (WINOGRAD and WINO_FUSED and g.k == 3 and g.stride == 1 and g.dil == 1 and g.pad == 1 and g.cin_alg is None
             and cin % 64 == 0 and cout % 64 == 0):
@@ -294,6 +298,8 @@ def winograd_fused_ok(g, B=None, H=None, W=None, dgrad=False):
 def winograd_fused_dgrad2_ok(g, B=None, H=None, W=None):
     """the skip-source data-gradient of a [upsample(x0) | x1] -> Cout mirrored 3x3 convolution as the one-kernel Winograd
     convolution Cout -> C1 (+ border kernel)"""
+    if g.compute:
+        return False
     if not (WINOGRAD and WINO_FUSED and WINO_FUSED_DGRAD_EXT and WINO_FUSED_DGRAD2 and BORDERS2 and g.k == 3 and g.stride == 1 and g.dil == 1
             and g.pad == 1 and g.reflect and g.up0 and g.C1 and g.cin_alg is None and g.C1 % 64 == 0 and g.Cout % 64 == 0
             and g.C0 % 64 == 0       # (the slice starts on a 64-filter block of the blocked pack layout)
@@ -438,6 +444,8 @@ WINO_FUSED_WGRAD_MIN_FOLD = float(os.environ.get("SEGSDE_WINO_FUSED_WGRAD_MIN_FO
 
 
 def winograd_fused_wgrad_ok(g, B=None, H=None, W=None):
+    if g.compute:            # half-precision operand mode: the direct / folded kernels (ConvGeom.compute)
+        return False
     if not (WINOGRAD and WINO_FUSED and WINO_FUSED_WGRAD and g.k == 3 and g.stride == 1 and g.dil == 1 and g.pad == 1
             and g.cin_alg is None and g.C0 % 32 == 0 and g.C1 % 32 == 0 and g.Cout % 64 == 0 and g.Cout <= WINO_FUSED_WGRAD_MAX_CH):
         return False
@@ -482,6 +490,7 @@ def _tag(g, H, W):
     return "%d+%d->%d k%d s%d d%d %dx%d%s%s" % (g.C0, g.C1, g.Cout, g.k, g.stride, g.dil, H, W, " up" if g.up0 else "",
                                                 " refl" if g.reflect else "")
 PAD_ZERO, PAD_REFLECT, PAD_REFLECT_ADJOINT = 0, 1, 2
+COMPUTE_F16 = [False]      # see ConvGeom.compute
 
 
 # the current stream's handle straight from the C binding (torch.cuda.current_stream(device).cuda_stream builds a Stream object
@@ -537,6 +546,10 @@ class ConvGeom:
         self.C0, self.C1, self.Cout, self.k = int(C0), int(C1), int(Cout), int(k)
         self.cin_alg = int(cin_alg) if cin_alg else None
         self.stride, self.dil, self.pad, self.reflect, self.up0 = int(stride), int(dil), int(pad), bool(reflect), bool(up0)
+        # segsde_conv_desc.compute of every launch of this convolution (forward, data-gradient, weight gradient): 1 under the
+        # half-precision operand mode of `amp: True` (COMPUTE_F16, set by functional.fp32_region), where the Winograd routes --
+        # fp32 kernels, and 16 / 36 of the multiply-adds at 1 / 16 of the fp16 matrix rate -- are not taken
+        self.compute = 1 if COMPUTE_F16[0] else 0
         if reflect and (self.k != 3 or self.stride != 1 or self.dil != 1 or self.pad != 1):
             raise NotImplementedError("reflection padding is implemented for the reference's 3x3/s1/p1 Conv3x3 only")
 
@@ -625,7 +638,7 @@ def conv_forward(g, x0, x1, wpack, bias, act="none", want_stats=False, wfold=Non
     d = ConvDesc(B=B, H=H, W=W, C0=g.C0, C1=g.C1, ld0=nhwc_ld(x0), ld1=nhwc_ld(x1) if x1 is not None else 0,
                  up0=int(g.up0), Ho=Ho, Wo=Wo, Cout=g.Cout, ldy=g.Cout, ldy2=0, nsplit=0, KH=g.k, KW=g.k,
                  stride=g.stride, dil=g.dil, pad=g.pad, pad_mode=PAD_REFLECT if g.reflect else PAD_ZERO, in_div=1,
-                 act=ACT[act], sum2x2=0)
+                 act=ACT[act], sum2x2=0, compute=g.compute)
     flops = 2.0 * B * Ho * Wo * g.Cout * g.CinAlg * g.k * g.k
     flops_x = flops * g.Cin / g.CinAlg * _live_tap_frac(g, H, W)   # executed: zero pad channels of a stem are multiplied too, dead tap rows are not
     if isinstance(wino, _KnPack):
@@ -713,7 +726,7 @@ def conv_dgrad(g, dy, wdpack, w_oihw, in_hw, need0=True, need1=True, accumulate_
         return ConvDesc(B=B, H=Ho, W=Wo, C0=Cout, C1=0, ld0=nhwc_ld(dy), ld1=0, up0=0, Ho=H, Wo=W, Cout=g.Cin, ldy=g.C0,
                         ldy2=g.C1, nsplit=g.C0, KH=g.k, KW=g.k, stride=1, dil=g.dil, pad=(g.k - 1) * g.dil - g.pad,
                         pad_mode=PAD_REFLECT_ADJOINT if g.reflect else PAD_ZERO, in_div=g.stride, act=0, sum2x2=sum2x2,
-                        accumulate=accumulate)
+                        accumulate=accumulate, compute=g.compute)
 
     def launch(d, y, y2, fuse):
         return L.segsde_conv2d_dgrad_actgrad(ctypes.byref(d), _p(_f32(dy)), None, _p(wdpack), None, _p(y), _p(y2), None,
@@ -771,7 +784,7 @@ def conv_dgrad(g, dy, wdpack, w_oihw, in_hw, need0=True, need1=True, accumulate_
                 return None, w1
             dx1f = None
         df = ConvDesc(B=B, H=H, W=W, C0=g.C0, C1=g.C1, ld0=g.C0, ld1=g.C1, up0=1, Ho=Ho, Wo=Wo, Cout=Cout, ldy=Cout, ldy2=0,
-                      nsplit=0, KH=3, KW=3, stride=1, dil=1, pad=1, pad_mode=PAD_REFLECT, in_div=1, act=0, sum2x2=0)
+                      nsplit=0, KH=3, KW=3, stride=1, dil=1, pad=1, pad_mode=PAD_REFLECT, in_div=1, act=0, sum2x2=0, compute=g.compute)
         fr = ((4.0 * g.C0 if dx0 is not None else 0.0) + (9.0 * g.C1 if dx1f is not None else 0.0)) / (9.0 * g.Cin)
         if w1 is not None:
             flops = flops * g.C0 / g.Cin          # the skip channels' multiply-adds were counted (and timed) with the Winograd launch
@@ -828,7 +841,7 @@ def conv_wgrad(g, x0, x1, dy, wino_v=None, out=None):
     _, Ho, Wo, Cout = dy.shape
     d = ConvDesc(B=B, H=H, W=W, C0=g.C0, C1=g.C1, ld0=nhwc_ld(x0), ld1=nhwc_ld(x1) if x1 is not None else 0,
                  up0=int(g.up0), Ho=Ho, Wo=Wo, Cout=Cout, ldy=Cout, ldy2=0, nsplit=0, KH=g.k, KW=g.k, stride=g.stride,
-                 dil=g.dil, pad=g.pad, pad_mode=PAD_REFLECT if g.reflect else PAD_ZERO, in_div=1, act=0, sum2x2=0)
+                 dil=g.dil, pad=g.pad, pad_mode=PAD_REFLECT if g.reflect else PAD_ZERO, in_div=1, act=0, sum2x2=0, compute=g.compute)
     L = _lib.lib()
     if out is not None and tuple(out.shape) == (Cout, g.Cin, g.k, g.k) and out.is_contiguous() and out.dtype == torch.float32:
         dw = out

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SEGSDE_ABI_VERSION 12
+#define SEGSDE_ABI_VERSION 13
 
 enum { SEGSDE_ERR_NULL = -1, SEGSDE_ERR_SHAPE = -2, SEGSDE_ERR_WORKSPACE = -3, SEGSDE_ERR_UNSUPPORTED = -4 };
 enum { SEGSDE_ACT_NONE = 0, SEGSDE_ACT_RELU = 1, SEGSDE_ACT_ELU = 2, SEGSDE_ACT_SIGMOID = 3 };
@@ -55,6 +55,10 @@ typedef struct segsde_conv_desc {
   int accumulate;   /* 1: y += result instead of y = result (the gradient of a tensor with a second consumer -- a residual
                        block's input -- lands on the gradient that is already there; no separate add pass).  Single
                        destination, no activation; SEGSDE_ERR_UNSUPPORTED when the shape does not take the staged epilogue. */
+  int compute;      /* 0: fp32 operands (exact fp32 products, the judged arithmetic).  1: the operands are rounded to fp16
+                       inside the kernel and multiplied on v_mfma_f32_32x32x16_f16 with fp32 accumulation -- what
+                       torch.cuda.amp.autocast makes of the reference's convolutions under `amp: True` (train.py:468,502).
+                       Launches whose shape does not take the LDS-DMA loop compute in fp32 whatever this says.            */
 } segsde_conv_desc;
 
 /* y[b,ho,wo,n] = act(bias[n] + sum_{kh,kw,c} x[b, ho*stride-pad+kh*dil, wo*stride-pad+kw*dil, c] * wpack[n][kh][kw][c])

@@ -76,7 +76,7 @@ struct State {
   ucontext_t sched; std::vector<Fiber> fibers; Fiber* cur = nullptr; dim3 bid, bdim, gdim;
   Barrier block_bar; std::vector<Barrier> wave_bar; std::function<void()> body;
   // rendezvous scratch per wave
-  std::vector<float> xa, xb; std::vector<double> xd; std::vector<long long> xi;
+  std::vector<float> xa, xb, xa8, xb8; std::vector<double> xd; std::vector<long long> xi;
   unsigned char* lds = nullptr;     // this host thread's 160 KB of "LDS" (one block runs per host thread at a time)
 };
 // one interpreter state per host thread (the blocks of a launch are dealt out to a small pool, see launch()); the TLS slot
@@ -294,6 +294,24 @@ inline emu_f32x4 emu_mfma_16x16x4(float a, float b, emu_f32x4 c, int, int, int) 
   }
   barrier_wait(wbar()); return d;
 }
+// v_mfma_f32_32x32x16_f16: lane l supplies A[i=l&31][k=8*(l>>5)..+7], B[k=8*(l>>5)..+7][j=l&31] as halves; fp32 accumulation
+typedef _Float16 emu_f16x8 __attribute__((ext_vector_type(8)));
+inline emu_f32x16 emu_mfma_32x32x16_f16(emu_f16x8 a, emu_f16x8 b, emu_f32x16 c, int, int, int) {
+  using namespace emu; State& s = S(); int base = wave() * 64, l = lane();
+  if (s.xa8.size() < s.xa.size() * 8) { s.xa8.assign(s.xa.size() * 8, 0.f); s.xb8.assign(s.xa.size() * 8, 0.f); }
+  for (int q = 0; q < 8; ++q) { s.xa8[(base + l) * 8 + q] = (float)a[q]; s.xb8[(base + l) * 8 + q] = (float)b[q]; }
+  barrier_wait(wbar());
+  emu_f32x16 d = c; int col = l & 31;
+  for (int r = 0; r < 16; ++r) {
+    int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+    float acc = c[r];
+    for (int h = 0; h < 2; ++h)
+      for (int q = 0; q < 8; ++q) acc = fmaf(s.xa8[(base + row + 32 * h) * 8 + q], s.xb8[(base + col + 32 * h) * 8 + q], acc);
+    d[r] = acc;
+  }
+  barrier_wait(wbar()); return d;
+}
+#define __builtin_amdgcn_mfma_f32_32x32x16_f16 emu_mfma_32x32x16_f16
 #define __builtin_amdgcn_mfma_f32_32x32x2f32 emu_mfma_32x32x2
 #define __builtin_amdgcn_mfma_f32_16x16x4f32 emu_mfma_16x16x4
 #define HIP_SYMBOL(x) (&x)

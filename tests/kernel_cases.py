@@ -1734,3 +1734,43 @@ def run_bn_partials_case(device):
         assert_close(rm, (0.1 * mu).float(), rtol=1e-6, atol=1e-8, what=what + " running_mean")
         assert_close(rv, (0.9 + 0.1 * var * M / (M - 1)).float(), rtol=1e-6, atol=0, what=what + " running_var")
         assert int(nbt) == 1
+
+
+def run_f16_operand_convolutions(device):
+    """segsde_conv_desc.compute = 1 (the `amp: True` arithmetic: operands rounded to fp16 in the kernel, v_mfma_f32_32x32x16_f16,
+    fp32 accumulation) on the three directions of the implicit GEMM: within fp16 round-off of a float64 convolution (tolerance
+    1.5e-3 of the result's maximum; measured 3e-4), the fp32 mode of the same launches within 1e-5.  Shapes that take the LDS-DMA
+    loop (channels a multiple of 32): 1x1, 3x3 zero- and mirror-padded, dilated, two-source upsampled (the folded route)."""
+    import torch.nn.functional as F
+    from improving_segmentation_with_selfsupervised_depth_amd import hipops as H
+    torch.manual_seed(5)
+    B = 2
+    cases = [(16, 32, 64, 128, 1, 1, 0, False), (16, 32, 64, 64, 3, 1, 1, False), (16, 32, 64, 64, 3, 1, 1, True),
+             (24, 32, 128, 64, 3, 6, 6, False)]
+    for Hh, W, C, Co, k, dil, pad, refl in cases:
+        x = torch.relu(torch.randn(B, Hh, W, C)).to(device)
+        dy = torch.randn(B, Hh, W, Co).to(device)
+        w = (torch.randn(Co, C, k, k) * (2.0 / (k * k * C)) ** 0.5).to(device)
+        xr = x.cpu().permute(0, 3, 1, 2).double().requires_grad_(True)
+        wr = w.cpu().double().requires_grad_(True)
+        xin = F.pad(xr, (1, 1, 1, 1), mode="reflect") if refl else xr
+        yr = F.conv2d(xin, wr, padding=0 if refl else pad, dilation=dil)
+        yr.backward(dy.cpu().permute(0, 3, 1, 2).double())
+        want = (yr.detach().permute(0, 2, 3, 1), xr.grad.permute(0, 2, 3, 1), wr.grad)
+        wp, wdp = H.pack_weight_both(w)
+        for mode, tol in ((0, 1e-5), (1, 1.5e-3)):
+            H.COMPUTE_F16[0] = bool(mode)
+            try:
+                g = H.ConvGeom(C, Co, k, 1, dil, pad, refl, 0, False)
+            finally:
+                H.COMPUTE_F16[0] = False
+            assert g.compute == mode
+            got = (H.conv_forward(g, x, None, wp, None), H.conv_dgrad(g, dy, wdp, w, (Hh, W))[0], H.conv_wgrad(g, x, None, dy))
+            for name, a, b in zip(("forward", "data-gradient", "weight gradient"), got, want):
+                err = float((a.cpu().double() - b).abs().max() / b.abs().max())
+                assert err <= tol, ("compute=%d %s %s: %.2e > %.1e" % (mode, (Hh, W, C, Co, k, dil, refl), name, err, tol))
+            if mode == 1:
+                e32 = float((H.conv_forward(H.ConvGeom(C, Co, k, 1, dil, pad, refl, 0, False), x, None, wp, None).cpu().double()
+                             - want[0]).abs().max() / want[0].abs().max())
+                e16 = float((got[0].cpu().double() - want[0]).abs().max() / want[0].abs().max())
+                assert e16 > 10 * e32, "the half-precision mode did not take the half-precision kernel (%g vs %g)" % (e16, e32)

@@ -124,6 +124,10 @@ def test_jitter_blur_properties():
     KC.run_jitter_blur_properties("cpu")
 
 
+def test_f16_operand_convolutions():
+    KC.run_f16_operand_convolutions("cpu")
+
+
 def test_winograd_route():
     KC.run_winograd_cases("cpu")
 

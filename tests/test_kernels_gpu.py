@@ -178,6 +178,10 @@ def test_jitter_blur_properties():
     KC.run_jitter_blur_properties("cuda")
 
 
+def test_f16_operand_convolutions():
+    KC.run_f16_operand_convolutions("cuda")
+
+
 def test_winograd_route():
     KC.run_winograd_cases("cuda")
 

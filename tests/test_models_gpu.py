@@ -571,6 +571,65 @@ def test_train_step_under_the_amp_protocol():
     assert float(scaler.get_scale()) == 65536.0          # no overflow was seen: the scale never backed off
 
 
+def test_train_step_amp_with_f16_operands():
+    """``amp: True`` with the reference's reduced-precision arithmetic (functional.AMP_COMPUTE = "f16": the convolutions created
+    under autocast round their operands to fp16 in the kernel -- v_mfma_f32_32x32x16_f16, fp32 accumulation -- in all three
+    directions; BatchNorm, losses, optimizer fp32; GradScaler protocol of train.py:468-528).  Against the fp32 step on the same
+    weights and batch: losses within 1 %, the parameter update points the same way (cosine > 0.98 over all parameters, > 0.9
+    for every sub-model), nothing overflowed (the loss scale did not back off), and the half-precision kernels really ran."""
+    import trainstep_case as TC
+    from improving_segmentation_with_selfsupervised_depth_amd import functional as Fn
+    from improving_segmentation_with_selfsupervised_depth_amd import trainer as T
+    from improving_segmentation_with_selfsupervised_depth_amd.loss import get_monodepth_loss, get_segmentation_loss_function
+    from improving_segmentation_with_selfsupervised_depth_amd.models import get_model
+    scenario = "joint"
+    runs = {}
+    for tag, amp, comp in (("f32", False, "f32"), ("f16", True, "f16")):
+        cfg = TC.full_cfg(scenario)
+        cfg["training"]["amp"] = amp
+        model = get_model(cfg["model"], TC.NCLS)
+        model.load_state_dict(TC.state_dict(scenario), strict=True)
+        TC.no_dropout(model)
+        model.cuda()
+        o = cfg["training"]["optimizer"]
+        opt = torch.optim.SGD(T.get_train_params(model, cfg), lr=o["lr"], weight_decay=o["weight_decay"], momentum=o["momentum"])
+        mono = get_monodepth_loss(cfg, is_train=True)
+        mono.tiebreak_noise = {s: n.cuda() for s, n in TC.noise().items()}
+        before = {k: p.detach().clone() for k, p in model.named_parameters()}
+        scaler = torch.amp.GradScaler("cuda", enabled=amp)
+        old, Fn.AMP_COMPUTE[0] = Fn.AMP_COMPUTE[0], comp
+        seen = []
+        orig = H.conv_forward
+
+        def spy(g, *a, **k):
+            seen.append(g.compute)
+            return orig(g, *a, **k)
+        H.conv_forward = spy
+        try:
+            losses = T.train_step(model, opt, TC.batch(100), 0, cfg, get_segmentation_loss_function(cfg), mono, scaler=scaler)
+        finally:
+            Fn.AMP_COMPUTE[0], H.conv_forward = old, orig
+        assert all(c == (1 if amp else 0) for c in seen) and seen, (tag, set(seen))
+        if amp:
+            assert float(scaler.get_scale()) == 65536.0
+        runs[tag] = (losses, {k: (p.detach() - before[k]) for k, p in model.named_parameters()})
+    l32, l16 = runs["f32"][0], runs["f16"][0]
+    for k in ("mono_loss", "segmentation_loss", "total_loss"):
+        a, b = float(l32[k]), float(l16[k])
+        assert abs(a - b) <= 1e-2 * abs(a), (k, a, b)
+    u32, u16 = runs["f32"][1], runs["f16"][1]
+
+    def cos(keys):
+        a = torch.cat([u32[k].flatten() for k in keys]).double()
+        b = torch.cat([u16[k].flatten() for k in keys]).double()
+        return float((a @ b) / (a.norm() * b.norm() + 1e-30))
+    assert cos(list(u32)) > 0.98, cos(list(u32))
+    for sub in ("models.encoder.", "models.depth.", "models.segmentation.", "models.pose_encoder.", "models.pose."):
+        keys = [k for k in u32 if k.startswith(sub) and float(u32[k].abs().max()) > 0]
+        if keys:
+            assert cos(keys) > 0.9, (sub, cos(keys))
+
+
 def test_skip_gradient_fanout():
     MC.run_skip_gradient_fanout("cuda")
 
