@@ -2116,7 +2116,8 @@ int launch_adjoint_by_borders(const ConvP& p, hipStream_t s, bool with_main = tr
 bool adjoint_by_borders_ok(const ConvP& p) {
   // measured (profiles/experiments_r03.md): the five extra launches cost ~70 us per call -- a gain only on the largest maps
   // (128 -> 64 @256x512 x 16: 5.63 -> 5.46 ms/step), a loss below (256 -> 256 @32x64: 0.69 -> 1.15); adjb=2 forces it everywhere
-  const bool big = (long)p.B * p.H * p.W >= (1L << 21) || tune().adjb == 2;
+  // (half-precision operand mode: always -- the in-kernel adjoint, MODE 3, has no half-precision variant and would run in fp32)
+  const bool big = (long)p.B * p.H * p.W >= (1L << 21) || tune().adjb == 2 || p.f16;
   return tune().adjb && big && p.pad_mode == SEGSDE_PAD_REFLECT_ADJOINT && igemm_fast_ok(p) && !p.sum2x2 && p.vecout && p.H >= 4 &&
          p.W >= 4 && p.C1 == 0 && p.KH == 3 && p.KW == 3 && p.nb == 0 && p.ne == p.N;
 }
