@@ -18,6 +18,7 @@ cp $OUT/traffic_r06.json profiles/traffic_r06.json 2>/dev/null
 SEGSDE_BENCH_LAYERS=$OUT/layers_r06_latest.txt python bench.py > $OUT/bench_r06_cfg3_default_run.json 2> $OUT/bench_r06_cfg3_default_run.err
 bash tools/runs/trace.sh r06_final
 bash tools/runs/trace.sh r06_reference_step --step reference
+bash tools/runs/trace.sh r06_amp_step --step amp
 cd $ROOT
 timeout 600 python bench.py --workload cfg1 --steps 20 --warmup 5 --cpu-baseline-timeout 120 > $OUT/bench_r06_cfg1.json 2> $OUT/bench_r06_cfg1.err
 timeout 600 python bench.py --workload cfg2 --steps 20 --warmup 5 --cpu-baseline-timeout 120 > $OUT/bench_r06_cfg2.json 2> $OUT/bench_r06_cfg2.err
