@@ -643,7 +643,18 @@ def defer_gate(tensors, owner, eboxes=None, new_group=False):
     old = _TRUNKS.get(owner)
     old = old() if old is not None else None
     if old is not None and old.has_pending():
-        _trunk_guard()
+        # the previous forward of this module never got its releasing backward: say so ONCE (its graph is being replaced anyway;
+        # a training loop that catches the error and goes on must not meet it again at every forward)
+        passes = old.passes
+        for st in _trunk_states():           # every gate of that forward (the PAD decoder's sits above the encoder's)
+            if st.group == old.group:
+                st.pending, st.roots = [None] * len(st.pending), None
+                _TRUNKS.pop(st.owner, None)
+        raise RuntimeError(
+            "deferred trunk backward: %d backward pass(es) of the previous forward kept their graph (retain_graph=True) and none "
+            "released it, so the graph behind the gate was never back-propagated -- those gradients are lost.  End the forward's "
+            "losses on a plain backward(), call functional.flush_deferred_trunks() after the last one, or switch "
+            "model.defer_trunk_backward off for this configuration." % passes)
     if _TRUNK_HOOK[0] is None:
         from torch.optim.optimizer import register_optimizer_step_pre_hook
         _TRUNK_HOOK[0] = register_optimizer_step_pre_hook(_trunk_guard)

@@ -903,16 +903,24 @@ def run_deferred_trunk_backward(device):
         l = losses()
         l[0].backward(retain_graph=True)
         opt = torch.optim.SGD([p for m in mods for p in m.parameters()], lr=0.0)
-        for what in (opt.step, lambda: enc(img)):
+
+        def must_raise(what):
             try:
                 what()
             except RuntimeError as e:
                 assert "deferred trunk backward" in str(e)
             else:
                 raise AssertionError("parked encoder gradient went unnoticed")
+        must_raise(opt.step)                       # any optimizer step refuses, until the parked backward is flushed by hand
         Fn.flush_deferred_trunks()
         assert Fn.pending_deferred_trunks() == 0 and all(p.grad is not None for p in enc.encoder.layer1.parameters())
         opt.step()
+        l = losses()
+        l[0].backward(retain_graph=True)
+        must_raise(lambda: enc(img))               # the next forward says so once, the lost gradients are dropped
+        assert Fn.pending_deferred_trunks() == 0
+        l = losses()
+        (l[0] + l[1]).backward()
         # without a gradient (validation) the gate is not built at all
         with torch.no_grad():
             f = enc(img)
