@@ -15,8 +15,12 @@
 //    the implicit-GEMM epilogue's).
 // 16 instead of 36 multiply-adds per output, and no transform traffic: x is read once (+ halo), y written once.
 #include <stdlib.h>
+#include <type_traits>
 #include "segsde_common.h"
 #include "winograd.h"
+#ifndef WINO_UP_SKIP
+#define WINO_UP_SKIP 1        // 0: build without the zero-position skipping of upsampled-source fills (A/B)
+#endif
 
 namespace {
 #define ST(s) static_cast<hipStream_t>(s)
@@ -57,7 +61,9 @@ struct WinoAg { const float* agy; int agld, agkind; };
 // UBLK: the transformed weights in the BLOCKED layout U[row w][c][block of 64 filters][32 lanes][4 positions of the row][2 filter
 // halves] -- the eight B operands of a lane and step are 32 contiguous bytes (two 16-byte requests, 1 KiB per wave-instruction)
 // instead of eight 4-byte requests in eight position planes
-template <bool STATS, bool UBLK>
+// UPSKIP: the launch has a nearest-upsampled source (see the K loop).  A launch-level template parameter: as a run-time flag the
+// wave-uniform branches around the two MFMAs cost the single-source launches 2-4 % (probe_r06_upskip_single_source.log).
+template <bool STATS, bool UBLK, bool UPSKIP>
 __global__ __launch_bounds__(256, 2) void wino_fused_kernel(WinoSrc src, int B, int H, int W, int C, int reflect,
                                                             const float* U, int ldu, int Co, const float* bias, int act, float* y, int ldy,
                                                             double* part, int accumulate, WinoAg ag) {
@@ -224,29 +230,41 @@ __global__ __launch_bounds__(256, 2) void wino_fused_kernel(WinoSrc src, int B, 
       const int cp = (bb & 1) ? FODD + (bb >> 1) : (bb >> 1);
       rv[0][bb] = SEGSDE_LDS_READ_IMM(src + o1, cp); rv[0][4 + bb] = SEGSDE_LDS_READ_IMM(src + o2, cp);
     };
+    // A fill from the NEAREST-UPSAMPLED source (the decoders' [upsample(x0) | x1] layers): rows 2 t and 2 t + 1 of an output
+    // tile's 4 x 4 patch are the same low-resolution row, columns likewise, so B^T d B is identically zero in transform row 2 and
+    // in transform column 2 (d2 - d1 = 0) -- seven of the sixteen positions multiply zeros.  SKIP2: wave 2 (transform row 2)
+    // sits such a fill out, the others leave out position 2 of their row: 6 MFMAs per step instead of 8 on three of the four
+    // SIMDs.  (Exactly the products that are 0 * w; mirrored / zero padding keeps rows 2 t, 2 t + 1 on one source row.)
+    // (ONE loop body with a wave-uniform branch around the two MFMAs: two copies of the unrolled loop behind a branch made the
+    // register allocator spill 170 registers at the join of the 128 accumulators)
+    const bool skip2 = UPSKIP && c0 < src.C0;            // (UPSKIP launches: src.up0 is set)
+    if (!(skip2 && wave_u == 2)) {
 #pragma unroll
-    for (int s = 0; s < PD - 1; ++s) fetch_b(s, s);
+      for (int s = 0; s < PD - 1; ++s) fetch_b(s, s);
 #pragma unroll
-    for (int bb = 0; bb < 4; ++bb) fetch_a2(0, bb);
-    form_a(0, 0); form_a(0, 1);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int s = 0; s < NS_RUN; ++s) {
-      const int q = s & 1, qb = s % PD;
-      const bool nx = s + 1 < NS;
-#define WINO_MF_(j, nb, bi) acc[j][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(An[q][j], bv[qb][bi], acc[j][nb], 0, 0, 0); __builtin_amdgcn_sched_barrier(0)
-      WINO_MF_(0, 0, 0); if (nx) fetch_a2(s + 1, 0); __builtin_amdgcn_sched_barrier(0);
-      WINO_MF_(0, 1, 1); if (nx) fetch_a2(s + 1, 1); __builtin_amdgcn_sched_barrier(0);
-      WINO_MF_(1, 0, 2); if (nx) fetch_a2(s + 1, 2); __builtin_amdgcn_sched_barrier(0);
-      WINO_MF_(1, 1, 3); if (nx) fetch_a2(s + 1, 3); __builtin_amdgcn_sched_barrier(0);
-      WINO_MF_(2, 0, 4); __builtin_amdgcn_sched_barrier(0);
-      WINO_MF_(2, 1, 5); __builtin_amdgcn_sched_barrier(0);
-      // (the weight requests of step s + PD - 1 overwrite bv[(s - 1) % PD]: last read by the previous step)
-      if (s + PD - 1 < NS) fetch_b(s + PD - 1, (s + PD - 1) % PD);
+      for (int bb = 0; bb < 4; ++bb) fetch_a2(0, bb);
+      form_a(0, 0); form_a(0, 1);
       __builtin_amdgcn_sched_barrier(0);
-      WINO_MF_(3, 0, 6); if (nx) form_a(q ^ 1, 0); __builtin_amdgcn_sched_barrier(0);
-      WINO_MF_(3, 1, 7); if (nx) form_a(q ^ 1, 1); __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s = 0; s < NS_RUN; ++s) {
+        const int q = s & 1, qb = s % PD;
+        const bool nx = s + 1 < NS;
+#define WINO_MF_(j, nb, bi) acc[j][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(An[q][j], bv[qb][bi], acc[j][nb], 0, 0, 0); __builtin_amdgcn_sched_barrier(0)
+        WINO_MF_(0, 0, 0); if (nx) fetch_a2(s + 1, 0); __builtin_amdgcn_sched_barrier(0);
+        WINO_MF_(0, 1, 1); if (nx) fetch_a2(s + 1, 1); __builtin_amdgcn_sched_barrier(0);
+        WINO_MF_(1, 0, 2); if (nx) fetch_a2(s + 1, 2); __builtin_amdgcn_sched_barrier(0);
+        WINO_MF_(1, 1, 3); if (nx) fetch_a2(s + 1, 3); __builtin_amdgcn_sched_barrier(0);
+        if (!skip2) {
+          WINO_MF_(2, 0, 4); __builtin_amdgcn_sched_barrier(0);
+          WINO_MF_(2, 1, 5); __builtin_amdgcn_sched_barrier(0);
+        }
+        // (the weight requests of step s + PD - 1 overwrite bv[(s - 1) % PD]: last read by the previous step)
+        if (s + PD - 1 < NS) fetch_b(s + PD - 1, (s + PD - 1) % PD);
+        __builtin_amdgcn_sched_barrier(0);
+        WINO_MF_(3, 0, 6); if (nx) form_a(q ^ 1, 0); __builtin_amdgcn_sched_barrier(0);
+        WINO_MF_(3, 1, 7); if (nx) form_a(q ^ 1, 1); __builtin_amdgcn_sched_barrier(0);
 #undef WINO_MF_
+      }
     }
   }
 
@@ -565,8 +583,13 @@ int launch_fused(const WinoSrc& src, int B, int H, int W, int C, int reflect, co
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_LDS);
     hipLaunchKernelGGL(k, grid, dim3(256), F_LDS, ST(stream), src, B, H, W, C, reflect, u_kn, ldu, Cout, bias, act, y, ldy, st, accumulate, ag);
   };
-  if (stats) { if (ublk) go(wino_fused_kernel<true, true>, stats); else go(wino_fused_kernel<true, false>, stats); }
-  else { if (ublk) go(wino_fused_kernel<false, true>, (double*)nullptr); else go(wino_fused_kernel<false, false>, (double*)nullptr); }
+  const bool upskip = WINO_UP_SKIP && src.up0;
+  auto pick = [&](auto st_tag, double* st) {
+    constexpr bool ST = decltype(st_tag)::value;
+    if (upskip) { if (ublk) go(wino_fused_kernel<ST, true, true>, st); else go(wino_fused_kernel<ST, false, true>, st); }
+    else { if (ublk) go(wino_fused_kernel<ST, true, false>, st); else go(wino_fused_kernel<ST, false, false>, st); }
+  };
+  if (stats) pick(std::true_type{}, stats); else pick(std::false_type{}, (double*)nullptr);
   SEGSDE_CHECK_LAUNCH();
   return 0;
 }

@@ -47,7 +47,11 @@ struct Geo {
   static constexpr int STAGE = XF + YPX * NC;             // floats of one stage
 };
 
-template <int WT_H, bool DB, int MINB>
+// UPSKIP (launch-level): the launch has a nearest-upsampled source that carries at least half of the input channels; workgroups
+// whose 32 channels come from it skip the Winograd positions that are identically zero there (see `compute`).  Only these
+// launches carry the wave-uniform branches around the two MFMAs -- they cost a workgroup of the OTHER source 2-3 %
+// (probe_r06_upskip_wgrad.log), so launches where that source dominates keep the plain kernel.
+template <int WT_H, bool DB, int MINB, bool UPSKIP>
 __global__ __launch_bounds__(256, MINB) void wino_wgrad_fused_kernel(WgradP p) {
   using G = Geo<WT_H>;
   SEGSDE_SMEM;
@@ -65,6 +69,7 @@ __global__ __launch_bounds__(256, MINB) void wino_wgrad_fused_kernel(WgradP p) {
   const float* xs = s0 ? p.x0 : p.x1;
   const int ldx = s0 ? p.ld0 : p.ld1, cb = s0 ? cin0 : cin0 - p.C0, sh = (s0 && p.up0) ? 1 : 0;
   const int Hs = p.H >> sh, Ws = p.W >> sh;
+  const bool skip2 = UPSKIP && sh;                      // this workgroup's input channels are nearest-upsampled (see compute)
   const unsigned lds0 = segsde_lds_addr(lds);
 
   // rows of the patch that transform row `wave` of B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1] combines (winograd_fused.hip)
@@ -195,6 +200,10 @@ __global__ __launch_bounds__(256, MINB) void wino_wgrad_fused_kernel(WgradP p) {
         Bn[q][nb][1] = Bn[q][nb][0] + Bn[q][nb][3]; Bn[q][nb][2] = Bn[q][nb][0] - Bn[q][nb][3];
       }
     };
+    // Input channels from the NEAREST-UPSAMPLED source: rows 2 t / 2 t + 1 of a tile's patch are one low-resolution row (columns
+    // likewise), so V = B^T d B is identically zero in transform row 2 and column 2 and so is dU there -- wave 2 (row 2) sits the
+    // workgroup's blocks out, the others leave out position 2 of their row (6 MFMAs per step instead of 8; winograd_fused.hip)
+    if (skip2 && wv == 2) return;
     rd_x(0, 0); rd_x(0, 1); rd_y(0, 0); rd_y(0, 1);
     form_a(0, 0); form_a(0, 1); form_b(0, 0, 0); form_b(0, 0, 1); form_b(0, 1, 0); form_b(0, 1, 1);
     __builtin_amdgcn_sched_barrier(0);
@@ -207,8 +216,12 @@ __global__ __launch_bounds__(256, MINB) void wino_wgrad_fused_kernel(WgradP p) {
       WG_MF_(0, 1); if (nx) rd_x(s + 1, 1); __builtin_amdgcn_sched_barrier(0);
       WG_MF_(1, 0); if (nx) rd_y(s + 1, 0); __builtin_amdgcn_sched_barrier(0);
       WG_MF_(1, 1); if (nx) rd_y(s + 1, 1); __builtin_amdgcn_sched_barrier(0);
-      WG_MF_(2, 0); if (nx) form_a(q ^ 1, 0); __builtin_amdgcn_sched_barrier(0);
-      WG_MF_(2, 1); if (nx) { form_a(q ^ 1, 1); form_b(q ^ 1, 0, 0); } __builtin_amdgcn_sched_barrier(0);
+      if (!skip2) { WG_MF_(2, 0); }
+      if (nx) form_a(q ^ 1, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (!skip2) { WG_MF_(2, 1); }
+      if (nx) { form_a(q ^ 1, 1); form_b(q ^ 1, 0, 0); }
+      __builtin_amdgcn_sched_barrier(0);
       WG_MF_(3, 0); if (nx) { form_b(q ^ 1, 0, 1); form_b(q ^ 1, 1, 0); } __builtin_amdgcn_sched_barrier(0);
       WG_MF_(3, 1); if (nx) form_b(q ^ 1, 1, 1); __builtin_amdgcn_sched_barrier(0);
 #undef WG_MF_
@@ -335,21 +348,24 @@ extern "C" int segsde_conv2d_wgrad_winograd_fused(const segsde_conv_desc* d, con
   p.part = static_cast<float*>(workspace);
   const dim3 grid((unsigned)(pl.ncol * pl.S));
   const int var = variant(d);
+  // zero-position skipping for upsampled-source channel blocks: only where that source carries at least half of the channels
+  // (SEGSDE_WGRAD_FUSED_UPSKIP=0: never)
+  static int upskip_on = -1;
+  if (upskip_on < 0) { const char* e = getenv("SEGSDE_WGRAD_FUSED_UPSKIP"); upskip_on = e ? (atoi(e) != 0) : 1; }
+  const bool upskip = upskip_on && p.up0 && 2 * d->C0 >= d->C0 + d->C1;
+  auto go = [&](auto k, size_t lb) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
+    hipLaunchKernelGGL(k, grid, dim3(256), lb, ST(stream), p);
+  };
   if (var == 1) {
-    auto k = wino_wgrad_fused_kernel<2, true, 2>;
     const size_t lb = (size_t)2 * Geo<2>::STAGE * sizeof(float);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
-    hipLaunchKernelGGL(k, grid, dim3(256), lb, ST(stream), p);
+    if (upskip) go(wino_wgrad_fused_kernel<2, true, 2, true>, lb); else go(wino_wgrad_fused_kernel<2, true, 2, false>, lb);
   } else if (var == 2) {
-    auto k = wino_wgrad_fused_kernel<4, true, 1>;
     const size_t lb = (size_t)2 * Geo<4>::STAGE * sizeof(float);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
-    hipLaunchKernelGGL(k, grid, dim3(256), lb, ST(stream), p);
+    if (upskip) go(wino_wgrad_fused_kernel<4, true, 1, true>, lb); else go(wino_wgrad_fused_kernel<4, true, 1, false>, lb);
   } else {
-    auto k = wino_wgrad_fused_kernel<4, false, 2>;
     const size_t lb = (size_t)Geo<4>::STAGE * sizeof(float);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
-    hipLaunchKernelGGL(k, grid, dim3(256), lb, ST(stream), p);
+    if (upskip) go(wino_wgrad_fused_kernel<4, false, 2, true>, lb); else go(wino_wgrad_fused_kernel<4, false, 2, false>, lb);
   }
   SEGSDE_CHECK_LAUNCH();
   return segsde_wino_wgrad_finish(p.part, pl.S, p.C, p.Co, dw_oihw, stream);

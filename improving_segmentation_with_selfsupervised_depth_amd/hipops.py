@@ -440,7 +440,9 @@ def reflect_borders_ok(B, H, W, Cout, Cin, lddy, ag_ld=0):
 WINO_FUSED_WGRAD = os.environ.get("SEGSDE_WINO_FUSED_WGRAD", "1") != "0"
 WINO_FUSED_WGRAD_MAX_CH = int(os.environ.get("SEGSDE_WINO_FUSED_WGRAD_MAX_CH", "256"))
 WINO_FUSED_WGRAD_MAX_CIN2 = int(os.environ.get("SEGSDE_WINO_FUSED_WGRAD_MAX_CIN2", "768"))
-WINO_FUSED_WGRAD_MIN_FOLD = float(os.environ.get("SEGSDE_WINO_FUSED_WGRAD_MIN_FOLD", "0.6"))
+# (round 6: 0.6 -> 0.4 -- with the zero positions of an upsampled source skipped, the pure upsampled layer 64 -> 64 @512x1024, share
+# 4/9, runs 1.23x the folded route: 2272 -> 1849 us, profiles/probe_r06_upskip_wgrad.log)
+WINO_FUSED_WGRAD_MIN_FOLD = float(os.environ.get("SEGSDE_WINO_FUSED_WGRAD_MIN_FOLD", "0.4"))
 
 
 def winograd_fused_wgrad_ok(g, B=None, H=None, W=None):
