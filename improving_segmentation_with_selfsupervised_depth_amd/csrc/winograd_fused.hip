@@ -583,7 +583,9 @@ int launch_fused(const WinoSrc& src, int B, int H, int W, int C, int reflect, co
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_LDS);
     hipLaunchKernelGGL(k, grid, dim3(256), F_LDS, ST(stream), src, B, H, W, C, reflect, u_kn, ldu, Cout, bias, act, y, ldy, st, accumulate, ag);
   };
-  const bool upskip = WINO_UP_SKIP && src.up0;
+  static int upskip_on = -1;       // SEGSDE_WINO_UP_SKIP=0: never (A/B; hipops reads the same variable for its executed-flop count)
+  if (upskip_on < 0) { const char* e = getenv("SEGSDE_WINO_UP_SKIP"); upskip_on = e ? (atoi(e) != 0) : 1; }
+  const bool upskip = WINO_UP_SKIP && upskip_on && src.up0;
   auto pick = [&](auto st_tag, double* st) {
     constexpr bool ST = decltype(st_tag)::value;
     if (upskip) { if (ublk) go(wino_fused_kernel<ST, true, true>, st); else go(wino_fused_kernel<ST, false, true>, st); }

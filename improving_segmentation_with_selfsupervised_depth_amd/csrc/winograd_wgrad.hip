@@ -349,9 +349,9 @@ extern "C" int segsde_conv2d_wgrad_winograd_fused(const segsde_conv_desc* d, con
   const dim3 grid((unsigned)(pl.ncol * pl.S));
   const int var = variant(d);
   // zero-position skipping for upsampled-source channel blocks: only where that source carries at least half of the channels
-  // (SEGSDE_WGRAD_FUSED_UPSKIP=0: never)
+  // (SEGSDE_WINO_UP_SKIP=0: never)
   static int upskip_on = -1;
-  if (upskip_on < 0) { const char* e = getenv("SEGSDE_WGRAD_FUSED_UPSKIP"); upskip_on = e ? (atoi(e) != 0) : 1; }
+  if (upskip_on < 0) { const char* e = getenv("SEGSDE_WINO_UP_SKIP"); upskip_on = e ? (atoi(e) != 0) : 1; }
   const bool upskip = upskip_on && p.up0 && 2 * d->C0 >= d->C0 + d->C1;
   auto go = [&](auto k, size_t lb) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);

@@ -238,6 +238,9 @@ WINO_FUSED_MAX_CH = int(os.environ.get("SEGSDE_WINO_FUSED_MAX_CH", "256"))
 # (4/9 on the upsampled channels, 9/9 on the skip) is above WINO_FUSED2_MIN_FOLD: the route runs all channels at 16/36 but at
 # ~0.75 of the direct kernel's multiply-add rate (profiles/probe_r05_*.log); SEGSDE_WINO_FUSED2=0: off
 WINO_FUSED2 = os.environ.get("SEGSDE_WINO_FUSED2", "1") != "0"
+# the kernels' zero-position skipping on nearest-upsampled sources (SEGSDE_WINO_UP_SKIP=0 switches it off in both csrc launchers;
+# here only the reported `executed` multiply-add counts depend on it)
+WINO_UP_SKIP = os.environ.get("SEGSDE_WINO_UP_SKIP", "1") != "0"
 WINO_FUSED2_MAX_CIN = int(os.environ.get("SEGSDE_WINO_FUSED2_MAX_CIN", "768"))
 WINO_FUSED2_MIN_FOLD = float(os.environ.get("SEGSDE_WINO_FUSED2_MIN_FOLD", "0.6"))
 # round 5: data-gradients of the mirrored-padding Conv3x3 (zero-padded one-kernel launch + border launches) and data-gradients
@@ -373,7 +376,10 @@ def winograd_fused(kind, x, u_kn, bias=None, act="none", want_stats=False, tag=N
         assert accumulate_into is None and actgrad is None and adjoint is None
         rc = _timed(kind, flops, x, lambda: L.segsde_conv2d_winograd_fused2(
             _p(_f32(x)), nhwc_ld(x), C0, 1 if up0 else 0, _p(x1), nhwc_ld(x1) if x1 is not None else 0, C1, B, H, W, 1 if reflect else 0,
-            _p(u_kn), N, _p(bias), ACT[act], _p(y), N, _p(part), _stream(x)), tagf, executed=flops * 16.0 / 36.0)
+            _p(u_kn), N, _p(bias), ACT[act], _p(y), N, _p(part), _stream(x)), tagf,
+            # issued multiply-adds: 16 / 36 of the algorithmic count, 9 / 36 on the channels of a nearest-upsampled source (seven of
+            # the sixteen positions are identically zero there and skipped: csrc/winograd_fused.hip, UPSKIP)
+            executed=flops * ((9.0 * C0 + 16.0 * C1) / (36.0 * (C0 + C1)) if (up0 and WINO_UP_SKIP) else 16.0 / 36.0))
         if rc == -4:
             return None
         check(rc, "conv2d_winograd_fused2")
@@ -857,7 +863,11 @@ def conv_wgrad(g, x0, x1, dy, wino_v=None, out=None):
             ws = _ws(nbytes, dy)
             rc = _timed("conv_wgrad", flops, dy, lambda: L.segsde_conv2d_wgrad_winograd_fused(
                 ctypes.byref(d), _p(_f32(x0)), _p(x1), _p(_f32(dy)), nhwc_ld(dy), _p(dw), _p(ws), nbytes, _stream(dy)),
-                _tag(g, H, W) + " wino-fused", executed=flops * 16.0 / 36.0)
+                _tag(g, H, W) + " wino-fused",
+                # (9 / 36 on the upsampled source's channels where the launch skips its zero positions: that source carries at
+                # least half of the channels, csrc/winograd_wgrad.hip)
+                executed=flops * ((9.0 * g.C0 + 16.0 * g.C1) / (36.0 * g.Cin)
+                                  if (g.up0 and WINO_UP_SKIP and 2 * g.C0 >= g.Cin) else 16.0 / 36.0))
             if rc == 0:
                 WINO_FUSED_TAKEN["wgrad"] += 1
                 return dw
