@@ -344,29 +344,43 @@ __global__ __launch_bounds__(256) void reproj_err_bwd_kernel(const float* pred, 
 }
 
 // ---------------------------------------------------------------------------------------- auto-mask min
+// n source frames (monodepth_loss.py:136-177 loops over frame_ids[1:], whatever their number): ident / reproj are [B,n,H,W], noise
+// [B, avg ? 1 : n, H, W]; avg = the channel mean of each group first (torch's mean: the sum in channel order, divided by n)
+#define SEGSDE_AUTOMASK_MAX_FRAMES 8
 __global__ __launch_bounds__(256) void automask_fwd_kernel(const float* ident, const float* noise, const float* reproj,
                                                            int n_reproj, int avg, long total, long HW, uint8_t* sel,
                                                            float* isel, double* part) {
   SEGSDE_SMEM;
   double* sh = reinterpret_cast<double*>(segsde_smem);
-  const int ni_in = ident ? 2 : 0;
-  const int ni = ident ? (avg ? 1 : 2) : 0;
+  const int ni = ident ? (avg ? 1 : n_reproj) : 0;
+  const float fn = (float)n_reproj;
   double acc = 0.0;
   for (long e = blockIdx.x * 256L + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
     const long b = e / HW, p = e - b * HW;
-    float v[4]; int n = 0;
+    float best = 0.f; int bi = 0, n = 0;
+    auto offer = [&](float v) { if (n == 0 || v < best) { best = v; bi = n; } ++n; };   // the first minimum wins (torch.min)
     if (ident) {
-      const float i0 = ident[(b * ni_in) * HW + p], i1 = ident[(b * ni_in + 1) * HW + p];
-      if (avg) { v[n] = (i0 + i1) / 2.f; if (noise) v[n] += noise[b * HW + p] * 0.00001f; ++n; }
-      else {
-        v[n] = i0; if (noise) v[n] += noise[(b * 2) * HW + p] * 0.00001f; ++n;
-        v[n] = i1; if (noise) v[n] += noise[(b * 2 + 1) * HW + p] * 0.00001f; ++n;
+      if (avg) {
+        float a = ident[(b * n_reproj) * HW + p];
+        for (int j = 1; j < n_reproj; ++j) a += ident[(b * n_reproj + j) * HW + p];
+        a = a / fn;
+        if (noise) a += noise[b * HW + p] * 0.00001f;
+        offer(a);
+      } else {
+        for (int j = 0; j < n_reproj; ++j) {
+          float a = ident[(b * n_reproj + j) * HW + p];
+          if (noise) a += noise[(b * n_reproj + j) * HW + p] * 0.00001f;
+          offer(a);
+        }
       }
     }
-    if (avg && n_reproj == 2) v[n++] = (reproj[(b * 2) * HW + p] + reproj[(b * 2 + 1) * HW + p]) / 2.f;
-    else for (int j = 0; j < n_reproj; ++j) v[n++] = reproj[(b * n_reproj + j) * HW + p];
-    float best = v[0]; int bi = 0;
-    for (int j = 1; j < n; ++j) if (v[j] < best) { best = v[j]; bi = j; }
+    if (avg && n_reproj > 1) {
+      float a = reproj[(b * n_reproj) * HW + p];
+      for (int j = 1; j < n_reproj; ++j) a += reproj[(b * n_reproj + j) * HW + p];
+      offer(a / fn);
+    } else {
+      for (int j = 0; j < n_reproj; ++j) offer(reproj[(b * n_reproj + j) * HW + p]);
+    }
     sel[e] = (uint8_t)bi;
     if (isel) isel[e] = bi > ni - 1 ? 1.f : 0.f;
     acc += (double)best;
@@ -386,19 +400,19 @@ __global__ __launch_bounds__(256) void sum_finalize_kernel(const double* part, i
 
 __global__ __launch_bounds__(256) void automask_bwd_kernel(const uint8_t* sel, int ni, int n_reproj, int avg, long total,
                                                            long HW, float scale, float* greproj) {
+  const float ga = scale / (float)n_reproj;
   for (long e = blockIdx.x * 256L + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
     const long b = e / HW, p = e - b * HW;
     const int s = sel[e];
-    if (avg && n_reproj == 2) {
-      const float g = (s == ni) ? 0.5f * scale : 0.f;
-      greproj[(b * 2) * HW + p] = g; greproj[(b * 2 + 1) * HW + p] = g;
+    if (avg && n_reproj > 1) {
+      const float g = (s == ni) ? ga : 0.f;
+      for (int j = 0; j < n_reproj; ++j) greproj[(b * n_reproj + j) * HW + p] = g;
     } else {
       for (int j = 0; j < n_reproj; ++j) greproj[(b * n_reproj + j) * HW + p] = (s == ni + j) ? scale : 0.f;
     }
   }
 }
 
-// ---------------------------------------------------------------------------------------- smoothness
 __global__ __launch_bounds__(256) void plane_sum_kernel(const float* x, long n, double* part) {
   // grid (nblk, B): per-batch plane sums
   SEGSDE_SMEM;
@@ -1347,7 +1361,7 @@ extern "C" int segsde_automask_min_forward(const float* ident, const float* nois
                                            int avg, int B, int H, int W, uint8_t* sel, float* identity_selection,
                                            float* sum_out, void* ws_, size_t ws_bytes, void* stream) {
   if (!reproj || !sel || !sum_out || !ws_) return SEGSDE_ERR_NULL;
-  if (n_reproj < 1 || n_reproj > 2) return SEGSDE_ERR_SHAPE;
+  if (n_reproj < 1 || n_reproj > SEGSDE_AUTOMASK_MAX_FRAMES) return SEGSDE_ERR_SHAPE;
   if (ws_bytes < segsde_automask_workspace(B, H, W)) return SEGSDE_ERR_WORKSPACE;
   const long total = (long)B * H * W;
   const int nb = flat_blocks(total);
@@ -1362,8 +1376,9 @@ extern "C" int segsde_automask_min_forward(const float* ident, const float* nois
 extern "C" int segsde_automask_min_backward(const uint8_t* sel, int n_ident, int n_reproj, int avg, int B, int H, int W,
                                             float scale, float* greproj, void* stream) {
   if (!sel || !greproj) return SEGSDE_ERR_NULL;
+  if (n_reproj < 1 || n_reproj > SEGSDE_AUTOMASK_MAX_FRAMES) return SEGSDE_ERR_SHAPE;
   const long total = (long)B * H * W;
-  const int ni = n_ident ? (avg ? 1 : 2) : 0;
+  const int ni = n_ident ? (avg ? 1 : n_reproj) : 0;
   hipLaunchKernelGGL(automask_bwd_kernel, dim3(flat_blocks(total)), dim3(256), 0, ST(stream), sel, ni, n_reproj, avg, total,
                      (long)H * W, scale, greproj);
   SEGSDE_CHECK_LAUNCH();

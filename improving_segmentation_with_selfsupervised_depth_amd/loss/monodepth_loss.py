@@ -117,7 +117,8 @@ class _MonoLossFn(Function):
         automask = not obj.disable_automasking
         avg = bool(obj.avg_reprojection)
         nf = len(frames)
-        assert nf in (1, 2), "the auto-mask kernel is written for the reference's two source frames"
+        if nf > 2:
+            return _MonoLossFn._forward_staged(ctx, obj, inputs, cache, outputs, disps, Ts, frames)
         # one source frame (the stereo-only set (0, "s")): the two-frame kernels run on that frame twice.  The minimum / mean over
         # two identical candidates is the candidate, a tie goes to the first index like torch.min's, the tie-break noise of the one
         # identity channel (reference :163-164, shape [B, 1, H, W]) sits in both slots, and the two pose-gradient slots add up
@@ -166,7 +167,83 @@ class _MonoLossFn(Function):
         return (total,) + tuple(losses)
 
     @staticmethod
+    def _forward_staged(ctx, obj, inputs, cache, outputs, disps, Ts, frames):
+        """Three or more source frames (monodepth2's (0, -1, 1, "s"); reference :136-177 loops over ``frame_ids[1:]`` whatever their
+        number).  The packed kernels above are written for the two frames of every shipped configuration; a larger set runs the
+        per-stage entry points frame by frame: warp, SSIM + L1 error into a channel of [B, nf, H, W], one n-way minimum."""
+        S, nf = obj.num_scales, len(frames)
+        target = inputs[("color", 0, 0)].contiguous()
+        B, _, Hh, W = target.shape
+        dev = target.device
+        automask, avg = not obj.disable_automasking, bool(obj.avg_reprojection)
+        srcs = [inputs[("color", f, 0)].contiguous() for f in frames]
+        inv_K, K = inputs[("inv_K", 0)].contiguous(), inputs[("K", 0)].contiguous()
+        ident = None
+        if automask:                                   # the same for every scale
+            ident = torch.empty((B, nf, Hh, W), dtype=torch.float32, device=dev)
+            for j in range(nf):
+                H.reprojection_error(srcs[j], target, obj.no_ssim, ident[:, j])
+        losses, saved = [], []
+        for s in range(S):
+            colors = []
+            reproj = torch.empty((B, nf, Hh, W), dtype=torch.float32, device=dev)
+            for j, f in enumerate(frames):
+                col = cache.get(("color", f, s)) if cache is not None else None
+                if col is None:
+                    col, _, _ = H.warp_forward(disps[s], inv_K, K, Ts[j], srcs[j], obj.min_depth, obj.max_depth)
+                colors.append(col)
+                H.reprojection_error(col, target, obj.no_ssim, reproj[:, j])
+            noise = None
+            if automask:
+                if obj.tiebreak_noise is not None:
+                    noise = obj.tiebreak_noise[s].to(dev).float().contiguous()
+                else:
+                    noise = torch.randn((B, 1 if avg else nf, Hh, W), device=dev)
+            ssum, sel, isel = H.automask_min(ident, noise, reproj, avg)
+            if automask:
+                outputs["identity_selection/{}".format(s)] = isel
+            color_s = inputs[("color", 0, s)].contiguous()
+            smooth, mean_disp = H.smoothness_forward(disps[s], color_s)
+            losses.append(ssum[0] / float(B * Hh * W) + smooth[0] * (obj.disparity_smoothness / (2 ** s)))
+            saved.append((sel, colors, mean_disp, color_s))
+        total = losses[0]
+        for l in losses[1:]:
+            total = total + l
+        total = total / S
+        ctx.obj, ctx.saved, ctx.disps, ctx.Ts, ctx.srcs, ctx.target = obj, saved, disps, Ts, srcs, target
+        ctx.geo = (inv_K, K)
+        ctx.automask, ctx.avg, ctx.dup, ctx.staged = automask, avg, False, True
+        return (total,) + tuple(losses)
+
+    @staticmethod
+    def _backward_staged(ctx, g_total, g_scales):
+        obj, S, nf = ctx.obj, ctx.obj.num_scales, len(ctx.srcs)
+        inv_K, K = ctx.geo
+        target = ctx.target
+        B, _, Hh, W = target.shape
+        dev = target.device
+        gd_out = []
+        gT_acc = [torch.zeros((B, 4, 4), dtype=torch.float32, device=dev) for _ in range(nf)]
+        for s in range(S):
+            sel, colors, mean_disp, color_s = ctx.saved[s]
+            w_s = (g_total / S + g_scales[s]).reshape(1).contiguous()
+            greproj = H.automask_min_backward(sel, ctx.automask, nf, ctx.avg, 1.0 / float(B * Hh * W))
+            gup = torch.zeros((B, Hh, W), dtype=torch.float32, device=dev)
+            for j in range(nf):
+                gpred = H.reprojection_error_backward(colors[j], target, greproj[:, j], obj.no_ssim)
+                gT = torch.zeros((B, 4, 4), dtype=torch.float32, device=dev)
+                H.warp_backward(gpred, ctx.disps[s], inv_K, K, ctx.Ts[j], ctx.srcs[j], obj.min_depth, obj.max_depth, gup, gT)
+                gT_acc[j].add_(gT * w_s)
+            hs, ws = ctx.disps[s].shape[-2:]
+            gdisp = H.resize_bilinear_backward(gup.reshape(B, Hh, W, 1), (hs, ws), False).reshape(B, 1, hs, ws)
+            H.smoothness_backward(ctx.disps[s], color_s, mean_disp, obj.disparity_smoothness / (2 ** s), gdisp)
+            gd_out.append(H.axpby_dev(w_s, gdisp))
+        return (None, None, None, None) + tuple(gd_out) + tuple(gT_acc)
+
+    @staticmethod
     def backward(ctx, g_total, *g_scales):
+        if getattr(ctx, "staged", False):
+            return _MonoLossFn._backward_staged(ctx, g_total, g_scales)
         obj, S = ctx.obj, ctx.obj.num_scales
         inv_K, K = ctx.geo
         target = ctx.target
@@ -207,11 +284,11 @@ class MonodepthLoss:
         self.disable_automasking = disable_automasking
         self.device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
         self.depth_metric_names = ["abs_rel", "sq_rel", "rms", "log_rms", "a1", "a2", "a3"]
-        if len(self.frame_ids) not in (2, 3):
-            # the auto-mask / photometric kernels take two source frames (the reference configs' temporal pair, or one temporal +
-            # the stereo frame "s") or one (the stereo-only set (0, "s"), run as a pair of itself); the four-frame set
-            # (0, -1, 1, "s") of monodepth2 is not built
-            raise NotImplementedError("MonodepthLoss: one or two source frames expected, got frame_ids = %r" % (self.frame_ids,))
+        # source frames: two (the shipped configs' temporal pair, or one temporal frame + the stereo frame "s") run the packed
+        # photometric kernels, one (the stereo-only set (0, "s")) runs them as a pair of itself, three or more (monodepth2's
+        # (0, -1, 1, "s")) the per-stage kernels frame by frame (_MonoLossFn._forward_staged)
+        if not 2 <= len(self.frame_ids) <= 9:
+            raise NotImplementedError("MonodepthLoss: one to eight source frames expected, got frame_ids = %r" % (self.frame_ids,))
         self.tiebreak_noise = None    # tests: dict scale -> tensor replacing the fresh randn of reference :163-164
         self._cache = None
 

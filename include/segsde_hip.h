@@ -359,8 +359,10 @@ size_t segsde_reprojection_error_backward_workspace(int B, int H, int W);
 int segsde_reprojection_error_backward(const float* pred, const float* target, const float* gerr, long gerr_bstride, int B,
                                        int H, int W, int no_ssim, float* gpred, void* workspace, size_t workspace_bytes,
                                        void* stream);
-/* per-pixel min over [identity(+1e-5*noise) | reprojection] channels (monodepth_loss.py:147-177).
- * ident/noise may be NULL (disable_automasking); avg=1 averages the two channels of each group first.
+/* per-pixel min over [identity(+1e-5*noise) | reprojection] channels (monodepth_loss.py:136-177) for any number of source
+ * frames n_reproj (1..8: the loop over frame_ids[1:]): reproj and ident are [B,n_reproj,H,W], noise [B, avg ? 1 : n_reproj, H, W].
+ * ident/noise may be NULL (disable_automasking); avg=1 averages the channels of each group first.  n_ident of the adjoint: nonzero
+ * if the forward had identity terms.
  * Outputs: sel [B,H,W] uint8 = argmin index in the combined order, identity_selection [B,H,W] float (nullable),
  * sum_out[0] = sum of the minima (the caller divides by B*H*W). */
 size_t segsde_automask_workspace(int B, int H, int W);

@@ -217,6 +217,69 @@ def gen_loss_stereo():
     save("loss_stereo", d)
 
 
+def gen_loss_frames4():
+    """monodepth2's four-frame set (0, -1, 1, "s") through the reference's loss (monodepth_loss.py:80-85 picks the pose per frame,
+    :136-177 loops over however many source frames there are): three source frames, so the auto-mask's noise is [B, 3, H, W] (or
+    [B, 1, H, W] when averaging) and the minimum runs over six (two) candidates."""
+    B, H, W = 2, 32, 64
+    frames = [-1, 1, "s"]
+    base = dict(num_scales=4, frame_ids=[0] + frames, height=H, width=W, batch_size=B, min_depth=0.1, max_depth=100,
+                test_min_depth=1e-3, test_max_depth=80, disparity_smoothness=1e-3, no_ssim=False,
+                avg_reprojection=False, disable_automasking=False)
+    variants = {"default": {}, "no_ssim": {"no_ssim": True}, "avg_reprojection": {"avg_reprojection": True},
+                "disable_automasking": {"disable_automasking": True}}
+    d = {}
+    for vi, (name, over) in enumerate(variants.items()):
+        gen = torch.Generator().manual_seed(400 + vi)
+        inputs, disps, aa, tr = make_loss_inputs(B, H, W, gen)
+        lo = torch.rand(B, 3, H // 4, W // 4, generator=gen)
+        inputs[("color", "s", 0)] = (F.interpolate(lo, size=(H, W), mode="bilinear", align_corners=False) * 0.8
+                                     + 0.2 * torch.rand(B, 3, H, W, generator=gen)).contiguous()
+        T = torch.eye(4).unsqueeze(0).repeat(B, 1, 1)
+        T[0, 0, 3], T[1, 0, 3] = 0.1, -0.1
+        T[:, 1, 3] = 0.003 * torch.randn(B, generator=gen)
+        inputs["stereo_T"] = T
+        cfg = dict(base, **over)
+        loss_obj = RefMonodepthLoss(**cfg)
+        dleaf = {s_: disps[s_].clone().requires_grad_(True) for s_ in range(4)}
+        out = {("disp", s_): dleaf[s_] for s_ in range(4)}
+        Tleaf = {}
+        for i, f in enumerate((-1, 1)):
+            Tf = ref_layers.transformation_from_parameters(aa[:, i], tr[:, i], invert=(f < 0))
+            Tleaf[f] = Tf.detach().clone().requires_grad_(True)
+            out[("cam_T_cam", 0, f)] = Tleaf[f]
+        nch = 1 if cfg["avg_reprojection"] else 3
+        noise = {s_: torch.randn(B, nch, H, W, generator=gen) for s_ in range(4)}
+        queue = [noise[s_] for s_ in range(4)]
+        real_randn = torch.randn
+        loss_obj.generate_images_pred(inputs, out)
+        torch.randn = lambda *a, **k: queue.pop(0)
+        try:
+            losses = loss_obj.compute_losses(inputs, out)
+        finally:
+            torch.randn = real_randn
+        losses["loss"].backward()
+        d[name + "_cfg_json"] = json.dumps(cfg)
+        for k in [("color", f, 0) for f in [0] + frames] + [("color", 0, 1), ("color", 0, 2), ("color", 0, 3), ("K", 0), ("inv_K", 0)]:
+            d[name + "_in_" + "_".join(str(x) for x in k)] = inputs[k]
+        d[name + "_stereo_T"] = T
+        d[name + "_loss"] = losses["loss"]
+        for f in (-1, 1):
+            tag = "m1" if f < 0 else "p1"
+            d["%s_T_%s" % (name, tag)] = Tleaf[f]
+            d["%s_grad_T_%s" % (name, tag)] = Tleaf[f].grad
+        for s_ in range(4):
+            d[name + "_disp_%d" % s_] = disps[s_]
+            d[name + "_grad_disp_%d" % s_] = dleaf[s_].grad
+            d[name + "_loss_%d" % s_] = losses["loss/%d" % s_]
+            if not cfg["disable_automasking"]:
+                d[name + "_noise_%d" % s_] = noise[s_]
+                d[name + "_identity_selection_%d" % s_] = out["identity_selection/%d" % s_]
+        d[name + "_color_s_0"] = out[("color", "s", 0)]
+        d[name + "_color_m1_2"] = out[("color", -1, 2)]
+    save("loss_frames4", d)
+
+
 def gen_geom():
     gen = torch.Generator().manual_seed(7)
     B, H, W = 3, 6, 10
@@ -823,7 +886,7 @@ def gen_valtail():
     save("valtail", d)
 
 
-ALL = ["loss", "loss_stereo", "geom", "ssim_smooth", "segmix", "blocks", "decoders", "encoder", "nets", "trainer", "usegt", "valtail", "poseall"]
+ALL = ["loss", "loss_stereo", "loss_frames4", "geom", "ssim_smooth", "segmix", "blocks", "decoders", "encoder", "nets", "trainer", "usegt", "valtail", "poseall"]
 
 
 def check(which):

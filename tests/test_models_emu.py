@@ -74,6 +74,10 @@ def test_monodepth_loss_stereo_only(golden):
     MC.run_loss_stereo_only("cpu", golden)
 
 
+def test_monodepth_loss_four_frames(golden):
+    MC.run_loss_four_frames("cpu", golden)
+
+
 def test_convblock_dropout2d():
     MC.run_convblock_dropout2d("cpu")
 

@@ -32,6 +32,10 @@ def test_monodepth_loss_stereo_only(golden):
     MC.run_loss_stereo_only("cuda", golden)
 
 
+def test_monodepth_loss_four_frames(golden):
+    MC.run_loss_four_frames("cuda", golden)
+
+
 @pytest.mark.parametrize("which", ["dd1", "dd2", "jsd1", "jsd2", "pad1", "pad2"])
 def test_decoders(golden, which):
     MC.run_decoders("cuda", golden, (which,))

@@ -101,6 +101,31 @@ def test_loss_stereo_only_matches_reference(golden, variant):
     close(out[("sample", "s", 0)], g[variant + "_sample_s_0"], atol=1e-5)
 
 
+@pytest.mark.parametrize("variant", ["default", "no_ssim", "avg_reprojection", "disable_automasking"])
+def test_loss_four_frames_matches_reference(golden, variant):
+    """the oracle on monodepth2's four-frame set (0, -1, 1, "s") (monodepth_loss.py:80-85, 136-177: three source frames)"""
+    from model_cases import frames4_case
+    g = golden("loss_frames4")
+    cfg, inputs, Ts = frames4_case(g, variant)
+    obj = P.MonodepthLossOracle(**cfg)
+    disps = {s: g["%s_disp_%d" % (variant, s)].clone().requires_grad_(True) for s in range(4)}
+    out = {("disp", s): disps[s] for s in range(4)}
+    out.update({("cam_T_cam", 0, f): T for f, T in Ts.items()})
+    obj.generate_images_pred(inputs, out)
+    noise = None if cfg["disable_automasking"] else {s: g["%s_noise_%d" % (variant, s)] for s in range(4)}
+    losses = obj.compute_losses(inputs, out, tiebreak_noise=noise)
+    losses["loss"].backward()
+    close(losses["loss"], g[variant + "_loss"])
+    for s in range(4):
+        close(losses["loss/%d" % s], g["%s_loss_%d" % (variant, s)])
+        close(disps[s].grad, g["%s_grad_disp_%d" % (variant, s)], rtol=1e-4, atol=1e-8)
+        if not cfg["disable_automasking"]:
+            assert torch.equal(out["identity_selection/%d" % s], g["%s_identity_selection_%d" % (variant, s)])
+    for f, tag in ((-1, "m1"), (1, "p1")):
+        close(Ts[f].grad, g["%s_grad_T_%s" % (variant, tag)], rtol=1e-4, atol=1e-8)
+    close(out[("color", "s", 0)], g[variant + "_color_s_0"], atol=1e-5)
+
+
 def test_geometry(golden):
     g = golden("geom")
     sdisp, depth = G.disp_to_depth(g["disp"], 0.1, 100)
@@ -521,7 +546,7 @@ def test_fixture_recipe_regenerates_committed_files():
     run here; ``python tests/golden/make_golden.py --check`` runs all of them."""
     import subprocess
     r = subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), "golden", "make_golden.py"), "--check",
-                        "geom", "ssim_smooth", "segmix", "trainer", "usegt", "poseall", "loss_stereo"], capture_output=True, text=True, timeout=600)
+                        "geom", "ssim_smooth", "segmix", "trainer", "usegt", "poseall", "loss_stereo", "loss_frames4"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "make_golden --check: OK" in r.stdout
 
