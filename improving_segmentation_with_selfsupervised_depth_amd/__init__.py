@@ -5,3 +5,5 @@ Sub-packages mirror the reference's import surface (``models``, ``loss``, ``load
 hand-written HIP kernels (``csrc/``) reached through the C ABI of ``include/segsde_hip.h``.
 """
 __version__ = "0.1.0"
+
+from . import torch_ops  # noqa: E402,F401  (registers torch.ops.segsde.*; loads no library until an operator runs)

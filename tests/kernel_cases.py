@@ -1781,3 +1781,110 @@ def run_f16_operand_convolutions(device):
                              - want[0]).abs().max() / want[0].abs().max())
                 e16 = float((got[0].cpu().double() - want[0]).abs().max() / want[0].abs().max())
                 assert e16 > 10 * e32, "the half-precision mode did not take the half-precision kernel (%g vs %g)" % (e16, e32)
+
+
+def run_torch_ops(device, golden):
+    """torch.ops.segsde.* (improving_segmentation_with_selfsupervised_depth_amd/torch_ops.py): every registered operator runs on the
+    HIP kernels and differentiates like the package's modules -- an encoder-style chain against ATen in float64, the loss stages
+    against the reference vectors, the mask / mix operators against their defining formulas (bit-exact)"""
+    import improving_segmentation_with_selfsupervised_depth_amd as pkg
+    ops = torch.ops.segsde
+    d = lambda t: t.to(device)
+    gen = torch.Generator().manual_seed(21)
+    assert len(pkg.torch_ops.names()) >= 18 and all(hasattr(ops, n.split("::")[1]) for n in pkg.torch_ops.names())
+    # conv -> BatchNorm + ReLU -> max-pool -> reflected 3x3 on [upsampled | skip] -> resize -> global pool, gradients to everything
+    B, Hh, W = 2, 16, 24
+    x = torch.randn(B, 8, Hh, W, generator=gen)
+    w1, b1 = 0.2 * torch.randn(16, 8, 3, 3, generator=gen), 0.1 * torch.randn(16, generator=gen)
+    gam, bet = 1.0 + 0.1 * torch.randn(16, generator=gen), 0.1 * torch.randn(16, generator=gen)
+    skip = torch.randn(B, 8, Hh, W, generator=gen)
+    w2 = 0.2 * torch.randn(8, 24, 3, 3, generator=gen)
+    wgt = torch.randn(B, 8, 10, 14, generator=gen)
+    leaves = [t.clone().to(device).requires_grad_(True) for t in (x, w1, b1, gam, bet, skip, w2)]
+    X, W1, B1, G, Bt, S, W2 = leaves
+    rm, rv = torch.zeros(16, device=device), torch.ones(16, device=device)
+    h = ops.conv2d(ops.to_nhwc(X), W1, B1, None, 1, 2, 2)
+    h = ops.batch_norm_act(h, G, Bt, rm, rv, None, True, 0.1, 1e-5, "relu")
+    h = ops.max_pool_3x3_s2(h)
+    h = ops.conv2d(h, W2, None, ops.to_nhwc(S), 1, 1, 1, True, True)
+    r = ops.resize_bilinear(h, [10, 14], False)
+    out = (ops.to_nchw(r) * d(wgt)).sum() + 3.0 * ops.global_avg_pool(h).sum()
+    out.backward()
+    ref = [t.double().clone().requires_grad_(True) for t in (x, w1, b1, gam, bet, skip, w2)]
+    Xr, W1r, B1r, Gr, Btr, Sr, W2r = ref
+    rmr, rvr = torch.zeros(16, dtype=torch.float64), torch.ones(16, dtype=torch.float64)
+    hr = F.conv2d(Xr, W1r, B1r, 1, 2, 2)
+    hr = F.relu(F.batch_norm(hr, rmr, rvr, Gr, Btr, True, 0.1, 1e-5))
+    hr = F.max_pool2d(hr, 3, 2, 1)
+    hr = F.conv2d(F.pad(torch.cat([F.interpolate(hr, scale_factor=2, mode="nearest"), Sr], 1), (1, 1, 1, 1), mode="reflect"), W2r)
+    rr = F.interpolate(hr, size=(10, 14), mode="bilinear", align_corners=False)
+    outr = (rr * wgt.double()).sum() + 3.0 * hr.mean((2, 3)).sum()
+    outr.backward()
+    assert_close(out, outr.float(), rtol=1e-4, what="torch.ops chain value")
+    assert_close(rm, rmr.float(), rtol=1e-4, atol=1e-6, what="torch.ops running mean")
+    for a, b, name in zip(leaves, ref, ("x", "w1", "b1", "gamma", "beta", "skip", "w2")):
+        # (the bias in front of a training-mode BatchNorm has gradient zero: what arrives is rounding noise -> an absolute floor)
+        assert_close(a.grad, b.grad.float(), rtol=1e-3, atol=1e-4 * max(float(b.grad.abs().max()), 0.1), what="torch.ops chain d/d" + name)
+    # pose matrix, geometry, warp against the reference vectors
+    q = golden("geom")
+    aa, tr = d(q["axisangle"]).clone().requires_grad_(True), d(q["translation"]).clone().requires_grad_(True)
+    M = ops.pose_matrix(aa, tr, True)
+    assert_close(M, q["M_inv"], rtol=1e-5, atol=1e-6, what="torch.ops pose_matrix")
+    (M * d(q["M_weight"])).sum().backward()
+    assert_close(aa.grad, q["grad_aa_inv"], rtol=1e-3, atol=1e-6, what="torch.ops pose_matrix adjoint")
+    Bq, _, Hq, Wq = q["depth"].shape
+    cam = ops.backproject_depth(d(q["depth"]), d(q["inv_K"]))
+    assert_close(cam, q["cam_points"], rtol=1e-5, atol=1e-6, what="torch.ops backproject_depth")
+    assert_close(ops.project3d(cam, d(q["K"]), d(q["T"]), Hq, Wq), q["grid"], rtol=1e-4, atol=1e-5, what="torch.ops project3d")
+    gl = golden("loss_default")
+    col, grid, depth = ops.warp(d(gl["disp_2"]), d(gl["in_inv_K_0"]), d(gl["in_K_0"]), d(gl["T_m1"]), d(gl["in_color_-1_0"]), 0.1, 100.0)
+    assert_close(col, gl["color_m1_2"], rtol=1e-3, atol=1e-4, what="torch.ops warp colour")
+    assert_close(grid, gl["sample_m1_2"], rtol=1e-4, atol=1e-5, what="torch.ops warp grid")
+    assert_close(depth, gl["depth_2"], rtol=1e-4, atol=1e-5, what="torch.ops warp depth")
+    # SSIM / smoothness / reprojection error / auto-mask
+    g = golden("ssim_smooth")
+    xs = d(g["x"]).clone().requires_grad_(True)
+    v = ops.ssim(xs, d(g["y"]))
+    assert_close(v, g["ssim"], rtol=1e-4, atol=1e-6, what="torch.ops ssim")
+    (v * d(g["w"])).sum().backward()
+    assert_close(xs.grad, g["grad_x"], rtol=1e-3, atol=2e-5, what="torch.ops ssim adjoint")
+    disp = d(g["sm_disp"]).clone().requires_grad_(True)
+    sm = ops.smooth_loss(disp, d(g["sm_img"]))
+    sm.backward()
+    assert_close(sm, g["smooth"], rtol=1e-5, what="torch.ops smooth_loss")
+    assert_close(disp.grad, g["grad_sm_disp"], rtol=1e-4, atol=1e-7, what="torch.ops smooth_loss adjoint")
+    from oracle import photometric as OP
+    tgt, pred = gl["in_color_0_0"], gl["color_m1_0"]
+    err = ops.reprojection_error(d(pred), d(tgt), False)
+    assert_close(err, OP.reprojection_error(pred, tgt, False), rtol=1e-4, atol=1e-6, what="torch.ops reprojection_error")
+    ident, reproj = torch.rand(2, 3, 6, 9, generator=gen), torch.rand(2, 3, 6, 9, generator=gen)
+    noise = torch.randn(2, 3, 6, 9, generator=gen)
+    ssum, sel, isel = ops.automask_min(d(ident), d(noise), d(reproj), False)
+    mn, ix = torch.min(torch.cat([ident + noise * 0.00001, reproj], 1), 1)
+    assert torch.equal(sel.cpu().long(), ix) and torch.equal(isel.cpu(), (ix > 2).float())
+    assert_close(ssum, mn.sum().reshape(1), rtol=1e-5, what="torch.ops automask_min")
+    ssum2, sel2, isel2 = ops.automask_min(None, None, d(reproj), False)
+    assert isel2 is None and torch.equal(sel2.cpu().long(), reproj.min(1)[1])
+    # segmentation loss, mix, depthcomp mask
+    logits = torch.randn(2, 19, 12, 20, generator=gen)
+    target = torch.randint(0, 19, (2, 12, 20), generator=gen)
+    target[0, :3] = 250
+    lg = d(logits).clone().requires_grad_(True)
+    ce = ops.cross_entropy2d(lg, d(target))
+    ce.backward()
+    lr = logits.double().clone().requires_grad_(True)
+    cer = F.cross_entropy(lr, target, ignore_index=250)
+    cer.backward()
+    assert_close(ce, cer.float(), rtol=1e-5, what="torch.ops cross_entropy2d")
+    assert_close(lg.grad, lr.grad.float(), rtol=1e-3, atol=1e-8, what="torch.ops cross_entropy2d adjoint")
+    mask = (torch.rand(2, 12, 20, generator=gen) > 0.5).long()
+    data = torch.randn(2, 3, 12, 20, generator=gen)
+    mixed = ops.mix(d(mask), d(data))
+    mf = mask.float().unsqueeze(1)
+    assert torch.equal(mixed.cpu(), mf * data + (1 - mf) * torch.roll(data, -1, 0))
+    labels = ops.mix(d(mask), d(target))
+    assert torch.equal(labels.cpu(), mask * target + (1 - mask) * torch.roll(target, -1, 0))
+    depths = torch.rand(2, 12, 20, generator=gen)
+    dm = ops.depthcomp_mask(d(depths), 0.05, 0.3)
+    want = ((depths >= torch.roll(depths, -1, 0) - 0.05) & (depths >= 0.3)).long()
+    assert torch.equal(dm.cpu(), want)

@@ -120,6 +120,10 @@ def test_monodepth_layer_callables(golden):
     KC.run_monodepth_layer_callables("cpu", golden)
 
 
+def test_torch_ops_namespace(golden):
+    KC.run_torch_ops("cpu", golden)
+
+
 def test_jitter_blur_properties():
     KC.run_jitter_blur_properties("cpu")
 

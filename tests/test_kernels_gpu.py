@@ -174,6 +174,10 @@ def test_monodepth_layer_callables(golden):
     KC.run_monodepth_layer_callables("cuda", golden)
 
 
+def test_torch_ops_namespace(golden):
+    KC.run_torch_ops("cuda", golden)
+
+
 def test_jitter_blur_properties():
     KC.run_jitter_blur_properties("cuda")
 
