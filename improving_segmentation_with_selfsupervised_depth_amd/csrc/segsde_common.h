@@ -57,6 +57,14 @@ __device__ __forceinline__ void segsde_buffer_store4_nt(segsde_rsrc r, unsigned 
   d.x = __float_as_uint(v.x); d.y = __float_as_uint(v.y); d.z = __float_as_uint(v.z); d.w = __float_as_uint(v.w);
   __builtin_amdgcn_raw_buffer_store_b128(d, r, voff, soff, 2);
 }
+// one dword per lane: with the lane's constant offset in the VGPR and everything wave-uniform in the SGPR offset a store / load of a
+// row of pixels costs no vector address arithmetic (the Winograd epilogue: 32 stores per thread)
+__device__ __forceinline__ void segsde_buffer_store1(segsde_rsrc r, unsigned voff, unsigned soff, float v) {
+  __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, voff, soff, 0);
+}
+__device__ __forceinline__ void segsde_buffer_store1_nt(segsde_rsrc r, unsigned voff, unsigned soff, float v) {
+  __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, voff, soff, 2);
+}
 // LDS-DMA: the same raw buffer load, but the 16 bytes of lane l land in LDS at lds_wave_base + 16*l without passing
 // through VGPRs (buffer_load_dwordx4 ... offen lds; destination = M0 + 16*lane, so the LDS image of one instruction is
 // 1 KiB lane-linear -- a swizzled layout is obtained by permuting which SOURCE element each lane fetches).  Out-of-range

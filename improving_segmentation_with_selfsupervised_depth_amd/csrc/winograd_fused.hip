@@ -306,10 +306,22 @@ __global__ __launch_bounds__(256, 2) void wino_fused_kernel(WinoSrc src, int B, 
         *reinterpret_cast<float4*>(zw + (64 + nb * 32) * FZP + 8 * rg) = c1v;
       }
   }
-  const int n = tid & 63, tg = tid >> 6;               // thread: filter n, tiles 8 tg .. 8 tg + 7 (tile row tg of the block)
+  // thread: filter n, tiles 8 tg .. 8 tg + 7 (tile row tg of the block).  tg is the wave: everything in a pixel's address except the
+  // filter is wave-uniform, so the epilogue's loads and stores are raw buffer operations on the image with the lane's filter offset in
+  // the vector register and the pixel's offset in a scalar one -- no 64-bit vector address arithmetic (it was about a quarter of the
+  // epilogue's vector instructions), and the range tests are scalar branches
+  const int n = tid & 63, tg = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool post = bias != nullptr || act != SEGSDE_ACT_NONE;
   const int co = co0 + n;
   const int ti = bh * FT_H + tg;
+  const unsigned lane_b = (unsigned)co * 4u;
+#ifdef WINO_EPI_POINTERS       // A/B: the per-thread pointer epilogue of round 5
+  constexpr bool kBuf = false;
+#else
+  constexpr bool kBuf = true;
+#endif
+  const segsde_rsrc yr = segsde_make_rsrc(y + (long)b * H * W * ldy);
+  const segsde_rsrc agr = segsde_make_rsrc(ag.agy ? ag.agy + (long)b * H * W * ag.agld : y);
   // the data-gradient epilogues read memory (the saved activation output for its derivative, the gradient already in dx for the
   // accumulation): all 8 x 4 requests of a thread are issued HERE, before the barrier of the Z exchange -- inside the tile loop
   // below every tile waited a full memory latency for its own four (round 5, first version: +55 % on a 64-channel layer)
@@ -319,9 +331,17 @@ __global__ __launch_bounds__(256, 2) void wino_fused_kernel(WinoSrc src, int B, 
     for (int q = 0; q < FT_W; ++q) {
       const int tj = bw * FT_W + q;
       const bool ok = ti < H2 && tj < W2;
-      const float* ap = ag.agy + ((long)(b * H + 2 * ti) * W + 2 * tj) * ag.agld + co;
-      agv[q][0] = ok ? ap[0] : 0.f; agv[q][1] = ok ? ap[ag.agld] : 0.f;
-      agv[q][2] = ok ? ap[(long)W * ag.agld] : 0.f; agv[q][3] = ok ? ap[(long)W * ag.agld + ag.agld] : 0.f;
+      if (kBuf) {
+        const unsigned s0 = (unsigned)((2 * ti) * W + 2 * tj) * (unsigned)ag.agld * 4u, sr = (unsigned)W * (unsigned)ag.agld * 4u;
+        if (ok) {
+          agv[q][0] = segsde_buffer_load1(agr, lane_b, s0); agv[q][1] = segsde_buffer_load1(agr, lane_b, s0 + (unsigned)ag.agld * 4u);
+          agv[q][2] = segsde_buffer_load1(agr, lane_b, s0 + sr); agv[q][3] = segsde_buffer_load1(agr, lane_b, s0 + sr + (unsigned)ag.agld * 4u);
+        } else { agv[q][0] = agv[q][1] = agv[q][2] = agv[q][3] = 0.f; }
+      } else {
+        const float* ap = ag.agy + ((long)(b * H + 2 * ti) * W + 2 * tj) * ag.agld + co;
+        agv[q][0] = ok ? ap[0] : 0.f; agv[q][1] = ok ? ap[ag.agld] : 0.f;
+        agv[q][2] = ok ? ap[(long)W * ag.agld] : 0.f; agv[q][3] = ok ? ap[(long)W * ag.agld + ag.agld] : 0.f;
+      }
     }
   }
   if (accumulate & 1) {
@@ -329,9 +349,17 @@ __global__ __launch_bounds__(256, 2) void wino_fused_kernel(WinoSrc src, int B, 
     for (int q = 0; q < FT_W; ++q) {
       const int tj = bw * FT_W + q;
       const bool ok = ti < H2 && tj < W2;
-      const float* yp = y + ((long)(b * H + 2 * ti) * W + 2 * tj) * ldy + co;
-      oldv[q][0] = ok ? yp[0] : 0.f; oldv[q][1] = ok ? yp[ldy] : 0.f;
-      oldv[q][2] = ok ? yp[(long)W * ldy] : 0.f; oldv[q][3] = ok ? yp[(long)W * ldy + ldy] : 0.f;
+      if (kBuf) {
+        const unsigned s0 = (unsigned)((2 * ti) * W + 2 * tj) * (unsigned)ldy * 4u, sr = (unsigned)W * (unsigned)ldy * 4u;
+        if (ok) {
+          oldv[q][0] = segsde_buffer_load1(yr, lane_b, s0); oldv[q][1] = segsde_buffer_load1(yr, lane_b, s0 + (unsigned)ldy * 4u);
+          oldv[q][2] = segsde_buffer_load1(yr, lane_b, s0 + sr); oldv[q][3] = segsde_buffer_load1(yr, lane_b, s0 + sr + (unsigned)ldy * 4u);
+        } else { oldv[q][0] = oldv[q][1] = oldv[q][2] = oldv[q][3] = 0.f; }
+      } else {
+        const float* yp = y + ((long)(b * H + 2 * ti) * W + 2 * tj) * ldy + co;
+        oldv[q][0] = ok ? yp[0] : 0.f; oldv[q][1] = ok ? yp[ldy] : 0.f;
+        oldv[q][2] = ok ? yp[(long)W * ldy] : 0.f; oldv[q][3] = ok ? yp[(long)W * ldy + ldy] : 0.f;
+      }
     }
   }
   __syncthreads();
@@ -376,7 +404,16 @@ __global__ __launch_bounds__(256, 2) void wino_fused_kernel(WinoSrc src, int B, 
 #ifdef WINO_DBG_FEW_STORES     // phase-cost probe: one tile of eight is stored
       if (q == 0)
 #endif
-      if (accumulate & 2) {   // streaming stores (the launcher sets the bit for outputs that no cache level can hold)
+      if (kBuf) {
+        const unsigned s0 = (unsigned)((2 * ti) * W + 2 * tj) * (unsigned)ldy * 4u, sr = (unsigned)W * (unsigned)ldy * 4u, sc = (unsigned)ldy * 4u;
+        if (accumulate & 2) {   // streaming stores (the launcher sets the bit for outputs that no cache level can hold)
+          segsde_buffer_store1_nt(yr, lane_b, s0, o[0]); segsde_buffer_store1_nt(yr, lane_b, s0 + sc, o[1]);
+          segsde_buffer_store1_nt(yr, lane_b, s0 + sr, o[2]); segsde_buffer_store1_nt(yr, lane_b, s0 + sr + sc, o[3]);
+        } else {
+          segsde_buffer_store1(yr, lane_b, s0, o[0]); segsde_buffer_store1(yr, lane_b, s0 + sc, o[1]);
+          segsde_buffer_store1(yr, lane_b, s0 + sr, o[2]); segsde_buffer_store1(yr, lane_b, s0 + sr + sc, o[3]);
+        }
+      } else if (accumulate & 2) {
         __builtin_nontemporal_store(o[0], yp); __builtin_nontemporal_store(o[1], yp + ldy);
         __builtin_nontemporal_store(o[2], yp + (long)W * ldy); __builtin_nontemporal_store(o[3], yp + (long)W * ldy + ldy);
       } else { yp[0] = o[0]; yp[ldy] = o[1]; yp[(long)W * ldy] = o[2]; yp[(long)W * ldy + ldy] = o[3]; }
@@ -603,7 +640,7 @@ extern "C" int segsde_conv2d_winograd_fused(const float* x, int ldx, int B, int 
                                             int Cout, const float* bias, int act, float* y, int ldy, int accumulate, double* stats,
                                             void* stream) {
   if (!x || !u_kn || !y) return SEGSDE_ERR_NULL;
-  if (!segsde_winograd_fused_ok(B, H, W, C, Cout) || ldx < C || ldx % 4 != 0 || !pitch_ok(H, W, ldx) || ldy < Cout || (accumulate && (stats || bias || act)))
+  if (!segsde_winograd_fused_ok(B, H, W, C, Cout) || ldx < C || ldx % 4 != 0 || !pitch_ok(H, W, ldx) || ldy < Cout || !pitch_ok(H, W, ldy) || (accumulate && (stats || bias || act)))
     return SEGSDE_ERR_UNSUPPORTED;
   const WinoSrc src{x, nullptr, ldx, 0, C, 0};
   return launch_fused(src, B, H, W, C, reflect, u_kn, Cout, Cout, bias, act, y, ldy, accumulate, stats, WinoAg{nullptr, 0, 0}, stream);
@@ -617,7 +654,7 @@ extern "C" int segsde_conv2d_winograd_fused2(const float* x0, int ld0, int C0, i
   if (!x0 || !u_kn || !y || (C1 > 0 && !x1)) return SEGSDE_ERR_NULL;
   const int C = C0 + (C1 > 0 ? C1 : 0);
   if (!segsde_winograd_fused_ok(B, H, W, C, Cout) || C0 <= 0 || C0 % FCH || ld0 < C0 || ld0 % 4 != 0 || (C1 > 0 && (ld1 < C1 || ld1 % 4 != 0 || !pitch_ok(H, W, ld1))) ||
-      !pitch_ok(H >> (up0 ? 1 : 0), W >> (up0 ? 1 : 0), ld0) || ldy < Cout)
+      !pitch_ok(H >> (up0 ? 1 : 0), W >> (up0 ? 1 : 0), ld0) || ldy < Cout || !pitch_ok(H, W, ldy))
     return SEGSDE_ERR_UNSUPPORTED;
   const WinoSrc src{x0, x1, ld0, ld1, C0, up0 ? 1 : 0};
   return launch_fused(src, B, H, W, C, reflect, u_kn, Cout, Cout, bias, act, y, ldy, 0, stats, WinoAg{nullptr, 0, 0}, stream);
@@ -633,8 +670,8 @@ extern "C" int segsde_conv2d_winograd_fused_dgrad(const float* dy, int lddy, int
                                                   int Cin, float* dx, int lddx, int accumulate, const float* act_out, int act_ld,
                                                   int act_kind, void* stream) {
   if (!dy || !ud_kn || !dx) return SEGSDE_ERR_NULL;
-  if (!segsde_winograd_fused_ok(B, H, W, Cout, Cin) || ldu < Cin || (long)16 * Cout * ldu >= (1L << 28) || lddy < Cout || lddy % 4 != 0 || !pitch_ok(H, W, lddy) || lddx < Cin ||
-      (act_out && (act_kind < SEGSDE_ACT_RELU || act_kind > SEGSDE_ACT_SIGMOID || act_ld < Cin)))
+  if (!segsde_winograd_fused_ok(B, H, W, Cout, Cin) || ldu < Cin || (long)16 * Cout * ldu >= (1L << 28) || lddy < Cout || lddy % 4 != 0 || !pitch_ok(H, W, lddy) || lddx < Cin || !pitch_ok(H, W, lddx) ||
+      (act_out && (act_kind < SEGSDE_ACT_RELU || act_kind > SEGSDE_ACT_SIGMOID || act_ld < Cin || !pitch_ok(H, W, act_ld))))
     return SEGSDE_ERR_UNSUPPORTED;
   const WinoSrc src{dy, nullptr, lddy, 0, Cout, 0};
   return launch_fused(src, B, H, W, Cout, 0, ud_kn, ldu, Cin, nullptr, SEGSDE_ACT_NONE, dx, lddx, accumulate, nullptr,

@@ -226,6 +226,11 @@ inline void segsde_buffer_store4(segsde_rsrc r, unsigned voff, unsigned soff, fl
   memcpy(const_cast<char*>(r.base) + (size_t)voff + soff, &v, sizeof(v));
 }
 inline void segsde_buffer_store4_nt(segsde_rsrc r, unsigned voff, unsigned soff, float4 v) { segsde_buffer_store4(r, voff, soff, v); }
+inline void segsde_buffer_store1(segsde_rsrc r, unsigned voff, unsigned soff, float v) {
+  if (voff >= r.n) return;
+  memcpy(const_cast<char*>(r.base) + (size_t)voff + soff, &v, sizeof(v));
+}
+inline void segsde_buffer_store1_nt(segsde_rsrc r, unsigned voff, unsigned soff, float v) { segsde_buffer_store1(r, voff, soff, v); }
 
 // LDS-DMA flavour: lane l's 16 bytes land at lds_wave_base + 16*l (executed synchronously here: the interpreter cannot
 // model a missing wait, only wrong addresses / wrong buffer hand-over order)
