@@ -343,45 +343,51 @@ def test_headline_model_two_steps_vs_oracle(workload):
             assert abs(got[step][i] - ref[step][i]) <= tol * abs(ref[step][i]) + 1e-12, (step, what, got[step][i], ref[step][i])
 
 
-def test_cfg2_batch8_replication_property():
-    """BASELINE configs[1] at its own size AND batch: ResNet-50 monodepth, 512x1024, batch 8.  Size-independent property: a batch
-    made of four copies of a batch of two (frames, intrinsics and tie-break noise alike) has the same BatchNorm statistics, so in
-    exact arithmetic the mean losses and -- the loss being a batch mean -- every parameter gradient of the batch-8 step equal
-    those of the batch-2 step.  The float64 evaluation of the CPU oracle at batch 2 is therefore the truth for BOTH steps.  The
-    product's gradients at batch 2 and at batch 8 (four times the rows: other tile counts / split plans in every kernel) are
-    judged against it with the vector criterion of DESIGN.md 4: as close to the truth as the oracle's own fp32 arithmetic is.
-    (Comparing two fp32 evaluations with each other says little here: this randomly initialised BatchNorm network moves its
-    whole gradient by 1-2 % when reductions are merely re-associated -- the oracle's own fp32 batch-2 and batch-8 evaluations
-    differ by a median 1.4 % per parameter at this size, 4e-10 in float64.)"""
+def _replication_property(workload, rep):
+    """A batch made of ``rep`` copies of a batch of two (frames, labels, intrinsics and tie-break noise alike) has the same BatchNorm
+    statistics, so in exact arithmetic the mean losses and -- every loss being a batch mean -- every parameter gradient of the
+    large-batch step equal those of the batch-2 step.  The float64 evaluation of the CPU oracle at batch 2 is therefore the truth
+    for BOTH steps.  The product's gradients at batch 2 and at batch 2 * rep (rep times the rows: other tile counts / split plans /
+    routes in every kernel) are judged against it with the vector criterion of DESIGN.md 4: as close to the truth as the oracle's
+    own fp32 arithmetic is.  (Comparing two fp32 evaluations with each other says little here: a randomly initialised BatchNorm
+    network moves its whole gradient by 1-2 % when reductions are merely re-associated -- the oracle's own fp32 batch-2 and batch-8
+    evaluations of cfg2 differ by a median 1.4 % per parameter at this size, 4e-10 in float64.)"""
     from improving_segmentation_with_selfsupervised_depth_amd.models import get_model
     from improving_segmentation_with_selfsupervised_depth_amd.loss import get_monodepth_loss
-    from oracle import nets as N, photometric as P
+    from improving_segmentation_with_selfsupervised_depth_amd.loss.loss import cross_entropy2d
+    from oracle import nets as N, photometric as P, segmix as S
     import bench
     import model_cases as MC
     Hh, W = 512, 1024
-    cfg = bench.model_cfg("cfg2", Hh, W)
+    cfg = bench.model_cfg(workload, Hh, W)
+    with_seg = workload != "cfg2"
     sd = N.build_state_dict(cfg, 19, seed=11, randomize_bn=False)
-    inp2 = bench.synthetic_inputs(2, Hh, W, "cpu", 1234, with_labels=False)
+    inp2 = bench.synthetic_inputs(2, Hh, W, "cpu", 1234, with_labels=with_seg)
     gen = torch.Generator().manual_seed(12)
     noise2 = {s: torch.randn(2, 2, Hh, W, generator=gen) for s in range(4)}
 
-    def run(rep):
-        B = 2 * rep
+    def run(rep_):
+        B = 2 * rep_
         model = get_model(cfg, 19)
         model.load_state_dict(sd, strict=True)
         model.cuda().train()
         MC.dropout_eval(model)
-        inp = {k: v.repeat((rep,) + (1,) * (v.dim() - 1)).cuda() for k, v in inp2.items()}
+        inp = {k: v.repeat((rep_,) + (1,) * (v.dim() - 1)).cuda() for k, v in inp2.items()}
         lo = get_monodepth_loss(bench.loss_cfg(B, Hh, W), True)
-        lo.tiebreak_noise = {s: n.repeat(rep, 1, 1, 1).cuda() for s, n in noise2.items()}
+        lo.tiebreak_noise = {s: n.repeat(rep_, 1, 1, 1).cuda() for s, n in noise2.items()}
         out = model(inp)
         lo.generate_images_pred(inp, out)
         losses = lo.compute_losses(inp, out)
-        losses["loss"].backward()
+        total = losses["loss"]
         res = {k: float(v.detach()) for k, v in losses.items()}
+        if with_seg:
+            seg = cross_entropy2d(out["semantics"], inp["lbl"])
+            res["seg"] = float(seg.detach())
+            total = total + seg
+        total.backward()
         bn = model.models["encoder"].encoder.bn1.running_mean.detach().cpu().clone()
         peak = torch.cuda.max_memory_allocated() / 2 ** 30
-        del out, losses
+        del out, losses, total
         return res, model, bn, peak
 
     def run_oracle(dt):
@@ -393,6 +399,8 @@ def test_cfg2_batch8_replication_property():
         out = N.model_forward(sdo, cfg, inp, train=True, dropout=False)
         lo.generate_images_pred(inp, out)
         L = lo.compute_losses(inp, out, tiebreak_noise={s: cast(n) for s, n in noise2.items()})["loss"]
+        if with_seg:
+            L = L + S.cross_entropy2d(out["semantics"], inp["lbl"])
         L.backward()
         return float(L), {k: v.grad for k, v in sdo.items() if v.is_floating_point() and v.requires_grad}
 
@@ -400,18 +408,33 @@ def test_cfg2_batch8_replication_property():
     l32, g32 = run_oracle(torch.float32)
     l64, g64 = run_oracle(torch.float64)
     l2, m2, bn2, _ = run(1)
-    MC.gradients_vs_truth(list(m2.named_parameters()), g32, g64, "cfg2 at batch 2 (512x1024)")
+    MC.gradients_vs_truth(list(m2.named_parameters()), g32, g64, "%s at batch 2 (512x1024)" % workload)
     del m2
     torch.cuda.empty_cache()
-    l8, m8, bn8, peak = run(4)
-    print("cfg2 losses at batch 2:", l2, "\n       at batch 8:", l8, "peak memory %.1f GB" % peak, "\n oracle fp32 / fp64:", l32, l64)
-    assert all(np.isfinite(v) for v in l8.values())
+    lb, mb, bnb, peak = run(rep)
+    print("%s losses at batch 2:" % workload, l2, "\n       at batch %d:" % (2 * rep), lb, "peak memory %.1f GB" % peak,
+          "\n oracle fp32 / fp64:", l32, l64)
+    assert all(np.isfinite(v) for v in lb.values())
     for k in l2:
-        assert abs(l8[k] - l2[k]) <= 1e-4 * abs(l2[k]), (k, l8[k], l2[k])
-    assert abs(l8["loss"] - l64) <= 1e-3 * abs(l64) and abs(l2["loss"] - l64) <= 1e-3 * abs(l64)
-    assert_close(bn8, bn2, rtol=1e-5, atol=1e-7, what="stem BatchNorm running mean (same statistics)")
-    MC.gradients_vs_truth(list(m8.named_parameters()), g32, g64, "cfg2 at batch 8 = 4 copies of the batch of 2 (512x1024)")
+        assert abs(lb[k] - l2[k]) <= 1e-4 * abs(l2[k]), (k, lb[k], l2[k])
+    tot2, totb = l2["loss"] + l2.get("seg", 0.0), lb["loss"] + lb.get("seg", 0.0)
+    assert abs(totb - l64) <= 1e-3 * abs(l64) and abs(tot2 - l64) <= 1e-3 * abs(l64)
+    assert_close(bnb, bn2, rtol=1e-5, atol=1e-7, what="stem BatchNorm running mean (same statistics)")
+    MC.gradients_vs_truth(list(mb.named_parameters()), g32, g64,
+                          "%s at batch %d = %d copies of the batch of 2 (512x1024)" % (workload, 2 * rep, rep))
     assert peak < 288.0
+
+
+def test_cfg2_batch8_replication_property():
+    """BASELINE configs[1] at its own size AND batch: ResNet-50 monodepth, 512x1024, batch 8 (see _replication_property)"""
+    _replication_property("cfg2", 4)
+
+
+def test_cfg3_batch16_replication_property():
+    """the headline configuration at its own size AND batch (BASELINE configs[2]: ResNet-101 joint seg + depth, 512x1024, batch 16 --
+    what bench.py times): every kernel with the tile counts, split plans and routes of the benchmark step, photometric +
+    segmentation loss, every parameter gradient against the float64 oracle (see _replication_property)"""
+    _replication_property("cfg3", 8)
 
 
 def test_cfg5_pad_unlabeled_step_at_1024x2048():
