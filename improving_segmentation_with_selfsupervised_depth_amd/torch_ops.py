@@ -18,7 +18,10 @@ from . import functional as Fn
 from . import hipops as H
 
 NAMESPACE = "segsde"
-_lib = torch.library.Library(NAMESPACE, "DEF")
+try:
+    _lib = torch.library.Library(NAMESPACE, "DEF")
+except RuntimeError:      # the namespace exists already in this process (the module imported a second time under another name)
+    _lib = torch.library.Library(NAMESPACE, "FRAGMENT")
 SCHEMAS = {}
 
 
@@ -26,8 +29,12 @@ def _op(schema):
     name = schema.split("(", 1)[0]
 
     def deco(fn):
-        _lib.define(schema)
-        _lib.impl(name, fn, "CompositeImplicitAutograd")
+        try:
+            _lib.define(schema)
+            _lib.impl(name, fn, "CompositeImplicitAutograd")
+        except RuntimeError:
+            if not hasattr(getattr(torch.ops, NAMESPACE), name):      # anything but "registered before": a real error
+                raise
         SCHEMAS[name] = schema
         return fn
     return deco
